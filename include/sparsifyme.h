@@ -1,0 +1,150 @@
+/*
+ * sparsifyme.h -- C ABI of libsparsifyme.so, the MI355X (gfx950) back end of the sparsify.me
+ * hot path: prune to 2:4 -> compress -> sparse x dense matmul, measured against the library's
+ * own dense batched GEMM.
+ *
+ * This is the drop-in boundary.  The reference (owensgroup/sparsify.me) is a header-only CUDA C++
+ * template API; each entry point below replaces the vendor call(s) named next to it, and the
+ * templates in include/sparsify.me/ *.hxx (same paths, namespace and signatures as the reference)
+ * forward to these symbols.  Everything is `extern "C"`, plain pointers and sizes.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the comment says host;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream);
+ *   - functions only enqueue work on `stream` (no allocation, no synchronisation), so a caller
+ *     may capture them into a hipGraph; they return SM_STATUS_* (0 = success) and never throw;
+ *   - fp16 data are IEEE binary16 bit patterns (`_Float16` / `__half` / uint16_t storage).
+ *
+ * 2:4 compressed blob (produced by sm_compress24_*, consumed by sm_spmma_* / sm_decompress24_*),
+ * for `batch` row-major m x k matrices, M = batch*m rows:
+ *   kc       = k rounded up to a multiple of 64
+ *   values   : [M][kc/2] elements at byte 0 (kept pair of strip q at [R][2q], [R][2q+1])
+ *   metadata : [M][kc/8] bytes at byte round_up(M*(kc/2)*elt, 256); strip q's nibble
+ *              (p0 | p1 << 2, p0 < p1 kept positions) in bits 4*(q&1).. of byte [R][q/2]
+ *   size     = sm_compress24_size()
+ */
+#ifndef SPARSIFYME_H_
+#define SPARSIFYME_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SM_STATUS_SUCCESS 0
+#define SM_STATUS_INVALID_VALUE 1   /* bad pointer / size / flag                          */
+#define SM_STATUS_NOT_SUPPORTED 2   /* valid request this build has no kernel for          */
+#define SM_STATUS_LAUNCH_FAILED 3   /* HIP reported an error at launch                     */
+#define SM_STATUS_NO_DEVICE 4       /* no gfx950 device visible                            */
+
+#define SM_PRUNE_TILE 0   /* cusparseLtPruneAlg_t numbering used at spmma.hxx:86 */
+#define SM_PRUNE_STRIP 1
+
+#define SM_OP_N 0
+#define SM_OP_T 1
+
+typedef void* sm_stream_t; /* hipStream_t */
+
+/* Library / device info (host). */
+const char* sm_version(void);
+/* 0 when a gfx950 device is usable by this process, else SM_STATUS_NO_DEVICE. */
+int sm_device_check(void);
+/* Message of the last failing call made by the calling thread ("" if none). */
+const char* sm_last_error(void);
+
+/* ---- (a1) positional sparsify: replaces the Thrust fill + transform of
+ *      include/sparsify.me/sparsify.hxx:71-81 (sparsifyme::sparsify<BLK_M,BLK_N,type_t>).
+ *      weights: m*n elements of elt_bytes (2, 4 or 8), zeroed in place; mask: m*n uint64
+ *      (the reference's std::size_t mask), written in full. */
+int sm_sparsify_positional(void* weights, uint64_t* mask, size_t m, size_t n, size_t elt_bytes,
+                           size_t blk_m, size_t blk_n, float sparsity_factor, sm_stream_t stream);
+int sm_sparsify_positional_f16(void* weights, uint64_t* mask, size_t m, size_t n,
+                               float sparsity_factor, sm_stream_t stream);
+int sm_sparsify_positional_f32(float* weights, uint64_t* mask, size_t m, size_t n,
+                               float sparsity_factor, sm_stream_t stream);
+int sm_sparsify_positional_f64(double* weights, uint64_t* mask, size_t m, size_t n,
+                               float sparsity_factor, sm_stream_t stream);
+
+/* ---- (a2) prune to 2:4: replaces cusparseLtSpMMAPrune (spmma.hxx:86-87).
+ *      A_in / A_out row-major m x k, leading dimension ld elements; may alias (in place). */
+int sm_prune24_f16(const void* A_in, void* A_out, size_t m, size_t k, size_t ld, int alg,
+                   sm_stream_t stream);
+int sm_prune24_f32(const float* A_in, float* A_out, size_t m, size_t k, size_t ld, int alg,
+                   sm_stream_t stream);
+
+/* ---- (a2) prune check: replaces cusparseLtSpMMAPruneCheck (spmma.hxx:88).
+ *      *d_valid (device int) = 0 iff every 1x4 strip has <= 2 non-zeros, else 1. */
+int sm_prune24_check_f16(const void* A, size_t m, size_t k, size_t ld, int* d_valid,
+                         sm_stream_t stream);
+int sm_prune24_check_f32(const float* A, size_t m, size_t k, size_t ld, int* d_valid,
+                         sm_stream_t stream);
+
+/* ---- (a3) compress: replaces cusparseLtSpMMACompressedSize + cusparseLtSpMMACompress
+ *      (spmma.hxx:100-103).  A: batch matrices, row-major m x k, ld, batch stride strideA
+ *      elements.  Keeps the two largest |x| of every strip (STRIP rule), i.e. for an already
+ *      pruned A exactly its non-zeros; so compress alone is also the fused prune+compress. */
+int sm_compress24_size(size_t m, size_t k, size_t elt_bytes, size_t batch, size_t* bytes /*host*/);
+int sm_compress24_f16(const void* A, size_t m, size_t k, size_t ld, size_t batch, size_t strideA,
+                      void* blob, sm_stream_t stream);
+int sm_compress24_f32(const float* A, size_t m, size_t k, size_t ld, size_t batch, size_t strideA,
+                      void* blob, sm_stream_t stream);
+/* Inverse (test/debug aid; no reference counterpart). */
+int sm_decompress24_f16(const void* blob, size_t m, size_t k, size_t ld, size_t batch,
+                        size_t strideA, void* A, sm_stream_t stream);
+int sm_decompress24_f32(const void* blob, size_t m, size_t k, size_t ld, size_t batch,
+                        size_t strideA, float* A, sm_stream_t stream);
+
+/* ---- (a4) 2:4 sparse x dense matmul: replaces cusparseLtMatmul (spmma.hxx:112-113).
+ *      C_b = alpha * A_b * B_b + beta * C_b, row-major, ld(B) = ld(C) = n (spmma.hxx:56-64);
+ *      B_b = B + b*strideB (strideB = 0: one shared B), C_b = C + b*strideC (elements).
+ *      fp16: v_smfmac_f32_16x16x64_f16, fp32 accumulate, one rounding to fp16. */
+int sm_spmma_f16(const void* blob, const void* B, void* C, size_t m, size_t n, size_t k,
+                 size_t batch, size_t strideB, size_t strideC, float alpha, float beta,
+                 sm_stream_t stream);
+int sm_spmma_f32(const void* blob, const float* B, float* C, size_t m, size_t n, size_t k,
+                 size_t batch, size_t strideB, size_t strideC, float alpha, float beta,
+                 sm_stream_t stream);
+
+/* ---- (a5) dense batched GEMM: replaces cublas{H,S,D}gemmBatched (gemm.hxx:80-81, 133-134,
+ *      186-187).  COLUMN-major, lda = m, ldb = k, ldc = m as the reference passes them;
+ *      A_ptrs/B_ptrs/C_ptrs are device arrays of `batch` device pointers (examples/gemm.cu:65-90). */
+int sm_gemm_batched_f16(const void* const* A_ptrs, const void* const* B_ptrs, void* const* C_ptrs,
+                        size_t m, size_t n, size_t k, size_t batch, int ta, int tb, float alpha,
+                        float beta, sm_stream_t stream);
+int sm_gemm_batched_f32(const float* const* A_ptrs, const float* const* B_ptrs, float* const* C_ptrs,
+                        size_t m, size_t n, size_t k, size_t batch, int ta, int tb, float alpha,
+                        float beta, sm_stream_t stream);
+int sm_gemm_batched_f64(const double* const* A_ptrs, const double* const* B_ptrs,
+                        double* const* C_ptrs, size_t m, size_t n, size_t k, size_t batch, int ta,
+                        int tb, double alpha, double beta, sm_stream_t stream);
+
+/* Dense GEMM in the layout sm_spmma_* uses (row-major, strided batch): the like-for-like dense
+ * denominator for the 2:4 kernel.  No reference counterpart (the reference's only dense GEMM is
+ * the column-major pointer-array one above). */
+int sm_gemm_rowmajor_f16(const void* A, const void* B, void* C, size_t m, size_t n, size_t k,
+                         size_t lda, size_t batch, size_t strideA, size_t strideB, size_t strideC,
+                         float alpha, float beta, sm_stream_t stream);
+int sm_gemm_rowmajor_f32(const float* A, const float* B, float* C, size_t m, size_t n, size_t k,
+                         size_t lda, size_t batch, size_t strideA, size_t strideB, size_t strideC,
+                         float alpha, float beta, sm_stream_t stream);
+
+/* ---- (a6) unstructured SpMM: replace cusparseSpMM on Blocked-ELL (spmm.hxx:57-67,107-110) and
+ *      on strided-batch COO (spmm.hxx:164-187).  Column-major dense operands. */
+int sm_spmm_bell_f32(const float* values, const uint64_t* column_indices, size_t rows, size_t cols,
+                     size_t block_size, size_t ell_cols, const float* B, float* C, size_t n,
+                     float alpha, float beta, sm_stream_t stream);
+int sm_spmm_coo_f32(size_t A_num_rows, size_t A_num_cols, size_t A_nnz, size_t B_num_cols,
+                    size_t num_batches, const int* rows, const int* cols, const float* vals,
+                    const float* B, float* C, float alpha, float beta, sm_stream_t stream);
+
+/* ---- support: counter-based uniform fill (replaces the Thrust RNG transform of
+ *      include/sparsify.me/util/gen.hxx:12-20); element i depends only on (seed, i). */
+int sm_fill_uniform_f16(void* out, size_t count, uint64_t seed, float lo, float hi, sm_stream_t stream);
+int sm_fill_uniform_f32(float* out, size_t count, uint64_t seed, float lo, float hi, sm_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPARSIFYME_H_ */

@@ -1,0 +1,192 @@
+"""sparsify.me_amd -- ctypes front end of libsparsifyme.so (the gfx950 HIP back end).
+
+This package is plumbing for tests and bench.py: it hands torch-owned device pointers to the
+C ABI declared in include/sparsifyme.h.  There is NO CPU fallback here: if the HIP library is
+missing or a call fails, the functions raise.  The C++ mirror of the reference's operator API
+lives in include/sparsify.me/*.hxx; the function names below follow it
+(sparsify, spmma, batched gemm -- reference include/sparsify.me/{sparsify,spmma,gemm}.hxx).
+
+The directory name contains a dot, so import it through __graft_entry__.load_package(), which
+registers it as module `sparsifyme_amd`.
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsparsifyme.so")
+
+PRUNE_TILE = 0
+PRUNE_STRIP = 1
+
+_lib = None
+
+_c_size = ctypes.c_size_t
+_c_ptr = ctypes.c_void_p
+_c_f = ctypes.c_float
+_c_i = ctypes.c_int
+
+# name -> argtypes (restype is always int unless listed in _RET)
+_SIGS = {
+    "sm_device_check": [],
+    "sm_sparsify_positional": [_c_ptr, _c_ptr, _c_size, _c_size, _c_size, _c_size, _c_size, _c_f, _c_ptr],
+    "sm_sparsify_positional_f16": [_c_ptr, _c_ptr, _c_size, _c_size, _c_f, _c_ptr],
+    "sm_sparsify_positional_f32": [_c_ptr, _c_ptr, _c_size, _c_size, _c_f, _c_ptr],
+    "sm_sparsify_positional_f64": [_c_ptr, _c_ptr, _c_size, _c_size, _c_f, _c_ptr],
+    "sm_prune24_f16": [_c_ptr, _c_ptr, _c_size, _c_size, _c_size, _c_i, _c_ptr],
+    "sm_prune24_f32": [_c_ptr, _c_ptr, _c_size, _c_size, _c_size, _c_i, _c_ptr],
+    "sm_prune24_check_f16": [_c_ptr, _c_size, _c_size, _c_size, _c_ptr, _c_ptr],
+    "sm_prune24_check_f32": [_c_ptr, _c_size, _c_size, _c_size, _c_ptr, _c_ptr],
+    "sm_compress24_size": [_c_size, _c_size, _c_size, _c_size, ctypes.POINTER(_c_size)],
+    "sm_compress24_f16": [_c_ptr, _c_size, _c_size, _c_size, _c_size, _c_size, _c_ptr, _c_ptr],
+    "sm_compress24_f32": [_c_ptr, _c_size, _c_size, _c_size, _c_size, _c_size, _c_ptr, _c_ptr],
+    "sm_decompress24_f16": [_c_ptr, _c_size, _c_size, _c_size, _c_size, _c_size, _c_ptr, _c_ptr],
+    "sm_decompress24_f32": [_c_ptr, _c_size, _c_size, _c_size, _c_size, _c_size, _c_ptr, _c_ptr],
+    "sm_spmma_f16": [_c_ptr, _c_ptr, _c_ptr, _c_size, _c_size, _c_size, _c_size, _c_size, _c_size, _c_f, _c_f, _c_ptr],
+    "sm_spmma_f32": [_c_ptr, _c_ptr, _c_ptr, _c_size, _c_size, _c_size, _c_size, _c_size, _c_size, _c_f, _c_f, _c_ptr],
+    "sm_gemm_batched_f16": [_c_ptr, _c_ptr, _c_ptr, _c_size, _c_size, _c_size, _c_size, _c_i, _c_i, _c_f, _c_f, _c_ptr],
+    "sm_gemm_batched_f32": [_c_ptr, _c_ptr, _c_ptr, _c_size, _c_size, _c_size, _c_size, _c_i, _c_i, _c_f, _c_f, _c_ptr],
+    "sm_gemm_batched_f64": [_c_ptr, _c_ptr, _c_ptr, _c_size, _c_size, _c_size, _c_size, _c_i, _c_i,
+                            ctypes.c_double, ctypes.c_double, _c_ptr],
+    "sm_gemm_rowmajor_f16": [_c_ptr, _c_ptr, _c_ptr, _c_size, _c_size, _c_size, _c_size, _c_size, _c_size, _c_size,
+                             _c_size, _c_f, _c_f, _c_ptr],
+    "sm_gemm_rowmajor_f32": [_c_ptr, _c_ptr, _c_ptr, _c_size, _c_size, _c_size, _c_size, _c_size, _c_size, _c_size,
+                             _c_size, _c_f, _c_f, _c_ptr],
+    "sm_spmm_bell_f32": [_c_ptr, _c_ptr, _c_size, _c_size, _c_size, _c_size, _c_ptr, _c_ptr, _c_size, _c_f, _c_f, _c_ptr],
+    "sm_spmm_coo_f32": [_c_size, _c_size, _c_size, _c_size, _c_size, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_f, _c_f,
+                        _c_ptr],
+    "sm_fill_uniform_f16": [_c_ptr, _c_size, ctypes.c_uint64, _c_f, _c_f, _c_ptr],
+    "sm_fill_uniform_f32": [_c_ptr, _c_size, ctypes.c_uint64, _c_f, _c_f, _c_ptr],
+}
+_RET = {"sm_version": ctypes.c_char_p, "sm_last_error": ctypes.c_char_p}
+
+# every symbol include/sparsifyme.h declares (checked by tests/test_abi.py without a GPU)
+EXPORTED_SYMBOLS = sorted(list(_SIGS) + list(_RET))
+
+
+class SparsifymeError(RuntimeError):
+    pass
+
+
+def build(verbose=False):
+    """Compile csrc/*.hip for gfx950 into libsparsifyme.so (hipcc cross-compiles without a GPU)."""
+    res = subprocess.run(["make", "-C", _HERE, "-j4"], capture_output=not verbose, text=True)
+    if res.returncode != 0:
+        raise SparsifymeError("building libsparsifyme.so failed:\n" + (res.stdout or "") + (res.stderr or ""))
+    return LIB_PATH
+
+
+def lib():
+    """The loaded HIP library; raises (never falls back) when it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SparsifymeError(
+                f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(there is no CPU fallback for the product path)")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, args in _SIGS.items():
+            fn = getattr(L, name)
+            fn.argtypes = args
+            fn.restype = ctypes.c_int
+        for name, ret in _RET.items():
+            fn = getattr(L, name)
+            fn.argtypes = []
+            fn.restype = ret
+        _lib = L
+    return _lib
+
+
+def _check(status, what):
+    if status != 0:
+        msg = lib().sm_last_error().decode()
+        raise SparsifymeError(f"{what} failed with status {status}: {msg}")
+
+
+def _stream():
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev(t):
+    if not t.is_cuda:
+        raise SparsifymeError("expected a device tensor (the product path has no host implementation)")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _sfx(t):
+    import torch
+    return {torch.float16: "f16", torch.float32: "f32", torch.float64: "f64"}[t.dtype]
+
+
+def version():
+    return lib().sm_version().decode()
+
+
+def device_check():
+    _check(lib().sm_device_check(), "sm_device_check")
+
+
+# ---- operators -------------------------------------------------------------------------------
+def sparsify(weights, mask, m, n, sparsity_factor=0.5, blk_m=2, blk_n=2):
+    """sparsifyme::sparsify<BLK_M,BLK_N> (sparsify.hxx:24-30): in place on `weights`
+    (m*n elements) and `mask` (m*n int64/uint64)."""
+    assert weights.numel() >= m * n and mask.numel() >= m * n and mask.element_size() == 8
+    _check(lib().sm_sparsify_positional(_dev(weights), _dev(mask), m, n, weights.element_size(), blk_m, blk_n,
+                                        float(sparsity_factor), _stream()), "sm_sparsify_positional")
+
+
+def prune24(A_in, A_out, m, k, ld, alg=PRUNE_STRIP):
+    fn = getattr(lib(), "sm_prune24_" + _sfx(A_in))
+    _check(fn(_dev(A_in), _dev(A_out), m, k, ld, alg, _stream()), "sm_prune24")
+
+
+def prune24_check(A, m, k, ld, d_valid):
+    fn = getattr(lib(), "sm_prune24_check_" + _sfx(A))
+    _check(fn(_dev(A), m, k, ld, _dev(d_valid), _stream()), "sm_prune24_check")
+
+
+def compress24_size(m, k, elt_bytes, batch=1):
+    out = ctypes.c_size_t(0)
+    _check(lib().sm_compress24_size(m, k, elt_bytes, batch, ctypes.byref(out)), "sm_compress24_size")
+    return out.value
+
+
+def compress24(A, m, k, ld, batch, strideA, blob):
+    fn = getattr(lib(), "sm_compress24_" + _sfx(A))
+    _check(fn(_dev(A), m, k, ld, batch, strideA, _dev(blob), _stream()), "sm_compress24")
+
+
+def decompress24(blob, m, k, ld, batch, strideA, A):
+    fn = getattr(lib(), "sm_decompress24_" + _sfx(A))
+    _check(fn(_dev(blob), m, k, ld, batch, strideA, _dev(A), _stream()), "sm_decompress24")
+
+
+def spmma(blob, B, C, m, n, k, batch=1, strideB=0, strideC=None, alpha=1.0, beta=0.0):
+    """The matmul step of sparsifyme::spmma (spmma.hxx:112-113) on a compressed blob."""
+    if strideC is None:
+        strideC = m * n
+    fn = getattr(lib(), "sm_spmma_" + _sfx(B))
+    _check(fn(_dev(blob), _dev(B), _dev(C), m, n, k, batch, strideB, strideC, float(alpha), float(beta), _stream()),
+           "sm_spmma")
+
+
+def gemm_batched(A_ptrs, B_ptrs, C_ptrs, m, n, k, batch, dtype_suffix, alpha=1.0, beta=0.0, ta=0, tb=0):
+    """sparsifyme::batched::gemm (gemm.hxx:25-36): column-major, device pointer arrays (int64 tensors)."""
+    fn = getattr(lib(), "sm_gemm_batched_" + dtype_suffix)
+    _check(fn(_dev(A_ptrs), _dev(B_ptrs), _dev(C_ptrs), m, n, k, batch, ta, tb, alpha, beta, _stream()),
+           "sm_gemm_batched")
+
+
+def gemm_rowmajor(A, B, C, m, n, k, lda=None, batch=1, strideA=None, strideB=0, strideC=None, alpha=1.0, beta=0.0):
+    lda = k if lda is None else lda
+    strideA = m * lda if strideA is None else strideA
+    strideC = m * n if strideC is None else strideC
+    fn = getattr(lib(), "sm_gemm_rowmajor_" + _sfx(A))
+    _check(fn(_dev(A), _dev(B), _dev(C), m, n, k, lda, batch, strideA, strideB, strideC, float(alpha), float(beta),
+              _stream()), "sm_gemm_rowmajor")
+
+
+def fill_uniform(out, seed, lo=0.0, hi=1.0):
+    fn = getattr(lib(), "sm_fill_uniform_" + _sfx(out))
+    _check(fn(_dev(out), out.numel(), seed, float(lo), float(hi), _stream()), "sm_fill_uniform")

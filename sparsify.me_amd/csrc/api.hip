@@ -1,0 +1,84 @@
+// api.hip -- library-level entry points of libsparsifyme.so: version, device check, error text,
+// and the counter-based uniform fill (support kernel K10 of SURVEY.md 2.2; replaces the Thrust
+// transform of include/sparsify.me/util/gen.hxx:12-20).
+#include <stdarg.h>
+#include <string.h>
+
+#include "sm_common.h"
+
+namespace sm {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+// splitmix64 of (seed, i): element i depends on nothing else, so a fill is reproducible for any
+// grid shape and can be regenerated per GPU from (seed, layer, batch) without host traffic.
+__device__ __forceinline__ float uniform01(uint64_t seed, uint64_t i) {
+  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (i + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return (float)(z >> 40) * 5.9604644775390625e-8f;  // 24 bits -> [0, 1)
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void fill_uniform_kernel(T* out, size_t count, uint64_t seed, float lo, float span) {
+  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) {
+    const float v = __fadd_rn(lo, __fmul_rn(span, uniform01(seed, i)));
+    out[i] = (T)v;
+  }
+}
+
+template <typename T>
+static int launch_fill(void* out, size_t count, uint64_t seed, float lo, float hi, hipStream_t st) {
+  if (!out && count) {
+    set_error("sm_fill_uniform: null output");
+    return SM_STATUS_INVALID_VALUE;
+  }
+  if (count == 0) return SM_STATUS_SUCCESS;
+  fill_uniform_kernel<T><<<stream_grid(count, 256), 256, 0, st>>>((T*)out, count, seed, lo, hi - lo);
+  return check_launch("fill_uniform_kernel");
+}
+
+}  // namespace sm
+
+extern "C" {
+
+const char* sm_version(void) { return "sparsifyme-amd 0.1.0 (gfx950)"; }
+
+const char* sm_last_error(void) { return sm::g_err; }
+
+int sm_device_check(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n == 0) {
+    (void)hipGetLastError();
+    sm::set_error("no HIP device visible");
+    return SM_STATUS_NO_DEVICE;
+  }
+  int dev = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+    sm::set_error("cannot query the current HIP device");
+    return SM_STATUS_NO_DEVICE;
+  }
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    sm::set_error("device %d is %s; this library contains gfx950 code only", dev, prop.gcnArchName);
+    return SM_STATUS_NO_DEVICE;
+  }
+  return SM_STATUS_SUCCESS;
+}
+
+int sm_fill_uniform_f16(void* out, size_t count, uint64_t seed, float lo, float hi, sm_stream_t s) {
+  return sm::launch_fill<_Float16>(out, count, seed, lo, hi, (hipStream_t)s);
+}
+int sm_fill_uniform_f32(float* out, size_t count, uint64_t seed, float lo, float hi, sm_stream_t s) {
+  return sm::launch_fill<float>(out, count, seed, lo, hi, (hipStream_t)s);
+}
+
+}  // extern "C"

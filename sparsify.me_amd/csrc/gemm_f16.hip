@@ -1,0 +1,282 @@
+// gemm_f16.hip -- dense fp16 GEMM on v_mfma_f32_16x16x32_f16 (fp32 accumulate, one rounding).
+// It is the metric's denominator: the hand-written replacement of cublasHgemmBatched
+// (include/sparsify.me/gemm.hxx:80-81) and the like-for-like dense form of the 2:4 kernel.
+//
+// One kernel computes the row-major product  C[M x N] = alpha * A[M x K] * B[K x N] + beta * C
+// (A rows K-contiguous, B rows N-contiguous).  The reference's column-major batched GEMM
+// (lda = m, ldb = k, ldc = m) is the same memory seen transposed: C^T[n x m] = B^T[n x k] A^T[k x m],
+// all three row-major, so sm_gemm_batched_f16 launches this kernel with (M, N, K) = (n, m, k) and the
+// operand roles swapped -- no data movement.
+//
+// Structure: 256 threads = 4 waves, BM x BN output tile, BK = 64.  Global -> registers (16 B per
+// lane, zero-filled out of range) -> swizzled LDS images (mma_tile.h); the next K-tile's global
+// loads are issued before the current tile's MFMAs.  The MFMA is issued with its operands swapped
+// (B fragment as srcA) so each lane ends up with four CONSECUTIVE n of one row; the epilogue packs
+// them to 8 bytes, stages the tile in LDS and writes C with 16-byte row-contiguous stores.
+#include "mma_tile.h"
+
+namespace sm {
+
+struct GemmArgs {
+  const half_t* A;
+  const half_t* B;
+  half_t* C;
+  const half_t* const* Ap;  // optional device pointer arrays (batch entries); null -> base + b*stride
+  const half_t* const* Bp;
+  half_t* const* Cp;
+  size_t sA, sB, sC;        // batch strides in elements
+  int M, N, K;
+  int lda, ldb, ldc;
+  int batch, tiles_m, tiles_n;
+  float alpha, beta;
+};
+
+// 8 halves starting at p[col]; elements at or beyond `limit` columns read as zero.
+template <bool VEC>
+__device__ __forceinline__ u4 load_chunk(const half_t* rowp, int col, int limit, bool row_ok) {
+  u4 v = {0u, 0u, 0u, 0u};
+  if (!row_ok || col >= limit) return v;
+  if (VEC && col + 8 <= limit) return *reinterpret_cast<const u4*>(rowp + col);
+  h8 e;
+#pragma unroll
+  for (int t = 0; t < 8; ++t) e[t] = (col + t < limit) ? rowp[col + t] : (half_t)0.0f;
+  return __builtin_bit_cast(u4, e);
+}
+
+template <int BM, int BN, int WM, int WN, bool VEC>
+__global__ __launch_bounds__(256) void gemm_f16_kernel(const GemmArgs p) {
+  static_assert(WM * WN == 4, "4 waves");
+  constexpr int TM = BM / WM, TN = BN / WN, FM = TM / 16, FN = TN / 16;
+  constexpr int A_CH = BM * 8 / 256;   // 16-byte chunks of the A tile per thread
+  constexpr int B_CH = BN / 32;        // 64 k-rows x BN/8 chunks / 256 threads
+  constexpr int CPITCH = BN * 2 + 16;  // bytes per row of the epilogue image
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* As = smem;
+  char* Bs = smem + BM * 128;
+
+  const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const unsigned wm = wave / WN, wn = wave % WN;
+
+  const unsigned tiles = (unsigned)p.tiles_m * (unsigned)p.tiles_n;
+  const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
+  const unsigned b = lid / tiles, trem = lid - b * tiles;
+  const unsigned tile_m = trem / (unsigned)p.tiles_n, tile_n = trem - tile_m * (unsigned)p.tiles_n;
+  const int m0 = (int)tile_m * BM, n0 = (int)tile_n * BN;
+
+  const half_t* A = p.Ap ? p.Ap[b] : p.A + (size_t)b * p.sA;
+  const half_t* B = p.Bp ? p.Bp[b] : p.B + (size_t)b * p.sB;
+  half_t* C = p.Cp ? p.Cp[b] : p.C + (size_t)b * p.sC;
+
+  f4 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+
+  u4 ra[A_CH], rb[B_CH];
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i) {
+      const unsigned q = tid + 256u * i, row = q >> 3, ch = q & 7u;
+      const int gr = m0 + (int)row;
+      ra[i] = load_chunk<VEC>(A + (size_t)gr * p.lda, k0 + 8 * (int)ch, p.K, gr < p.M);
+    }
+#pragma unroll
+    for (int i = 0; i < B_CH; ++i) {
+      const unsigned q = tid + 256u * i, kr = q / (BN / 8), cn = q % (BN / 8);
+      const int gk = k0 + (int)kr;
+      rb[i] = load_chunk<VEC>(B + (size_t)gk * p.ldb, n0 + 8 * (int)cn, p.N, gk < p.K);
+    }
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i) {
+      const unsigned q = tid + 256u * i, row = q >> 3, ch = q & 7u;
+      *reinterpret_cast<u4*>(As + a_off(row, ch)) = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < B_CH; ++i) {
+      const unsigned q = tid + 256u * i, kr = q / (BN / 8), cn = q % (BN / 8);
+      *reinterpret_cast<u4*>(Bs + b_off<64>(kr, 8u * cn)) = rb[i];
+    }
+  };
+
+  const int nkt = (p.K + 63) / 64;
+  gload(0);
+  for (int kt = 0; kt < nkt; ++kt) {
+    lstore();
+    __syncthreads();
+    if (kt + 1 < nkt) gload((kt + 1) * 64);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      h8 af[FM], bf[FN];
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        const unsigned row = wm * TM + i * 16 + (lane & 15u);
+        af[i] = *reinterpret_cast<const h8*>(As + a_off(row, 4u * s + (lane >> 4)));
+      }
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const unsigned col0 = wn * TN + j * 16, kr0 = 32u * s + 8u * (lane >> 4);
+        const s4 lo = b_read_tr<64>(Bs, kr0, col0, lane);
+        const s4 hi = b_read_tr<64>(Bs, kr0 + 4u, col0, lane);
+        typedef short s8 __attribute__((ext_vector_type(8)));
+        const s8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        bf[j] = __builtin_bit_cast(h8, both);
+      }
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+          // operands swapped: D = B^T-fragment x A^T-fragment = (A*B)^T tile, i.e. this lane holds
+          // C[row (lane&15)][cols 4*(lane>>4) .. +3] of fragment (i, j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue
+  const bool c_vec = VEC && (p.ldc % 8 == 0) && ((reinterpret_cast<uintptr_t>(C) & 15u) == 0);
+  if (p.beta == 0.0f && c_vec) {
+    char* Cs = smem;  // [BM][CPITCH]
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const unsigned row = wm * TM + i * 16 + (lane & 15u), col = wn * TN + j * 16 + 4u * (lane >> 4);
+        h4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = (half_t)(p.alpha * acc[i][j][r]);
+        *reinterpret_cast<h4*>(Cs + row * CPITCH + col * 2) = o;
+      }
+    __syncthreads();
+    constexpr int C_CH = BM * (BN / 8) / 256;
+#pragma unroll
+    for (int i = 0; i < C_CH; ++i) {
+      const unsigned q = tid + 256u * i, row = q / (BN / 8), cn = q % (BN / 8);
+      const int gr = m0 + (int)row, gc = n0 + 8 * (int)cn;
+      if (gr >= p.M || gc >= p.N) continue;
+      const u4 v = *reinterpret_cast<const u4*>(Cs + row * CPITCH + cn * 16);
+      half_t* dst = C + (size_t)gr * p.ldc + gc;
+      if (gc + 8 <= p.N) {
+        *reinterpret_cast<u4*>(dst) = v;
+      } else {
+        const h8 e = __builtin_bit_cast(h8, v);
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+          if (gc + t < p.N) dst[t] = e[t];
+      }
+    }
+  } else {
+    // general alpha/beta or unaligned C: straight from the accumulators, one rounding
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const int gr = m0 + (int)(wm * TM + i * 16 + (lane & 15u));
+        const int gc = n0 + (int)(wn * TN + j * 16 + 4u * (lane >> 4));
+        if (gr >= p.M) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (gc + r >= p.N) continue;
+          half_t* dst = C + (size_t)gr * p.ldc + gc + r;
+          float v = p.alpha * acc[i][j][r];
+          if (p.beta != 0.0f) v += p.beta * (float)*dst;
+          *dst = (half_t)v;
+        }
+      }
+  }
+}
+
+template <int BM, int BN, int WM, int WN>
+static int launch_cfg(const GemmArgs& a0, bool vec, hipStream_t st) {
+  GemmArgs a = a0;
+  a.tiles_m = (a.M + BM - 1) / BM;
+  a.tiles_n = (a.N + BN - 1) / BN;
+  const size_t nwg = (size_t)a.tiles_m * a.tiles_n * a.batch;
+  if (nwg == 0) return SM_STATUS_SUCCESS;
+  if (nwg > 0x7fffffffu) {
+    set_error("gemm_f16: grid too large");
+    return SM_STATUS_NOT_SUPPORTED;
+  }
+  constexpr size_t lds_main = (size_t)BM * 128 + (size_t)BN * 128;
+  constexpr size_t lds_epi = (size_t)BM * (BN * 2 + 16);
+  constexpr size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
+  if (vec)
+    gemm_f16_kernel<BM, BN, WM, WN, true><<<dim3((unsigned)nwg), dim3(256), lds, st>>>(a);
+  else
+    gemm_f16_kernel<BM, BN, WM, WN, false><<<dim3((unsigned)nwg), dim3(256), lds, st>>>(a);
+  return check_launch("gemm_f16_kernel");
+}
+
+// Tile choice: the streamed dimension gets the long tile edge; narrow problems get a tile as wide
+// as they are, so the big operand is read from HBM exactly once.
+static int launch_gemm_f16(const GemmArgs& a, hipStream_t st) {
+  const bool vec = (a.lda % 8 == 0) && (a.ldb % 8 == 0) && (a.sA % 8 == 0) && (a.sB % 8 == 0) &&
+                   (a.Ap || aligned16(a.A)) && (a.Bp || aligned16(a.B));
+  // pointer-array batches: per-batch base alignment is the caller's (hipMalloc gives 256 B);
+  if (a.N <= 64) return launch_cfg<128, 64, 4, 1>(a, vec, st);
+  if (a.M <= 64) return launch_cfg<64, 128, 1, 4>(a, vec, st);
+  return launch_cfg<128, 128, 2, 2>(a, vec, st);
+}
+
+}  // namespace sm
+
+using namespace sm;
+
+extern "C" {
+
+int sm_gemm_rowmajor_f16(const void* A, const void* B, void* C, size_t m, size_t n, size_t k, size_t lda,
+                         size_t batch, size_t strideA, size_t strideB, size_t strideC, float alpha, float beta,
+                         sm_stream_t stream) {
+  if (!A || !B || !C || lda < k) {
+    set_error("sm_gemm_rowmajor_f16: invalid argument");
+    return SM_STATUS_INVALID_VALUE;
+  }
+  if (m == 0 || n == 0 || batch == 0) return SM_STATUS_SUCCESS;
+  if (m * batch > 0x7fffffffull || n > 0x7fffffffull || k > 0x7fffffffull || lda > 0x7fffffffull) {
+    set_error("sm_gemm_rowmajor_f16: dimension exceeds 2^31-1");
+    return SM_STATUS_NOT_SUPPORTED;
+  }
+  GemmArgs a = {};
+  a.A = (const half_t*)A; a.B = (const half_t*)B; a.C = (half_t*)C;
+  a.M = (int)m; a.N = (int)n; a.K = (int)k;
+  a.lda = (int)lda; a.ldb = (int)n; a.ldc = (int)n;
+  a.sA = strideA; a.sB = strideB; a.sC = strideC;
+  a.batch = (int)batch; a.alpha = alpha; a.beta = beta;
+  // a batch that shares B and stacks A and C contiguously is one tall matrix: no per-batch tails
+  if (batch > 1 && strideB == 0 && strideA == m * lda && strideC == m * n) {
+    a.M = (int)(m * batch);
+    a.batch = 1;
+  }
+  return launch_gemm_f16(a, (hipStream_t)stream);
+}
+
+int sm_gemm_batched_f16(const void* const* A_ptrs, const void* const* B_ptrs, void* const* C_ptrs, size_t m,
+                        size_t n, size_t k, size_t batch, int ta, int tb, float alpha, float beta,
+                        sm_stream_t stream) {
+  if (!A_ptrs || !B_ptrs || !C_ptrs) {
+    set_error("sm_gemm_batched_f16: null pointer array");
+    return SM_STATUS_INVALID_VALUE;
+  }
+  if (ta != SM_OP_N || tb != SM_OP_N) {
+    set_error("sm_gemm_batched_f16: transposed operands are not implemented (no reference driver passes them)");
+    return SM_STATUS_NOT_SUPPORTED;
+  }
+  if (m == 0 || n == 0 || batch == 0) return SM_STATUS_SUCCESS;
+  if (m > 0x7fffffffull || n > 0x7fffffffull || k > 0x7fffffffull || batch > 0x7fffffffull) {
+    set_error("sm_gemm_batched_f16: dimension exceeds 2^31-1");
+    return SM_STATUS_NOT_SUPPORTED;
+  }
+  // column-major C = A*B  <=>  row-major C^T[n x m] = B^T[n x k] * A^T[k x m]
+  GemmArgs a = {};
+  a.Ap = (const half_t* const*)B_ptrs;  // "A" of the row-major product is the reference's B
+  a.Bp = (const half_t* const*)A_ptrs;
+  a.Cp = (half_t* const*)C_ptrs;
+  a.M = (int)n; a.N = (int)m; a.K = (int)k;
+  a.lda = (int)k; a.ldb = (int)m; a.ldc = (int)m;
+  a.batch = (int)batch; a.alpha = alpha; a.beta = beta;
+  return launch_gemm_f16(a, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,564 @@
+// prune.hip -- HBM-bound streaming kernels of the sparsify.me hot path on gfx950:
+//   positional sparsify (reference: include/sparsify.me/sparsify.hxx:24-82),
+//   2:4 magnitude prune STRIP / TILE, prune check, compress, decompress
+//   (reference call sites: include/sparsify.me/spmma.hxx:86-88, 100-103).
+// All kernels move 16 B per lane per access, each wave-instruction covering 1 KiB of contiguous
+// memory; selection is pure register work (integer compares on sign-cleared bit patterns), and
+// the byte-granular metadata is staged through LDS so it leaves the CU as coalesced dwords.
+// Semantics are frozen by oracle/sm_oracle.c; results must match it bit for bit.
+#include "sm_common.h"
+
+namespace sm {
+
+// ---------------------------------------------------------------------------------------------
+// selection rules (mirror oracle/sm_oracle.c: strip_select, tile_select)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t key_of(uint16_t v) { return v & 0x7fffu; }
+__device__ __forceinline__ uint32_t key_of(uint32_t v) { return v & 0x7fffffffu; }
+
+// 4-bit keep mask (bit t = position t kept) of the STRIP rule: top-2 keys, ties -> lower index.
+__device__ __forceinline__ unsigned strip_keepmask(uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3) {
+  const unsigned r0 = (k1 > k0) + (k2 > k0) + (k3 > k0);
+  const unsigned r1 = (k0 >= k1) + (k2 > k1) + (k3 > k1);
+  const unsigned r2 = (k0 >= k2) + (k1 >= k2) + (k3 > k2);
+  const unsigned r3 = (k0 >= k3) + (k1 >= k3) + (k2 >= k3);
+  return (r0 < 2 ? 1u : 0u) | (r1 < 2 ? 2u : 0u) | (r2 < 2 ? 4u : 0u) | (r3 < 2 ? 8u : 0u);
+}
+// keep mask (exactly two bits set) -> metadata nibble p0 | p1 << 2.
+__device__ __forceinline__ unsigned nibble_of(unsigned keep) {
+  const unsigned p0 = __builtin_ctz(keep);
+  const unsigned p1 = 31u - __builtin_clz(keep);
+  return p0 | (p1 << 2);
+}
+
+__device__ __forceinline__ float mag_of(uint16_t v) {
+  const uint16_t k = v & 0x7fffu;
+  if (k > 0x7c00u) return __builtin_inff();
+  return (float)__builtin_bit_cast(_Float16, k);
+}
+__device__ __forceinline__ float mag_of(uint32_t v) {
+  const uint32_t k = v & 0x7fffffffu;
+  if (k > 0x7f800000u) return __builtin_inff();
+  return __builtin_bit_cast(float, k);
+}
+
+// TILE rule: 16-bit keep mask (bit 4*r + c) of the best of the 90 candidates.
+__device__ __forceinline__ unsigned tile_keepmask(const float (&mag)[4][4]) {
+  float s0[6], s1[6], s2[6], s3[6];
+#define SM_PAIRS(S, R)            \
+  S[0] = mag[R][0] + mag[R][1];   \
+  S[1] = mag[R][0] + mag[R][2];   \
+  S[2] = mag[R][0] + mag[R][3];   \
+  S[3] = mag[R][1] + mag[R][2];   \
+  S[4] = mag[R][1] + mag[R][3];   \
+  S[5] = mag[R][2] + mag[R][3];
+  SM_PAIRS(s0, 0) SM_PAIRS(s1, 1) SM_PAIRS(s2, 2) SM_PAIRS(s3, 3)
+#undef SM_PAIRS
+  float best = -1.0f;
+  unsigned bm = 0;
+#define TILE_CAND(I, P0, P1, P2, P3, MK)                        \
+  {                                                             \
+    const float sc = (s0[P0] + s1[P1]) + (s2[P2] + s3[P3]);     \
+    if (sc > best) {                                            \
+      best = sc;                                                \
+      bm = MK;                                                  \
+    }                                                           \
+  }
+#include "tile_patterns.inc"
+#undef TILE_CAND
+  return bm;
+}
+
+// ---------------------------------------------------------------------------------------------
+// (a1) positional sparsify, 2x2 blocks (the only shape the reference instantiates,
+//      examples/sparsify.cu:46): fused K1 (mask fill) + K2 (scatter) of SURVEY.md 2.2.
+// ---------------------------------------------------------------------------------------------
+// zmask: bit o set <=> offset o of every block of 4 consecutive elements is zeroed
+// (visit order 0,2,1,3 of sparsify.hxx:53-60).  limit = 4 * (m/2) * (n/2).
+template <typename VT /*one element's storage type*/>
+__global__ __launch_bounds__(256) void sparsify22_kernel(VT* __restrict__ w, uint64_t* __restrict__ mask,
+                                                         size_t total, size_t limit, unsigned zmask) {
+  constexpr unsigned E = 16 / sizeof(VT);  // elements per 16-byte vector
+  const size_t nchunk = (total + 256 * E - 1) / (256 * E);
+  for (size_t chunk = blockIdx.x; chunk < nchunk; chunk += gridDim.x) {
+    const size_t e0 = (chunk * 256 + threadIdx.x) * E;  // first element of this lane's vector
+    if (e0 < limit) {
+      if (e0 + E <= total) {
+        u4 v = *reinterpret_cast<const u4*>(w + e0);
+        VT* ve = reinterpret_cast<VT*>(&v);
+#pragma unroll
+        for (unsigned j = 0; j < E; ++j)
+          if (e0 + j < limit && ((zmask >> ((e0 + j) & 3)) & 1u)) ve[j] = 0;
+        *reinterpret_cast<u4*>(w + e0) = v;
+      } else {
+        for (unsigned j = 0; j < E && e0 + j < total; ++j)
+          if (e0 + j < limit && ((zmask >> ((e0 + j) & 3)) & 1u)) w[e0 + j] = 0;
+      }
+    }
+    // mask: this block's chunk spans 256*E entries = 128*E 16-byte vectors, E/2 per lane,
+    // each store instruction covering 256 consecutive vectors.
+#pragma unroll
+    for (unsigned j = 0; j < E / 2; ++j) {
+      const size_t me = chunk * 256 * E + ((size_t)j * 256 + threadIdx.x) * 2;
+      if (me >= total) continue;
+      const uint64_t a = (me < limit && ((zmask >> (me & 3)) & 1u)) ? 0ull : 1ull;
+      if (me + 1 < total) {
+        const uint64_t b = (me + 1 < limit && ((zmask >> ((me + 1) & 3)) & 1u)) ? 0ull : 1ull;
+        typedef uint64_t ul2 __attribute__((ext_vector_type(2)));
+        ul2 mv = {a, b};
+        *reinterpret_cast<ul2*>(mask + me) = mv;
+      } else {
+        mask[me] = a;
+      }
+    }
+  }
+}
+
+// Generic restatement for any block shape / unaligned buffers: K1 then K2 as two launches,
+// following sparsify.hxx:71 and :43-68 literally (slow path, never used by the drivers).
+__global__ void mask_fill_kernel(uint64_t* mask, size_t total) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
+    mask[i] = 1;
+}
+template <typename VT>
+__global__ void sparsify_generic_kernel(VT* w, uint64_t* mask, size_t nblk, size_t blk_m, size_t blk_n,
+                                        size_t nz) {
+  for (size_t blk = blockIdx.x * (size_t)blockDim.x + threadIdx.x; blk < nblk;
+       blk += (size_t)gridDim.x * blockDim.x) {
+    const size_t g = blk * blk_m * blk_n;
+    size_t done = 0;
+    for (size_t h = 0; h < blk_m; ++h)
+      for (size_t ww = 0; ww < blk_n; ++ww) {
+        if (done == nz) break;
+        const size_t idx = g + h + ww * blk_n;
+        w[idx] = 0;
+        mask[idx] = 0;
+        ++done;
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// element access helpers: 8 consecutive k of one row, vector path when aligned and in range
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+struct Vec8;  // 8 elements of storage type T
+template <>
+struct Vec8<uint16_t> {
+  uint16_t e[8];
+  __device__ __forceinline__ void load_vec(const uint16_t* p) { *reinterpret_cast<u4*>(e) = *reinterpret_cast<const u4*>(p); }
+  __device__ __forceinline__ void store_vec(uint16_t* p) const { *reinterpret_cast<u4*>(p) = *reinterpret_cast<const u4*>(e); }
+};
+template <>
+struct Vec8<uint32_t> {
+  uint32_t e[8];
+  __device__ __forceinline__ void load_vec(const uint32_t* p) {
+    reinterpret_cast<u4*>(e)[0] = reinterpret_cast<const u4*>(p)[0];
+    reinterpret_cast<u4*>(e)[1] = reinterpret_cast<const u4*>(p)[1];
+  }
+  __device__ __forceinline__ void store_vec(uint32_t* p) const {
+    reinterpret_cast<u4*>(p)[0] = reinterpret_cast<const u4*>(e)[0];
+    reinterpret_cast<u4*>(p)[1] = reinterpret_cast<const u4*>(e)[1];
+  }
+};
+
+template <typename T>
+__device__ __forceinline__ void load8(Vec8<T>& v, const T* p, size_t nvalid, bool vec_ok) {
+  if (vec_ok && nvalid >= 8) {
+    v.load_vec(p);
+  } else {
+#pragma unroll
+    for (unsigned t = 0; t < 8; ++t) v.e[t] = t < nvalid ? p[t] : (T)0;
+  }
+}
+template <typename T>
+__device__ __forceinline__ void store8(const Vec8<T>& v, T* p, size_t nvalid, bool vec_ok) {
+  if (vec_ok && nvalid >= 8) {
+    v.store_vec(p);
+  } else {
+#pragma unroll
+    for (unsigned t = 0; t < 8; ++t)
+      if (t < nvalid) p[t] = v.e[t];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// (a2) prune STRIP: item = 8 consecutive k of one row (two strips)
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void prune_strip_kernel(const T* A_in, T* A_out, size_t m, size_t k,
+                                                          size_t ld, bool vec_ok) {
+  const size_t ipr = (k + 7) / 8;  // items per row
+  const size_t total = m * ipr;
+  for (size_t it = blockIdx.x * (size_t)256 + threadIdx.x; it < total; it += (size_t)gridDim.x * 256) {
+    const size_t row = it / ipr, c = (it - row * ipr) * 8;
+    const size_t nvalid = k - c < 8 ? k - c : 8;
+    Vec8<T> v;
+    load8(v, A_in + row * ld + c, nvalid, vec_ok);
+#pragma unroll
+    for (unsigned s = 0; s < 2; ++s) {
+      const unsigned keep = strip_keepmask(key_of(v.e[4 * s]), key_of(v.e[4 * s + 1]), key_of(v.e[4 * s + 2]),
+                                           key_of(v.e[4 * s + 3]));
+#pragma unroll
+      for (unsigned t = 0; t < 4; ++t)
+        if (!((keep >> t) & 1u)) v.e[4 * s + t] = 0;
+    }
+    store8(v, A_out + row * ld + c, nvalid, vec_ok);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// (a2) prune TILE: item = one 4x4 tile (K3 of SURVEY.md 2.2, the variant spmma.hxx:86 asks for)
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void prune_tile_kernel(const T* A_in, T* A_out, size_t m, size_t k,
+                                                         size_t ld, bool vec_ok) {
+  const size_t tpr = (k + 3) / 4, trows = (m + 3) / 4;
+  const size_t total = tpr * trows;
+  for (size_t it = blockIdx.x * (size_t)256 + threadIdx.x; it < total; it += (size_t)gridDim.x * 256) {
+    const size_t tr = it / tpr, tc = it - tr * tpr;
+    const size_t r0 = tr * 4, c0 = tc * 4;
+    const unsigned ncol = k - c0 < 4 ? (unsigned)(k - c0) : 4u;
+    T v[4][4];
+    float mag[4][4];
+#pragma unroll
+    for (unsigned r = 0; r < 4; ++r) {
+      const bool rv = r0 + r < m;
+      const T* p = A_in + (r0 + r) * ld + c0;
+      if (rv && vec_ok && ncol == 4) {
+        if constexpr (sizeof(T) == 2) {
+          *reinterpret_cast<u2*>(v[r]) = *reinterpret_cast<const u2*>(p);
+        } else {
+          *reinterpret_cast<u4*>(v[r]) = *reinterpret_cast<const u4*>(p);
+        }
+      } else {
+#pragma unroll
+        for (unsigned t = 0; t < 4; ++t) v[r][t] = (rv && t < ncol) ? p[t] : (T)0;
+      }
+#pragma unroll
+      for (unsigned t = 0; t < 4; ++t) mag[r][t] = mag_of(v[r][t]);
+    }
+    const unsigned keep = tile_keepmask(mag);
+#pragma unroll
+    for (unsigned r = 0; r < 4; ++r) {
+      if (r0 + r >= m) continue;
+#pragma unroll
+      for (unsigned t = 0; t < 4; ++t)
+        if (!((keep >> (4 * r + t)) & 1u)) v[r][t] = 0;
+      T* p = A_out + (r0 + r) * ld + c0;
+      if (vec_ok && ncol == 4) {
+        if constexpr (sizeof(T) == 2) {
+          *reinterpret_cast<u2*>(p) = *reinterpret_cast<const u2*>(v[r]);
+        } else {
+          *reinterpret_cast<u4*>(p) = *reinterpret_cast<const u4*>(v[r]);
+        }
+      } else {
+#pragma unroll
+        for (unsigned t = 0; t < 4; ++t)
+          if (t < ncol) p[t] = v[r][t];
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// (a2) prune check (K4): any strip with more than two non-zeros -> *d_valid |= 1
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void prune_check_kernel(const T* A, size_t m, size_t k, size_t ld,
+                                                          bool vec_ok, int* d_valid) {
+  const size_t ipr = (k + 7) / 8;
+  const size_t total = m * ipr;
+  bool bad = false;
+  for (size_t it = blockIdx.x * (size_t)256 + threadIdx.x; it < total; it += (size_t)gridDim.x * 256) {
+    const size_t row = it / ipr, c = (it - row * ipr) * 8;
+    const size_t nvalid = k - c < 8 ? k - c : 8;
+    Vec8<T> v;
+    load8(v, A + row * ld + c, nvalid, vec_ok);
+#pragma unroll
+    for (unsigned s = 0; s < 2; ++s) {
+      unsigned nnz = 0;
+#pragma unroll
+      for (unsigned t = 0; t < 4; ++t) nnz += key_of(v.e[4 * s + t]) != 0;
+      bad |= nnz > 2;
+    }
+  }
+  if (__any(bad)) {
+    if ((threadIdx.x & 63) == 0) atomicOr(d_valid, 1);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// (a3) compress (K5, fused with the STRIP selection): item = 8 dense k of one blob row ->
+//      4 kept values (one 8- or 16-byte store) + 1 metadata byte (staged through LDS).
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void compress_kernel(const T* A, size_t m, size_t k, size_t ld,
+                                                       size_t strideA, size_t kc, size_t M, T* vals,
+                                                       unsigned char* meta, bool vec_ok) {
+  __shared__ __attribute__((aligned(16))) unsigned char smeta[1024];
+  const size_t ipr = kc / 8;        // items per blob row
+  const size_t total = M * ipr;     // a multiple of 8 (kc % 64 == 0)
+  const size_t nchunk = (total + 1023) / 1024;
+  for (size_t chunk = blockIdx.x; chunk < nchunk; chunk += gridDim.x) {
+#pragma unroll
+    for (unsigned j = 0; j < 4; ++j) {
+      const size_t it = chunk * 1024 + j * 256 + threadIdx.x;
+      unsigned char mb = 0x44;
+      if (it < total) {
+        const size_t R = it / ipr, c = (it - R * ipr) * 8;
+        T out[4] = {0, 0, 0, 0};
+        if (c < k) {
+          const size_t b = R / m, i = R - b * m;
+          const size_t nvalid = k - c < 8 ? k - c : 8;
+          Vec8<T> v;
+          load8(v, A + b * strideA + i * ld + c, nvalid, vec_ok);
+          unsigned nib[2];
+#pragma unroll
+          for (unsigned s = 0; s < 2; ++s) {
+            // a strip wholly at or beyond k keeps the padding nibble 0x4 and zero values
+            const unsigned keep = (c + 4 * s < k)
+                                      ? strip_keepmask(key_of(v.e[4 * s]), key_of(v.e[4 * s + 1]),
+                                                       key_of(v.e[4 * s + 2]), key_of(v.e[4 * s + 3]))
+                                      : 3u;
+            nib[s] = nibble_of(keep);
+            // select the two kept values without dynamic register indexing
+            const unsigned p0 = nib[s] & 3u, p1 = nib[s] >> 2;
+            T a0 = v.e[4 * s], a1 = v.e[4 * s + 1];
+            a0 = p0 == 1 ? v.e[4 * s + 1] : a0;
+            a0 = p0 == 2 ? v.e[4 * s + 2] : a0;
+            a1 = p1 == 2 ? v.e[4 * s + 2] : a1;
+            a1 = p1 == 3 ? v.e[4 * s + 3] : a1;
+            out[2 * s] = a0;
+            out[2 * s + 1] = a1;
+          }
+          mb = (unsigned char)(nib[0] | (nib[1] << 4));
+        }
+        if constexpr (sizeof(T) == 2) {
+          *reinterpret_cast<u2*>(vals + it * 4) = *reinterpret_cast<const u2*>(out);
+        } else {
+          *reinterpret_cast<u4*>(vals + it * 4) = *reinterpret_cast<const u4*>(out);
+        }
+      }
+      smeta[j * 256 + threadIdx.x] = mb;
+    }
+    __syncthreads();
+    {
+      const size_t mbyte = chunk * 1024 + threadIdx.x * 4;
+      if (mbyte < total) *reinterpret_cast<unsigned*>(meta + mbyte) = reinterpret_cast<const unsigned*>(smeta)[threadIdx.x];
+    }
+    __syncthreads();
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void decompress_kernel(const T* vals, const unsigned char* meta, size_t m,
+                                                         size_t k, size_t ld, size_t strideA, size_t kc,
+                                                         size_t M, T* A, bool vec_ok) {
+  const size_t ipr = kc / 8;
+  const size_t total = M * ipr;
+  for (size_t it = blockIdx.x * (size_t)256 + threadIdx.x; it < total; it += (size_t)gridDim.x * 256) {
+    const size_t R = it / ipr, c = (it - R * ipr) * 8;
+    if (c >= k) continue;
+    const size_t b = R / m, i = R - b * m;
+    const unsigned mb = meta[it];
+    T in[4];
+    if constexpr (sizeof(T) == 2) {
+      *reinterpret_cast<u2*>(in) = *reinterpret_cast<const u2*>(vals + it * 4);
+    } else {
+      *reinterpret_cast<u4*>(in) = *reinterpret_cast<const u4*>(vals + it * 4);
+    }
+    Vec8<T> v;
+#pragma unroll
+    for (unsigned s = 0; s < 2; ++s) {
+      const unsigned nib = (mb >> (4 * s)) & 0xfu, p0 = nib & 3u, p1 = nib >> 2;
+#pragma unroll
+      for (unsigned t = 0; t < 4; ++t) v.e[4 * s + t] = t == p0 ? in[2 * s] : (t == p1 ? in[2 * s + 1] : (T)0);
+    }
+    const size_t nvalid = k - c < 8 ? k - c : 8;
+    store8(v, A + b * strideA + i * ld + c, nvalid, vec_ok);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+template <typename VT>
+static int launch_sparsify(void* weights, uint64_t* mask, size_t m, size_t n, size_t blk_m, size_t blk_n,
+                           float sf, hipStream_t st) {
+  const size_t total = m * n;
+  const size_t blk_size = blk_m * blk_n;
+  const size_t nblk = (m / blk_m) * (n / blk_n);
+  const float nzf = floorf((float)blk_size * sf);  // sparsify.hxx:42
+  size_t nz = nzf <= 0.0f ? 0 : (size_t)nzf;
+  if (nz > blk_size) nz = blk_size;
+  if (total == 0) return SM_STATUS_SUCCESS;
+  if (blk_m == 2 && blk_n == 2 && aligned16(weights) && aligned16(mask)) {
+    static const unsigned ZM[5] = {0x0u, 0x1u, 0x5u, 0x7u, 0xfu};  // visit order 0,2,1,3
+    constexpr unsigned E = 16 / sizeof(VT);
+    const unsigned grid = stream_grid(ceil_div(total, E), 256);
+    sparsify22_kernel<VT><<<grid, 256, 0, st>>>((VT*)weights, mask, total, nblk * 4, ZM[nz]);
+    return check_launch("sparsify22_kernel");
+  }
+  // generic: refuse what would write outside the buffer (the reference would, sparsify.hxx:60)
+  if (nblk > 0 && nz > 0) {
+    size_t max_off = 0, cnt = 0;
+    for (size_t h = 0; h < blk_m && cnt < nz; ++h)
+      for (size_t w = 0; w < blk_n && cnt < nz; ++w, ++cnt)
+        if (h + w * blk_n > max_off) max_off = h + w * blk_n;
+    if ((nblk - 1) * blk_size + max_off >= total) {
+      set_error("sm_sparsify_positional: block shape %zux%zu indexes outside the %zux%zu buffer", blk_m, blk_n, m, n);
+      return SM_STATUS_INVALID_VALUE;
+    }
+  }
+  mask_fill_kernel<<<stream_grid(total, 256), 256, 0, st>>>(mask, total);
+  if (nblk > 0 && nz > 0)
+    sparsify_generic_kernel<VT><<<stream_grid(nblk, 256), 256, 0, st>>>((VT*)weights, mask, nblk, blk_m, blk_n, nz);
+  return check_launch("sparsify_generic_kernel");
+}
+
+template <typename T>
+static bool vec_ok_2d(const void* a, const void* b, size_t ld, size_t stride) {
+  constexpr size_t per16 = 16 / sizeof(T);
+  // 8 elements are moved as one (f16) or two (f32) 16-byte accesses at element offsets that are
+  // multiples of 8, so rows and batches must start on 16-byte boundaries.
+  return aligned16(a) && aligned16(b) && ld % per16 == 0 && stride % per16 == 0;
+}
+
+template <typename T>
+static int launch_prune(const void* A_in, void* A_out, size_t m, size_t k, size_t ld, int alg, hipStream_t st) {
+  if (!A_in || !A_out || ld < k || (alg != SM_PRUNE_TILE && alg != SM_PRUNE_STRIP)) {
+    set_error("sm_prune24: invalid argument");
+    return SM_STATUS_INVALID_VALUE;
+  }
+  if (m == 0 || k == 0) return SM_STATUS_SUCCESS;
+  if (alg == SM_PRUNE_STRIP) {
+    const bool vec_ok = vec_ok_2d<T>(A_in, A_out, ld, 0);
+    prune_strip_kernel<T><<<stream_grid(m * ceil_div(k, 8), 256), 256, 0, st>>>((const T*)A_in, (T*)A_out, m, k, ld, vec_ok);
+    return check_launch("prune_strip_kernel");
+  }
+  // TILE moves 4 elements per row access: 8-byte (f16) / 16-byte (f32) alignment
+  const size_t per = 4;
+  const bool vec_ok = (reinterpret_cast<uintptr_t>(A_in) % (per * sizeof(T)) == 0) &&
+                      (reinterpret_cast<uintptr_t>(A_out) % (per * sizeof(T)) == 0) && ld % per == 0;
+  prune_tile_kernel<T><<<stream_grid(ceil_div(m, 4) * ceil_div(k, 4), 256), 256, 0, st>>>((const T*)A_in, (T*)A_out, m, k, ld, vec_ok);
+  return check_launch("prune_tile_kernel");
+}
+
+template <typename T>
+static int launch_check(const void* A, size_t m, size_t k, size_t ld, int* d_valid, hipStream_t st) {
+  if (!A || !d_valid || ld < k) {
+    set_error("sm_prune24_check: invalid argument");
+    return SM_STATUS_INVALID_VALUE;
+  }
+  if (hipMemsetAsync(d_valid, 0, sizeof(int), st) != hipSuccess) return check_launch("hipMemsetAsync");
+  if (m == 0 || k == 0) return SM_STATUS_SUCCESS;
+  const bool vec_ok = vec_ok_2d<T>(A, A, ld, 0);
+  prune_check_kernel<T><<<stream_grid(m * ceil_div(k, 8), 256), 256, 0, st>>>((const T*)A, m, k, ld, vec_ok, d_valid);
+  return check_launch("prune_check_kernel");
+}
+
+template <typename T>
+static int launch_compress(const void* A, size_t m, size_t k, size_t ld, size_t batch, size_t strideA, void* blob,
+                           hipStream_t st) {
+  if (!A || !blob || ld < k || !aligned16(blob)) {
+    set_error("sm_compress24: invalid argument (blob must be 16-byte aligned)");
+    return SM_STATUS_INVALID_VALUE;
+  }
+  const BlobLayout L = blob_layout(m, k, sizeof(T), batch);
+  if (L.M == 0 || k == 0) return SM_STATUS_SUCCESS;
+  // zero the alignment gaps so a blob is a pure function of its input
+  const size_t vbytes = L.M * (L.kc / 2) * sizeof(T), mbytes = L.M * (L.kc / 8);
+  if (L.meta_off > vbytes && hipMemsetAsync((char*)blob + vbytes, 0, L.meta_off - vbytes, st) != hipSuccess)
+    return check_launch("hipMemsetAsync");
+  if (L.total > L.meta_off + mbytes &&
+      hipMemsetAsync((char*)blob + L.meta_off + mbytes, 0, L.total - L.meta_off - mbytes, st) != hipSuccess)
+    return check_launch("hipMemsetAsync");
+  const bool vec_ok = vec_ok_2d<T>(A, A, ld, strideA);
+  const size_t items = L.M * (L.kc / 8);
+  const unsigned grid = stream_grid(ceil_div(items, 4), 256);
+  compress_kernel<T><<<grid, 256, 0, st>>>((const T*)A, m, k, ld, strideA, L.kc, L.M, (T*)blob,
+                                           (unsigned char*)blob + L.meta_off, vec_ok);
+  return check_launch("compress_kernel");
+}
+
+template <typename T>
+static int launch_decompress(const void* blob, size_t m, size_t k, size_t ld, size_t batch, size_t strideA, void* A,
+                             hipStream_t st) {
+  if (!A || !blob || ld < k) {
+    set_error("sm_decompress24: invalid argument");
+    return SM_STATUS_INVALID_VALUE;
+  }
+  const BlobLayout L = blob_layout(m, k, sizeof(T), batch);
+  if (L.M == 0 || k == 0) return SM_STATUS_SUCCESS;
+  const bool vec_ok = vec_ok_2d<T>(A, A, ld, strideA);
+  decompress_kernel<T><<<stream_grid(L.M * (L.kc / 8), 256), 256, 0, st>>>(
+      (const T*)blob, (const unsigned char*)blob + L.meta_off, m, k, ld, strideA, L.kc, L.M, (T*)A, vec_ok);
+  return check_launch("decompress_kernel");
+}
+
+}  // namespace sm
+
+using namespace sm;
+
+extern "C" {
+
+int sm_sparsify_positional(void* weights, uint64_t* mask, size_t m, size_t n, size_t elt_bytes, size_t blk_m,
+                           size_t blk_n, float sparsity_factor, sm_stream_t stream) {
+  if (!weights || !mask || blk_m == 0 || blk_n == 0) {
+    set_error("sm_sparsify_positional: invalid argument");
+    return SM_STATUS_INVALID_VALUE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  switch (elt_bytes) {
+    case 2: return launch_sparsify<uint16_t>(weights, mask, m, n, blk_m, blk_n, sparsity_factor, st);
+    case 4: return launch_sparsify<uint32_t>(weights, mask, m, n, blk_m, blk_n, sparsity_factor, st);
+    case 8: return launch_sparsify<uint64_t>(weights, mask, m, n, blk_m, blk_n, sparsity_factor, st);
+    default: set_error("sm_sparsify_positional: element size %zu not supported", elt_bytes); return SM_STATUS_INVALID_VALUE;
+  }
+}
+int sm_sparsify_positional_f16(void* w, uint64_t* mask, size_t m, size_t n, float sf, sm_stream_t s) {
+  return sm_sparsify_positional(w, mask, m, n, 2, 2, 2, sf, s);
+}
+int sm_sparsify_positional_f32(float* w, uint64_t* mask, size_t m, size_t n, float sf, sm_stream_t s) {
+  return sm_sparsify_positional(w, mask, m, n, 4, 2, 2, sf, s);
+}
+int sm_sparsify_positional_f64(double* w, uint64_t* mask, size_t m, size_t n, float sf, sm_stream_t s) {
+  return sm_sparsify_positional(w, mask, m, n, 8, 2, 2, sf, s);
+}
+
+int sm_prune24_f16(const void* A_in, void* A_out, size_t m, size_t k, size_t ld, int alg, sm_stream_t s) {
+  return launch_prune<uint16_t>(A_in, A_out, m, k, ld, alg, (hipStream_t)s);
+}
+int sm_prune24_f32(const float* A_in, float* A_out, size_t m, size_t k, size_t ld, int alg, sm_stream_t s) {
+  return launch_prune<uint32_t>(A_in, A_out, m, k, ld, alg, (hipStream_t)s);
+}
+int sm_prune24_check_f16(const void* A, size_t m, size_t k, size_t ld, int* d_valid, sm_stream_t s) {
+  return launch_check<uint16_t>(A, m, k, ld, d_valid, (hipStream_t)s);
+}
+int sm_prune24_check_f32(const float* A, size_t m, size_t k, size_t ld, int* d_valid, sm_stream_t s) {
+  return launch_check<uint32_t>(A, m, k, ld, d_valid, (hipStream_t)s);
+}
+
+int sm_compress24_size(size_t m, size_t k, size_t elt_bytes, size_t batch, size_t* bytes) {
+  if (!bytes || (elt_bytes != 2 && elt_bytes != 4)) {
+    set_error("sm_compress24_size: invalid argument");
+    return SM_STATUS_INVALID_VALUE;
+  }
+  *bytes = blob_layout(m, k, elt_bytes, batch).total;
+  return SM_STATUS_SUCCESS;
+}
+int sm_compress24_f16(const void* A, size_t m, size_t k, size_t ld, size_t batch, size_t strideA, void* blob, sm_stream_t s) {
+  return launch_compress<uint16_t>(A, m, k, ld, batch, strideA, blob, (hipStream_t)s);
+}
+int sm_compress24_f32(const float* A, size_t m, size_t k, size_t ld, size_t batch, size_t strideA, void* blob, sm_stream_t s) {
+  return launch_compress<uint32_t>(A, m, k, ld, batch, strideA, blob, (hipStream_t)s);
+}
+int sm_decompress24_f16(const void* blob, size_t m, size_t k, size_t ld, size_t batch, size_t strideA, void* A, sm_stream_t s) {
+  return launch_decompress<uint16_t>(blob, m, k, ld, batch, strideA, A, (hipStream_t)s);
+}
+int sm_decompress24_f32(const void* blob, size_t m, size_t k, size_t ld, size_t batch, size_t strideA, float* A, sm_stream_t s) {
+  return launch_decompress<uint32_t>(blob, m, k, ld, batch, strideA, A, (hipStream_t)s);
+}
+
+}  // extern "C"

@@ -1,0 +1,269 @@
+// spmma_f16.hip -- the 2:4 sparse x dense matmul on gfx950's native sparse matrix instruction
+// v_smfmac_f32_16x16x64_f16 (fp32 accumulate, one rounding to fp16).  Replaces cusparseLtMatmul as
+// include/sparsify.me/spmma.hxx:112-113 calls it: C[m x n] = alpha * A * B + beta * C, row-major,
+// A the compressed blob of sm_compress24_f16 (values [M][kc/2] + metadata [M][kc/8]).
+//
+// Per 128 dense k of a row the kernel moves 128 B of kept values + 16 B of metadata instead of the
+// dense kernel's 256 B, and issues half the matrix instructions: the hardware multiplies each kept
+// value with the B row its 2-bit index selects, so nothing is expanded and no zero is multiplied.
+// Tile: BM x BN outputs, BK = 128 dense k (two SMFMAC k-steps) per stage, 256 threads = 4 waves.
+// Global -> registers -> swizzled LDS images (mma_tile.h) with the next stage's loads in flight
+// during the current stage's SMFMACs.  The sparse operand must be srcA, so a lane ends with four
+// consecutive ROWS of one column; the epilogue transposes through LDS and stores 16-byte row pieces.
+#include "mma_tile.h"
+
+namespace sm {
+
+struct SpmmaArgs {
+  const char* vals;   // [Mtot][kc/2] halves, row pitch kc bytes
+  const char* meta;   // [Mtot][kc/8] bytes
+  const half_t* B;
+  half_t* C;
+  size_t sB, sC;      // batch strides (elements); rows of batch b are [b*m, (b+1)*m)
+  int m;              // rows per batch
+  int Mrows;          // rows this launch treats as one matrix (m, or m*batch when stacked)
+  int N, K, kc;
+  int batch;          // grid batches (1 when stacked)
+  int tiles_m, tiles_n;
+  float alpha, beta;
+};
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void spmma_f16_kernel(const SpmmaArgs p) {
+  static_assert(WM * WN == 4, "4 waves");
+  constexpr int TM = BM / WM, TN = BN / WN, FM = TM / 16, FN = TN / 16;
+  constexpr int A_CH = BM * 8 / 256;        // 16-byte value chunks per thread per stage
+  constexpr int M_CH = (BM * 2 + 255) / 256;  // 8-byte metadata pieces per thread per stage
+  constexpr int B_CH = 128 * (BN / 8) / 256;  // 128 k-rows x BN/8 chunks
+  constexpr int CPITCH = BN * 2 + 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* As = smem;                     // BM x 128 B
+  char* Ms = smem + BM * 128;          // BM x 16 B
+  char* Bs = smem + BM * 144;          // BN/64 panels x 128 rows x 128 B
+
+  const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const unsigned wm = wave / WN, wn = wave % WN;
+
+  const unsigned tiles = (unsigned)p.tiles_m * (unsigned)p.tiles_n;
+  const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
+  const unsigned b = lid / tiles, trem = lid - b * tiles;
+  const unsigned tile_m = trem / (unsigned)p.tiles_n, tile_n = trem - tile_m * (unsigned)p.tiles_n;
+  const int m0 = (int)tile_m * BM, n0 = (int)tile_n * BN;
+
+  const size_t row_base = (size_t)b * p.m;  // first blob row of this grid batch
+  const char* vals = p.vals + row_base * (size_t)p.kc;
+  const char* meta = p.meta + row_base * (size_t)(p.kc / 8);
+  const half_t* B = p.B + (size_t)b * p.sB;
+  half_t* C = p.C + (size_t)b * p.sC;
+
+  f4 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+
+  u4 ra[A_CH], rb[B_CH];
+  u2 rm[M_CH];
+  const bool b_vec = (p.N % 8 == 0) && ((reinterpret_cast<uintptr_t>(B) & 15u) == 0);
+
+  auto gload = [&](int kt) {
+    const int vb0 = kt * 128;  // byte offset of this stage inside a value row (kc bytes per row)
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i) {
+      const unsigned q = tid + 256u * i, row = q >> 3, ch = q & 7u;
+      const int gr = m0 + (int)row, vb = vb0 + 16 * (int)ch;
+      u4 v = {0u, 0u, 0u, 0u};
+      if (gr < p.Mrows && vb < p.kc) v = *reinterpret_cast<const u4*>(vals + (size_t)gr * p.kc + vb);
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < M_CH; ++i) {
+      const unsigned q = tid + 256u * i, row = q >> 1, part = q & 1u;
+      const int gr = m0 + (int)row, mb = kt * 16 + 8 * (int)part;
+      u2 v = {0x44444444u, 0x44444444u};
+      if (row < (unsigned)BM && gr < p.Mrows && mb < p.kc / 8)
+        v = *reinterpret_cast<const u2*>(meta + (size_t)gr * (p.kc / 8) + mb);
+      rm[i] = v;
+    }
+    const int k0 = kt * 128;
+#pragma unroll
+    for (int i = 0; i < B_CH; ++i) {
+      const unsigned q = tid + 256u * i, kr = q / (BN / 8), cn = q % (BN / 8);
+      const int gk = k0 + (int)kr, gc = n0 + 8 * (int)cn;
+      u4 v = {0u, 0u, 0u, 0u};
+      if (gk < p.K && gc < p.N) {
+        const half_t* src = B + (size_t)gk * p.N + gc;
+        if (b_vec && gc + 8 <= p.N) {
+          v = *reinterpret_cast<const u4*>(src);
+        } else {
+          h8 e;
+#pragma unroll
+          for (int t = 0; t < 8; ++t) e[t] = (gc + t < p.N) ? src[t] : (half_t)0.0f;
+          v = __builtin_bit_cast(u4, e);
+        }
+      }
+      rb[i] = v;
+    }
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i) {
+      const unsigned q = tid + 256u * i, row = q >> 3, ch = q & 7u;
+      *reinterpret_cast<u4*>(As + a_off(row, ch)) = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < M_CH; ++i) {
+      const unsigned q = tid + 256u * i, row = q >> 1, part = q & 1u;
+      if (row < (unsigned)BM) *reinterpret_cast<u2*>(Ms + row * 16u + 8u * part) = rm[i];
+    }
+#pragma unroll
+    for (int i = 0; i < B_CH; ++i) {
+      const unsigned q = tid + 256u * i, kr = q / (BN / 8), cn = q % (BN / 8);
+      *reinterpret_cast<u4*>(Bs + b_off<128>(kr, 8u * cn)) = rb[i];
+    }
+  };
+
+  const int nkt = (p.kc + 127) / 128;
+  gload(0);
+  for (int kt = 0; kt < nkt; ++kt) {
+    lstore();
+    __syncthreads();
+    if (kt + 1 < nkt) gload(kt + 1);
+    const int nstep = (p.kc - kt * 128) >= 128 ? 2 : 1;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      if (s < nstep) {
+        h8 af[FM];
+        int idx[FM];
+        h16 bf[FN];
+        const unsigned g = lane >> 4;
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+          const unsigned row = wm * TM + i * 16 + (lane & 15u);
+          af[i] = *reinterpret_cast<const h8*>(As + a_off(row, 4u * s + g));
+          idx[i] = (int)*reinterpret_cast<const unsigned short*>(Ms + row * 16u + 8u * s + 2u * g);
+        }
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+          const unsigned col0 = wn * TN + j * 16, kr0 = 64u * s + 8u * g;
+          const s4 v0 = b_read_tr<128>(Bs, kr0, col0, lane);
+          const s4 v1 = b_read_tr<128>(Bs, kr0 + 4u, col0, lane);
+          const s4 v2 = b_read_tr<128>(Bs, kr0 + 32u, col0, lane);
+          const s4 v3 = b_read_tr<128>(Bs, kr0 + 36u, col0, lane);
+          typedef short s16 __attribute__((ext_vector_type(16)));
+          const s16 all = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3],
+                           v2[0], v2[1], v2[2], v2[3], v3[0], v3[1], v3[2], v3[3]};
+          bf[j] = __builtin_bit_cast(h16, all);
+        }
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int j = 0; j < FN; ++j)
+            acc[i][j] = __builtin_amdgcn_smfmac_f32_16x16x64_f16(af[i], bf[j], acc[i][j], idx[i], 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane holds C[rows 4*(lane>>4) + r][col lane&15] of each fragment
+  const bool c_vec = (p.N % 8 == 0) && ((reinterpret_cast<uintptr_t>(C) & 15u) == 0);
+  if (p.beta == 0.0f && c_vec) {
+    char* Cs = smem;
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const unsigned row = wm * TM + i * 16 + 4u * (lane >> 4), col = wn * TN + j * 16 + (lane & 15u);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          *reinterpret_cast<half_t*>(Cs + (row + r) * CPITCH + col * 2) = (half_t)(p.alpha * acc[i][j][r]);
+      }
+    __syncthreads();
+    constexpr int C_CH = BM * (BN / 8) / 256;
+#pragma unroll
+    for (int i = 0; i < C_CH; ++i) {
+      const unsigned q = tid + 256u * i, row = q / (BN / 8), cn = q % (BN / 8);
+      const int gr = m0 + (int)row, gc = n0 + 8 * (int)cn;
+      if (gr >= p.Mrows || gc >= p.N) continue;
+      const u4 v = *reinterpret_cast<const u4*>(Cs + row * CPITCH + cn * 16);
+      half_t* dst = C + (size_t)gr * p.N + gc;
+      if (gc + 8 <= p.N) {
+        *reinterpret_cast<u4*>(dst) = v;
+      } else {
+        const h8 e = __builtin_bit_cast(h8, v);
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+          if (gc + t < p.N) dst[t] = e[t];
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const int gc = n0 + (int)(wn * TN + j * 16 + (lane & 15u));
+        if (gc >= p.N) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int gr = m0 + (int)(wm * TM + i * 16 + 4u * (lane >> 4)) + r;
+          if (gr >= p.Mrows) continue;
+          half_t* dst = C + (size_t)gr * p.N + gc;
+          float v = p.alpha * acc[i][j][r];
+          if (p.beta != 0.0f) v += p.beta * (float)*dst;
+          *dst = (half_t)v;
+        }
+      }
+  }
+}
+
+template <int BM, int BN, int WM, int WN>
+static int launch_cfg(const SpmmaArgs& a0, hipStream_t st) {
+  SpmmaArgs a = a0;
+  a.tiles_m = (a.Mrows + BM - 1) / BM;
+  a.tiles_n = (a.N + BN - 1) / BN;
+  const size_t nwg = (size_t)a.tiles_m * a.tiles_n * a.batch;
+  if (nwg == 0) return SM_STATUS_SUCCESS;
+  if (nwg > 0x7fffffffu) {
+    set_error("spmma_f16: grid too large");
+    return SM_STATUS_NOT_SUPPORTED;
+  }
+  constexpr size_t lds_main = (size_t)BM * 144 + (size_t)(BN / 64) * 128 * 128;
+  constexpr size_t lds_epi = (size_t)BM * (BN * 2 + 16);
+  constexpr size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
+  spmma_f16_kernel<BM, BN, WM, WN><<<dim3((unsigned)nwg), dim3(256), lds, st>>>(a);
+  return check_launch("spmma_f16_kernel");
+}
+
+}  // namespace sm
+
+using namespace sm;
+
+extern "C" int sm_spmma_f16(const void* blob, const void* B, void* C, size_t m, size_t n, size_t k, size_t batch,
+                            size_t strideB, size_t strideC, float alpha, float beta, sm_stream_t stream) {
+  if (!blob || !B || !C || !aligned16(blob)) {
+    set_error("sm_spmma_f16: invalid argument (blob must be 16-byte aligned)");
+    return SM_STATUS_INVALID_VALUE;
+  }
+  if (m == 0 || n == 0 || batch == 0) return SM_STATUS_SUCCESS;
+  if (m * batch > 0x7fffffffull || n > 0x7fffffffull || k > 0x7fffffffull) {
+    set_error("sm_spmma_f16: dimension exceeds 2^31-1");
+    return SM_STATUS_NOT_SUPPORTED;
+  }
+  const BlobLayout L = blob_layout(m, k, 2, batch);
+  SpmmaArgs a = {};
+  a.vals = (const char*)blob;
+  a.meta = (const char*)blob + L.meta_off;
+  a.B = (const half_t*)B;
+  a.C = (half_t*)C;
+  a.sB = strideB; a.sC = strideC;
+  a.m = (int)m; a.Mrows = (int)m; a.N = (int)n; a.K = (int)k; a.kc = (int)L.kc;
+  a.batch = (int)batch; a.alpha = alpha; a.beta = beta;
+  // shared B + contiguous C: the batch is one tall matrix of batch*m blob rows
+  if (batch > 1 && strideB == 0 && strideC == m * n) {
+    a.Mrows = (int)(m * batch);
+    a.batch = 1;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (n <= 64) return launch_cfg<128, 64, 4, 1>(a, st);
+  return launch_cfg<128, 128, 2, 2>(a, st);
+}

@@ -1,0 +1,362 @@
+"""GPU parity tests (-m gpu): every HIP entry point, called through the C ABI, against the CPU oracle
+on the same seeded inputs.  Bit-exact for masks / pruned matrices / compressed blobs (integer and
+byte work); GEMM outputs within north_star's tolerance: 1e-2 relative for fp16, 1e-3 for fp32,
+relative to sum_k |a*b| (the natural scale of the accumulation)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+FP16_TOL = 1e-2
+FP32_TOL = 1e-3
+
+
+def bits(a):
+    return a.view({2: np.uint16, 4: np.uint32, 8: np.uint64}[a.dtype.itemsize])
+
+
+def to_dev(a):
+    import torch
+    return torch.from_numpy(a).cuda()
+
+
+def torch_dtype(np_dtype):
+    import torch
+    return {np.float16: torch.float16, np.float32: torch.float32, np.float64: torch.float64}[np_dtype]
+
+
+def host(t):
+    import torch
+    torch.cuda.synchronize()
+    return t.cpu().numpy()
+
+
+def rand(rng, n, dtype, kind="uniform"):
+    if kind == "ties":
+        return rng.integers(-3, 4, n).astype(dtype)
+    if kind == "u01":
+        return rng.uniform(0, 1, n).astype(dtype)
+    return rng.uniform(-1, 1, n).astype(dtype)
+
+
+# ---------------------------------------------------------------------------------------------
+# (a1) positional sparsify
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [np.float16, np.float32, np.float64])
+@pytest.mark.parametrize("shape", [(4, 4), (3, 5), (2, 2), (1, 7), (0, 4), (196, 512), (784, 147), (513, 1031), (64, 6)])
+@pytest.mark.parametrize("sf", [0.0, 0.25, 0.5, 0.75, 1.0])
+def test_sparsify_positional(gpu, orc, dtype, shape, sf):
+    import torch
+    m, n = shape
+    rng = np.random.default_rng(m * 1000 + n)
+    w = rand(rng, m * n, dtype) + dtype(2)  # no zeros in the input, so zeroed positions are visible
+    mask = np.full(m * n, 99, dtype=np.uint64)
+    ew, em = w.copy(), mask.copy()
+    orc.sparsify_positional(ew, em, m, n, sf)
+    dw = to_dev(w) if m * n else torch.empty(0, dtype=torch_dtype(dtype), device="cuda")
+    dm = torch.full((m * n,), 99, dtype=torch.int64, device="cuda")
+    if m * n:
+        gpu.sparsify(dw, dm, m, n, sf)
+        assert np.array_equal(bits(host(dw)), bits(ew))
+        assert np.array_equal(host(dm).view(np.uint64), em)
+
+
+def test_sparsify_positional_generic_block_and_unaligned(gpu, orc):
+    import torch
+    m, n = 8, 12
+    w = np.arange(1, m * n + 1, dtype=np.float32)
+    for (bm, bn, sf) in [(1, 4, 0.25), (2, 2, 0.5)]:
+        ew, em = w.copy(), np.zeros(m * n, dtype=np.uint64)
+        orc.sparsify_positional(ew, em, m, n, sf, bm, bn)
+        # an element-offset view: base pointer only 4-byte aligned -> generic path
+        buf = torch.zeros(m * n + 1, dtype=torch.float32, device="cuda")
+        dw = buf[1:]
+        dw.copy_(torch.from_numpy(w))
+        dm = torch.zeros(m * n, dtype=torch.int64, device="cuda")
+        gpu.sparsify(dw, dm, m, n, sf, bm, bn)
+        assert np.array_equal(host(dw), ew) and np.array_equal(host(dm).view(np.uint64), em)
+    with pytest.raises(gpu.SparsifymeError):
+        gpu.sparsify(dw, dm, m, n, 1.0, 1, 4)  # would index outside the buffer
+
+
+# ---------------------------------------------------------------------------------------------
+# (a2) prune STRIP / TILE + check
+# ---------------------------------------------------------------------------------------------
+PRUNE_SHAPES = [(1, 4, 4), (4, 4, 4), (3, 5, 5), (7, 147, 147), (10, 147, 152), (16, 64, 64), (33, 72, 80),
+                (196, 512, 512), (784, 1024, 1024), (130, 260, 264), (5, 3, 3), (257, 8, 8)]
+
+
+@pytest.mark.parametrize("dtype", [np.float16, np.float32])
+@pytest.mark.parametrize("alg", [0, 1], ids=["tile", "strip"])
+@pytest.mark.parametrize("shape", PRUNE_SHAPES)
+@pytest.mark.parametrize("kind", ["uniform", "ties"])
+def test_prune24(gpu, orc, dtype, alg, shape, kind):
+    import torch
+    m, k, ld = shape
+    rng = np.random.default_rng(m * 7919 + k * 13 + alg)
+    A = rand(rng, m * ld, dtype, kind)
+    want = orc.prune24(bits(A), m, k, ld, alg)
+    dA = to_dev(A)
+    dOut = torch.zeros_like(dA)
+    dOut.copy_(dA)  # padding columns must stay as they are
+    gpu.prune24(dA, dOut, m, k, ld, alg)
+    assert np.array_equal(bits(host(dOut)), want), "out-of-place prune differs from the oracle"
+    gpu.prune24(dA, dA, m, k, ld, alg)  # in place, as spmma.hxx:86 does
+    assert np.array_equal(bits(host(dA)), want), "in-place prune differs from the oracle"
+    valid = torch.full((1,), -7, dtype=torch.int32, device="cuda")
+    gpu.prune24_check(dA, m, k, ld, valid)
+    assert int(host(valid)[0]) == 0 == orc.prune24_check(want, m, k, ld)
+
+
+@pytest.mark.parametrize("dtype", [np.float16, np.float32])
+def test_prune_check_flags_dense_and_single_bad_strip(gpu, orc, dtype):
+    import torch
+    m, k = 300, 512
+    rng = np.random.default_rng(1)
+    A = rand(rng, m * k, dtype, "u01") + dtype(0.5)
+    valid = torch.zeros(1, dtype=torch.int32, device="cuda")
+    gpu.prune24_check(to_dev(A), m, k, k, valid)
+    assert int(host(valid)[0]) == 1 == orc.prune24_check(bits(A), m, k, k)
+    P = orc.prune24(bits(A), m, k, k, 1).view(dtype).copy()
+    P[(m - 1) * k + k - 4:(m - 1) * k + k] = 1  # one bad strip at the very end
+    gpu.prune24_check(to_dev(P), m, k, k, valid)
+    assert int(host(valid)[0]) == 1 == orc.prune24_check(bits(P), m, k, k)
+
+
+def test_prune_special_values(gpu, orc):
+    a = np.array([1.0, np.nan, np.inf, 2.0, -0.0, 0.0, -0.0, 0.0, np.nan, np.nan, np.nan, 1.0,
+                  6e-8, -6e-8, 6e-8, 0.0], dtype=np.float16)
+    for alg in (0, 1):
+        A = np.tile(a, 4)  # 4 x 16
+        want = orc.prune24(bits(A), 4, 16, 16, alg)
+        dA = to_dev(A)
+        gpu.prune24(dA, dA, 4, 16, 16, alg)
+        assert np.array_equal(bits(host(dA)), want)
+
+
+# ---------------------------------------------------------------------------------------------
+# (a3) compress / decompress
+# ---------------------------------------------------------------------------------------------
+COMPRESS_SHAPES = [(1, 4, 4, 1), (5, 147, 147, 3), (5, 147, 152, 2), (16, 64, 64, 2), (196, 512, 512, 2),
+                   (33, 72, 80, 1), (130, 1152, 1152, 1), (7, 8, 8, 5), (3, 200, 200, 1)]
+
+
+@pytest.mark.parametrize("dtype", [np.float16, np.float32])
+@pytest.mark.parametrize("shape", COMPRESS_SHAPES)
+@pytest.mark.parametrize("pruned_first", [False, True])
+def test_compress24_bit_exact(gpu, orc, dtype, shape, pruned_first):
+    import torch
+    m, k, ld, batch = shape
+    rng = np.random.default_rng(m + 31 * k + batch)
+    stride = m * ld + (8 if ld % 8 == 0 else 0)  # a padded batch stride
+    A = rand(rng, batch * stride, dtype, "ties" if m % 2 else "uniform")
+    if pruned_first:
+        for b in range(batch):
+            seg = A[b * stride:b * stride + m * ld]
+            seg[:] = orc.prune24(bits(seg), m, k, ld, 0).view(dtype)  # TILE-pruned input, as spmma feeds it
+    want = orc.compress24(bits(A), m, k, ld, batch, stride)
+    blob = torch.full((gpu.compress24_size(m, k, A.dtype.itemsize, batch),), 0xAB, dtype=torch.uint8, device="cuda")
+    assert blob.numel() == want.size
+    gpu.compress24(to_dev(A), m, k, ld, batch, stride, blob)
+    assert np.array_equal(host(blob), want), "compressed blob differs from the oracle"
+    # decompress on the GPU == oracle decompress == STRIP-pruned input
+    D = torch.zeros(batch * stride, dtype=torch_dtype(dtype), device="cuda")
+    gpu.decompress24(blob, m, k, ld, batch, stride, D)
+    wantD = orc.decompress24(want, m, k, ld, bits(A).dtype, batch, stride)
+    assert np.array_equal(bits(host(D)), wantD)
+
+
+# ---------------------------------------------------------------------------------------------
+# (a4) spmma and (a5) dense gemm
+# ---------------------------------------------------------------------------------------------
+def check_close(got, ref, scale, tol, what):
+    err = np.abs(got.astype(np.float64) - ref.astype(np.float64))
+    bad = err > tol * np.maximum(scale, 1e-30)
+    assert not bad.any(), f"{what}: {int(bad.sum())} of {bad.size} outside tol {tol}; max err {err.max():.3e}"
+
+
+def test_mfma_lane_maps_with_identity_and_asymmetric_b(gpu, orc):
+    """A = I (pruned 2:4-compatible: one non-zero per strip) with an ASYMMETRIC integer B: a swapped
+    row/col, a wrong k-slot or a wrong index nibble anywhere shows up exactly."""
+    import torch
+    for (m, n, k) in [(128, 64, 128), (128, 128, 256), (200, 72, 192), (64, 192, 64)]:
+        A = np.zeros((m, k), dtype=np.float16)
+        for i in range(m):
+            A[i, (i * 5 + 3) % k] = 1.0          # one element per row, varying strip position
+            A[i, (i * 11 + 64) % k] += 2.0
+        B = ((np.arange(k)[:, None] * 3 + np.arange(n)[None, :] * 7) % 61 - 30).astype(np.float16)
+        want = A.astype(np.float64) @ B.astype(np.float64)
+        assert orc.prune24_check(bits(A.reshape(-1)), m, k, k) == 0
+        blob = torch.empty(gpu.compress24_size(m, k, 2), dtype=torch.uint8, device="cuda")
+        dA, dB = to_dev(A.reshape(-1)), to_dev(B.reshape(-1))
+        gpu.compress24(dA, m, k, k, 1, m * k, blob)
+        C = torch.zeros(m * n, dtype=torch.float16, device="cuda")
+        gpu.spmma(blob, dB, C, m, n, k)
+        assert np.array_equal(host(C).astype(np.float64).reshape(m, n), want), f"spmma lane map {m}x{n}x{k}"
+        C2 = torch.zeros(m * n, dtype=torch.float16, device="cuda")
+        gpu.gemm_rowmajor(dA, dB, C2, m, n, k)
+        assert np.array_equal(host(C2).astype(np.float64).reshape(m, n), want), f"dense lane map {m}x{n}x{k}"
+
+
+SPMMA_SHAPES = [(128, 64, 128, 1), (196, 512, 256, 2), (130, 72, 200, 1), (784, 256, 1024, 1), (96, 64, 64, 3),
+                (12544, 64, 147, 1), (3136, 128, 576, 1), (17, 8, 4, 1), (300, 136, 320, 2)]
+
+
+@pytest.mark.parametrize("shape", SPMMA_SHAPES)
+@pytest.mark.parametrize("shared_b", [True, False])
+def test_spmma_f16_vs_oracle(gpu, orc, shape, shared_b):
+    import torch
+    m, n, k, batch = shape
+    rng = np.random.default_rng(m + n + k)
+    A = rand(rng, batch * m * k, np.float16)
+    nb = 1 if shared_b else batch
+    B = rand(rng, nb * k * n, np.float16)
+    strideB = 0 if shared_b else k * n
+    dA = to_dev(A)
+    blob = torch.empty(gpu.compress24_size(m, k, 2, batch), dtype=torch.uint8, device="cuda")
+    gpu.compress24(dA, m, k, k, batch, m * k, blob)   # fused prune + compress
+    C = torch.zeros(batch * m * n, dtype=torch.float16, device="cuda")
+    gpu.spmma(blob, to_dev(B), C, m, n, k, batch, strideB)
+    ob = orc.compress24(bits(A), m, k, k, batch)
+    assert np.array_equal(host(blob), ob)
+    Cref = np.zeros(batch * m * n, dtype=np.uint16)
+    orc.spmma(ob, bits(B), Cref, m, n, k, batch, strideB)
+    # scale = sum_k |a*b| of the pruned A
+    P = np.abs(orc.decompress24(ob, m, k, k, np.uint16, batch).view(np.float16).astype(np.float64)).reshape(batch, m, k)
+    Bm = np.abs(B.astype(np.float64)).reshape(nb, k, n)
+    scale = np.stack([P[b] @ Bm[b if not shared_b else 0] for b in range(batch)]).reshape(-1)
+    check_close(host(C), Cref.view(np.float16), scale, FP16_TOL, f"spmma {shape}")
+
+
+def test_spmma_alpha_beta(gpu, orc):
+    import torch
+    m, n, k = 140, 80, 192
+    rng = np.random.default_rng(5)
+    A, B = rand(rng, m * k, np.float16), rand(rng, k * n, np.float16)
+    C0 = rand(rng, m * n, np.float16)
+    blob = torch.empty(gpu.compress24_size(m, k, 2), dtype=torch.uint8, device="cuda")
+    gpu.compress24(to_dev(A), m, k, k, 1, m * k, blob)
+    C = to_dev(C0.copy())
+    gpu.spmma(blob, to_dev(B), C, m, n, k, alpha=0.5, beta=-2.0)
+    ob = orc.compress24(bits(A), m, k, k)
+    Cref = bits(C0.copy())
+    orc.spmma(ob, bits(B), Cref, m, n, k, alpha=0.5, beta=-2.0)
+    scale = np.abs(A.astype(np.float64)).reshape(m, k) @ np.abs(B.astype(np.float64)).reshape(k, n) + 2 * np.abs(C0.astype(np.float64)).reshape(m, n)
+    check_close(host(C), Cref.view(np.float16), scale.reshape(-1), FP16_TOL, "spmma alpha/beta")
+
+
+GEMM_SHAPES = [(128, 64, 64, 1), (196, 512, 256, 2), (130, 72, 200, 1), (784, 256, 1024, 1), (64, 12544, 147, 1),
+               (17, 9, 5, 2), (300, 136, 320, 2), (256, 64, 576, 3)]
+
+
+@pytest.mark.parametrize("shape", GEMM_SHAPES)
+def test_gemm_rowmajor_f16_vs_oracle(gpu, orc, shape):
+    import torch
+    m, n, k, batch = shape
+    rng = np.random.default_rng(m * 3 + n * 5 + k)
+    A, B = rand(rng, batch * m * k, np.float16), rand(rng, k * n, np.float16)
+    C = torch.zeros(batch * m * n, dtype=torch.float16, device="cuda")
+    gpu.gemm_rowmajor(to_dev(A), to_dev(B), C, m, n, k, batch=batch)
+    Cref = np.zeros(batch * m * n, dtype=np.uint16)
+    orc.gemm_rowmajor(bits(A), bits(B), Cref, m, n, k, batch=batch)
+    scale = (np.abs(A.astype(np.float64)).reshape(batch * m, k) @ np.abs(B.astype(np.float64)).reshape(k, n)).reshape(-1)
+    check_close(host(C), Cref.view(np.float16), scale, FP16_TOL, f"gemm_rowmajor {shape}")
+
+
+@pytest.mark.parametrize("shape", [(128, 64, 64, 2), (196, 512, 256, 2), (130, 72, 200, 3), (3136, 128, 576, 2), (12544, 64, 147, 1)])
+def test_gemm_batched_column_major_f16_vs_oracle(gpu, orc, shape):
+    """The reference's call: column-major, lda=m ldb=k ldc=m, device arrays of pointers, one shared B
+    repeated `batch` times (examples/gemm.cu:40,60,86)."""
+    import torch
+    m, n, k, batch = shape
+    rng = np.random.default_rng(m + 2 * n + 3 * k)
+    As = [rand(rng, m * k, np.float16) for _ in range(batch)]
+    Bsh = rand(rng, k * n, np.float16)
+    dAs = [to_dev(a) for a in As]
+    dB = to_dev(Bsh)
+    dCs = [torch.zeros(m * n, dtype=torch.float16, device="cuda") for _ in range(batch)]
+    ptr = lambda ts: torch.tensor([t.data_ptr() for t in ts], dtype=torch.int64, device="cuda")
+    gpu.gemm_batched(ptr(dAs), ptr([dB] * batch), ptr(dCs), m, n, k, batch, "f16")
+    Cs = [np.zeros(m * n, dtype=np.uint16) for _ in range(batch)]
+    orc.gemm_batched([bits(a) for a in As], [bits(Bsh)] * batch, Cs, m, n, k)
+    Bm = np.abs(Bsh.astype(np.float64)).reshape(n, k).T            # column-major k x n
+    for b in range(batch):
+        Am = np.abs(As[b].astype(np.float64)).reshape(k, m).T      # column-major m x k
+        scale = (Am @ Bm).T.reshape(-1)                            # column-major m x n
+        check_close(host(dCs[b]), Cs[b].view(np.float16), scale, FP16_TOL, f"gemm_batched {shape} batch {b}")
+
+
+def test_spmma_equals_dense_gemm_of_pruned_on_gpu(gpu, orc):
+    """spmma(compress(A), B) and gemm(prune(A), B) accumulate the same products in fp32: the results
+    agree to a couple of fp16 ulps (they may differ in summation order only)."""
+    import torch
+    m, n, k, batch = 784, 256, 1152, 2
+    rng = np.random.default_rng(9)
+    A, B = rand(rng, batch * m * k, np.float16, "u01"), rand(rng, k * n, np.float16, "u01")
+    dA, dB = to_dev(A), to_dev(B)
+    blob = torch.empty(gpu.compress24_size(m, k, 2, batch), dtype=torch.uint8, device="cuda")
+    gpu.compress24(dA, m, k, k, batch, m * k, blob)
+    C1 = torch.zeros(batch * m * n, dtype=torch.float16, device="cuda")
+    gpu.spmma(blob, dB, C1, m, n, k, batch)
+    gpu.prune24(dA, dA, batch * m, k, k, gpu.PRUNE_STRIP)
+    C2 = torch.zeros_like(C1)
+    gpu.gemm_rowmajor(dA, dB, C2, m, n, k, batch=batch)
+    a, b = host(C1).astype(np.float64), host(C2).astype(np.float64)
+    assert np.abs(a - b).max() <= 4 * 2.0 ** -11 * np.abs(b).max()
+
+
+# ---------------------------------------------------------------------------------------------
+# full-size, size-independent properties on BASELINE.json's ResNet-50 shapes (b = 32)
+# ---------------------------------------------------------------------------------------------
+RESNET50_UNIQUE = [(12544, 64, 147), (12544, 64, 64), (12544, 64, 576), (12544, 256, 64), (12544, 64, 256),
+                   (12544, 128, 256), (3136, 128, 1152), (3136, 512, 128), (3136, 128, 512), (3136, 256, 512),
+                   (784, 256, 2304), (784, 1024, 256), (784, 256, 1024), (784, 512, 1024), (196, 512, 4608),
+                   (196, 2048, 512), (196, 512, 2048)]
+
+
+@pytest.mark.parametrize("shape", RESNET50_UNIQUE, ids=lambda s: "x".join(map(str, s)))
+def test_full_size_properties_resnet50(gpu, orc, shape):
+    """At b = 32 the oracle is too slow to run in full, so check properties that do not depend on size:
+    prune is idempotent and passes the check, decompress(compress(A)) == prune(A) bit for bit,
+    spmma is linear in B (spmma(A, 2B) == 2 * spmma(A, B) exactly in fp16 for power-of-two scaling),
+    spmma == dense gemm of the pruned matrix, and one sampled batch matches the oracle."""
+    import torch
+    m, n, k = shape
+    batch = 32
+    dA = torch.empty(batch * m * k, dtype=torch.float16, device="cuda")
+    gpu.fill_uniform(dA, 0x5EED + m + k, 0.0, 1.0)
+    dB = torch.empty(k * n, dtype=torch.float16, device="cuda")
+    gpu.fill_uniform(dB, 0xB0B + n, 0.0, 1.0)
+    blob = torch.empty(gpu.compress24_size(m, k, 2, batch), dtype=torch.uint8, device="cuda")
+    gpu.compress24(dA, m, k, k, batch, m * k, blob)
+    P = dA.clone()
+    gpu.prune24(P, P, batch * m, k, k, gpu.PRUNE_STRIP)
+    valid = torch.ones(1, dtype=torch.int32, device="cuda")
+    gpu.prune24_check(P, batch * m, k, k, valid)
+    assert int(valid.item()) == 0
+    P2 = P.clone()
+    gpu.prune24(P2, P2, batch * m, k, k, gpu.PRUNE_STRIP)
+    assert torch.equal(P.view(torch.int16), P2.view(torch.int16)), "prune not idempotent"
+    D = torch.full_like(P, 7.0)
+    gpu.decompress24(blob, m, k, k, batch, m * k, D)
+    assert torch.equal(D.view(torch.int16), P.view(torch.int16)), "decompress(compress(A)) != prune(A)"
+    exactly_half = (P != 0).sum().item() <= batch * m * ((k + 3) // 4) * 2
+    assert exactly_half
+    C = torch.empty(batch * m * n, dtype=torch.float16, device="cuda")
+    gpu.spmma(blob, dB, C, m, n, k, batch)
+    C2 = torch.empty_like(C)
+    gpu.spmma(blob, dB * 2, C2, m, n, k, batch)
+    assert torch.equal((C * 2).view(torch.int16), C2.view(torch.int16)), "spmma not linear in B"
+    Cd = torch.empty_like(C)
+    gpu.gemm_rowmajor(P, dB, Cd, m, n, k, batch=batch)
+    assert (C.float() - Cd.float()).abs().max().item() <= 4 * 2.0 ** -11 * Cd.float().abs().max().item()
+    # one sampled batch against the oracle (rows of the last batch)
+    b = batch - 1
+    rows = min(m, 64)
+    Ah = host(dA[b * m * k: b * m * k + rows * k])
+    ob = orc.compress24(bits(Ah), rows, k, k)
+    Cref = np.zeros(rows * n, dtype=np.uint16)
+    orc.spmma(ob, bits(host(dB)), Cref, rows, n, k)
+    got = host(C[b * m * n: b * m * n + rows * n])
+    scale = (np.abs(Ah.astype(np.float64)).reshape(rows, k) @ np.abs(host(dB).astype(np.float64)).reshape(k, n)).reshape(-1)
+    check_close(got, Cref.view(np.float16), scale, FP16_TOL, f"sampled batch {shape}")
