@@ -1,0 +1,118 @@
+#!/usr/bin/env python3
+"""Layer sweep over a shape table (the build's counterpart of the reference's examples/profiling.py:4-44,
+written from scratch: it drives the C ABI in-process instead of shelling out to one binary per number).
+
+For every row (or every unique shape with --unique) of datasets/<table>.csv it times, with HIP events on
+resident, randomised inputs:  gemm (reference layout: column-major pointer-array batched, one shared B),
+gemm_rm (row-major, the 2:4 kernel's layout), prune (sm_sparsify_positional on m x k, as
+profiling.py:11-12 does), prune24 STRIP / TILE, check, compress, spmma.  Output: a CSV with the reference's
+columns m,n,k,b,gemm,prune (ms) extended with the 2:4 stages, and a printed table with effective GF/s,
+algorithmic GB/s and the fraction of the per-shape roofline max(bytes / 8 TB/s, flops / peak).
+"""
+import argparse
+import csv
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+HBM = 8.0e12
+MFMA_F16 = 2.5e15
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--table", default="resnet50")
+    ap.add_argument("--unique", action="store_true")
+    ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--out", default=None)
+    ap.add_argument("--only", default=None, help="comma list of stages to run")
+    args = ap.parse_args()
+    import torch
+    import __graft_entry__ as ge
+    sm = ge.load_package()
+    sm.device_check()
+    dev = torch.device("cuda", 0)
+    path = os.path.join(ROOT, "datasets", args.table + ".csv")
+    rows = [tuple(int(x) for x in r[:4]) for r in list(csv.reader(open(path)))[1:] if r]
+    if args.unique:
+        seen, uniq = set(), []
+        for r in rows:
+            if r not in seen:
+                seen.add(r)
+                uniq.append((r, rows.count(r)))
+    else:
+        uniq = [(r, 1) for r in rows]
+    only = set(args.only.split(",")) if args.only else None
+
+    def timeit(fn):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(args.reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / args.reps  # ms
+
+    out_rows = []
+    tot = {}
+    hdr = ("m", "n", "k", "b", "cnt", "stage", "ms", "effTF/s", "GB/s", "roof_us", "frac")
+    print("%6s %5s %5s %3s %3s %-10s %9s %9s %8s %8s %6s" % hdr)
+    for (m, n, k, b), cnt in uniq:
+        s = 2
+        A = torch.empty(b * m * k, dtype=torch.float16, device=dev)
+        Bm = torch.empty(k * n, dtype=torch.float16, device=dev)
+        sm.fill_uniform(A, 1234 + m + k, 0.0, 1.0)
+        sm.fill_uniform(Bm, 99 + n, 0.0, 1.0)
+        A2 = A.clone()
+        C = torch.empty(b * m * n, dtype=torch.float16, device=dev)
+        blob = torch.empty(sm.compress24_size(m, k, 2, b), dtype=torch.uint8, device=dev)
+        mask = torch.empty(m * k, dtype=torch.int64, device=dev)
+        valid = torch.zeros(1, dtype=torch.int32, device=dev)
+        Ap = torch.tensor([A.data_ptr() + 2 * i * m * k for i in range(b)], dtype=torch.int64, device=dev)
+        Bp = torch.tensor([Bm.data_ptr()] * b, dtype=torch.int64, device=dev)
+        Cp = torch.tensor([C.data_ptr() + 2 * i * m * n for i in range(b)], dtype=torch.int64, device=dev)
+        sm.compress24(A, m, k, k, b, m * k, blob)
+        flops = 2.0 * m * n * k * b
+        dense_bytes = b * s * (m * k + m * n) + s * k * n
+        sp_bytes = b * (m * k * s / 2 + m * k / 8 + m * n * s) + s * k * n
+        stages = [
+            ("gemm", lambda: sm.gemm_batched(Ap, Bp, Cp, m, n, k, b, "f16"), flops, dense_bytes, MFMA_F16),
+            ("gemm_rm", lambda: sm.gemm_rowmajor(A, Bm, C, m, n, k, batch=b), flops, dense_bytes, MFMA_F16),
+            ("spmma", lambda: sm.spmma(blob, Bm, C, m, n, k, b, 0), flops, sp_bytes, 2 * MFMA_F16),
+            ("compress", lambda: sm.compress24(A, m, k, k, b, m * k, blob), 0, b * m * k * (s + s / 2 + 1 / 8), 0),
+            ("prune_s", lambda: sm.prune24(A2, A2, b * m, k, k, sm.PRUNE_STRIP), 0, 2 * b * m * k * s, 0),
+            ("prune_t", lambda: sm.prune24(A2, A2, b * m, k, k, sm.PRUNE_TILE), 0, 2 * b * m * k * s, 0),
+            ("check", lambda: sm.prune24_check(A2, b * m, k, k, valid), 0, b * m * k * s, 0),
+            ("prune", lambda: sm.sparsify(A2[: m * k], mask, m, k, 0.5), 0, m * k * (s + s + 8), 0),
+        ]
+        rec = {"m": m, "n": n, "k": k, "b": b}
+        for name, fn, fl, by, peak in stages:
+            if only and name not in only:
+                continue
+            ms = timeit(fn)
+            roof = max(by / HBM, fl / peak if peak else 0.0)
+            print("%6d %5d %5d %3d %3d %-10s %9.4f %9.1f %8.0f %8.1f %6.3f" %
+                  (m, n, k, b, cnt, name, ms, fl / ms / 1e9, by / ms / 1e6, roof * 1e6, roof * 1e3 / ms))
+            rec[name] = ms
+            t = tot.setdefault(name, [0.0, 0.0, 0.0, 0.0])
+            t[0] += ms * cnt; t[1] += fl * cnt; t[2] += by * cnt; t[3] += roof * cnt
+        out_rows.append(rec)
+        del A, A2, C, blob
+    print("---- table totals (count-weighted)")
+    for name, (ms, fl, by, roof) in tot.items():
+        print("%-10s %9.3f ms  %9.1f effTF/s  %8.0f GB/s  roofline %8.1f us  frac %.3f" %
+              (name, ms, fl / ms / 1e9, by / ms / 1e6, roof * 1e6, roof * 1e3 / ms))
+    if args.out:
+        keys = ["m", "n", "k", "b"] + [k for k in out_rows[0] if k not in ("m", "n", "k", "b")]
+        with open(args.out, "w", newline="") as f:
+            w = csv.DictWriter(f, fieldnames=keys)
+            w.writeheader()
+            w.writerows(out_rows)
+
+
+if __name__ == "__main__":
+    main()
