@@ -216,6 +216,211 @@ __global__ __launch_bounds__(256) void spmma_f16_kernel(const SpmmaArgs p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Fast path (K % 64 == 0, N % 8 == 0, 16-byte aligned B): LDS-DMA double-buffered pipeline.
+// Stage = 64 dense k: A values [BM][64 B] + metadata [BM][8 B] + B [64][BN], all brought in by
+// global_load_lds (no VGPR staging, no ds_write); two LDS buffers, the DMA of stage t+1 is in
+// flight while stage t's SMFMACs run; one barrier per stage.  LDS images are lane-linear for the
+// DMA, so the bank swizzles are applied to the per-lane SOURCE address and again on the read.
+// Rows / columns past the matrix edge are clamped to the last valid one (their products land in
+// outputs that are never stored), so no lane is ever predicated off.
+// ---------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(1))) const void gptr_t;
+typedef __attribute__((address_space(3))) void lptr_t;
+
+// 64-byte-row A image: 16-byte chunk c of row r lives at chunk c ^ ((-(r >> 2)) & 3).
+__device__ __forceinline__ unsigned a64_swz(unsigned row) { return (0u - (row >> 2)) & 3u; }
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void spmma_f16_dma_kernel(const SpmmaArgs p) {
+  static_assert(WM * WN == 4, "4 waves");
+  constexpr int TM = BM / WM, TN = BN / WN, FM = TM / 16, FN = TN / 16;
+  constexpr int SA = BM * 64, SM_ = BM * 8, SB = 64 * BN * 2, STAGE = SA + SM_ + SB;
+  constexpr int A_WI = BM / 16 / 4;   // A wave-instructions (1 KiB each) per wave per stage
+  constexpr int M_WI = BM / 32 / 4;   // metadata wave-instructions (256 B each) per wave per stage
+  constexpr int B_WI = BN / 8 / 4;    // B wave-instructions per wave per stage
+  static_assert(A_WI >= 1 && M_WI >= 1 && B_WI >= 1, "tile too small for 4 waves");
+  constexpr int CPITCH = BN * 2 + 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const unsigned wm = wave / WN, wn = wave % WN;
+  const unsigned tiles = (unsigned)p.tiles_m * (unsigned)p.tiles_n;
+  const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
+  const unsigned b = lid / tiles, trem = lid - b * tiles;
+  const unsigned tile_m = trem / (unsigned)p.tiles_n, tile_n = trem - tile_m * (unsigned)p.tiles_n;
+  const int m0 = (int)tile_m * BM, n0 = (int)tile_n * BN;
+
+  const size_t row_base = (size_t)b * p.m;
+  const char* vals = p.vals + row_base * (size_t)p.kc;
+  const char* meta = p.meta + row_base * (size_t)(p.kc / 8);
+  const half_t* B = p.B + (size_t)b * p.sB;
+  half_t* C = p.C + (size_t)b * p.sC;
+  const int mlast = p.Mrows - 1;
+
+  // per-lane source addresses for stage 0 (advanced by a constant per stage)
+  const char* a_src[A_WI];
+#pragma unroll
+  for (int i = 0; i < A_WI; ++i) {
+    const unsigned j = wave + 4u * i, row = 16u * j + (lane >> 2), cs = (lane & 3u) ^ a64_swz(row);
+    int gr = m0 + (int)row;
+    gr = gr < mlast ? gr : mlast;
+    a_src[i] = vals + (size_t)gr * p.kc + 16u * cs;
+  }
+  const char* m_src[M_WI];
+#pragma unroll
+  for (int i = 0; i < M_WI; ++i) {
+    const unsigned L = 64u * (wave + 4u * i) + lane, row = L >> 1, part = L & 1u;
+    int gr = m0 + (int)row;
+    gr = gr < mlast ? gr : mlast;
+    m_src[i] = meta + (size_t)gr * (p.kc / 8) + 4u * part;
+  }
+  const char* b_src[B_WI];
+#pragma unroll
+  for (int i = 0; i < B_WI; ++i) {
+    const unsigned j = wave + 4u * i, panel = j >> 3, kr = 8u * (j & 7u) + (lane >> 3);
+    const unsigned cs = (lane & 7u) ^ b_swz(kr);
+    int gc = n0 + (int)(64u * panel + 8u * cs);
+    gc = gc <= p.N - 8 ? gc : p.N - 8;
+    b_src[i] = reinterpret_cast<const char*>(B + (size_t)kr * p.N + gc);
+  }
+  const size_t b_step = (size_t)64 * p.N * 2;
+
+  auto stage = [&](int kt, int buf) {
+    char* base = smem + buf * STAGE;
+#pragma unroll
+    for (int i = 0; i < A_WI; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t*)(a_src[i] + (size_t)kt * 64), (lptr_t*)(base + (wave + 4u * i) * 1024u), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < M_WI; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t*)(m_src[i] + (size_t)kt * 8), (lptr_t*)(base + SA + (wave + 4u * i) * 256u), 4, 0, 0);
+#pragma unroll
+    for (int i = 0; i < B_WI; ++i) {
+      const unsigned j = wave + 4u * i;
+      __builtin_amdgcn_global_load_lds((gptr_t*)(b_src[i] + (size_t)kt * b_step),
+                                       (lptr_t*)(base + SA + SM_ + (j >> 3) * 8192u + (j & 7u) * 1024u), 16, 0, 0);
+    }
+  };
+
+  f4 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+
+  const int nkt = p.kc / 64;
+  stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  const unsigned g = lane >> 4, r = lane & 15u;
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nkt) stage(kt + 1, cur ^ 1);
+    const char* As = smem + cur * STAGE;
+    const char* Ms = As + SA;
+    const char* Bs = Ms + SM_;
+    h8 af[FM];
+    int idx[FM];
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      const unsigned row = wm * TM + i * 16 + r;
+      af[i] = *reinterpret_cast<const h8*>(As + row * 64u + 16u * (g ^ a64_swz(row)));
+      idx[i] = (int)*reinterpret_cast<const unsigned short*>(Ms + row * 8u + 2u * g);
+    }
+    // B fragments by hand-issued transposed reads (the compiler would drain the in-flight DMA in
+    // front of the intrinsic form): fragment j+1's four reads are issued before fragment j's wait.
+    const unsigned bs_addr = (unsigned)(uintptr_t)(lds_char*)Bs;
+    s4 t0[2], t1[2], t2[2], t3[2];
+    auto issue = [&](int j, s4& v0, s4& v1, s4& v2, s4& v3) {
+      const unsigned col0 = wn * TN + j * 16, q = r >> 2, pp = r & 3u;
+      const unsigned a = bs_addr + b_off<64>(8u * g + q, col0 + 4u * pp);
+      asm volatile("ds_read_b64_tr_b16 %0, %4\n\tds_read_b64_tr_b16 %1, %4 offset:512\n\t"
+                   "ds_read_b64_tr_b16 %2, %4 offset:4096\n\tds_read_b64_tr_b16 %3, %4 offset:4608"
+                   : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3) : "v"(a) : "memory");
+    };
+    issue(0, t0[0], t1[0], t2[0], t3[0]);
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      const int c = j & 1, n = c ^ 1;
+      if (j + 1 < FN) {
+        issue(j + 1, t0[n], t1[n], t2[n], t3[n]);
+        asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(t0[c]), "+v"(t1[c]), "+v"(t2[c]), "+v"(t3[c]) :: "memory");
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t0[c]), "+v"(t1[c]), "+v"(t2[c]), "+v"(t3[c]) :: "memory");
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      typedef short s16 __attribute__((ext_vector_type(16)));
+      const s16 all = {t0[c][0], t0[c][1], t0[c][2], t0[c][3], t1[c][0], t1[c][1], t1[c][2], t1[c][3],
+                       t2[c][0], t2[c][1], t2[c][2], t2[c][3], t3[c][0], t3[c][1], t3[c][2], t3[c][3]};
+      const h16 bf = __builtin_bit_cast(h16, all);
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+        acc[i][j] = __builtin_amdgcn_smfmac_f32_16x16x64_f16(af[i], bf, acc[i][j], idx[i], 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  // ---- epilogue (lane holds C[rows 4*(lane>>4) + r][col lane&15] of each fragment)
+  const bool c_vec = (reinterpret_cast<uintptr_t>(C) & 15u) == 0;
+  if (p.beta == 0.0f && c_vec) {
+    char* Cs = smem;
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const unsigned row = wm * TM + i * 16 + 4u * g, col = wn * TN + j * 16 + r;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          *reinterpret_cast<half_t*>(Cs + (row + q) * CPITCH + col * 2) = (half_t)(p.alpha * acc[i][j][q]);
+      }
+    __syncthreads();
+    constexpr int C_CH = BM * (BN / 8) / 256;
+#pragma unroll
+    for (int i = 0; i < C_CH; ++i) {
+      const unsigned q = tid + 256u * i, row = q / (BN / 8), cn = q % (BN / 8);
+      const int gr = m0 + (int)row, gc = n0 + 8 * (int)cn;
+      if (gr >= p.Mrows || gc >= p.N) continue;  // N % 8 == 0: a chunk is all in or all out
+      *reinterpret_cast<u4*>(C + (size_t)gr * p.N + gc) = *reinterpret_cast<const u4*>(Cs + row * CPITCH + cn * 16);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const int gc = n0 + (int)(wn * TN + j * 16 + r);
+        if (gc >= p.N) continue;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int gr = m0 + (int)(wm * TM + i * 16 + 4u * g) + q;
+          if (gr >= p.Mrows) continue;
+          half_t* dst = C + (size_t)gr * p.N + gc;
+          float v = p.alpha * acc[i][j][q];
+          if (p.beta != 0.0f) v += p.beta * (float)*dst;
+          *dst = (half_t)v;
+        }
+      }
+  }
+}
+
+template <int BM, int BN, int WM, int WN>
+static int launch_dma(const SpmmaArgs& a0, hipStream_t st) {
+  SpmmaArgs a = a0;
+  a.tiles_m = (a.Mrows + BM - 1) / BM;
+  a.tiles_n = (a.N + BN - 1) / BN;
+  const size_t nwg = (size_t)a.tiles_m * a.tiles_n * a.batch;
+  if (nwg == 0) return SM_STATUS_SUCCESS;
+  if (nwg > 0x7fffffffu) {
+    set_error("spmma_f16: grid too large");
+    return SM_STATUS_NOT_SUPPORTED;
+  }
+  constexpr size_t lds_main = 2 * ((size_t)BM * 72 + (size_t)64 * BN * 2);
+  constexpr size_t lds_epi = (size_t)BM * (BN * 2 + 16);
+  constexpr size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
+  spmma_f16_dma_kernel<BM, BN, WM, WN><<<dim3((unsigned)nwg), dim3(256), lds, st>>>(a);
+  return check_launch("spmma_f16_dma_kernel");
+}
+
 template <int BM, int BN, int WM, int WN>
 static int launch_cfg(const SpmmaArgs& a0, hipStream_t st) {
   SpmmaArgs a = a0;
@@ -264,6 +469,11 @@ extern "C" int sm_spmma_f16(const void* blob, const void* B, void* C, size_t m, 
     a.batch = 1;
   }
   hipStream_t st = (hipStream_t)stream;
+  const bool fast = (k % 64 == 0) && (n % 8 == 0) && n >= 8 && aligned16(B) && (strideB % 8 == 0);
+  if (fast) {
+    if (n <= 64) return launch_dma<128, 64, 4, 1>(a, st);
+    return launch_dma<128, 128, 2, 2>(a, st);
+  }
   if (n <= 64) return launch_cfg<128, 64, 4, 1>(a, st);
   return launch_cfg<128, 128, 2, 2>(a, st);
 }
