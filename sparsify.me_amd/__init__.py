@@ -103,9 +103,21 @@ def _check(status, what):
         raise SparsifymeError(f"{what} failed with status {status}: {msg}")
 
 
+_torch = None
+_SFX = None
+
+
+def _t():
+    global _torch, _SFX
+    if _torch is None:
+        import torch
+        _torch = torch
+        _SFX = {torch.float16: "f16", torch.float32: "f32", torch.float64: "f64"}
+    return _torch
+
+
 def _stream():
-    import torch
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return ctypes.c_void_p(_t().cuda.current_stream().cuda_stream)
 
 
 def _dev(t):
@@ -115,8 +127,32 @@ def _dev(t):
 
 
 def _sfx(t):
-    import torch
-    return {torch.float16: "f16", torch.float32: "f32", torch.float64: "f64"}[t.dtype]
+    _t()
+    return _SFX[t.dtype]
+
+
+def graph_time_ms(fn, iters=20, replays=3):
+    """Device time of one call of `fn` in ms: `iters` calls are captured into one hipGraph (so the
+    host-side ctypes/launch cost is not on the clock) and the graph is replayed `replays` times
+    between two HIP events on the capture stream's parent.  fn must only enqueue work on the
+    current stream."""
+    torch = _t()
+    fn()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        for _ in range(iters):
+            fn()
+    g.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(replays):
+        g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / (iters * replays)
 
 
 def version():

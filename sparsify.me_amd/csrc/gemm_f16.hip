@@ -32,18 +32,32 @@ struct GemmArgs {
 };
 
 // 8 halves starting at p[col]; elements at or beyond `limit` columns read as zero.
-template <bool VEC>
+// VEC = guaranteed alignment of rowp + col in halves: 8 (one 16-byte load), 4 (8-byte loads), 1.
+template <int VEC>
 __device__ __forceinline__ u4 load_chunk(const half_t* rowp, int col, int limit, bool row_ok) {
   u4 v = {0u, 0u, 0u, 0u};
   if (!row_ok || col >= limit) return v;
-  if (VEC && col + 8 <= limit) return *reinterpret_cast<const u4*>(rowp + col);
+  if (VEC == 8 && col + 8 <= limit) return *reinterpret_cast<const u4*>(rowp + col);
+  if (VEC == 4 && col + 4 <= limit) {
+    const u2 lo = *reinterpret_cast<const u2*>(rowp + col);
+    u2 hi = {0u, 0u};
+    if (col + 8 <= limit) {
+      hi = *reinterpret_cast<const u2*>(rowp + col + 4);
+    } else if (col + 4 < limit) {
+      h4 e;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) e[t] = (col + 4 + t < limit) ? rowp[col + 4 + t] : (half_t)0.0f;
+      hi = __builtin_bit_cast(u2, e);
+    }
+    return u4{lo[0], lo[1], hi[0], hi[1]};
+  }
   h8 e;
 #pragma unroll
   for (int t = 0; t < 8; ++t) e[t] = (col + t < limit) ? rowp[col + t] : (half_t)0.0f;
   return __builtin_bit_cast(u4, e);
 }
 
-template <int BM, int BN, int WM, int WN, bool VEC>
+template <int BM, int BN, int WM, int WN, int VEC>
 __global__ __launch_bounds__(256) void gemm_f16_kernel(const GemmArgs p) {
   static_assert(WM * WN == 4, "4 waves");
   constexpr int TM = BM / WM, TN = BN / WN, FM = TM / 16, FN = TN / 16;
@@ -136,7 +150,7 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(const GemmArgs p) {
   }
 
   // ---- epilogue
-  const bool c_vec = VEC && (p.ldc % 8 == 0) && ((reinterpret_cast<uintptr_t>(C) & 15u) == 0);
+  const bool c_vec = VEC == 8 && (p.ldc % 8 == 0) && ((reinterpret_cast<uintptr_t>(C) & 15u) == 0);
   if (p.beta == 0.0f && c_vec) {
     char* Cs = smem;  // [BM][CPITCH]
 #pragma unroll
@@ -169,6 +183,7 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(const GemmArgs p) {
     }
   } else {
     // general alpha/beta or unaligned C: straight from the accumulators, one rounding
+    const bool c8 = (p.ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(C) & 7u) == 0);
 #pragma unroll
     for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -176,6 +191,13 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(const GemmArgs p) {
         const int gr = m0 + (int)(wm * TM + i * 16 + (lane & 15u));
         const int gc = n0 + (int)(wn * TN + j * 16 + 4u * (lane >> 4));
         if (gr >= p.M) continue;
+        if (p.beta == 0.0f && c8 && gc + 4 <= p.N) {  // four consecutive n of one row: one 8-byte store
+          h4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = (half_t)(p.alpha * acc[i][j][r]);
+          *reinterpret_cast<h4*>(C + (size_t)gr * p.ldc + gc) = o;
+          continue;
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           if (gc + r >= p.N) continue;
@@ -188,8 +210,202 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(const GemmArgs p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Fast path (K % 64 == 0, N % 8 == 0, rows of A and B 8-byte aligned or better): the same LDS-DMA
+// ring as the 2:4 kernel (spmma_f16.hip).  Stage = 64 k: A [BM][128 B] + B [64][BN]; images are
+// lane-linear for the DMA with the swizzle on the per-lane source address.  Edge rows / columns are
+// clamped to the last valid one (their products land in outputs that are never stored).
+// ---------------------------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN, int NS>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_f16_dma_kernel(const GemmArgs p) {
+  constexpr int NW = WM * WN;
+  static_assert(NW == 4 || NW == 8 || NW == 16, "4, 8 or 16 waves");
+  constexpr int TM = BM / WM, TN = BN / WN, FM = TM / 16, FN = TN / 16;
+  static_assert(FM >= 1 && FN >= 1, "wave tile");
+  constexpr int SA = BM * 128, SB = 64 * BN * 2, STAGE = SA + SB;
+  constexpr int A_N = BM / 8, B_N = BN / 8, W = A_N + B_N;  // 1 KiB DMA wave-instructions per stage
+  constexpr int SL = (W + NW - 1) / NW;
+  constexpr int LPS = W / NW;
+  static_assert(LPS >= 1, "every wave must issue at least one DMA per stage");
+  constexpr int CPITCH = BN * 2 + 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const unsigned tid = threadIdx.x, lane = tid & 63u;
+  const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const unsigned wm = wave / WN, wn = wave % WN;
+  const unsigned tiles = (unsigned)p.tiles_m * (unsigned)p.tiles_n;
+  const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
+  const unsigned b = lid / tiles, trem = lid - b * tiles;
+  const unsigned tile_m = trem / (unsigned)p.tiles_n, tile_n = trem - tile_m * (unsigned)p.tiles_n;
+  const int m0 = (int)tile_m * BM, n0 = (int)tile_n * BN;
+
+  const half_t* A = p.Ap ? p.Ap[b] : p.A + (size_t)b * p.sA;
+  const half_t* B = p.Bp ? p.Bp[b] : p.B + (size_t)b * p.sB;
+  half_t* C = p.Cp ? p.Cp[b] : p.C + (size_t)b * p.sC;
+  const int mlast = p.M - 1;
+
+  const char* src[SL];
+  size_t step[SL];
+  unsigned loff[SL];
+#pragma unroll
+  for (int i = 0; i < SL; ++i) {
+    const unsigned t = wave + (unsigned)NW * i;
+    if (t < (unsigned)A_N) {
+      const unsigned row = 8u * t + (lane >> 3), cs = (lane & 7u) ^ (row & 7u);
+      int gr = m0 + (int)row;
+      gr = gr < mlast ? gr : mlast;
+      src[i] = reinterpret_cast<const char*>(A + (size_t)gr * p.lda + 8u * cs);
+      step[i] = 128;
+      loff[i] = t * 1024u;
+    } else {
+      const unsigned j = t - A_N, panel = j >> 3, kr = 8u * (j & 7u) + (lane >> 3);
+      const unsigned cs = (lane & 7u) ^ b_swz(kr);
+      int gc = n0 + (int)(64u * panel + 8u * cs);
+      gc = gc <= p.N - 8 ? gc : p.N - 8;
+      src[i] = reinterpret_cast<const char*>(B + (size_t)kr * p.ldb + gc);
+      step[i] = (size_t)64 * p.ldb * 2;
+      loff[i] = SA + panel * 8192u + (j & 7u) * 1024u;
+    }
+  }
+  auto stage = [&](int kt, int buf) {
+    char* base = smem + buf * STAGE;
+#pragma unroll
+    for (int i = 0; i < SL; ++i) {
+      const unsigned t = wave + (unsigned)NW * i;
+      if (t >= (unsigned)W) continue;
+      __builtin_amdgcn_global_load_lds((gptr_t*)(src[i] + (size_t)kt * step[i]), (lptr_t*)(base + loff[i]), 16, 0, 0);
+    }
+  };
+
+  f4 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+
+  const int nkt = p.K / 64;
+#pragma unroll
+  for (int s = 0; s < NS - 1; ++s)
+    if (s < nkt) stage(s, s);
+  const unsigned g = lane >> 4, r = lane & 15u;
+  int cur = 0, fill = NS - 1;
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int ahead = (nkt - 1 - kt) < (NS - 2) ? (nkt - 1 - kt) : (NS - 2);
+    if (NS >= 4 && ahead == 2) wait_dma_and_barrier<2 * LPS>();
+    else if (NS >= 3 && ahead == 1) wait_dma_and_barrier<LPS>();
+    else wait_dma_and_barrier<0>();
+    if (kt + NS - 1 < nkt) stage(kt + NS - 1, fill);
+    const char* As = smem + cur * STAGE;
+    const char* Bs = As + SA;
+    const unsigned bs_addr = (unsigned)(uintptr_t)(lds_char*)Bs;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      h8 af[FM];
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        const unsigned row = wm * TM + i * 16 + r;
+        af[i] = *reinterpret_cast<const h8*>(As + a_off(row, 4u * s + g));
+      }
+      s4 lo[2], hi[2];
+      auto issue = [&](int j, s4& v0, s4& v1) {
+        const unsigned col0 = wn * TN + j * 16, q = r >> 2, pp = r & 3u;
+        const unsigned a = bs_addr + b_off<64>(32u * s + 8u * g + q, col0 + 4u * pp);
+        asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:512"
+                     : "=&v"(v0), "=&v"(v1) : "v"(a) : "memory");
+      };
+      issue(0, lo[0], hi[0]);
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const int c = j & 1, n = c ^ 1;
+        if (j + 1 < FN) {
+          issue(j + 1, lo[n], hi[n]);
+          asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(lo[c]), "+v"(hi[c]) :: "memory");
+        } else {
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo[c]), "+v"(hi[c]) :: "memory");
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        typedef short s8 __attribute__((ext_vector_type(8)));
+        const s8 both = {lo[c][0], lo[c][1], lo[c][2], lo[c][3], hi[c][0], hi[c][1], hi[c][2], hi[c][3]};
+        const h8 bf = __builtin_bit_cast(h8, both);
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf, af[i], acc[i][j], 0, 0, 0);  // swapped: C^T layout
+      }
+    }
+    cur = cur + 1 == NS ? 0 : cur + 1;
+    fill = fill + 1 == NS ? 0 : fill + 1;
+  }
+  __syncthreads();
+
+  // ---- epilogue: lane holds C[row lane&15][cols 4*(lane>>4) .. +3] of each fragment
+  const bool c_vec = (p.ldc % 8 == 0) && ((reinterpret_cast<uintptr_t>(C) & 15u) == 0);
+  if (p.beta == 0.0f && c_vec) {
+    char* Cs = smem;
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const unsigned row = wm * TM + i * 16 + r, col = wn * TN + j * 16 + 4u * g;
+        h4 o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o[q] = (half_t)(p.alpha * acc[i][j][q]);
+        *reinterpret_cast<h4*>(Cs + row * CPITCH + col * 2) = o;
+      }
+    __syncthreads();
+    constexpr int C_CH = BM * (BN / 8) / (64 * NW);
+#pragma unroll
+    for (int i = 0; i < C_CH; ++i) {
+      const unsigned q = tid + 64u * NW * i, row = q / (BN / 8), cn = q % (BN / 8);
+      const int gr = m0 + (int)row, gc = n0 + 8 * (int)cn;
+      if (gr >= p.M || gc >= p.N) continue;
+      *reinterpret_cast<u4*>(C + (size_t)gr * p.ldc + gc) = *reinterpret_cast<const u4*>(Cs + row * CPITCH + cn * 16);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const int gr = m0 + (int)(wm * TM + i * 16 + r);
+        const int gc = n0 + (int)(wn * TN + j * 16 + 4u * g);
+        if (gr >= p.M) continue;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if (gc + q >= p.N) continue;
+          half_t* dst = C + (size_t)gr * p.ldc + gc + q;
+          float v = p.alpha * acc[i][j][q];
+          if (p.beta != 0.0f) v += p.beta * (float)*dst;
+          *dst = (half_t)v;
+        }
+      }
+  }
+}
+
+template <int BM, int BN, int WM, int WN, int NS>
+static int launch_dma(const GemmArgs& a0, hipStream_t st) {
+  GemmArgs a = a0;
+  a.tiles_m = (a.M + BM - 1) / BM;
+  a.tiles_n = (a.N + BN - 1) / BN;
+  const size_t nwg = (size_t)a.tiles_m * a.tiles_n * a.batch;
+  if (nwg == 0) return SM_STATUS_SUCCESS;
+  if (nwg > 0x7fffffffu) {
+    set_error("gemm_f16: grid too large");
+    return SM_STATUS_NOT_SUPPORTED;
+  }
+  constexpr size_t lds_main = NS * ((size_t)BM * 128 + (size_t)64 * BN * 2);
+  constexpr size_t lds_epi = (size_t)BM * (BN * 2 + 16);
+  constexpr size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
+  static bool attr_set = false;
+  if (lds > 64 * 1024 && !attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16_dma_kernel<BM, BN, WM, WN, NS>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  gemm_f16_dma_kernel<BM, BN, WM, WN, NS><<<dim3((unsigned)nwg), dim3(64 * WM * WN), lds, st>>>(a);
+  return check_launch("gemm_f16_dma_kernel");
+}
+
 template <int BM, int BN, int WM, int WN>
-static int launch_cfg(const GemmArgs& a0, bool vec, hipStream_t st) {
+static int launch_cfg(const GemmArgs& a0, int vec, hipStream_t st) {
   GemmArgs a = a0;
   a.tiles_m = (a.M + BM - 1) / BM;
   a.tiles_n = (a.N + BN - 1) / BN;
@@ -202,19 +418,35 @@ static int launch_cfg(const GemmArgs& a0, bool vec, hipStream_t st) {
   constexpr size_t lds_main = (size_t)BM * 128 + (size_t)BN * 128;
   constexpr size_t lds_epi = (size_t)BM * (BN * 2 + 16);
   constexpr size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
-  if (vec)
-    gemm_f16_kernel<BM, BN, WM, WN, true><<<dim3((unsigned)nwg), dim3(256), lds, st>>>(a);
+  if (vec == 8)
+    gemm_f16_kernel<BM, BN, WM, WN, 8><<<dim3((unsigned)nwg), dim3(256), lds, st>>>(a);
+  else if (vec == 4)
+    gemm_f16_kernel<BM, BN, WM, WN, 4><<<dim3((unsigned)nwg), dim3(256), lds, st>>>(a);
   else
-    gemm_f16_kernel<BM, BN, WM, WN, false><<<dim3((unsigned)nwg), dim3(256), lds, st>>>(a);
+    gemm_f16_kernel<BM, BN, WM, WN, 1><<<dim3((unsigned)nwg), dim3(256), lds, st>>>(a);
   return check_launch("gemm_f16_kernel");
 }
 
 // Tile choice: the streamed dimension gets the long tile edge; narrow problems get a tile as wide
 // as they are, so the big operand is read from HBM exactly once.
 static int launch_gemm_f16(const GemmArgs& a, hipStream_t st) {
-  const bool vec = (a.lda % 8 == 0) && (a.ldb % 8 == 0) && (a.sA % 8 == 0) && (a.sB % 8 == 0) &&
-                   (a.Ap || aligned16(a.A)) && (a.Bp || aligned16(a.B));
+  auto aligned_to = [&](unsigned halves) {
+    const uintptr_t mask = halves * 2u - 1u;
+    return (a.lda % halves == 0) && (a.ldb % halves == 0) && (a.sA % halves == 0) && (a.sB % halves == 0) &&
+           (a.Ap || (reinterpret_cast<uintptr_t>(a.A) & mask) == 0) && (a.Bp || (reinterpret_cast<uintptr_t>(a.B) & mask) == 0);
+  };
+  const int vec = aligned_to(8) ? 8 : (aligned_to(4) ? 4 : 1);
   // pointer-array batches: per-batch base alignment is the caller's (hipMalloc gives 256 B);
+  // DMA fast path: whole 64-deep K stages, whole 8-column chunks, rows on 8-byte boundaries (a
+  // 16-byte global access needs only dword alignment; the LDS side is aligned by construction)
+  const bool fast = (a.K % 64 == 0) && (a.N % 8 == 0) && a.N >= 8 && (a.lda % 4 == 0) && (a.ldb % 4 == 0) &&
+                    (a.sA % 4 == 0) && (a.sB % 4 == 0) && (a.Ap || (reinterpret_cast<uintptr_t>(a.A) & 7u) == 0) &&
+                    (a.Bp || (reinterpret_cast<uintptr_t>(a.B) & 7u) == 0);
+  if (fast) {
+    if (a.N <= 64) return launch_dma<128, 64, 4, 1, 2>(a, st);
+    if (a.M <= 64) return launch_dma<64, 128, 1, 4, 2>(a, st);
+    return launch_dma<128, 128, 2, 2, 2>(a, st);
+  }
   if (a.N <= 64) return launch_cfg<128, 64, 4, 1>(a, vec, st);
   if (a.M <= 64) return launch_cfg<64, 128, 1, 4>(a, vec, st);
   return launch_cfg<128, 128, 2, 2>(a, vec, st);

@@ -55,4 +55,16 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned id, unsigned nwg) {
   return base + (id >> 3);
 }
 
+// ---- LDS-DMA (global_load_lds) plumbing shared by the pipelined kernels
+typedef __attribute__((address_space(1))) const void gptr_t;
+typedef __attribute__((address_space(3))) void lptr_t;
+
+// s_waitcnt vmcnt(N) + s_barrier as ONE statement: the DMA of the stage about to be read has landed
+// for every wave, and every wave has finished reading the buffer about to be refilled.  (A plain
+// __syncthreads() would drain vmcnt to 0 and serialise the ring.)
+template <int N>
+__device__ __forceinline__ void wait_dma_and_barrier() {
+  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
 }  // namespace sm

@@ -10,7 +10,13 @@
 // Global -> registers -> swizzled LDS images (mma_tile.h) with the next stage's loads in flight
 // during the current stage's SMFMACs.  The sparse operand must be srcA, so a lane ends with four
 // consecutive ROWS of one column; the epilogue transposes through LDS and stores 16-byte row pieces.
+#include <stdlib.h>
+
 #include "mma_tile.h"
+
+#ifndef SM_NT_A
+#define SM_NT_A 0
+#endif
 
 namespace sm {
 
@@ -225,25 +231,30 @@ __global__ __launch_bounds__(256) void spmma_f16_kernel(const SpmmaArgs p) {
 // Rows / columns past the matrix edge are clamped to the last valid one (their products land in
 // outputs that are never stored), so no lane is ever predicated off.
 // ---------------------------------------------------------------------------------------------
-typedef __attribute__((address_space(1))) const void gptr_t;
-typedef __attribute__((address_space(3))) void lptr_t;
 
 // 64-byte-row A image: 16-byte chunk c of row r lives at chunk c ^ ((-(r >> 2)) & 3).
 __device__ __forceinline__ unsigned a64_swz(unsigned row) { return (0u - (row >> 2)) & 3u; }
 
-template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void spmma_f16_dma_kernel(const SpmmaArgs p) {
-  static_assert(WM * WN == 4, "4 waves");
+template <int BM, int BN, int WM, int WN, int NS>
+__global__ __launch_bounds__(64 * WM * WN) void spmma_f16_dma_kernel(const SpmmaArgs p) {
+  constexpr int NW = WM * WN;  // waves per workgroup: 4 for big grids, 8 / 16 when few tiles exist
+  static_assert(NW == 4 || NW == 8 || NW == 16, "4, 8 or 16 waves");
+  static_assert(NS >= 2 && NS <= 4, "ring depth");
   constexpr int TM = BM / WM, TN = BN / WN, FM = TM / 16, FN = TN / 16;
+  static_assert(FM >= 1 && FN >= 1, "wave tile");
   constexpr int SA = BM * 64, SM_ = BM * 8, SB = 64 * BN * 2, STAGE = SA + SM_ + SB;
-  constexpr int A_WI = BM / 16 / 4;   // A wave-instructions (1 KiB each) per wave per stage
-  constexpr int M_WI = BM / 32 / 4;   // metadata wave-instructions (256 B each) per wave per stage
-  constexpr int B_WI = BN / 8 / 4;    // B wave-instructions per wave per stage
-  static_assert(A_WI >= 1 && M_WI >= 1 && B_WI >= 1, "tile too small for 4 waves");
+  // One stage = W DMA wave-instructions: A_N of 1 KiB (16 rows x 64 B), M_N of 256 B (32 rows x 8 B),
+  // B_N of 1 KiB (8 k-rows x 128 B).  Instruction t belongs to wave t % NW (slot t / NW).
+  constexpr int A_N = BM / 16, M_N = BM / 32, B_N = BN / 8, W = A_N + M_N + B_N;
+  constexpr int SL = (W + NW - 1) / NW;  // slots per wave
+  constexpr int LPS = W / NW;            // least DMA instructions any wave issues per stage (vmcnt unit)
+  static_assert(LPS >= 1, "every wave must issue at least one DMA per stage");
   constexpr int CPITCH = BN * 2 + 16;
+  constexpr int NT_A = SM_NT_A;  // cache policy bits of the A-side DMA (2 = nt)
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
-  const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const unsigned tid = threadIdx.x, lane = tid & 63u;
+  const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const unsigned wm = wave / WN, wn = wave % WN;
   const unsigned tiles = (unsigned)p.tiles_m * (unsigned)p.tiles_n;
   const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
@@ -258,47 +269,54 @@ __global__ __launch_bounds__(256) void spmma_f16_dma_kernel(const SpmmaArgs p) {
   half_t* C = p.C + (size_t)b * p.sC;
   const int mlast = p.Mrows - 1;
 
-  // per-lane source addresses for stage 0 (advanced by a constant per stage)
-  const char* a_src[A_WI];
+  // per-slot source address of stage 0 (advanced by `step` bytes per stage) and LDS offset in a stage
+  const char* src[SL];
+  size_t step[SL];
+  unsigned loff[SL];
 #pragma unroll
-  for (int i = 0; i < A_WI; ++i) {
-    const unsigned j = wave + 4u * i, row = 16u * j + (lane >> 2), cs = (lane & 3u) ^ a64_swz(row);
-    int gr = m0 + (int)row;
-    gr = gr < mlast ? gr : mlast;
-    a_src[i] = vals + (size_t)gr * p.kc + 16u * cs;
+  for (int i = 0; i < SL; ++i) {
+    const unsigned t = wave + (unsigned)NW * i;
+    if (t < (unsigned)A_N) {
+      const unsigned row = 16u * t + (lane >> 2), cs = (lane & 3u) ^ a64_swz(row);
+      int gr = m0 + (int)row;
+      gr = gr < mlast ? gr : mlast;
+      src[i] = vals + (size_t)gr * p.kc + 16u * cs;
+      step[i] = 64;
+      loff[i] = t * 1024u;
+    } else if (t < (unsigned)(A_N + M_N)) {
+      const unsigned u = t - A_N, L = 64u * u + lane, row = L >> 1, part = L & 1u;
+      int gr = m0 + (int)row;
+      gr = gr < mlast ? gr : mlast;
+      src[i] = meta + (size_t)gr * (p.kc / 8) + 4u * part;
+      step[i] = 8;
+      loff[i] = SA + u * 256u;
+    } else {
+      const unsigned j = t - (A_N + M_N), panel = j >> 3, kr = 8u * (j & 7u) + (lane >> 3);
+      const unsigned cs = (lane & 7u) ^ b_swz(kr);
+      int gc = n0 + (int)(64u * panel + 8u * cs);
+      gc = gc <= p.N - 8 ? gc : p.N - 8;
+      src[i] = reinterpret_cast<const char*>(B + (size_t)kr * p.N + gc);
+      step[i] = (size_t)64 * p.N * 2;
+      loff[i] = SA + SM_ + panel * 8192u + (j & 7u) * 1024u;
+    }
   }
-  const char* m_src[M_WI];
-#pragma unroll
-  for (int i = 0; i < M_WI; ++i) {
-    const unsigned L = 64u * (wave + 4u * i) + lane, row = L >> 1, part = L & 1u;
-    int gr = m0 + (int)row;
-    gr = gr < mlast ? gr : mlast;
-    m_src[i] = meta + (size_t)gr * (p.kc / 8) + 4u * part;
-  }
-  const char* b_src[B_WI];
-#pragma unroll
-  for (int i = 0; i < B_WI; ++i) {
-    const unsigned j = wave + 4u * i, panel = j >> 3, kr = 8u * (j & 7u) + (lane >> 3);
-    const unsigned cs = (lane & 7u) ^ b_swz(kr);
-    int gc = n0 + (int)(64u * panel + 8u * cs);
-    gc = gc <= p.N - 8 ? gc : p.N - 8;
-    b_src[i] = reinterpret_cast<const char*>(B + (size_t)kr * p.N + gc);
-  }
-  const size_t b_step = (size_t)64 * p.N * 2;
 
   auto stage = [&](int kt, int buf) {
     char* base = smem + buf * STAGE;
 #pragma unroll
-    for (int i = 0; i < A_WI; ++i)
-      __builtin_amdgcn_global_load_lds((gptr_t*)(a_src[i] + (size_t)kt * 64), (lptr_t*)(base + (wave + 4u * i) * 1024u), 16, 0, 0);
-#pragma unroll
-    for (int i = 0; i < M_WI; ++i)
-      __builtin_amdgcn_global_load_lds((gptr_t*)(m_src[i] + (size_t)kt * 8), (lptr_t*)(base + SA + (wave + 4u * i) * 256u), 4, 0, 0);
-#pragma unroll
-    for (int i = 0; i < B_WI; ++i) {
-      const unsigned j = wave + 4u * i;
-      __builtin_amdgcn_global_load_lds((gptr_t*)(b_src[i] + (size_t)kt * b_step),
-                                       (lptr_t*)(base + SA + SM_ + (j >> 3) * 8192u + (j & 7u) * 1024u), 16, 0, 0);
+    for (int i = 0; i < SL; ++i) {
+      const unsigned t = wave + (unsigned)NW * i;  // wave-uniform
+      if (t >= (unsigned)W) continue;
+      gptr_t* g = (gptr_t*)(src[i] + (size_t)kt * step[i]);
+      lptr_t* l = (lptr_t*)(base + loff[i]);
+      // A values and metadata are read exactly once (non-temporal: keep them from evicting B, which
+      // every workgroup re-reads from L2); B uses the default policy.
+      if (t < (unsigned)A_N)
+        __builtin_amdgcn_global_load_lds(g, l, 16, 0, NT_A);
+      else if (t < (unsigned)(A_N + M_N))
+        __builtin_amdgcn_global_load_lds(g, l, 4, 0, NT_A);
+      else
+        __builtin_amdgcn_global_load_lds(g, l, 16, 0, 0);
     }
   };
 
@@ -308,14 +326,21 @@ __global__ __launch_bounds__(256) void spmma_f16_dma_kernel(const SpmmaArgs p) {
 #pragma unroll
     for (int j = 0; j < FN; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
 
+  // Ring of NS stage buffers.  Iteration kt: (1) wait until this wave's DMA of stage kt has landed
+  // (stages kt+1 .. kt+NS-2 may stay in flight: counted vmcnt), (2) barrier, (3) refill the buffer
+  // read in iteration kt-1 with stage kt+NS-1, (4) compute stage kt.  One barrier per stage.
   const int nkt = p.kc / 64;
-  stage(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+#pragma unroll
+  for (int s = 0; s < NS - 1; ++s)
+    if (s < nkt) stage(s, s);
   const unsigned g = lane >> 4, r = lane & 15u;
+  int cur = 0, fill = NS - 1;  // buffer of stage kt, buffer of stage kt+NS-1
   for (int kt = 0; kt < nkt; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nkt) stage(kt + 1, cur ^ 1);
+    const int ahead = (nkt - 1 - kt) < (NS - 2) ? (nkt - 1 - kt) : (NS - 2);
+    if (NS >= 4 && ahead == 2) wait_dma_and_barrier<2 * LPS>();
+    else if (NS >= 3 && ahead == 1) wait_dma_and_barrier<LPS>();
+    else wait_dma_and_barrier<0>();
+    if (kt + NS - 1 < nkt) stage(kt + NS - 1, fill);
     const char* As = smem + cur * STAGE;
     const char* Ms = As + SA;
     const char* Bs = Ms + SM_;
@@ -357,9 +382,10 @@ __global__ __launch_bounds__(256) void spmma_f16_dma_kernel(const SpmmaArgs p) {
       for (int i = 0; i < FM; ++i)
         acc[i][j] = __builtin_amdgcn_smfmac_f32_16x16x64_f16(af[i], bf, acc[i][j], idx[i], 0, 0);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    cur = cur + 1 == NS ? 0 : cur + 1;
+    fill = fill + 1 == NS ? 0 : fill + 1;
   }
+  __syncthreads();  // nothing is in flight here: the last NS-1 iterations issued no DMA
 
   // ---- epilogue (lane holds C[rows 4*(lane>>4) + r][col lane&15] of each fragment)
   const bool c_vec = (reinterpret_cast<uintptr_t>(C) & 15u) == 0;
@@ -375,10 +401,10 @@ __global__ __launch_bounds__(256) void spmma_f16_dma_kernel(const SpmmaArgs p) {
           *reinterpret_cast<half_t*>(Cs + (row + q) * CPITCH + col * 2) = (half_t)(p.alpha * acc[i][j][q]);
       }
     __syncthreads();
-    constexpr int C_CH = BM * (BN / 8) / 256;
+    constexpr int C_CH = BM * (BN / 8) / (64 * NW);
 #pragma unroll
     for (int i = 0; i < C_CH; ++i) {
-      const unsigned q = tid + 256u * i, row = q / (BN / 8), cn = q % (BN / 8);
+      const unsigned q = tid + 64u * NW * i, row = q / (BN / 8), cn = q % (BN / 8);
       const int gr = m0 + (int)row, gc = n0 + 8 * (int)cn;
       if (gr >= p.Mrows || gc >= p.N) continue;  // N % 8 == 0: a chunk is all in or all out
       *reinterpret_cast<u4*>(C + (size_t)gr * p.N + gc) = *reinterpret_cast<const u4*>(Cs + row * CPITCH + cn * 16);
@@ -403,7 +429,7 @@ __global__ __launch_bounds__(256) void spmma_f16_dma_kernel(const SpmmaArgs p) {
   }
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int NS>
 static int launch_dma(const SpmmaArgs& a0, hipStream_t st) {
   SpmmaArgs a = a0;
   a.tiles_m = (a.Mrows + BM - 1) / BM;
@@ -414,10 +440,16 @@ static int launch_dma(const SpmmaArgs& a0, hipStream_t st) {
     set_error("spmma_f16: grid too large");
     return SM_STATUS_NOT_SUPPORTED;
   }
-  constexpr size_t lds_main = 2 * ((size_t)BM * 72 + (size_t)64 * BN * 2);
+  constexpr size_t lds_main = NS * ((size_t)BM * 72 + (size_t)64 * BN * 2);
   constexpr size_t lds_epi = (size_t)BM * (BN * 2 + 16);
   constexpr size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
-  spmma_f16_dma_kernel<BM, BN, WM, WN><<<dim3((unsigned)nwg), dim3(256), lds, st>>>(a);
+  static bool attr_set = false;
+  if (lds > 64 * 1024 && !attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spmma_f16_dma_kernel<BM, BN, WM, WN, NS>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  spmma_f16_dma_kernel<BM, BN, WM, WN, NS><<<dim3((unsigned)nwg), dim3(64 * WM * WN), lds, st>>>(a);
   return check_launch("spmma_f16_dma_kernel");
 }
 
@@ -471,8 +503,28 @@ extern "C" int sm_spmma_f16(const void* blob, const void* B, void* C, size_t m, 
   hipStream_t st = (hipStream_t)stream;
   const bool fast = (k % 64 == 0) && (n % 8 == 0) && n >= 8 && aligned16(B) && (strideB % 8 == 0);
   if (fast) {
-    if (n <= 64) return launch_dma<128, 64, 4, 1>(a, st);
-    return launch_dma<128, 128, 2, 2>(a, st);
+    // Workgroup shape by how many tiles exist: with thousands of tiles 4 waves per tile and several
+    // tiles per CU overlap each other's latencies; with about one tile per CU the same tile is spread
+    // over 8 or 16 waves so that every SIMD still holds several waves.  SM_SPMMA_CFG (tuning aid):
+    // "<waves>x<ring>" forces a configuration.
+    static const char* cfg_env = getenv("SM_SPMMA_CFG");
+    const size_t Mr = (size_t)a.Mrows;
+    int nw, ns;
+    if (n <= 64) {
+      const size_t tiles = ceil_div(Mr, 128) * a.batch;
+      nw = tiles >= 1024 ? 4 : 8;
+      ns = 2;
+      if (cfg_env) sscanf(cfg_env, "%dx%d", &nw, &ns);
+      if (nw >= 8) return ns >= 3 ? launch_dma<128, 64, 4, 2, 3>(a, st) : launch_dma<128, 64, 4, 2, 2>(a, st);
+      return ns >= 3 ? launch_dma<128, 64, 4, 1, 3>(a, st) : launch_dma<128, 64, 4, 1, 2>(a, st);
+    }
+    const size_t tiles = ceil_div(Mr, 128) * ceil_div(n, 128) * a.batch;
+    nw = tiles >= 1024 ? 4 : (tiles >= 512 ? 8 : 16);
+    ns = (tiles < 512 && k >= 1024) ? 3 : 2;
+    if (cfg_env) sscanf(cfg_env, "%dx%d", &nw, &ns);
+    if (nw >= 16) return ns >= 3 ? launch_dma<128, 128, 4, 4, 3>(a, st) : launch_dma<128, 128, 4, 4, 2>(a, st);
+    if (nw >= 8) return ns >= 3 ? launch_dma<128, 128, 2, 4, 3>(a, st) : launch_dma<128, 128, 2, 4, 2>(a, st);
+    return ns >= 3 ? launch_dma<128, 128, 2, 2, 3>(a, st) : launch_dma<128, 128, 2, 2, 2>(a, st);
   }
   if (n <= 64) return launch_cfg<128, 64, 4, 1>(a, st);
   return launch_cfg<128, 128, 2, 2>(a, st);

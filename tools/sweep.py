@@ -47,15 +47,8 @@ def main():
     only = set(args.only.split(",")) if args.only else None
 
     def timeit(fn):
-        fn()
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(args.reps):
-            fn()
-        e1.record()
-        torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / args.reps  # ms
+        # hipGraph replay: device time only (a Python/ctypes call costs ~10 us, more than the small kernels)
+        return sm.graph_time_ms(fn, iters=args.reps, replays=3)
 
     out_rows = []
     tot = {}
