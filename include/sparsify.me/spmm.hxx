@@ -1,0 +1,84 @@
+// spmm.hxx -- sparsifyme::batched::spmm (Blocked-ELL x dense) and batched::strided_coo (one COO
+// matrix x a strided batch of dense matrices).
+// Signatures of the reference's include/sparsify.me/spmm.hxx:30-41 and :140-153.  There: one
+// cuSPARSE call per batch from one OpenMP host thread per batch on per-batch streams (:94-111), and
+// a strided-batch COO call that does not compile as committed (:172,175,187).  Here: one batched
+// kernel launch each.  Dense operands are column-major as the reference declares them
+// (B k x n ld k, C_i m x n ld m: spmm.hxx:63,67); `As` and `Cs` are HOST arrays
+// (examples/spmm.cu:96,102,115), `B` is shared by all batches.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+#include <iostream>
+#include <vector>
+
+#include <sparsifyme.h>
+#include <sparsify.me/containers/ell.hxx>
+#include <sparsify.me/gemm.hxx>  // operation_t
+#include <sparsify.me/util/util.hxx>
+
+namespace sparsifyme {
+namespace batched {
+
+template <typename type_t>
+float spmm(ell_t<type_t, memory_space_t::device>* As,
+           type_t* B,
+           type_t** Cs,
+           std::size_t m,
+           std::size_t n,
+           std::size_t k,
+           std::size_t batch_size,
+           operation_t transpose_a = operation_t::N,
+           operation_t transpose_b = operation_t::N,
+           float alpha = 1.0f,
+           float beta = 0.0f) {
+  static_assert(sizeof(type_t) == 4, "this build implements the fp32 Blocked-ELL SpMM");
+  (void)transpose_a;
+  (void)transpose_b;
+  (void)hipDeviceSynchronize();
+  util::timer_t t;
+  t.begin();
+  int rc = SM_STATUS_SUCCESS;
+  for (std::size_t b = 0; b < batch_size; ++b) {
+    auto& A = As[b];
+    rc |= sm_spmm_bell_f32(reinterpret_cast<const float*>(A.values.data().get()),
+                           reinterpret_cast<const std::uint64_t*>(A.column_indices.data().get()), A.rows, A.cols,
+                           A.block_size, A.ell_cols, reinterpret_cast<const float*>(B), reinterpret_cast<float*>(Cs[b]),
+                           n, alpha, beta, nullptr);
+  }
+  (void)m;
+  (void)k;
+  t.end();
+  if (rc != SM_STATUS_SUCCESS) std::cerr << "sparsifyme::batched::spmm: " << sm_last_error() << std::endl;
+  return t.milliseconds();
+}
+
+template <typename type_t>
+float strided_coo(std::size_t A_num_rows,
+                  std::size_t A_num_cols,
+                  std::size_t A_nnz,
+                  std::size_t B_num_rows,
+                  std::size_t B_num_cols,
+                  std::size_t num_batches,
+                  int* dA_rows,
+                  int* dA_cols,
+                  type_t* dA_values,
+                  type_t* dB,
+                  type_t* dC,
+                  type_t alpha = 1.0f,
+                  type_t beta = 0.0f) {
+  static_assert(sizeof(type_t) == 4, "this build implements the fp32 COO SpMM");
+  (void)B_num_rows;  // == A_num_cols
+  util::timer_t t;
+  t.begin();
+  const int rc = sm_spmm_coo_f32(A_num_rows, A_num_cols, A_nnz, B_num_cols, num_batches, dA_rows, dA_cols,
+                                 reinterpret_cast<const float*>(dA_values), reinterpret_cast<const float*>(dB),
+                                 reinterpret_cast<float*>(dC), alpha, beta, nullptr);
+  t.end();
+  if (rc != SM_STATUS_SUCCESS) std::cerr << "sparsifyme::batched::strided_coo: " << sm_last_error() << std::endl;
+  return t.milliseconds();
+}
+}  // namespace batched
+}  // namespace sparsifyme

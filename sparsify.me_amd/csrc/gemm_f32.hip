@@ -1,0 +1,353 @@
+// gemm_f32.hip -- fp32 matrix kernels on the exact-fp32 matrix instruction v_mfma_f32_16x16x4_f32
+// (result bit-for-bit a k-ordered fmaf chain; gfx950 has no TF32/xf32 path):
+//   sm_gemm_rowmajor_f32 / sm_gemm_batched_f32  -- dense, replaces cublasSgemmBatched
+//                                                  (include/sparsify.me/gemm.hxx:133-134)
+//   sm_spmma_f32                                 -- 2:4 A from the compressed blob; there is no fp32
+//                                                  sparse matrix instruction, so the kept values are
+//                                                  expanded into the dense LDS tile while staging and
+//                                                  the contraction runs dense: A's HBM bytes halve,
+//                                                  the MFMA work does not
+//   sm_gemm_batched_f64                          -- fp64, plain FMA tiles (lowest priority, a5)
+// One register-staged, LDS-tiled kernel template serves the fp32 variants: 128 x BN tile, BK = 32,
+// 256 threads = 4 waves; the operands of the MFMA are swapped so a lane ends with four consecutive
+// columns of one row and stores them as one 16-byte access.
+#include "mma_tile.h"
+
+namespace sm {
+
+struct Gemm32Args {
+  const float* A;      // dense A (row-major M x K, lda) -- or null when `vals` is set
+  const char* vals;    // 2:4 blob values  [Mtot][kc/2] floats
+  const char* meta;    // 2:4 blob metadata [Mtot][kc/8] bytes
+  const float* B;
+  float* C;
+  const float* const* Ap;
+  const float* const* Bp;
+  float* const* Cp;
+  size_t sA, sB, sC;   // batch strides (elements); for the blob sA counts ROWS (m)
+  int M, N, K, kc;
+  int lda, ldb, ldc;
+  int batch, tiles_m, tiles_n;
+  float alpha, beta;
+};
+
+constexpr int BK32 = 32;
+constexpr int APITCH = BK32 + 1;  // floats per A row in LDS: column reads by 16 rows x 2 k hit 32 distinct banks
+
+template <int BM, int BN, int WM, int WN, bool SPARSE>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const Gemm32Args p) {
+  static_assert(WM * WN == 4, "4 waves");
+  constexpr int TM = BM / WM, TN = BN / WN, FM = TM / 16, FN = TN / 16;
+  constexpr int BPITCH = BN + 16;  // the two k-rows a 32-lane half reads land on different bank halves
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* As = reinterpret_cast<float*>(smem);     // [BM][APITCH]
+  float* Bs = As + BM * APITCH;                   // [BK32][BPITCH]
+
+  const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const unsigned wm = wave / WN, wn = wave % WN;
+  const unsigned tiles = (unsigned)p.tiles_m * (unsigned)p.tiles_n;
+  const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
+  const unsigned b = lid / tiles, trem = lid - b * tiles;
+  const unsigned tile_m = trem / (unsigned)p.tiles_n, tile_n = trem - tile_m * (unsigned)p.tiles_n;
+  const int m0 = (int)tile_m * BM, n0 = (int)tile_n * BN;
+
+  const float* A = SPARSE ? nullptr : (p.Ap ? p.Ap[b] : p.A + (size_t)b * p.sA);
+  const float* B = p.Bp ? p.Bp[b] : p.B + (size_t)b * p.sB;
+  float* C = p.Cp ? p.Cp[b] : p.C + (size_t)b * p.sC;
+  const size_t row_base = SPARSE ? (size_t)b * p.sA : 0;  // first blob row of this grid batch
+  const bool a_vec = !SPARSE && (p.lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(A) & 15u) == 0);
+  const bool b_vec = (p.ldb % 4 == 0) && ((reinterpret_cast<uintptr_t>(B) & 15u) == 0);
+
+  f4 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+
+  // staging registers: A tile BM x 32 floats = BM*8 float4 / 256 threads; B tile 32 x BN
+  constexpr int A_CH = BM * 8 / 256, B_CH = 32 * (BN / 4) / 256;
+  f4 ra[A_CH], rb[B_CH];
+
+  auto load4 = [](const float* rowp, int col, int limit, bool row_ok, bool vec) -> f4 {
+    f4 v = {0.f, 0.f, 0.f, 0.f};
+    if (!row_ok || col >= limit) return v;
+    if (vec && col + 4 <= limit) return *reinterpret_cast<const f4*>(rowp + col);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) v[t] = (col + t < limit) ? rowp[col + t] : 0.0f;
+    return v;
+  };
+
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i) {
+      const unsigned q = tid + 256u * i, row = q >> 3, ch = q & 7u;  // 8 strips of 4 dense k per row
+      const int gr = m0 + (int)row, kk = k0 + 4 * (int)ch;
+      if constexpr (SPARSE) {
+        // expand one strip: two kept values + their nibble -> four dense k
+        f4 v = {0.f, 0.f, 0.f, 0.f};
+        if (gr < p.M && kk < p.kc) {
+          const size_t R = row_base + (size_t)gr;
+          const float* vp = reinterpret_cast<const float*>(p.vals) + R * (size_t)(p.kc / 2) + kk / 2;
+          const float a0 = vp[0], a1 = vp[1];
+          const unsigned mb = *reinterpret_cast<const unsigned char*>(p.meta + R * (size_t)(p.kc / 8) + kk / 8);
+          const unsigned nib = (mb >> (4 * ((kk >> 2) & 1))) & 0xfu, p0 = nib & 3u, p1 = nib >> 2;
+#pragma unroll
+          for (unsigned t = 0; t < 4; ++t) v[t] = t == p0 ? a0 : (t == p1 ? a1 : 0.0f);
+        }
+        ra[i] = v;
+      } else {
+        ra[i] = load4(A + (size_t)gr * p.lda, kk, p.K, gr < p.M, a_vec);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < B_CH; ++i) {
+      const unsigned q = tid + 256u * i, kr = q / (BN / 4), cn = q % (BN / 4);
+      const int gk = k0 + (int)kr;
+      rb[i] = load4(B + (size_t)gk * p.ldb, n0 + 4 * (int)cn, p.N, gk < p.K, b_vec);
+    }
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i) {
+      const unsigned q = tid + 256u * i, row = q >> 3, ch = q & 7u;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) As[row * APITCH + 4 * ch + t] = ra[i][t];
+    }
+#pragma unroll
+    for (int i = 0; i < B_CH; ++i) {
+      const unsigned q = tid + 256u * i, kr = q / (BN / 4), cn = q % (BN / 4);
+      *reinterpret_cast<f4*>(Bs + kr * BPITCH + 4 * cn) = rb[i];
+    }
+  };
+
+  const int Kloop = SPARSE ? p.kc : p.K;
+  const int nkt = (Kloop + BK32 - 1) / BK32;
+  gload(0);
+  for (int kt = 0; kt < nkt; ++kt) {
+    lstore();
+    __syncthreads();
+    if (kt + 1 < nkt) gload((kt + 1) * BK32);
+#pragma unroll
+    for (int s = 0; s < BK32 / 4; ++s) {
+      float af[FM], bf[FN];
+#pragma unroll
+      for (int i = 0; i < FM; ++i) af[i] = As[(wm * TM + i * 16 + (lane & 15u)) * APITCH + 4 * s + (lane >> 4)];
+#pragma unroll
+      for (int j = 0; j < FN; ++j) bf[j] = Bs[(4 * s + (lane >> 4)) * BPITCH + wn * TN + j * 16 + (lane & 15u)];
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+          // swapped operands: lane holds C[row lane&15][cols 4*(lane>>4) .. +3]
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j], af[i], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  const bool c_vec = (p.ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(C) & 15u) == 0);
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      const int gr = m0 + (int)(wm * TM + i * 16 + (lane & 15u));
+      const int gc = n0 + (int)(wn * TN + j * 16 + 4u * (lane >> 4));
+      if (gr >= p.M || gc >= p.N) continue;
+      float* dst = C + (size_t)gr * p.ldc + gc;
+      f4 v;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = p.alpha * acc[i][j][r];
+      if (c_vec && gc + 4 <= p.N) {
+        if (p.beta != 0.0f) {
+          const f4 old = *reinterpret_cast<const f4*>(dst);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += p.beta * old[r];
+        }
+        *reinterpret_cast<f4*>(dst) = v;
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (gc + r < p.N) dst[r] = p.beta != 0.0f ? v[r] + p.beta * dst[r] : v[r];
+      }
+    }
+}
+
+template <int BM, int BN, int WM, int WN, bool SPARSE>
+static int launch32(const Gemm32Args& a0, hipStream_t st) {
+  Gemm32Args a = a0;
+  a.tiles_m = (a.M + BM - 1) / BM;
+  a.tiles_n = (a.N + BN - 1) / BN;
+  const size_t nwg = (size_t)a.tiles_m * a.tiles_n * a.batch;
+  if (nwg == 0) return SM_STATUS_SUCCESS;
+  if (nwg > 0x7fffffffu) {
+    set_error("gemm_f32: grid too large");
+    return SM_STATUS_NOT_SUPPORTED;
+  }
+  constexpr size_t lds = ((size_t)BM * APITCH + (size_t)BK32 * (BN + 16)) * sizeof(float);
+  gemm_f32_kernel<BM, BN, WM, WN, SPARSE><<<dim3((unsigned)nwg), dim3(256), lds, st>>>(a);
+  return check_launch("gemm_f32_kernel");
+}
+
+template <bool SPARSE>
+static int dispatch32(const Gemm32Args& a, hipStream_t st) {
+  if (a.N <= 64) return launch32<128, 64, 4, 1, SPARSE>(a, st);
+  if (a.M <= 64) return launch32<64, 128, 1, 4, SPARSE>(a, st);
+  return launch32<128, 128, 2, 2, SPARSE>(a, st);
+}
+
+// ---- fp64: plain FMA tiles, 64 x 64 outputs per 256-thread workgroup, 4 x 4 per thread ------------
+struct Gemm64Args {
+  const double* const* Ap;
+  const double* const* Bp;
+  double* const* Cp;
+  int M, N, K, lda, ldb, ldc;  // row-major view (see sm_gemm_batched_f64)
+  double alpha, beta;
+};
+__global__ __launch_bounds__(256) void gemm_f64_kernel(const Gemm64Args p) {
+  __shared__ double As[64][17], Bs[16][65];
+  const unsigned tid = threadIdx.x, tx = tid & 15u, ty = tid >> 4;
+  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  const double* A = p.Ap[blockIdx.z];
+  const double* B = p.Bp[blockIdx.z];
+  double* C = p.Cp[blockIdx.z];
+  double acc[4][4] = {};
+  for (int k0 = 0; k0 < p.K; k0 += 16) {
+    for (unsigned q = tid; q < 64 * 16; q += 256) {
+      const int r = q >> 4, c = q & 15;
+      As[r][c] = (m0 + r < p.M && k0 + c < p.K) ? A[(size_t)(m0 + r) * p.lda + k0 + c] : 0.0;
+    }
+    for (unsigned q = tid; q < 16 * 64; q += 256) {
+      const int r = q >> 6, c = q & 63;
+      Bs[r][c] = (k0 + r < p.K && n0 + c < p.N) ? B[(size_t)(k0 + r) * p.ldb + n0 + c] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      double a[4], bb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = As[ty * 4 + i][kk];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bb[j] = Bs[kk][tx * 4 + j];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = fma(a[i], bb[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) {
+      const int r = m0 + ty * 4 + i, c = n0 + tx * 4 + j;
+      if (r < p.M && c < p.N) {
+        double* d = C + (size_t)r * p.ldc + c;
+        *d = p.beta != 0.0 ? p.alpha * acc[i][j] + p.beta * *d : p.alpha * acc[i][j];
+      }
+    }
+}
+
+}  // namespace sm
+
+using namespace sm;
+
+extern "C" {
+
+int sm_gemm_rowmajor_f32(const float* A, const float* B, float* C, size_t m, size_t n, size_t k, size_t lda, size_t batch,
+                         size_t strideA, size_t strideB, size_t strideC, float alpha, float beta, sm_stream_t stream) {
+  if (!A || !B || !C || lda < k) {
+    set_error("sm_gemm_rowmajor_f32: invalid argument");
+    return SM_STATUS_INVALID_VALUE;
+  }
+  if (m == 0 || n == 0 || batch == 0) return SM_STATUS_SUCCESS;
+  if (m * batch > 0x7fffffffull || n > 0x7fffffffull || k > 0x7fffffffull || lda > 0x7fffffffull) {
+    set_error("sm_gemm_rowmajor_f32: dimension exceeds 2^31-1");
+    return SM_STATUS_NOT_SUPPORTED;
+  }
+  Gemm32Args a = {};
+  a.A = A; a.B = B; a.C = C;
+  a.M = (int)m; a.N = (int)n; a.K = (int)k;
+  a.lda = (int)lda; a.ldb = (int)n; a.ldc = (int)n;
+  a.sA = strideA; a.sB = strideB; a.sC = strideC;
+  a.batch = (int)batch; a.alpha = alpha; a.beta = beta;
+  if (batch > 1 && strideB == 0 && strideA == m * lda && strideC == m * n) {
+    a.M = (int)(m * batch);
+    a.batch = 1;
+  }
+  return dispatch32<false>(a, (hipStream_t)stream);
+}
+
+int sm_gemm_batched_f32(const float* const* A_ptrs, const float* const* B_ptrs, float* const* C_ptrs, size_t m, size_t n,
+                        size_t k, size_t batch, int ta, int tb, float alpha, float beta, sm_stream_t stream) {
+  if (!A_ptrs || !B_ptrs || !C_ptrs) {
+    set_error("sm_gemm_batched_f32: null pointer array");
+    return SM_STATUS_INVALID_VALUE;
+  }
+  if (ta != SM_OP_N || tb != SM_OP_N) {
+    set_error("sm_gemm_batched_f32: transposed operands are not implemented (no reference driver passes them)");
+    return SM_STATUS_NOT_SUPPORTED;
+  }
+  if (m == 0 || n == 0 || batch == 0) return SM_STATUS_SUCCESS;
+  if (m > 0x7fffffffull || n > 0x7fffffffull || k > 0x7fffffffull || batch > 0x7fffffffull) {
+    set_error("sm_gemm_batched_f32: dimension exceeds 2^31-1");
+    return SM_STATUS_NOT_SUPPORTED;
+  }
+  // column-major C = A*B  <=>  row-major C^T[n x m] = B^T[n x k] * A^T[k x m]
+  Gemm32Args a = {};
+  a.Ap = B_ptrs; a.Bp = A_ptrs; a.Cp = C_ptrs;
+  a.M = (int)n; a.N = (int)m; a.K = (int)k;
+  a.lda = (int)k; a.ldb = (int)m; a.ldc = (int)m;
+  a.batch = (int)batch; a.alpha = alpha; a.beta = beta;
+  return dispatch32<false>(a, (hipStream_t)stream);
+}
+
+int sm_spmma_f32(const void* blob, const float* B, float* C, size_t m, size_t n, size_t k, size_t batch, size_t strideB,
+                 size_t strideC, float alpha, float beta, sm_stream_t stream) {
+  if (!blob || !B || !C) {
+    set_error("sm_spmma_f32: invalid argument");
+    return SM_STATUS_INVALID_VALUE;
+  }
+  if (m == 0 || n == 0 || batch == 0) return SM_STATUS_SUCCESS;
+  if (m * batch > 0x7fffffffull || n > 0x7fffffffull || k > 0x7fffffffull) {
+    set_error("sm_spmma_f32: dimension exceeds 2^31-1");
+    return SM_STATUS_NOT_SUPPORTED;
+  }
+  const BlobLayout L = blob_layout(m, k, 4, batch);
+  Gemm32Args a = {};
+  a.vals = (const char*)blob;
+  a.meta = (const char*)blob + L.meta_off;
+  a.B = B; a.C = C;
+  a.M = (int)m; a.N = (int)n; a.K = (int)k; a.kc = (int)L.kc;
+  a.ldb = (int)n; a.ldc = (int)n;
+  a.sA = m; a.sB = strideB; a.sC = strideC;
+  a.batch = (int)batch; a.alpha = alpha; a.beta = beta;
+  if (batch > 1 && strideB == 0 && strideC == m * n) {
+    a.M = (int)(m * batch);
+    a.batch = 1;
+  }
+  return dispatch32<true>(a, (hipStream_t)stream);
+}
+
+int sm_gemm_batched_f64(const double* const* A_ptrs, const double* const* B_ptrs, double* const* C_ptrs, size_t m, size_t n,
+                        size_t k, size_t batch, int ta, int tb, double alpha, double beta, sm_stream_t stream) {
+  if (!A_ptrs || !B_ptrs || !C_ptrs) {
+    set_error("sm_gemm_batched_f64: null pointer array");
+    return SM_STATUS_INVALID_VALUE;
+  }
+  if (ta != SM_OP_N || tb != SM_OP_N) {
+    set_error("sm_gemm_batched_f64: transposed operands are not implemented (no reference driver passes them)");
+    return SM_STATUS_NOT_SUPPORTED;
+  }
+  if (m == 0 || n == 0 || batch == 0) return SM_STATUS_SUCCESS;
+  if (m > 0x7fffffffull || n > 0x7fffffffull || k > 0x7fffffffull || batch > 65535) {
+    set_error("sm_gemm_batched_f64: dimension not supported");
+    return SM_STATUS_NOT_SUPPORTED;
+  }
+  Gemm64Args a = {};
+  a.Ap = B_ptrs; a.Bp = A_ptrs; a.Cp = C_ptrs;  // transposed view, as for fp32
+  a.M = (int)n; a.N = (int)m; a.K = (int)k;
+  a.lda = (int)k; a.ldb = (int)m; a.ldc = (int)m;
+  a.alpha = alpha; a.beta = beta;
+  dim3 grid((unsigned)ceil_div(a.N, 64), (unsigned)ceil_div(a.M, 64), (unsigned)batch);
+  gemm_f64_kernel<<<grid, dim3(256), 0, (hipStream_t)stream>>>(a);
+  return check_launch("gemm_f64_kernel");
+}
+
+}  // extern "C"
