@@ -4,14 +4,17 @@
 Metric: effective GF/s (2:4 spmma vs dense gemm) on the ResNet-50 layer shapes, fp16, b = 32.
 A "step" is one pass of the hot path over the whole table: for each of the 49 layers, compress
 (the fused 2:4 prune + compress of the per-batch activation operand A) and then the 2:4
-sparse x dense matmul.  value = dense-equivalent flops (2*m*n*k*b summed over the table, times the
-number of ranks) / time.  Inputs are generated on the device and are resident in HBM before the
-timed region starts.  Multi-GPU: every rank runs the same table on its own seeded batch (weak
-scaling, no data-path collective); one tiny all-reduce (RCCL) takes the max time over ranks.
+sparse x dense matmul.  value = dense-equivalent flops (2*m*n*k*b summed over the table, summed
+over ranks) / time.  Inputs are generated on the device and are resident in HBM before the timed
+region starts.  The step's 98 launches are captured once into a hipGraph and replayed (the launches
+are 7-80 us each; without the graph the Python/ctypes call cost would be on the clock).
 
-Besides the contract line's fields the JSON carries: per-stage throughputs (matmul only, compress,
-prune, the dense GEMMs that are the metric's denominator), `roofline` for the dominant kernel and
-`cpu_baseline` (the oracle's arithmetic timed on the host cores; rank 0, N = 1 only).
+Multi-GPU: one process per GPU; every rank runs the same table on its own seeded batch (weak
+scaling, no data-path collective); one tiny all-reduce (RCCL) gives sum(flops) and max(time).
+
+Besides the contract line's fields the JSON carries `stages` (matmul only, compress only, and the
+dense GEMMs that are the metric's denominator), `roofline` for the dominant kernel of the timed step
+and `cpu_baseline` (the oracle's arithmetic timed on the host cores; rank 0, N = 1 only).
 """
 import argparse
 import csv
@@ -35,11 +38,12 @@ def read_shapes(path):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--table", default=os.path.join(ROOT, "datasets", "resnet50.csv"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the per-stage / denominator passes")
+    ap.add_argument("--eager", action="store_true", help="launch from Python instead of replaying a hipGraph")
     args = ap.parse_args()
 
     import torch
@@ -59,6 +63,7 @@ def main():
     dev = torch.device("cuda", torch.cuda.current_device())
 
     sm = ge.load_package()
+    mg = ge.load_package_module("multigpu")
     sm.device_check()  # raises when the HIP library or a gfx950 device is missing: no fallback
 
     shapes = read_shapes(args.table)
@@ -83,28 +88,38 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed(fn, steps, warmup):
+    def make_runner(fn):
+        """fn replayed from a hipGraph (one graph = one call of fn), or fn itself with --eager."""
+        fn()  # first call outside capture: lazy module loads, function attributes
+        torch.cuda.synchronize()
+        if args.eager:
+            return fn
+        try:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=torch.cuda.Stream()):
+                fn()
+            return g.replay
+        except Exception as e:  # capture unsupported: fall back to eager launches, and say so
+            sys.stderr.write(f"bench: hipGraph capture failed ({e}); launching eagerly\n")
+            return fn
+
+    def timed(run, steps, warmup):
         for _ in range(warmup):
-            fn()
+            run()
         barrier()
         t0 = time.perf_counter()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
         for _ in range(steps):
-            fn()
-        e1.record()
+            run()
         torch.cuda.synchronize()
         wall = time.perf_counter() - t0
         barrier()
-        return wall, e0.elapsed_time(e1) * 1e-3
+        return wall
 
-    wall, _ = timed(step_full, args.steps, args.warmup)
-    if world > 1:
-        t = torch.tensor([wall], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall = float(t.item())
-    ms_per_step = wall / args.steps * 1e3
-    value = flops * world / (wall / args.steps) / 1e9
+    run_full = make_runner(step_full)
+    wall = timed(run_full, args.steps, args.warmup)
+    tot_flops, wall_max = mg.rollup(flops * args.steps, wall, dev)
+    ms_per_step = wall_max / args.steps * 1e3
+    value = tot_flops / wall_max / 1e9
 
     out = {
         "metric": "effective GF/s (2:4 spmma vs dense gemm) on ResNet-50 layer shapes",
@@ -114,15 +129,15 @@ def main():
         "config": {"workload": "datasets/resnet50.csv: 49 conv layers as im2col GEMMs (m,n,k) at b=32, fp16; "
                                "step = per layer compress24 (fused 2:4 prune+compress of A) + 2:4 spmma",
                    "layers": len(layers), "batch": layers[0]["b"], "dense_equiv_gflop_per_step": flops / 1e9,
+                   "launch": "eager" if args.eager else "hipGraph replay of one step",
                    "parallelism": f"replicated table x{world}, per-rank batch, no data-path collective"},
     }
 
     if rank == 0 and not args.no_extras:
-        R = max(3, args.steps)
+        R = max(5, args.steps)
 
-        def dev_time(fn):
-            _, t = timed(fn, R, 1)
-            return t / R
+        def sec_per_call(fn):
+            return timed(make_runner(fn), R, 2) / R
 
         def spmma_only():
             for L in layers:
@@ -147,29 +162,37 @@ def main():
             for L in layers:
                 sm.gemm_batched(L["Ap"], L["Bp"], L["Cp"], L["m"], L["n"], L["k"], L["b"], "f16")
 
-        t_mul, t_cmp = dev_time(spmma_only), dev_time(compress_only)
-        t_drm, t_dcm = dev_time(dense_rowmajor), dev_time(dense_batched)
-        t_full = dev_time(step_full)
+        t_mul, t_cmp = sec_per_call(spmma_only), sec_per_call(compress_only)
+        t_drm, t_dcm = sec_per_call(dense_rowmajor), sec_per_call(dense_batched)
+        t_full = wall / args.steps
         gfs = lambda t: flops / t / 1e9
         out["stages"] = {
-            "spmma_mul_gfs": gfs(t_mul), "compress_ms": t_cmp * 1e3, "spmma_mul_ms": t_mul * 1e3,
-            "full_path_device_ms": t_full * 1e3,
-            "dense_gemm_batched_colmajor_gfs": gfs(t_dcm), "dense_gemm_rowmajor_gfs": gfs(t_drm),
-            "speedup_mul_vs_dense_batched": t_dcm / t_mul, "speedup_mul_vs_dense_rowmajor": t_drm / t_mul,
-            "speedup_full_vs_dense_batched": t_dcm / t_full,
+            "spmma_mul_gfs": gfs(t_mul), "spmma_mul_ms": t_mul * 1e3, "compress_ms": t_cmp * 1e3,
+            "dense_gemm_rowmajor_gfs": gfs(t_drm), "dense_gemm_rowmajor_ms": t_drm * 1e3,
+            "dense_gemm_batched_colmajor_gfs": gfs(t_dcm), "dense_gemm_batched_colmajor_ms": t_dcm * 1e3,
+            "speedup_mul_vs_dense_rowmajor": t_drm / t_mul, "speedup_mul_vs_dense_batched": t_dcm / t_mul,
+            "speedup_full_vs_dense_rowmajor": t_drm / t_full, "speedup_full_vs_dense_batched": t_dcm / t_full,
         }
-        # roofline of the dominant kernel of the timed step
+        # roofline of the dominant kernel of the timed step (algorithmic bytes: SURVEY.md 8(d))
         s = 2
         by_spmma = sum(L["b"] * (L["m"] * L["k"] * s / 2 + L["m"] * L["k"] / 8 + L["m"] * L["n"] * s) + s * L["k"] * L["n"]
                        for L in layers)
         by_cmp = sum(L["b"] * L["m"] * L["k"] * (s + s / 2 + 1 / 8) for L in layers)
-        dom, by, t = ("spmma_f16_kernel", by_spmma, t_mul) if t_mul >= t_cmp else ("compress_kernel", by_cmp, t_cmp)
+        dom, by, t = ("compress_kernel", by_cmp, t_cmp) if t_cmp >= t_mul else ("spmma_f16_dma_kernel", by_spmma, t_mul)
         ach = by / t / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")  # written by tools/pmc_traffic.py from rocprofv3 --pmc passes
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(dom, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
         out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": ach / HBM_PEAK_GBS, "traffic": None, "kernel": dom,
+                           "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "kernel": dom,
                            "launches_per_step": len(layers), "avg_launch_us": t / len(layers) * 1e6,
-                           "algorithmic_bytes_per_step": by,
-                           "other": {"compress_kernel_GBs": by_cmp / t_cmp / 1e9, "spmma_f16_kernel_GBs": by_spmma / t_mul / 1e9}}
+                           "algorithmic_bytes_per_launch": by / len(layers),
+                           "both_kernels_GBs": {"compress_kernel": by_cmp / t_cmp / 1e9,
+                                                "spmma_f16_dma_kernel": by_spmma / t_mul / 1e9}}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(ge, shapes)
@@ -183,7 +206,7 @@ def main():
 
 def cpu_baseline(ge, shapes):
     """The oracle's arithmetic ('port': fp32 accumulate, OpenMP over rows) on the host cores, on a
-    bounded sample: for every unique (m,n,k) of the table, `rows` rows of one batch; both the dense
+    bounded sample: one batch (b = 1) of every unique (m,n,k) of the table, repeated; both the dense
     product and the 2:4 path (STRIP selection fused with the two kept MACs per strip)."""
     import numpy as np
     orc = ge.load_oracle()
