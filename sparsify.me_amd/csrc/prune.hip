@@ -190,9 +190,10 @@ __global__ __launch_bounds__(256) void prune_strip_kernel(const T* A_in, T* A_ou
                                                           size_t ld, bool vec_ok) {
   const size_t ipr = (k + 7) / 8;  // items per row
   const size_t total = m * ipr;
+  const bool flat = ld == k && (k & 7) == 0;  // rows are back to back: no 64-bit division per item
   for (size_t it = blockIdx.x * (size_t)256 + threadIdx.x; it < total; it += (size_t)gridDim.x * 256) {
-    const size_t row = it / ipr, c = (it - row * ipr) * 8;
-    const size_t nvalid = k - c < 8 ? k - c : 8;
+    const size_t row = flat ? 0 : it / ipr, c = (it - row * ipr) * 8;
+    const size_t nvalid = flat ? 8 : (k - c < 8 ? k - c : 8);
     Vec8<T> v;
     load8(v, A_in + row * ld + c, nvalid, vec_ok);
 #pragma unroll
@@ -269,10 +270,11 @@ __global__ __launch_bounds__(256) void prune_check_kernel(const T* A, size_t m, 
                                                           bool vec_ok, int* d_valid) {
   const size_t ipr = (k + 7) / 8;
   const size_t total = m * ipr;
+  const bool flat = ld == k && (k & 7) == 0;
   bool bad = false;
   for (size_t it = blockIdx.x * (size_t)256 + threadIdx.x; it < total; it += (size_t)gridDim.x * 256) {
-    const size_t row = it / ipr, c = (it - row * ipr) * 8;
-    const size_t nvalid = k - c < 8 ? k - c : 8;
+    const size_t row = flat ? 0 : it / ipr, c = (it - row * ipr) * 8;
+    const size_t nvalid = flat ? 8 : (k - c < 8 ? k - c : 8);
     Vec8<T> v;
     load8(v, A + row * ld + c, nvalid, vec_ok);
 #pragma unroll
@@ -299,6 +301,7 @@ __global__ __launch_bounds__(256) void compress_kernel(const T* A, size_t m, siz
   __shared__ __attribute__((aligned(16))) unsigned char smeta[1024];
   const size_t ipr = kc / 8;        // items per blob row
   const size_t total = M * ipr;     // a multiple of 8 (kc % 64 == 0)
+  const bool flat = kc == k && ld == k && strideA == m * ld;
   const size_t nchunk = (total + 1023) / 1024;
   for (size_t chunk = blockIdx.x; chunk < nchunk; chunk += gridDim.x) {
 #pragma unroll
@@ -306,18 +309,19 @@ __global__ __launch_bounds__(256) void compress_kernel(const T* A, size_t m, siz
       const size_t it = chunk * 1024 + j * 256 + threadIdx.x;
       unsigned char mb = 0x44;
       if (it < total) {
-        const size_t R = it / ipr, c = (it - R * ipr) * 8;
+        // flat: no padding columns and batches/rows back to back -> item `it` is input elements [8*it, 8*it+8)
+        const size_t R = flat ? 0 : it / ipr, c = flat ? 0 : (it - R * ipr) * 8;
         T out[4] = {0, 0, 0, 0};
-        if (c < k) {
-          const size_t b = R / m, i = R - b * m;
-          const size_t nvalid = k - c < 8 ? k - c : 8;
+        if (flat || c < k) {
+          const size_t b = flat ? 0 : R / m, i = R - b * m;
+          const size_t nvalid = flat ? 8 : (k - c < 8 ? k - c : 8);
           Vec8<T> v;
-          load8(v, A + b * strideA + i * ld + c, nvalid, vec_ok);
+          load8(v, flat ? A + it * 8 : A + b * strideA + i * ld + c, nvalid, vec_ok);
           unsigned nib[2];
 #pragma unroll
           for (unsigned s = 0; s < 2; ++s) {
             // a strip wholly at or beyond k keeps the padding nibble 0x4 and zero values
-            const unsigned keep = (c + 4 * s < k)
+            const unsigned keep = (flat || c + 4 * s < k)
                                       ? strip_keepmask(key_of(v.e[4 * s]), key_of(v.e[4 * s + 1]),
                                                        key_of(v.e[4 * s + 2]), key_of(v.e[4 * s + 3]))
                                       : 3u;

@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--out", default=None)
     ap.add_argument("--only", default=None, help="comma list of stages to run")
+    ap.add_argument("--hot", action="store_true", help="one buffer set per shape (cache-resident for small layers)")
     args = ap.parse_args()
     import torch
     import __graft_entry__ as ge
@@ -56,31 +57,66 @@ def main():
     print("%6s %5s %5s %3s %3s %-10s %9s %9s %8s %8s %6s" % hdr)
     for (m, n, k, b), cnt in uniq:
         s = 2
-        A = torch.empty(b * m * k, dtype=torch.float16, device=dev)
+        # several buffer sets cycled call by call, so that a layer whose operands fit the 256 MiB Infinity
+        # Cache is not timed on cache-resident data (bench.py streams 10 GB per step; this mimics it)
+        foot = b * m * k * 2 * 1.6 + b * m * n * 2
+        nbuf = 1 if args.hot else max(1, min(8, int(1.0e9 // foot) + 1))
+        sets = []
+        for i in range(nbuf):
+            A = torch.empty(b * m * k, dtype=torch.float16, device=dev)
+            sm.fill_uniform(A, 1234 + m + k + 17 * i, 0.0, 1.0)
+            C = torch.empty(b * m * n, dtype=torch.float16, device=dev)
+            blob = torch.empty(sm.compress24_size(m, k, 2, b), dtype=torch.uint8, device=dev)
+            sm.compress24(A, m, k, k, b, m * k, blob)
+            Ap = torch.tensor([A.data_ptr() + 2 * j * m * k for j in range(b)], dtype=torch.int64, device=dev)
+            Cp = torch.tensor([C.data_ptr() + 2 * j * m * n for j in range(b)], dtype=torch.int64, device=dev)
+            sets.append(dict(A=A, A2=A.clone(), C=C, blob=blob, Ap=Ap, Cp=Cp))
         Bm = torch.empty(k * n, dtype=torch.float16, device=dev)
-        sm.fill_uniform(A, 1234 + m + k, 0.0, 1.0)
         sm.fill_uniform(Bm, 99 + n, 0.0, 1.0)
-        A2 = A.clone()
-        C = torch.empty(b * m * n, dtype=torch.float16, device=dev)
-        blob = torch.empty(sm.compress24_size(m, k, 2, b), dtype=torch.uint8, device=dev)
+        Bp = torch.tensor([Bm.data_ptr()] * b, dtype=torch.int64, device=dev)
         mask = torch.empty(m * k, dtype=torch.int64, device=dev)
         valid = torch.zeros(1, dtype=torch.int32, device=dev)
-        Ap = torch.tensor([A.data_ptr() + 2 * i * m * k for i in range(b)], dtype=torch.int64, device=dev)
-        Bp = torch.tensor([Bm.data_ptr()] * b, dtype=torch.int64, device=dev)
-        Cp = torch.tensor([C.data_ptr() + 2 * i * m * n for i in range(b)], dtype=torch.int64, device=dev)
-        sm.compress24(A, m, k, k, b, m * k, blob)
+        ctr = [0]
+
+        def nxt():
+            ctr[0] += 1
+            return sets[ctr[0] % nbuf]
         flops = 2.0 * m * n * k * b
         dense_bytes = b * s * (m * k + m * n) + s * k * n
         sp_bytes = b * (m * k * s / 2 + m * k / 8 + m * n * s) + s * k * n
+
+        def f_gemm():
+            S = nxt(); sm.gemm_batched(S["Ap"], Bp, S["Cp"], m, n, k, b, "f16")
+
+        def f_gemm_rm():
+            S = nxt(); sm.gemm_rowmajor(S["A"], Bm, S["C"], m, n, k, batch=b)
+
+        def f_spmma():
+            S = nxt(); sm.spmma(S["blob"], Bm, S["C"], m, n, k, b, 0)
+
+        def f_compress():
+            S = nxt(); sm.compress24(S["A"], m, k, k, b, m * k, S["blob"])
+
+        def f_prune_s():
+            S = nxt(); sm.prune24(S["A2"], S["A2"], b * m, k, k, sm.PRUNE_STRIP)
+
+        def f_prune_t():
+            S = nxt(); sm.prune24(S["A2"], S["A2"], b * m, k, k, sm.PRUNE_TILE)
+
+        def f_check():
+            S = nxt(); sm.prune24_check(S["A2"], b * m, k, k, valid)
+
+        def f_prune():
+            S = nxt(); sm.sparsify(S["A2"][: m * k], mask, m, k, 0.5)
         stages = [
-            ("gemm", lambda: sm.gemm_batched(Ap, Bp, Cp, m, n, k, b, "f16"), flops, dense_bytes, MFMA_F16),
-            ("gemm_rm", lambda: sm.gemm_rowmajor(A, Bm, C, m, n, k, batch=b), flops, dense_bytes, MFMA_F16),
-            ("spmma", lambda: sm.spmma(blob, Bm, C, m, n, k, b, 0), flops, sp_bytes, 2 * MFMA_F16),
-            ("compress", lambda: sm.compress24(A, m, k, k, b, m * k, blob), 0, b * m * k * (s + s / 2 + 1 / 8), 0),
-            ("prune_s", lambda: sm.prune24(A2, A2, b * m, k, k, sm.PRUNE_STRIP), 0, 2 * b * m * k * s, 0),
-            ("prune_t", lambda: sm.prune24(A2, A2, b * m, k, k, sm.PRUNE_TILE), 0, 2 * b * m * k * s, 0),
-            ("check", lambda: sm.prune24_check(A2, b * m, k, k, valid), 0, b * m * k * s, 0),
-            ("prune", lambda: sm.sparsify(A2[: m * k], mask, m, k, 0.5), 0, m * k * (s + s + 8), 0),
+            ("gemm", f_gemm, flops, dense_bytes, MFMA_F16),
+            ("gemm_rm", f_gemm_rm, flops, dense_bytes, MFMA_F16),
+            ("spmma", f_spmma, flops, sp_bytes, 2 * MFMA_F16),
+            ("compress", f_compress, 0, b * m * k * (s + s / 2 + 1 / 8), 0),
+            ("prune_s", f_prune_s, 0, 2 * b * m * k * s, 0),
+            ("prune_t", f_prune_t, 0, 2 * b * m * k * s, 0),
+            ("check", f_check, 0, b * m * k * s, 0),
+            ("prune", f_prune, 0, m * k * (s + s + 8), 0),
         ]
         rec = {"m": m, "n": n, "k": k, "b": b}
         for name, fn, fl, by, peak in stages:
@@ -94,7 +130,7 @@ def main():
             t = tot.setdefault(name, [0.0, 0.0, 0.0, 0.0])
             t[0] += ms * cnt; t[1] += fl * cnt; t[2] += by * cnt; t[3] += roof * cnt
         out_rows.append(rec)
-        del A, A2, C, blob
+        del sets
     print("---- table totals (count-weighted)")
     for name, (ms, fl, by, roof) in tot.items():
         print("%-10s %9.3f ms  %9.1f effTF/s  %8.0f GB/s  roofline %8.1f us  frac %.3f" %
