@@ -315,8 +315,9 @@ int sm_prune24_check_f32_ref(const float* A, size_t m, size_t k, size_t ld, int*
  *   values      : [M][kc/2] elements at byte 0; row R = b*m + i; the two kept elements of the
  *                 strip covering columns 4q..4q+3 sit at [R][2q], [R][2q+1] in k order;
  *                 strips at or beyond k hold +0
- *   metadata    : [M][kc/8] bytes at byte meta_off = round_up(M*(kc/2)*elt, 256); byte
- *                 [R][q/2] holds strip q's nibble in bits 4*(q&1)..4*(q&1)+3;
+ *   metadata    : [kc/64][M][8] bytes (stage-major, see meta_index) at byte
+ *                 meta_off = round_up(M*(kc/2)*elt, 256); byte [q/16][R][(q%16)/2] holds strip q's
+ *                 nibble in bits 4*(q&1)..4*(q&1)+3;
  *                 nibble = p0 | p1 << 2, p0 < p1 the kept positions (the 2-bit codes
  *                 v_smfmac_* consumes, see profiles/probe_gfx950_r01.txt); padding strips
  *                 carry 0x4 (positions 0,1)
@@ -326,6 +327,12 @@ int sm_prune24_check_f32_ref(const float* A, size_t m, size_t k, size_t ld, int*
  * strip has fewer than two), and compress(A) == compress(prune_strip(A)) for any A.
  */
 static size_t round_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+/* Byte of the metadata section that holds strip q (dense columns 4q..4q+3) of blob row R, M rows in all.
+ * The section is STAGE-major: plane s = q / 16 covers dense k 64s..64s+63 of every row, 8 bytes per row:
+ * [kc/64][M][8].  (A 128-row x 64-k tile of the matmul is then 1 KiB of contiguous metadata -- one
+ * 8-cache-line DMA -- instead of 128 eight-byte pieces on 128 lines: profiles/stamp_r01.txt.) */
+static size_t meta_index(size_t M, size_t R, size_t q) { return ((q / 16) * M + R) * 8 + (q % 16) / 2; }
 
 int sm_compress24_layout(size_t m, size_t k, size_t elt_bytes, size_t batch, size_t* kc_out,
                          size_t* meta_off_out, size_t* total_out) {
@@ -351,6 +358,7 @@ int sm_compress24_size_ref(size_t m, size_t k, size_t elt_bytes, size_t batch, s
     memset(blob, 0, total);                                                                      \
     T* vals = (T*)blob;                                                                          \
     unsigned char* meta = (unsigned char*)blob + meta_off;                                       \
+    const size_t M = m * batch;                                                                  \
     for (size_t b = 0; b < batch; ++b)                                                           \
       for (size_t i = 0; i < m; ++i) {                                                           \
         const size_t R = b * m + i;                                                              \
@@ -368,7 +376,7 @@ int sm_compress24_size_ref(size_t m, size_t k, size_t elt_bytes, size_t batch, s
           }                                                                                      \
           vals[R * (kc / 2) + 2 * q] = v[nib & 3u];                                              \
           vals[R * (kc / 2) + 2 * q + 1] = v[nib >> 2];                                          \
-          meta[R * (kc / 8) + q / 2] |= (unsigned char)(nib << (4 * (q & 1)));                   \
+          meta[meta_index(M, R, q)] |= (unsigned char)(nib << (4 * (q & 1)));                    \
         }                                                                                        \
       }                                                                                          \
     return SM_OK;                                                                                \
@@ -394,7 +402,7 @@ int sm_compress24_f32_ref(const float* A, size_t m, size_t k, size_t ld, size_t 
         T* row = A + b * strideA + i * ld;                                                       \
         for (size_t c = 0; c < k; ++c) row[c] = 0;                                               \
         for (size_t q = 0; 4 * q < k; ++q) {                                                     \
-          const unsigned nib = (meta[R * (kc / 8) + q / 2] >> (4 * (q & 1))) & 0xfu;             \
+          const unsigned nib = (meta[meta_index(m * batch, R, q)] >> (4 * (q & 1))) & 0xfu;      \
           const unsigned p0 = nib & 3u, p1 = nib >> 2;                                           \
           if (4 * q + p0 < k) row[4 * q + p0] = vals[R * (kc / 2) + 2 * q];                      \
           if (4 * q + p1 < k) row[4 * q + p1] = vals[R * (kc / 2) + 2 * q + 1];                  \
@@ -434,7 +442,7 @@ static int spmma_ref_impl(const void* blob, const void* B, void* C, size_t m, si
       const size_t R = b * m + i;
       for (size_t j = 0; j < n; ++j) acc[j] = 0.0;
       for (size_t q = 0; 4 * q < k; ++q) {
-        const unsigned nib = (meta[R * (kc / 8) + q / 2] >> (4 * (q & 1))) & 0xfu;
+        const unsigned nib = (meta[meta_index(m * batch, R, q)] >> (4 * (q & 1))) & 0xfu;
         const unsigned pos[2] = {nib & 3u, nib >> 2};
         for (int t = 0; t < 2; ++t) {
           const size_t kk = 4 * q + pos[t];

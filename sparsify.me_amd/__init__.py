@@ -14,7 +14,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsparsifyme.so")
+# SPARSIFYME_LIB: diagnostic builds only (e.g. the cycle-stamped library of tools/); default is the in-tree product library
+LIB_PATH = os.environ.get("SPARSIFYME_LIB") or os.path.join(_HERE, "libsparsifyme.so")
 
 PRUNE_TILE = 0
 PRUNE_STRIP = 1

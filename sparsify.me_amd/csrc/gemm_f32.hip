@@ -18,7 +18,8 @@ namespace sm {
 struct Gemm32Args {
   const float* A;      // dense A (row-major M x K, lda) -- or null when `vals` is set
   const char* vals;    // 2:4 blob values  [Mtot][kc/2] floats
-  const char* meta;    // 2:4 blob metadata [Mtot][kc/8] bytes
+  const char* meta;    // 2:4 blob metadata, stage-major [kc/64][Mtot][8 B]
+  size_t Mtot;         // rows of the whole blob (m * batch)
   const float* B;
   float* C;
   const float* const* Ap;
@@ -89,7 +90,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const Gemm32Args p) {
           const size_t R = row_base + (size_t)gr;
           const float* vp = reinterpret_cast<const float*>(p.vals) + R * (size_t)(p.kc / 2) + kk / 2;
           const float a0 = vp[0], a1 = vp[1];
-          const unsigned mb = *reinterpret_cast<const unsigned char*>(p.meta + R * (size_t)(p.kc / 8) + kk / 8);
+          const unsigned mb = *reinterpret_cast<const unsigned char*>(p.meta + ((size_t)(kk >> 6) * p.Mtot + R) * 8 + ((kk >> 3) & 7));
           const unsigned nib = (mb >> (4 * ((kk >> 2) & 1))) & 0xfu, p0 = nib & 3u, p1 = nib >> 2;
 #pragma unroll
           for (unsigned t = 0; t < 4; ++t) v[t] = t == p0 ? a0 : (t == p1 ? a1 : 0.0f);
@@ -313,6 +314,7 @@ int sm_spmma_f32(const void* blob, const float* B, float* C, size_t m, size_t n,
   Gemm32Args a = {};
   a.vals = (const char*)blob;
   a.meta = (const char*)blob + L.meta_off;
+  a.Mtot = L.M;
   a.B = B; a.C = C;
   a.M = (int)m; a.N = (int)n; a.K = (int)k; a.kc = (int)L.kc;
   a.ldb = (int)n; a.ldc = (int)n;

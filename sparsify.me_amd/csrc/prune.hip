@@ -6,6 +6,8 @@
 // memory; selection is pure register work (integer compares on sign-cleared bit patterns), and
 // the byte-granular metadata is staged through LDS so it leaves the CU as coalesced dwords.
 // Semantics are frozen by oracle/sm_oracle.c; results must match it bit for bit.
+#include <stdlib.h>
+
 #include "sm_common.h"
 
 namespace sm {
@@ -137,6 +139,10 @@ __global__ void sparsify_generic_kernel(VT* w, uint64_t* mask, size_t nblk, size
       }
   }
 }
+
+// Metadata section: stage-major [kc/64][M][8 B] (oracle/sm_oracle.c: meta_index).  Byte of item `c8`
+// (8 dense k = 2 strips) of blob row R:
+__device__ __forceinline__ size_t meta_byte(size_t M, size_t R, size_t c8) { return ((c8 >> 3) * M + R) * 8 + (c8 & 7); }
 
 // ---------------------------------------------------------------------------------------------
 // element access helpers: 8 consecutive k of one row, vector path when aligned and in range
@@ -348,10 +354,85 @@ __global__ __launch_bounds__(256) void compress_kernel(const T* A, size_t m, siz
     }
     __syncthreads();
     {
-      const size_t mbyte = chunk * 1024 + threadIdx.x * 4;
-      if (mbyte < total) *reinterpret_cast<unsigned*>(meta + mbyte) = reinterpret_cast<const unsigned*>(smeta)[threadIdx.x];
+      // four consecutive items (same row: ipr is a multiple of 8) -> four consecutive metadata bytes
+      const size_t it4 = chunk * 1024 + threadIdx.x * 4;
+      if (it4 < total) {
+        const size_t R4 = it4 / ipr, c4 = it4 - R4 * ipr;
+        *reinterpret_cast<unsigned*>(meta + meta_byte(M, R4, c4)) = reinterpret_cast<const unsigned*>(smeta)[threadIdx.x];
+      }
     }
     __syncthreads();
+  }
+}
+
+// Fast path of compress: dense input with no padding columns, rows and batches back to back, 16-byte
+// aligned (every ResNet layer but k = 147).  No division, no LDS, no barrier: each lane issues its four
+// 16-byte loads up front (A is read exactly once: non-temporal), and the four metadata bytes of four
+// consecutive items -- held by the four lanes of a quad -- are gathered with DPP quad permutes so the quad's
+// first lane writes one dword.
+template <typename T, bool NT>
+__global__ __launch_bounds__(256) void compress_flat_kernel(const T* __restrict__ A, size_t total /*items of 8 dense k*/,
+                                                            size_t ipr /*items per row*/, size_t M,
+                                                            T* __restrict__ vals, unsigned char* __restrict__ meta) {
+  const bool small = total < 0xffffffffull;  // 32-bit division is a fraction of the 64-bit one
+  const size_t nchunk = (total + 1023) / 1024;
+  for (size_t chunk = blockIdx.x; chunk < nchunk; chunk += gridDim.x) {
+    const size_t it0 = chunk * 1024 + threadIdx.x;
+    Vec8<T> v[4];
+#pragma unroll
+    for (unsigned j = 0; j < 4; ++j) {
+      const size_t it = it0 + j * 256;
+      if (it < total) {
+        const u4* p = reinterpret_cast<const u4*>(A + it * 8);
+        if constexpr (sizeof(T) == 2) {
+          *reinterpret_cast<u4*>(v[j].e) = NT ? __builtin_nontemporal_load(p) : *p;
+        } else {
+          reinterpret_cast<u4*>(v[j].e)[0] = NT ? __builtin_nontemporal_load(p) : p[0];
+          reinterpret_cast<u4*>(v[j].e)[1] = NT ? __builtin_nontemporal_load(p + 1) : p[1];
+        }
+      } else {
+#pragma unroll
+        for (unsigned t = 0; t < 8; ++t) v[j].e[t] = 0;
+      }
+    }
+#pragma unroll
+    for (unsigned j = 0; j < 4; ++j) {
+      const size_t it = it0 + j * 256;
+      T out[4];
+      unsigned nib[2];
+#pragma unroll
+      for (unsigned s = 0; s < 2; ++s) {
+        const unsigned keep = strip_keepmask(key_of(v[j].e[4 * s]), key_of(v[j].e[4 * s + 1]), key_of(v[j].e[4 * s + 2]),
+                                             key_of(v[j].e[4 * s + 3]));
+        nib[s] = nibble_of(keep);
+        const unsigned p0 = nib[s] & 3u, p1 = nib[s] >> 2;
+        T a0 = v[j].e[4 * s], a1 = v[j].e[4 * s + 1];
+        a0 = p0 == 1 ? v[j].e[4 * s + 1] : a0;
+        a0 = p0 == 2 ? v[j].e[4 * s + 2] : a0;
+        a1 = p1 == 2 ? v[j].e[4 * s + 2] : a1;
+        a1 = p1 == 3 ? v[j].e[4 * s + 3] : a1;
+        out[2 * s] = a0;
+        out[2 * s + 1] = a1;
+      }
+      const int mb = (int)(nib[0] | (nib[1] << 4));
+      // bytes of the quad's four lanes -> one dword (same value in all four lanes)
+      const unsigned b0 = (unsigned)__builtin_amdgcn_update_dpp(0, mb, 0x00, 0xf, 0xf, true);
+      const unsigned b1 = (unsigned)__builtin_amdgcn_update_dpp(0, mb, 0x55, 0xf, 0xf, true);
+      const unsigned b2 = (unsigned)__builtin_amdgcn_update_dpp(0, mb, 0xaa, 0xf, 0xf, true);
+      const unsigned b3 = (unsigned)__builtin_amdgcn_update_dpp(0, mb, 0xff, 0xf, 0xf, true);
+      if (it < total) {
+        if constexpr (sizeof(T) == 2) {
+          *reinterpret_cast<u2*>(vals + it * 4) = *reinterpret_cast<const u2*>(out);
+        } else {
+          *reinterpret_cast<u4*>(vals + it * 4) = *reinterpret_cast<const u4*>(out);
+        }
+        // total is a multiple of 8, so a quad is all in or all out
+        if ((threadIdx.x & 3u) == 0) {
+          const size_t R = small ? (size_t)((unsigned)it / (unsigned)ipr) : it / ipr;
+          *reinterpret_cast<unsigned*>(meta + meta_byte(M, R, it - R * ipr)) = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+        }
+      }
+    }
   }
 }
 
@@ -365,7 +446,7 @@ __global__ __launch_bounds__(256) void decompress_kernel(const T* vals, const un
     const size_t R = it / ipr, c = (it - R * ipr) * 8;
     if (c >= k) continue;
     const size_t b = R / m, i = R - b * m;
-    const unsigned mb = meta[it];
+    const unsigned mb = meta[meta_byte(M, R, it - R * ipr)];
     T in[4];
     if constexpr (sizeof(T) == 2) {
       *reinterpret_cast<u2*>(in) = *reinterpret_cast<const u2*>(vals + it * 4);
@@ -481,6 +562,14 @@ static int launch_compress(const void* A, size_t m, size_t k, size_t ld, size_t 
   const bool vec_ok = vec_ok_2d<T>(A, A, ld, strideA);
   const size_t items = L.M * (L.kc / 8);
   const unsigned grid = stream_grid(ceil_div(items, 4), 256);
+  if (vec_ok && L.kc == k && ld == k && (batch == 1 || strideA == m * ld)) {
+    static const bool nt = !(getenv("SM_COMPRESS_NT") && atoi(getenv("SM_COMPRESS_NT")) == 0);
+    if (nt)
+      compress_flat_kernel<T, true><<<grid, 256, 0, st>>>((const T*)A, items, L.kc / 8, L.M, (T*)blob, (unsigned char*)blob + L.meta_off);
+    else
+      compress_flat_kernel<T, false><<<grid, 256, 0, st>>>((const T*)A, items, L.kc / 8, L.M, (T*)blob, (unsigned char*)blob + L.meta_off);
+    return check_launch("compress_flat_kernel");
+  }
   compress_kernel<T><<<grid, 256, 0, st>>>((const T*)A, m, k, ld, strideA, L.kc, L.M, (T*)blob,
                                            (unsigned char*)blob + L.meta_off, vec_ok);
   return check_launch("compress_kernel");

@@ -12,6 +12,8 @@
 // consecutive ROWS of one column; the epilogue transposes through LDS and stores 16-byte row pieces.
 #include <stdlib.h>
 
+#include <vector>
+
 #include "mma_tile.h"
 
 #ifndef SM_NT_A
@@ -22,7 +24,8 @@ namespace sm {
 
 struct SpmmaArgs {
   const char* vals;   // [Mtot][kc/2] halves, row pitch kc bytes
-  const char* meta;   // [Mtot][kc/8] bytes
+  const char* meta;   // stage-major [kc/64][Mtot][8 B]
+  size_t Mtot;        // rows of the whole blob (m * batch)
   const half_t* B;
   half_t* C;
   size_t sB, sC;      // batch strides (elements); rows of batch b are [b*m, (b+1)*m)
@@ -32,7 +35,21 @@ struct SpmmaArgs {
   int batch;          // grid batches (1 when stacked)
   int tiles_m, tiles_n;
   float alpha, beta;
+#ifdef SM_STAMP
+  unsigned long long* dbg;  // diagnostic build only: per-wave cycle sums (never in the product library)
+#endif
 };
+
+#ifdef SM_STAMP
+__device__ __forceinline__ unsigned long long sm_stamp() {
+  unsigned long long t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  return t;
+}
+#define SM_T(...) __VA_ARGS__
+#else
+#define SM_T(...)
+#endif
 
 template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(256) void spmma_f16_kernel(const SpmmaArgs p) {
@@ -58,7 +75,7 @@ __global__ __launch_bounds__(256) void spmma_f16_kernel(const SpmmaArgs p) {
 
   const size_t row_base = (size_t)b * p.m;  // first blob row of this grid batch
   const char* vals = p.vals + row_base * (size_t)p.kc;
-  const char* meta = p.meta + row_base * (size_t)(p.kc / 8);
+  const char* meta = p.meta + row_base * 8;  // + stage * Mtot * 8 per 64-k stage
   const half_t* B = p.B + (size_t)b * p.sB;
   half_t* C = p.C + (size_t)b * p.sC;
 
@@ -85,10 +102,10 @@ __global__ __launch_bounds__(256) void spmma_f16_kernel(const SpmmaArgs p) {
 #pragma unroll
     for (int i = 0; i < M_CH; ++i) {
       const unsigned q = tid + 256u * i, row = q >> 1, part = q & 1u;
-      const int gr = m0 + (int)row, mb = kt * 16 + 8 * (int)part;
+      const int gr = m0 + (int)row, st64 = kt * 2 + (int)part;  // the 64-k stage this 8-byte piece belongs to
       u2 v = {0x44444444u, 0x44444444u};
-      if (row < (unsigned)BM && gr < p.Mrows && mb < p.kc / 8)
-        v = *reinterpret_cast<const u2*>(meta + (size_t)gr * (p.kc / 8) + mb);
+      if (row < (unsigned)BM && gr < p.Mrows && st64 * 64 < p.kc)
+        v = *reinterpret_cast<const u2*>(meta + ((size_t)st64 * p.Mtot + (size_t)gr) * 8);
       rm[i] = v;
     }
     const int k0 = kt * 128;
@@ -243,9 +260,11 @@ __global__ __launch_bounds__(64 * WM * WN) void spmma_f16_dma_kernel(const Spmma
   constexpr int TM = BM / WM, TN = BN / WN, FM = TM / 16, FN = TN / 16;
   static_assert(FM >= 1 && FN >= 1, "wave tile");
   constexpr int SA = BM * 64, SM_ = BM * 8, SB = 64 * BN * 2, STAGE = SA + SM_ + SB;
-  // One stage = W DMA wave-instructions: A_N of 1 KiB (16 rows x 64 B), M_N of 256 B (32 rows x 8 B),
-  // B_N of 1 KiB (8 k-rows x 128 B).  Instruction t belongs to wave t % NW (slot t / NW).
-  constexpr int A_N = BM / 16, M_N = BM / 32, B_N = BN / 8, W = A_N + M_N + B_N;
+  // One stage = W DMA wave-instructions of 1 KiB: A_N (16 rows x 64 B each), M_N (128 rows x 8 B of
+  // the stage-major metadata plane: contiguous), B_N (8 k-rows x 128 B).  Instruction t belongs to
+  // wave t % NW (slot t / NW).
+  static_assert(BM % 128 == 0, "metadata DMA moves 128 rows per instruction");
+  constexpr int A_N = BM / 16, M_N = BM / 128, B_N = BN / 8, W = A_N + M_N + B_N;
   constexpr int SL = (W + NW - 1) / NW;  // slots per wave
   constexpr int LPS = W / NW;            // least DMA instructions any wave issues per stage (vmcnt unit)
   static_assert(LPS >= 1, "every wave must issue at least one DMA per stage");
@@ -264,7 +283,7 @@ __global__ __launch_bounds__(64 * WM * WN) void spmma_f16_dma_kernel(const Spmma
 
   const size_t row_base = (size_t)b * p.m;
   const char* vals = p.vals + row_base * (size_t)p.kc;
-  const char* meta = p.meta + row_base * (size_t)(p.kc / 8);
+  const char* meta = p.meta + row_base * 8;  // plane of stage 0; + Mtot * 8 per stage
   const half_t* B = p.B + (size_t)b * p.sB;
   half_t* C = p.C + (size_t)b * p.sC;
   const int mlast = p.Mrows - 1;
@@ -284,12 +303,14 @@ __global__ __launch_bounds__(64 * WM * WN) void spmma_f16_dma_kernel(const Spmma
       step[i] = 64;
       loff[i] = t * 1024u;
     } else if (t < (unsigned)(A_N + M_N)) {
-      const unsigned u = t - A_N, L = 64u * u + lane, row = L >> 1, part = L & 1u;
-      int gr = m0 + (int)row;
-      gr = gr < mlast ? gr : mlast;
-      src[i] = meta + (size_t)gr * (p.kc / 8) + 4u * part;
-      step[i] = 8;
-      loff[i] = SA + u * 256u;
+      // lane moves the 16 bytes of tile rows 2*lane, 2*lane+1 (clamped to the batch's last row pair)
+      const unsigned u = t - A_N;
+      size_t off = ((size_t)m0 + 128u * u + 2u * lane) * 8;
+      const size_t last = (size_t)p.Mrows * 8 - 16;
+      off = off < last ? off : last;
+      src[i] = meta + off;
+      step[i] = p.Mtot * 8;
+      loff[i] = SA + u * 1024u;
     } else {
       const unsigned j = t - (A_N + M_N), panel = j >> 3, kr = 8u * (j & 7u) + (lane >> 3);
       const unsigned cs = (lane & 7u) ^ b_swz(kr);
@@ -311,10 +332,8 @@ __global__ __launch_bounds__(64 * WM * WN) void spmma_f16_dma_kernel(const Spmma
       lptr_t* l = (lptr_t*)(base + loff[i]);
       // A values and metadata are read exactly once (non-temporal: keep them from evicting B, which
       // every workgroup re-reads from L2); B uses the default policy.
-      if (t < (unsigned)A_N)
+      if (t < (unsigned)(A_N + M_N))
         __builtin_amdgcn_global_load_lds(g, l, 16, 0, NT_A);
-      else if (t < (unsigned)(A_N + M_N))
-        __builtin_amdgcn_global_load_lds(g, l, 4, 0, NT_A);
       else
         __builtin_amdgcn_global_load_lds(g, l, 16, 0, 0);
     }
@@ -335,12 +354,15 @@ __global__ __launch_bounds__(64 * WM * WN) void spmma_f16_dma_kernel(const Spmma
     if (s < nkt) stage(s, s);
   const unsigned g = lane >> 4, r = lane & 15u;
   int cur = 0, fill = NS - 1;  // buffer of stage kt, buffer of stage kt+NS-1
+  SM_T(unsigned long long tw = 0, ti = 0, tc = 0; unsigned long long st0 = sm_stamp(); const unsigned long long tstart = st0;)
   for (int kt = 0; kt < nkt; ++kt) {
     const int ahead = (nkt - 1 - kt) < (NS - 2) ? (nkt - 1 - kt) : (NS - 2);
     if (NS >= 4 && ahead == 2) wait_dma_and_barrier<2 * LPS>();
     else if (NS >= 3 && ahead == 1) wait_dma_and_barrier<LPS>();
     else wait_dma_and_barrier<0>();
+    SM_T(unsigned long long st1 = sm_stamp(); tw += st1 - st0;)
     if (kt + NS - 1 < nkt) stage(kt + NS - 1, fill);
+    SM_T(unsigned long long st2 = sm_stamp(); ti += st2 - st1;)
     const char* As = smem + cur * STAGE;
     const char* Ms = As + SA;
     const char* Bs = Ms + SM_;
@@ -384,8 +406,10 @@ __global__ __launch_bounds__(64 * WM * WN) void spmma_f16_dma_kernel(const Spmma
     }
     cur = cur + 1 == NS ? 0 : cur + 1;
     fill = fill + 1 == NS ? 0 : fill + 1;
+    SM_T(__builtin_amdgcn_sched_barrier(0); st0 = sm_stamp(); tc += st0 - st2;)
   }
   __syncthreads();  // nothing is in flight here: the last NS-1 iterations issued no DMA
+  SM_T(const unsigned long long tloop = sm_stamp();)
 
   // ---- epilogue (lane holds C[rows 4*(lane>>4) + r][col lane&15] of each fragment)
   const bool c_vec = (reinterpret_cast<uintptr_t>(C) & 15u) == 0;
@@ -427,6 +451,283 @@ __global__ __launch_bounds__(64 * WM * WN) void spmma_f16_dma_kernel(const Spmma
         }
       }
   }
+#ifdef SM_STAMP
+  if (p.dbg && lane == 0) {
+    const unsigned long long tend = sm_stamp();
+    unsigned long long* d = p.dbg + ((size_t)blockIdx.x * NW + wave) * 8;
+    d[0] = tw; d[1] = ti; d[2] = tc; d[3] = tloop - tstart; d[4] = tend - tloop; d[5] = tstart; d[6] = tend;
+    d[7] = __builtin_amdgcn_s_getreg(GETREG_IMMED(4 - 1, 0, 20 /*HW_REG_XCC_ID*/));
+  }
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------
+// Producer / consumer form of the same pipeline.  Cycle stamps of the kernel above (diagnostic build,
+// profiles/stamp_r01.txt) show a wave parked for 500-1800 cycles per stage in the ISSUE of its
+// global_load_lds instructions -- the vector-memory queue accepts them only as fast as L2 / HBM
+// delivers -- and only then starting its SMFMACs: transfer and compute were serialised per wave.
+// Here NL dedicated loader waves do nothing but issue the DMA (they are the ones that park), and the
+// WM x WN consumer waves do nothing but LDS reads + SMFMAC.  One s_barrier per stage joins them:
+//   loader  : wait vmcnt -> stage kt landed | barrier kt | issue stage kt+NS-1 (into the buffer the
+//             consumers finished before barrier kt)
+//   consumer:                                 barrier kt | compute stage kt
+// so the transfer of stages kt+1 .. kt+NS-1 runs under the compute of stage kt.
+// ---------------------------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN, int NL, int NS>
+__global__ __launch_bounds__(64 * (WM * WN + NL)) void spmma_f16_pc_kernel(const SpmmaArgs p) {
+  constexpr int NC = WM * WN, NW = NC + NL;
+  static_assert(NS >= 2 && NS <= 4, "ring depth");
+  constexpr int TM = BM / WM, TN = BN / WN, FM = TM / 16, FN = TN / 16;
+  static_assert(FM >= 1 && FN >= 1, "wave tile");
+  constexpr int SA = BM * 64, SM_ = BM * 8, SB = 64 * BN * 2, STAGE = SA + SM_ + SB;
+  static_assert(BM % 128 == 0, "metadata DMA moves 128 rows per instruction");
+  constexpr int A_N = BM / 16, M_N = BM / 128, B_N = BN / 8, W = A_N + M_N + B_N;
+  constexpr int SL = (W + NL - 1) / NL;  // DMA slots per loader wave
+  constexpr int LPS = W / NL;            // least any loader wave issues per stage: the vmcnt unit (a wave
+                                         // with one more then waits slightly longer than it must -- safe)
+  static_assert(LPS >= 1, "loader waves");
+  constexpr int CPITCH = BN * 2 + 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const unsigned tid = threadIdx.x, lane = tid & 63u;
+  const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const unsigned tiles = (unsigned)p.tiles_m * (unsigned)p.tiles_n;
+  const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
+  const unsigned b = lid / tiles, trem = lid - b * tiles;
+  const unsigned tile_m = trem / (unsigned)p.tiles_n, tile_n = trem - tile_m * (unsigned)p.tiles_n;
+  const int m0 = (int)tile_m * BM, n0 = (int)tile_n * BN;
+  const int nkt = p.kc / 64;
+  half_t* C = p.C + (size_t)b * p.sC;
+
+  f4 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+  const unsigned g = lane >> 4, r = lane & 15u;
+  const unsigned wm = wave / WN, wn = wave % WN;  // meaningful for consumer waves only
+
+  if (wave >= (unsigned)NC) {
+    // ------------------------------------------------------------------ loader wave
+    const unsigned lw = wave - NC;
+    const size_t row_base = (size_t)b * p.m;
+    const char* vals = p.vals + row_base * (size_t)p.kc;
+    const char* meta = p.meta + row_base * 8;
+    const half_t* B = p.B + (size_t)b * p.sB;
+    const int mlast = p.Mrows - 1;
+    const char* src[SL];
+    size_t step[SL];
+    unsigned loff[SL];
+#pragma unroll
+    for (int i = 0; i < SL; ++i) {
+      const unsigned t = lw + (unsigned)NL * i;
+      if (t < (unsigned)A_N) {
+        const unsigned row = 16u * t + (lane >> 2), cs = (lane & 3u) ^ a64_swz(row);
+        int gr = m0 + (int)row;
+        gr = gr < mlast ? gr : mlast;
+        src[i] = vals + (size_t)gr * p.kc + 16u * cs;
+        step[i] = 64;
+        loff[i] = t * 1024u;
+      } else if (t < (unsigned)(A_N + M_N)) {
+        const unsigned u = t - A_N;
+        size_t off = ((size_t)m0 + 128u * u + 2u * lane) * 8;
+        const size_t last = (size_t)p.Mrows * 8 - 16;
+        off = off < last ? off : last;
+        src[i] = meta + off;
+        step[i] = p.Mtot * 8;
+        loff[i] = SA + u * 1024u;
+      } else {
+        const unsigned j = t - (A_N + M_N), panel = j >> 3, kr = 8u * (j & 7u) + (lane >> 3);
+        const unsigned cs = (lane & 7u) ^ b_swz(kr);
+        int gc = n0 + (int)(64u * panel + 8u * cs);
+        gc = gc <= p.N - 8 ? gc : p.N - 8;
+        src[i] = reinterpret_cast<const char*>(B + (size_t)kr * p.N + gc);
+        step[i] = (size_t)64 * p.N * 2;
+        loff[i] = SA + SM_ + panel * 8192u + (j & 7u) * 1024u;
+      }
+    }
+    auto stage = [&](int kt, int buf) {
+      char* base = smem + buf * STAGE;
+#pragma unroll
+      for (int i = 0; i < SL; ++i) {
+        const unsigned t = lw + (unsigned)NL * i;  // wave-uniform
+        if (t >= (unsigned)W) continue;
+        gptr_t* gp = (gptr_t*)(src[i] + (size_t)kt * step[i]);
+        lptr_t* lp = (lptr_t*)(base + loff[i]);
+#ifdef SM_ABLATE  /* diagnostic timing builds only: 1 = no metadata DMA, 2 = no A DMA, 4 = no B DMA */
+        if ((SM_ABLATE & 1) && t >= (unsigned)A_N && t < (unsigned)(A_N + M_N)) continue;
+        if ((SM_ABLATE & 2) && t < (unsigned)A_N) continue;
+        if ((SM_ABLATE & 4) && t >= (unsigned)(A_N + M_N)) continue;
+#endif
+        __builtin_amdgcn_global_load_lds(gp, lp, 16, 0, 0);
+      }
+    };
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s)
+      if (s < nkt) stage(s, s);
+    int fill = NS - 1;
+    SM_T(unsigned long long tw = 0, tb = 0, ti = 0; unsigned long long s0 = sm_stamp();)
+    for (int kt = 0; kt < nkt; ++kt) {
+      const int ahead = (nkt - 1 - kt) < (NS - 2) ? (nkt - 1 - kt) : (NS - 2);
+#ifdef SM_STAMP
+      if (NS >= 4 && ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");
+      else if (NS >= 3 && ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      unsigned long long s1 = sm_stamp(); tw += s1 - s0;
+      asm volatile("s_barrier" ::: "memory");
+      unsigned long long s2 = sm_stamp(); tb += s2 - s1;
+#else
+      if (NS >= 4 && ahead == 2) wait_dma_and_barrier<2 * LPS>();
+      else if (NS >= 3 && ahead == 1) wait_dma_and_barrier<LPS>();
+      else wait_dma_and_barrier<0>();
+#endif
+      if (kt + NS - 1 < nkt) stage(kt + NS - 1, fill);
+      fill = fill + 1 == NS ? 0 : fill + 1;
+      SM_T(s0 = sm_stamp(); ti += s0 - s2;)
+    }
+    SM_T(if (p.dbg && lane == 0) { unsigned long long* d = p.dbg + ((size_t)blockIdx.x * NW + wave) * 8; d[0] = tw; d[1] = tb; d[2] = ti; d[3] = 1; })
+  } else {
+    // ------------------------------------------------------------------ consumer wave
+    int cur = 0;
+    SM_T(unsigned long long tb = 0, tc = 0; unsigned long long s0 = sm_stamp();)
+    for (int kt = 0; kt < nkt; ++kt) {
+      wait_dma_and_barrier<0>();  // a consumer has no DMA of its own: this is the stage barrier
+      SM_T(unsigned long long s1 = sm_stamp(); tb += s1 - s0;)
+      const char* As = smem + cur * STAGE;
+      const char* Ms = As + SA;
+      const char* Bs = Ms + SM_;
+      h8 af[FM];
+      int idx[FM];
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        const unsigned row = wm * TM + i * 16 + r;
+        af[i] = *reinterpret_cast<const h8*>(As + row * 64u + 16u * (g ^ a64_swz(row)));
+        idx[i] = (int)*reinterpret_cast<const unsigned short*>(Ms + row * 8u + 2u * g);
+      }
+      const unsigned bs_addr = (unsigned)(uintptr_t)(lds_char*)Bs;
+      s4 t0[2], t1[2], t2[2], t3[2];
+      auto issue = [&](int j, s4& v0, s4& v1, s4& v2, s4& v3) {
+        const unsigned col0 = wn * TN + j * 16, q = r >> 2, pp = r & 3u;
+        const unsigned a = bs_addr + b_off<64>(8u * g + q, col0 + 4u * pp);
+        asm volatile("ds_read_b64_tr_b16 %0, %4\n\tds_read_b64_tr_b16 %1, %4 offset:512\n\t"
+                     "ds_read_b64_tr_b16 %2, %4 offset:4096\n\tds_read_b64_tr_b16 %3, %4 offset:4608"
+                     : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3) : "v"(a) : "memory");
+      };
+      issue(0, t0[0], t1[0], t2[0], t3[0]);
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const int c = j & 1, n = c ^ 1;
+        if (j + 1 < FN) {
+          issue(j + 1, t0[n], t1[n], t2[n], t3[n]);
+          asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(t0[c]), "+v"(t1[c]), "+v"(t2[c]), "+v"(t3[c]) :: "memory");
+        } else {
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t0[c]), "+v"(t1[c]), "+v"(t2[c]), "+v"(t3[c]) :: "memory");
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        typedef short s16 __attribute__((ext_vector_type(16)));
+        const s16 all = {t0[c][0], t0[c][1], t0[c][2], t0[c][3], t1[c][0], t1[c][1], t1[c][2], t1[c][3],
+                         t2[c][0], t2[c][1], t2[c][2], t2[c][3], t3[c][0], t3[c][1], t3[c][2], t3[c][3]};
+        const h16 bf = __builtin_bit_cast(h16, all);
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+          acc[i][j] = __builtin_amdgcn_smfmac_f32_16x16x64_f16(af[i], bf, acc[i][j], idx[i], 0, 0);
+      }
+      cur = cur + 1 == NS ? 0 : cur + 1;
+      SM_T(__builtin_amdgcn_sched_barrier(0); s0 = sm_stamp(); tc += s0 - s1;)
+    }
+    SM_T(if (p.dbg && lane == 0) { unsigned long long* d = p.dbg + ((size_t)blockIdx.x * NW + wave) * 8; d[0] = 0; d[1] = tb; d[2] = tc; d[3] = 0; })
+  }
+  __syncthreads();  // both roles; nothing is in flight (the last NS-1 loader iterations issued no DMA)
+
+  // ---- epilogue: consumers stage their fragments, every wave (loaders too) stores 16-byte row pieces
+  const bool c_vec = (reinterpret_cast<uintptr_t>(C) & 15u) == 0;
+  if (p.beta == 0.0f && c_vec) {
+    char* Cs = smem;
+    if (wave < (unsigned)NC) {
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+          const unsigned row = wm * TM + i * 16 + 4u * g, col = wn * TN + j * 16 + r;
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<half_t*>(Cs + (row + q) * CPITCH + col * 2) = (half_t)(p.alpha * acc[i][j][q]);
+        }
+    }
+    __syncthreads();
+    constexpr int NCH = BM * (BN / 8);
+    for (unsigned q = tid; q < (unsigned)NCH; q += 64u * NW) {
+      const unsigned row = q / (BN / 8), cn = q % (BN / 8);
+      const int gr = m0 + (int)row, gc = n0 + 8 * (int)cn;
+      if (gr >= p.Mrows || gc >= p.N) continue;
+      *reinterpret_cast<u4*>(C + (size_t)gr * p.N + gc) = *reinterpret_cast<const u4*>(Cs + row * CPITCH + cn * 16);
+    }
+  } else if (wave < (unsigned)NC) {
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const int gc = n0 + (int)(wn * TN + j * 16 + r);
+        if (gc >= p.N) continue;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int gr = m0 + (int)(wm * TM + i * 16 + 4u * g) + q;
+          if (gr >= p.Mrows) continue;
+          half_t* dst = C + (size_t)gr * p.N + gc;
+          float v = p.alpha * acc[i][j][q];
+          if (p.beta != 0.0f) v += p.beta * (float)*dst;
+          *dst = (half_t)v;
+        }
+      }
+  }
+}
+
+template <int BM, int BN, int WM, int WN, int NL, int NS>
+static int launch_pc(const SpmmaArgs& a0, hipStream_t st) {
+  SpmmaArgs a = a0;
+  a.tiles_m = (a.Mrows + BM - 1) / BM;
+  a.tiles_n = (a.N + BN - 1) / BN;
+  const size_t nwg = (size_t)a.tiles_m * a.tiles_n * a.batch;
+  if (nwg == 0) return SM_STATUS_SUCCESS;
+  if (nwg > 0x7fffffffu) {
+    set_error("spmma_f16: grid too large");
+    return SM_STATUS_NOT_SUPPORTED;
+  }
+  constexpr size_t lds_main = NS * ((size_t)BM * 72 + (size_t)64 * BN * 2);
+  constexpr size_t lds_epi = (size_t)BM * (BN * 2 + 16);
+  constexpr size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
+  static bool attr_set = false;
+  if (lds > 64 * 1024 && !attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spmma_f16_pc_kernel<BM, BN, WM, WN, NL, NS>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+#ifdef SM_STAMP
+  {
+    static unsigned long long* dbg = nullptr;
+    constexpr int NWV = WM * WN + NL;
+    const size_t cnt = nwg * (size_t)NWV * 8;
+    static size_t cap = 0;
+    if (cnt > cap) { if (dbg) (void)hipFree(dbg); (void)hipMalloc((void**)&dbg, cnt * 8); cap = cnt; }
+    a.dbg = dbg;
+    spmma_f16_pc_kernel<BM, BN, WM, WN, NL, NS><<<dim3((unsigned)nwg), dim3(64 * NWV), lds, st>>>(a);
+    (void)hipDeviceSynchronize();
+    std::vector<unsigned long long> h(cnt);
+    (void)hipMemcpy(h.data(), dbg, cnt * 8, hipMemcpyDeviceToHost);
+    double L[3] = {0, 0, 0}, Cn[2] = {0, 0};
+    double nl = 0, nc = 0;
+    for (size_t i = 0; i < cnt / 8; ++i) {
+      if (h[i * 8 + 3] == 1) { L[0] += h[i * 8]; L[1] += h[i * 8 + 1]; L[2] += h[i * 8 + 2]; nl += 1; }
+      else { Cn[0] += h[i * 8 + 1]; Cn[1] += h[i * 8 + 2]; nc += 1; }
+    }
+    const double nk = (double)(a.kc / 64);
+    fprintf(stderr, "STAMP-PC %dx%dx%d NL=%d NS=%d tiles=%zu nkt=%d | loader per stage: vmcnt-wait %.0f barrier %.0f issue %.0f | consumer per stage: barrier %.0f compute %.0f\n",
+            a.Mrows, a.N, a.K, NL, NS, nwg, a.kc / 64, L[0] / nl / nk, L[1] / nl / nk, L[2] / nl / nk, Cn[0] / nc / nk, Cn[1] / nc / nk);
+    return check_launch("spmma_f16_pc_kernel");
+  }
+#endif
+  spmma_f16_pc_kernel<BM, BN, WM, WN, NL, NS><<<dim3((unsigned)nwg), dim3(64 * (WM * WN + NL)), lds, st>>>(a);
+  return check_launch("spmma_f16_pc_kernel");
 }
 
 template <int BM, int BN, int WM, int WN, int NS>
@@ -449,6 +750,31 @@ static int launch_dma(const SpmmaArgs& a0, hipStream_t st) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
+#ifdef SM_STAMP
+  {
+    static unsigned long long* dbg = nullptr;
+    const size_t cnt = nwg * (size_t)(WM * WN) * 8;
+    static size_t cap = 0;
+    if (cnt > cap) { if (dbg) (void)hipFree(dbg); (void)hipMalloc((void**)&dbg, cnt * 8); cap = cnt; }
+    a.dbg = dbg;
+    spmma_f16_dma_kernel<BM, BN, WM, WN, NS><<<dim3((unsigned)nwg), dim3(64 * WM * WN), lds, st>>>(a);
+    (void)hipDeviceSynchronize();
+    std::vector<unsigned long long> h(cnt);
+    (void)hipMemcpy(h.data(), dbg, cnt * 8, hipMemcpyDeviceToHost);
+    double s[5] = {0, 0, 0, 0, 0};
+    unsigned long long t_min = ~0ull, t_max = 0;
+    for (size_t i = 0; i < cnt / 8; ++i) {
+      for (int j = 0; j < 5; ++j) s[j] += (double)h[i * 8 + j];
+      if (h[i * 8 + 5] < t_min) t_min = h[i * 8 + 5];
+      if (h[i * 8 + 6] > t_max) t_max = h[i * 8 + 6];
+    }
+    const double nwv = (double)(cnt / 8), nk = (double)(a.kc / 64);
+    fprintf(stderr, "STAMP %dx%dx%d nw=%d ns=%d tiles=%zu nkt=%d | per wave per stage: wait %.0f issue %.0f compute %.0f | loop %.0f epilogue %.0f cycles | kernel span %.0f cycles (100MHz ticks? no: shader clk)\n",
+            a.Mrows, a.N, a.K, WM * WN, NS, nwg, a.kc / 64, s[0] / nwv / nk, s[1] / nwv / nk, s[2] / nwv / nk, s[3] / nwv, s[4] / nwv,
+            (double)(t_max - t_min));
+    return check_launch("spmma_f16_dma_kernel");
+  }
+#endif
   spmma_f16_dma_kernel<BM, BN, WM, WN, NS><<<dim3((unsigned)nwg), dim3(64 * WM * WN), lds, st>>>(a);
   return check_launch("spmma_f16_dma_kernel");
 }
@@ -490,6 +816,7 @@ extern "C" int sm_spmma_f16(const void* blob, const void* B, void* C, size_t m, 
   SpmmaArgs a = {};
   a.vals = (const char*)blob;
   a.meta = (const char*)blob + L.meta_off;
+  a.Mtot = L.M;
   a.B = (const half_t*)B;
   a.C = (half_t*)C;
   a.sB = strideB; a.sC = strideC;
@@ -501,12 +828,26 @@ extern "C" int sm_spmma_f16(const void* blob, const void* B, void* C, size_t m, 
     a.batch = 1;
   }
   hipStream_t st = (hipStream_t)stream;
-  const bool fast = (k % 64 == 0) && (n % 8 == 0) && n >= 8 && aligned16(B) && (strideB % 8 == 0);
+  // the metadata DMA moves 16-byte row pairs: batches and planes must start on even rows
+  const bool fast = (k % 64 == 0) && (n % 8 == 0) && n >= 8 && aligned16(B) && (strideB % 8 == 0) && (m % 2 == 0);
   if (fast) {
     // Workgroup shape by how many tiles exist: with thousands of tiles 4 waves per tile and several
     // tiles per CU overlap each other's latencies; with about one tile per CU the same tile is spread
     // over 8 or 16 waves so that every SIMD still holds several waves.  SM_SPMMA_CFG (tuning aid):
     // "<waves>x<ring>" forces a configuration.
+    static const char* pc_env = getenv("SM_SPMMA_PC");  // tuning aid: "<loaders>x<ring>", "0" = previous kernel
+    // default: long K -> producer/consumer kernel (4 loader waves, ring of 3); short K -> the kernel
+    // above with more tiles per CU (measured per shape on the ResNet tables, profiles/sweep_r01_*.txt)
+    int nl = k >= 512 ? 4 : 0, pns = 3;
+    if (pc_env) sscanf(pc_env, "%dx%d", &nl, &pns);
+    if (nl > 0) {
+      if (n <= 64) {
+        if (nl == 2) return pns >= 3 ? launch_pc<128, 64, 4, 1, 2, 3>(a, st) : launch_pc<128, 64, 4, 1, 2, 2>(a, st);
+        return pns >= 4 ? launch_pc<128, 64, 4, 1, 4, 4>(a, st) : (pns == 3 ? launch_pc<128, 64, 4, 1, 4, 3>(a, st) : launch_pc<128, 64, 4, 1, 4, 2>(a, st));
+      }
+      if (nl == 2) return pns >= 3 ? launch_pc<128, 128, 2, 2, 2, 3>(a, st) : launch_pc<128, 128, 2, 2, 2, 2>(a, st);
+      return pns >= 4 ? launch_pc<128, 128, 2, 2, 4, 4>(a, st) : (pns == 3 ? launch_pc<128, 128, 2, 2, 4, 3>(a, st) : launch_pc<128, 128, 2, 2, 4, 2>(a, st));
+    }
     static const char* cfg_env = getenv("SM_SPMMA_CFG");
     const size_t Mr = (size_t)a.Mrows;
     int nw, ns;

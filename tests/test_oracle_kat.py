@@ -242,8 +242,11 @@ def test_compress_layout_and_batches(orc):
         one = orc.compress24(bits(A[b * m * k:(b + 1) * m * k]), m, k, k, 1)
         kc1, mo1, _ = orc.compress24_layout(m, k, 2, 1)
         assert np.array_equal(blob[b * m * kc:(b + 1) * m * kc], one[: m * kc])
-        assert np.array_equal(blob[meta_off + b * m * (kc // 8): meta_off + (b + 1) * m * (kc // 8)],
-                              one[mo1: mo1 + m * (kc // 8)])
+        # metadata is stage-major: plane s holds 8 bytes per row for dense k 64s..64s+63 of ALL rows
+        M = batch * m
+        for s in range(kc // 64):
+            assert np.array_equal(blob[meta_off + (s * M + b * m) * 8: meta_off + (s * M + (b + 1) * m) * 8],
+                                  one[mo1 + s * m * 8: mo1 + (s + 1) * m * 8])
     D = orc.decompress24(blob, m, k, k, np.uint16, batch)
     assert np.array_equal(D, orc.prune24(bits(A), batch * m, k, k, orc.STRIP))
 
