@@ -1,0 +1,71 @@
+// sweep <shapes.csv> [out.csv] -- the layer sweep in C++ through the header-only API: for every row
+// (m,n,k,b) of a shape table it runs batched::gemm (column-major, one shared B), sparsify<2,2> on the
+// m x k operand and spmma, and writes one CSV row.  This is the in-process counterpart of the
+// reference's examples/profiling.py:4-44 (which shells out to bin/gemm, bin/sparsify, bin/spmm per
+// row and collects `m,n,k,b,gemm,prune,spmm` into compare.csv); the columns here keep `gemm` and
+// `prune` and add the three 2:4 stage times and effective GF/s (= 2*m*n*k*b / time).
+#include <cstdlib>
+#include <fstream>
+#include <iostream>
+#include <string>
+#include <vector>
+
+#include <sparsify.me/containers/vector.hxx>
+#include <sparsify.me/gemm.hxx>
+#include <sparsify.me/sparsify.hxx>
+#include <sparsify.me/spmma.hxx>
+#include <sparsify.me/util/gen.hxx>
+#include <sparsify.me/util/util.hxx>
+
+int main(int argc, char** argv) {
+  using namespace sparsifyme;
+  using type_t = _Float16;
+  if (argc < 2) {
+    std::cout << "Usage: ./sweep shapes.csv [out.csv]" << std::endl;
+    return EXIT_FAILURE;
+  }
+  std::vector<util::mat_sz> shapes;
+  try {
+    shapes = util::read_shapes(argv[1]);
+  } catch (const char* msg) {
+    std::cerr << msg << std::endl;
+    return EXIT_FAILURE;
+  }
+  std::ofstream out(argc > 2 ? argv[2] : "compare.csv");
+  out << "layer,m,n,k,b,gemm,prune,spmma_prune,spmma_compress,spmma_mul,gemm_gfs,spmma_mul_gfs\n";
+  double tg = 0, tm = 0, flops = 0;
+  for (std::size_t li = 0; li < shapes.size(); ++li) {
+    const std::size_t m = std::get<0>(shapes[li]), n = std::get<1>(shapes[li]), k = std::get<2>(shapes[li]),
+                      b = std::get<3>(shapes[li]);
+    device_vector<type_t> A(m * k * b), B(k * n * b), C(m * n * b);
+    util::random::uniform_distribution(A, 0.0f, 1.0f, 1000 + li);
+    util::random::uniform_distribution(B, 0.0f, 1.0f, 2000 + li);
+    host_vector<type_t*> hA(b), hB(b), hC(b);
+    for (std::size_t i = 0; i < b; ++i) {
+      hA[i] = A.data().get() + i * m * k;
+      hB[i] = B.data().get();  // one shared B (examples/gemm.cu:60,86)
+      hC[i] = C.data().get() + i * m * n;
+    }
+    device_vector<type_t*> pA = hA, pB = hB, pC = hC;
+    batched::gemm(pA.data().get(), pB.data().get(), pC.data().get(), m, n, k, b);  // warm
+    const float gemm_ms = batched::gemm(pA.data().get(), pB.data().get(), pC.data().get(), m, n, k, b);
+
+    device_vector<type_t> W(m * k);
+    device_vector<std::size_t> mask(m * k);
+    util::timer_t t;
+    sparsify<2, 2>(W.data().get(), mask.data().get(), m, k);
+    t.begin();
+    sparsify<2, 2>(W.data().get(), mask.data().get(), m, k);
+    const float prune_ms = t.end();
+
+    spmma(A.data().get(), B.data().get(), C.data().get(), m, n, k, b);  // warm (prunes A in place)
+    const auto st = spmma(A.data().get(), B.data().get(), C.data().get(), m, n, k, b);
+    const double fl = 2.0 * m * n * k * b;
+    out << li << "," << m << "," << n << "," << k << "," << b << "," << gemm_ms << "," << prune_ms << "," << st[0] << ","
+        << st[1] << "," << st[2] << "," << fl / gemm_ms / 1e6 << "," << fl / st[2] / 1e6 << "\n";
+    tg += gemm_ms; tm += st[2]; flops += fl;
+  }
+  std::cout << "layers " << shapes.size() << "  gemm " << tg << " ms (" << flops / tg / 1e6 << " GF/s)  spmma matmul " << tm
+            << " ms (" << flops / tm / 1e6 << " GF/s effective)  ratio " << tg / tm << std::endl;
+  return EXIT_SUCCESS;
+}

@@ -1,0 +1,32 @@
+// spmma_args.h -- argument block shared by the 2:4 matmul kernels (spmma_f16.hip, spmma_f16_pc.hip).
+#pragma once
+#include "mma_tile.h"
+
+namespace sm {
+
+struct SpmmaArgs {
+  const char* vals;   // [Mtot][kc/2] halves, row pitch kc bytes
+  const char* meta;   // stage-major [kc/64][Mtot][8 B]
+  size_t Mtot;        // rows of the whole blob (m * batch)
+  const half_t* B;
+  half_t* C;
+  size_t sB, sC;      // batch strides (elements); rows of batch b are [b*m, (b+1)*m)
+  int m;              // rows per batch
+  int Mrows;          // rows this launch treats as one matrix (m, or m*batch when stacked)
+  int N, K, kc;
+  int batch;          // grid batches (1 when stacked)
+  int tiles_m, tiles_n;
+  float alpha, beta;
+#ifdef SM_STAMP
+  unsigned long long* dbg;  // diagnostic build only: per-wave cycle sums (never in the product library)
+#endif
+};
+
+
+// 64-byte-row A image: 16-byte chunk c of row r lives at chunk c ^ ((-(r >> 2)) & 3).
+__device__ __forceinline__ unsigned a64_swz(unsigned row) { return (0u - (row >> 2)) & 3u; }
+
+// spmma_f16_pc.hip: producer/consumer kernels with BK = 128 stages.  cfg: 0 = 128x128, 1 = 256x128, 2 = 128x64.
+int spmma_f16_pc2_launch(const SpmmaArgs& a, int cfg, int ns, hipStream_t st);
+
+}  // namespace sm

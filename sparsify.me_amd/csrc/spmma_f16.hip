@@ -14,31 +14,13 @@
 
 #include <vector>
 
-#include "mma_tile.h"
+#include "spmma_args.h"
 
 #ifndef SM_NT_A
 #define SM_NT_A 0
 #endif
 
 namespace sm {
-
-struct SpmmaArgs {
-  const char* vals;   // [Mtot][kc/2] halves, row pitch kc bytes
-  const char* meta;   // stage-major [kc/64][Mtot][8 B]
-  size_t Mtot;        // rows of the whole blob (m * batch)
-  const half_t* B;
-  half_t* C;
-  size_t sB, sC;      // batch strides (elements); rows of batch b are [b*m, (b+1)*m)
-  int m;              // rows per batch
-  int Mrows;          // rows this launch treats as one matrix (m, or m*batch when stacked)
-  int N, K, kc;
-  int batch;          // grid batches (1 when stacked)
-  int tiles_m, tiles_n;
-  float alpha, beta;
-#ifdef SM_STAMP
-  unsigned long long* dbg;  // diagnostic build only: per-wave cycle sums (never in the product library)
-#endif
-};
 
 #ifdef SM_STAMP
 __device__ __forceinline__ unsigned long long sm_stamp() {
@@ -249,8 +231,6 @@ __global__ __launch_bounds__(256) void spmma_f16_kernel(const SpmmaArgs p) {
 // outputs that are never stored), so no lane is ever predicated off.
 // ---------------------------------------------------------------------------------------------
 
-// 64-byte-row A image: 16-byte chunk c of row r lives at chunk c ^ ((-(r >> 2)) & 3).
-__device__ __forceinline__ unsigned a64_swz(unsigned row) { return (0u - (row >> 2)) & 3u; }
 
 template <int BM, int BN, int WM, int WN, int NS>
 __global__ __launch_bounds__(64 * WM * WN) void spmma_f16_dma_kernel(const SpmmaArgs p) {
@@ -835,6 +815,17 @@ extern "C" int sm_spmma_f16(const void* blob, const void* B, void* C, size_t m, 
     // tiles per CU overlap each other's latencies; with about one tile per CU the same tile is spread
     // over 8 or 16 waves so that every SIMD still holds several waves.  SM_SPMMA_CFG (tuning aid):
     // "<waves>x<ring>" forces a configuration.
+    static const char* pc2_env = getenv("SM_SPMMA_PC2");  // tuning aid: "<cfg>x<ring>" forces a 128-deep-stage kernel
+    if (pc2_env) {
+      int cfg2 = 0, ns2 = 2;
+      sscanf(pc2_env, "%dx%d", &cfg2, &ns2);
+      if (cfg2 >= 0) return spmma_f16_pc2_launch(a, cfg2, ns2, st);
+    }
+    // 256 x 128 tiles with 128-deep stages pay when there are enough rows for ~100-400 such tiles, two or
+    // more n-tiles to share an A panel and a long K (profiles/sweep_r01_g.txt: 784x256x{1024,2304} b=32)
+    if (!pc2_env && !getenv("SM_SPMMA_PC") && !getenv("SM_SPMMA_CFG") && n >= 256 && n <= 256 && k >= 1024 &&
+        (size_t)a.Mrows >= 16384 && (size_t)a.Mrows <= 65536)
+      return spmma_f16_pc2_launch(a, 1, 2, st);
     static const char* pc_env = getenv("SM_SPMMA_PC");  // tuning aid: "<loaders>x<ring>", "0" = previous kernel
     // default: long K -> producer/consumer kernel (4 loader waves, ring of 3); short K -> the kernel
     // above with more tiles per CU (measured per shape on the ResNet tables, profiles/sweep_r01_*.txt)

@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--out", default=None)
     ap.add_argument("--only", default=None, help="comma list of stages to run")
+    ap.add_argument("--dtype", default="f16", choices=["f16", "f32"])
     ap.add_argument("--hot", action="store_true", help="one buffer set per shape (cache-resident for small layers)")
     args = ap.parse_args()
     import torch
@@ -55,23 +56,25 @@ def main():
     tot = {}
     hdr = ("m", "n", "k", "b", "cnt", "stage", "ms", "effTF/s", "GB/s", "roof_us", "frac")
     print("%6s %5s %5s %3s %3s %-10s %9s %9s %8s %8s %6s" % hdr)
+    tdt = torch.float16 if args.dtype == "f16" else torch.float32
+    peak = MFMA_F16 if args.dtype == "f16" else 157.3e12
     for (m, n, k, b), cnt in uniq:
-        s = 2
+        s = 2 if args.dtype == "f16" else 4
         # several buffer sets cycled call by call, so that a layer whose operands fit the 256 MiB Infinity
         # Cache is not timed on cache-resident data (bench.py streams 10 GB per step; this mimics it)
-        foot = b * m * k * 2 * 1.6 + b * m * n * 2
+        foot = b * m * k * s * 1.6 + b * m * n * s
         nbuf = 1 if args.hot else max(1, min(8, int(1.0e9 // foot) + 1))
         sets = []
         for i in range(nbuf):
-            A = torch.empty(b * m * k, dtype=torch.float16, device=dev)
+            A = torch.empty(b * m * k, dtype=tdt, device=dev)
             sm.fill_uniform(A, 1234 + m + k + 17 * i, 0.0, 1.0)
-            C = torch.empty(b * m * n, dtype=torch.float16, device=dev)
-            blob = torch.empty(sm.compress24_size(m, k, 2, b), dtype=torch.uint8, device=dev)
+            C = torch.empty(b * m * n, dtype=tdt, device=dev)
+            blob = torch.empty(sm.compress24_size(m, k, s, b), dtype=torch.uint8, device=dev)
             sm.compress24(A, m, k, k, b, m * k, blob)
-            Ap = torch.tensor([A.data_ptr() + 2 * j * m * k for j in range(b)], dtype=torch.int64, device=dev)
-            Cp = torch.tensor([C.data_ptr() + 2 * j * m * n for j in range(b)], dtype=torch.int64, device=dev)
+            Ap = torch.tensor([A.data_ptr() + s * j * m * k for j in range(b)], dtype=torch.int64, device=dev)
+            Cp = torch.tensor([C.data_ptr() + s * j * m * n for j in range(b)], dtype=torch.int64, device=dev)
             sets.append(dict(A=A, A2=A.clone(), C=C, blob=blob, Ap=Ap, Cp=Cp))
-        Bm = torch.empty(k * n, dtype=torch.float16, device=dev)
+        Bm = torch.empty(k * n, dtype=tdt, device=dev)
         sm.fill_uniform(Bm, 99 + n, 0.0, 1.0)
         Bp = torch.tensor([Bm.data_ptr()] * b, dtype=torch.int64, device=dev)
         mask = torch.empty(m * k, dtype=torch.int64, device=dev)
@@ -86,7 +89,7 @@ def main():
         sp_bytes = b * (m * k * s / 2 + m * k / 8 + m * n * s) + s * k * n
 
         def f_gemm():
-            S = nxt(); sm.gemm_batched(S["Ap"], Bp, S["Cp"], m, n, k, b, "f16")
+            S = nxt(); sm.gemm_batched(S["Ap"], Bp, S["Cp"], m, n, k, b, args.dtype)
 
         def f_gemm_rm():
             S = nxt(); sm.gemm_rowmajor(S["A"], Bm, S["C"], m, n, k, batch=b)
@@ -109,9 +112,9 @@ def main():
         def f_prune():
             S = nxt(); sm.sparsify(S["A2"][: m * k], mask, m, k, 0.5)
         stages = [
-            ("gemm", f_gemm, flops, dense_bytes, MFMA_F16),
-            ("gemm_rm", f_gemm_rm, flops, dense_bytes, MFMA_F16),
-            ("spmma", f_spmma, flops, sp_bytes, 2 * MFMA_F16),
+            ("gemm", f_gemm, flops, dense_bytes, peak),
+            ("gemm_rm", f_gemm_rm, flops, dense_bytes, peak),
+            ("spmma", f_spmma, flops, sp_bytes, 2 * peak if args.dtype == "f16" else peak),
             ("compress", f_compress, 0, b * m * k * (s + s / 2 + 1 / 8), 0),
             ("prune_s", f_prune_s, 0, 2 * b * m * k * s, 0),
             ("prune_t", f_prune_t, 0, 2 * b * m * k * s, 0),
