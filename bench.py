@@ -44,6 +44,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the per-stage / denominator passes")
     ap.add_argument("--eager", action="store_true", help="launch from Python instead of replaying a hipGraph")
+    ap.add_argument("--path", choices=["auto", "staged"], default="auto",
+                    help="auto: fused prune+compress+matmul kernel on the layers where it wins (n <= 128), the staged "
+                         "compress24 + spmma pair elsewhere; staged: the pair on every layer")
     ap.add_argument("--streams", type=int, default=4,
                     help="HIP streams the independent layers of a step are spread over (fork/join inside the step)")
     args = ap.parse_args()
@@ -104,8 +107,19 @@ def main():
         sm.compress24(L["A"], L["m"], L["k"], L["k"], L["b"], L["m"] * L["k"], L["blob"])
         sm.spmma(L["blob"], L["B"], L["C"], L["m"], L["n"], L["k"], L["b"], 0)
 
+    def use_fused(L):
+        return args.path == "auto" and L["n"] <= 128 and L["k"] % 64 == 0
+
+    # (f-1) the fused kernel computes the same C bit for bit straight from the dense A (the 2:4 selection
+    # and compaction happen in registers / LDS; no blob goes to HBM)
+    def layer_path(L):
+        if use_fused(L):
+            sm.spmma_fused(L["A"], L["B"], L["C"], L["m"], L["n"], L["k"], batch=L["b"])
+        else:
+            layer_full(L)
+
     def step_full():
-        forked(layer_full)
+        forked(layer_path)
 
     def barrier():
         if world > 1:
@@ -151,7 +165,10 @@ def main():
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f16", "data": "synthetic",
         "config": {"workload": "datasets/resnet50.csv: 49 conv layers as im2col GEMMs (m,n,k) at b=32, fp16; "
-                               "step = per layer compress24 (fused 2:4 prune+compress of A) + 2:4 spmma",
+                               "step = per layer 2:4 prune+compress+matmul (path: " + args.path + ")",
+                   "path": args.path + (": sm_spmma_fused_f16 on %d layers (n <= 128), sm_compress24_f16 + sm_spmma_f16 on %d"
+                                        % (sum(use_fused(L) for L in layers), sum(not use_fused(L) for L in layers))
+                                        if args.path == "auto" else ": sm_compress24_f16 + sm_spmma_f16 on every layer"),
                    "layers": len(layers), "batch": layers[0]["b"], "dense_equiv_gflop_per_step": flops / 1e9,
                    "launch": "eager" if args.eager else "hipGraph replay of one step", "streams": args.streams,
                    "parallelism": f"replicated table x{world}, per-rank batch, no data-path collective"},
@@ -172,15 +189,6 @@ def main():
         def dense_rowmajor():
             forked(lambda L: sm.gemm_rowmajor(L["A"], L["B"], L["C"], L["m"], L["n"], L["k"], batch=L["b"]))
 
-        # one stream, one kernel at a time: the per-kernel durations the roofline is computed from
-        def spmma_serial():
-            for L in layers:
-                sm.spmma(L["blob"], L["B"], L["C"], L["m"], L["n"], L["k"], L["b"], 0)
-
-        def compress_serial():
-            for L in layers:
-                sm.compress24(L["A"], L["m"], L["k"], L["k"], L["b"], L["m"] * L["k"], L["blob"])
-
         # the reference's dense path: column-major pointer-array batched GEMM, B shared (examples/gemm.cu:60,86)
         for L in layers:
             m, n, k, b = L["m"], L["n"], L["k"], L["b"]
@@ -192,9 +200,13 @@ def main():
             forked(lambda L: sm.gemm_batched(L["Ap"], L["Bp"], L["Cp"], L["m"], L["n"], L["k"], L["b"], "f16"))
 
         t_mul, t_cmp = sec_per_call(spmma_only), sec_per_call(compress_only)
-        ts_mul, ts_cmp = sec_per_call(spmma_serial), sec_per_call(compress_serial)
         t_drm, t_dcm = sec_per_call(dense_rowmajor), sec_per_call(dense_batched)
         t_full = wall / args.steps
+
+        def step_staged():
+            forked(layer_full)
+
+        t_staged = t_full if args.path == "staged" else sec_per_call(step_staged)
         gfs = lambda t: flops / t / 1e9
         out["stages"] = {
             "spmma_mul_gfs": gfs(t_mul), "spmma_mul_ms": t_mul * 1e3, "compress_ms": t_cmp * 1e3,
@@ -202,28 +214,53 @@ def main():
             "dense_gemm_batched_colmajor_gfs": gfs(t_dcm), "dense_gemm_batched_colmajor_ms": t_dcm * 1e3,
             "speedup_mul_vs_dense_rowmajor": t_drm / t_mul, "speedup_mul_vs_dense_batched": t_dcm / t_mul,
             "speedup_full_vs_dense_rowmajor": t_drm / t_full, "speedup_full_vs_dense_batched": t_dcm / t_full,
+            "full_path_staged_gfs": gfs(t_staged), "full_path_staged_ms": t_staged * 1e3,
+            "timed_path": args.path, "timed_path_ms": t_full * 1e3,
         }
-        # roofline of the dominant kernel of the timed step (algorithmic bytes: SURVEY.md 8(d))
+        # roofline of the dominant kernel family of the timed step: algorithmic bytes (SURVEY.md 8(d),
+        # DESIGN.md 4) / time of a single-stream pass that launches only that family on the layers it serves
         s = 2
-        by_spmma = sum(L["b"] * (L["m"] * L["k"] * s / 2 + L["m"] * L["k"] / 8 + L["m"] * L["n"] * s) + s * L["k"] * L["n"]
-                       for L in layers)
-        by_cmp = sum(L["b"] * L["m"] * L["k"] * (s + s / 2 + 1 / 8) for L in layers)
-        dom, by, t = ("compress_kernel", by_cmp, ts_cmp) if ts_cmp >= ts_mul else ("spmma_f16_dma_kernel", by_spmma, ts_mul)
-        ach = by / t / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")  # written by tools/pmc_traffic.py from rocprofv3 --pmc passes
+        fam = {"spmma_f16": dict(names=["spmma_f16_dma_kernel", "spmma_f16_pc_kernel", "spmma_f16_pc2_kernel", "spmma_f16_kernel"],
+                                 layers=[L for L in layers if not use_fused(L)],
+                                 call=lambda L: sm.spmma(L["blob"], L["B"], L["C"], L["m"], L["n"], L["k"], L["b"], 0),
+                                 bytes=lambda L: L["b"] * (L["m"] * L["k"] * s / 2 + L["m"] * L["k"] / 8 + L["m"] * L["n"] * s) + s * L["k"] * L["n"]),
+               "compress": dict(names=["compress_flat_kernel", "compress_kernel"],
+                                layers=[L for L in layers if not use_fused(L)],
+                                call=lambda L: sm.compress24(L["A"], L["m"], L["k"], L["k"], L["b"], L["m"] * L["k"], L["blob"]),
+                                bytes=lambda L: L["b"] * L["m"] * L["k"] * (s + s / 2 + 1 / 8)),
+               "spmma_f16_fused": dict(names=["spmma_f16_fused_kernel"],
+                                       layers=[L for L in layers if use_fused(L)],
+                                       call=lambda L: sm.spmma_fused(L["A"], L["B"], L["C"], L["m"], L["n"], L["k"], batch=L["b"]),
+                                       bytes=lambda L: L["b"] * s * (L["m"] * L["k"] + L["m"] * L["n"]) + s * L["k"] * L["n"])}
+        traffic_tab = {}
+        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")  # tools/pmc_traffic.py, from rocprofv3 --pmc passes
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(dom, {}).get("hbm_bytes_per_launch")
+                traffic_tab = json.load(open(tpath))
             except Exception:
-                traffic = None
-        out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "kernel": dom,
-                           "launches_per_step": len(layers), "avg_launch_us": t / len(layers) * 1e6,
-                           "algorithmic_bytes_per_launch": by / len(layers),
-                           "measured": "single stream, one kernel at a time (49 launches back to back)",
-                           "both_kernels_GBs": {"compress_kernel": by_cmp / ts_cmp / 1e9,
-                                                "spmma_f16_dma_kernel": by_spmma / ts_mul / 1e9}}
+                traffic_tab = {}
+        rows = {}
+        for name, f in fam.items():
+            if not f["layers"]:
+                continue
+
+            def serial(f=f):
+                for L in f["layers"]:
+                    f["call"](L)
+            t = sec_per_call(serial)
+            by = sum(f["bytes"](L) for L in f["layers"])
+            tb = [(traffic_tab[n]["hbm_bytes_per_launch"], traffic_tab[n]["launches_profiled"]) for n in f["names"] if n in traffic_tab]
+            traffic = sum(b_ * c_ for b_, c_ in tb) / sum(c_ for _, c_ in tb) if tb else None
+            rows[name] = dict(seconds=t, launches=len(f["layers"]), bytes=by, GBs=by / t / 1e9, traffic=traffic)
+        dom = max(rows, key=lambda n_: rows[n_]["seconds"])
+        d = rows[dom]
+        out["roofline"] = {"bound": "hbm", "achieved": d["GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": d["GBs"] / HBM_PEAK_GBS, "traffic": d["traffic"], "kernel": dom,
+                           "launches_per_step": d["launches"], "avg_launch_us": d["seconds"] / d["launches"] * 1e6,
+                           "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],
+                           "measured": "single stream, one kernel family at a time, hipGraph replay",
+                           "families": {n_: {"ms_per_step": r_["seconds"] * 1e3, "launches": r_["launches"], "GBs": r_["GBs"],
+                                             "hbm_traffic_per_launch": r_["traffic"]} for n_, r_ in rows.items()}}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(ge, shapes)

@@ -95,5 +95,22 @@ std::vector<float> spmma(type_t* dA,
   return {prune_time, compress_time, mul_time};
 }
 
+// Extension of this build (no reference counterpart): the same result as spmma()
+// -- C = alpha * prune_2:4(A) * B + beta * C -- in ONE kernel straight from the dense A: nothing is pruned in
+// place, no blob is built, A is read from HBM once.  fp16 only; needs k % 64 == 0, n % 8 == 0.  Returns the
+// elapsed milliseconds; falls back to nothing -- an unsupported shape prints the library's message.
+template <typename type_t>
+float spmma_fused(type_t* dA, type_t* dB, type_t* dC, std::size_t m, std::size_t n, std::size_t k, std::size_t batch_size,
+                  float alpha = 1.0f, float beta = 0.0f) {
+  static_assert(sizeof(type_t) == 2, "the fused kernel is fp16");
+  if (batch_size == 0) batch_size = 1;
+  util::timer_t timer;
+  timer.begin();
+  const int rc = sm_spmma_fused_f16(dA, dB, dC, m, n, k, k, batch_size, m * k, k * n, m * n, alpha, beta, nullptr);
+  const float ms = timer.end();
+  if (rc != SM_STATUS_SUCCESS) std::cerr << "sparsifyme::spmma_fused: " << sm_last_error() << std::endl;
+  return ms;
+}
+
 namespace batched {}  // namespace batched
 }  // namespace sparsifyme

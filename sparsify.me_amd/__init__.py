@@ -45,6 +45,8 @@ _SIGS = {
     "sm_decompress24_f32": [_c_ptr, _c_size, _c_size, _c_size, _c_size, _c_size, _c_ptr, _c_ptr],
     "sm_spmma_f16": [_c_ptr, _c_ptr, _c_ptr, _c_size, _c_size, _c_size, _c_size, _c_size, _c_size, _c_f, _c_f, _c_ptr],
     "sm_spmma_f32": [_c_ptr, _c_ptr, _c_ptr, _c_size, _c_size, _c_size, _c_size, _c_size, _c_size, _c_f, _c_f, _c_ptr],
+    "sm_spmma_fused_f16": [_c_ptr, _c_ptr, _c_ptr, _c_size, _c_size, _c_size, _c_size, _c_size, _c_size, _c_size, _c_size,
+                           _c_f, _c_f, _c_ptr],
     "sm_gemm_batched_f16": [_c_ptr, _c_ptr, _c_ptr, _c_size, _c_size, _c_size, _c_size, _c_i, _c_i, _c_f, _c_f, _c_ptr],
     "sm_gemm_batched_f32": [_c_ptr, _c_ptr, _c_ptr, _c_size, _c_size, _c_size, _c_size, _c_i, _c_i, _c_f, _c_f, _c_ptr],
     "sm_gemm_batched_f64": [_c_ptr, _c_ptr, _c_ptr, _c_size, _c_size, _c_size, _c_size, _c_i, _c_i,
@@ -206,6 +208,15 @@ def spmma(blob, B, C, m, n, k, batch=1, strideB=0, strideC=None, alpha=1.0, beta
     fn = getattr(lib(), "sm_spmma_" + _sfx(B))
     _check(fn(_dev(blob), _dev(B), _dev(C), m, n, k, batch, strideB, strideC, float(alpha), float(beta), _stream()),
            "sm_spmma")
+
+
+def spmma_fused(A, B, C, m, n, k, lda=None, batch=1, strideA=None, strideB=0, strideC=None, alpha=1.0, beta=0.0):
+    """Fused prune(STRIP) + compress + 2:4 matmul straight from the dense A (no blob)."""
+    lda = k if lda is None else lda
+    strideA = m * lda if strideA is None else strideA
+    strideC = m * n if strideC is None else strideC
+    _check(lib().sm_spmma_fused_f16(_dev(A), _dev(B), _dev(C), m, n, k, lda, batch, strideA, strideB, strideC,
+                                    float(alpha), float(beta), _stream()), "sm_spmma_fused_f16")
 
 
 def gemm_batched(A_ptrs, B_ptrs, C_ptrs, m, n, k, batch, dtype_suffix, alpha=1.0, beta=0.0, ta=0, tb=0):

@@ -1,0 +1,289 @@
+// spmma_f16_fused.hip -- fused prune -> compress -> 2:4 matmul (row f-1 of the hot-path table: "fused
+// prune->compress->SpMMA pipeline"; the reference re-creates and re-reads a compressed blob on every call,
+// include/sparsify.me/spmma.hxx:86-113).  C = alpha * prune24_strip(A) * B + beta * C straight from the
+// DENSE A: the 2:4 selection happens in the loader waves' registers and only the kept pair + its nibble
+// ever reach LDS, so per call the dense A is read once (m*k*s bytes) and no blob is written or re-read
+// (the staged path moves m*k*s + 2 * (m*k*s/2 + m*k/8) bytes for the same result).
+//
+// Same producer/consumer skeleton as spmma_f16.hip's pc kernel (64-deep stages, one barrier per stage):
+//   loader waves (4): B tile by LDS-DMA; A tile by plain 16-byte loads (8 rows x 128 B per wave
+//     instruction: whole cache lines), one stage ahead in registers; per 8 loaded halves (two strips)
+//     the STRIP rule (select24.h) -> 4 kept halves + 1 metadata byte, written with ds_write_b64 / b8
+//     into exactly the LDS images the consumers of the staged kernel read;
+//   consumer waves: unchanged (ds_read_b128 + ds_read_u16 + ds_read_b64_tr_b16 + v_smfmac).
+// The result is bit-identical to sm_spmma_f16(sm_compress24_f16(A), B): same kept values, same codes, same
+// instruction sequence on the same operands (tests/test_gpu_parity.py::test_fused_equals_staged).
+#include "select24.h"
+#include "spmma_args.h"
+
+namespace sm {
+
+struct FusedArgs {
+  const half_t* A;
+  const half_t* B;
+  half_t* C;
+  size_t sA, sB, sC;  // batch strides (elements)
+  int Mrows, N, K, lda;
+  int batch, tiles_m, tiles_n;
+  float alpha, beta;
+};
+
+template <int BN, int WM, int WN, int NS>
+__global__ __launch_bounds__(64 * (WM * WN + 4)) void spmma_f16_fused_kernel(const FusedArgs p) {
+  constexpr int BM = 128, NL = 4, NC = WM * WN, NW = NC + NL;
+  static_assert(NS == 2, "the loader keeps exactly one stage of A in registers");
+  constexpr int TM = BM / WM, TN = BN / WN, FM = TM / 16, FN = TN / 16;
+  constexpr int SA = BM * 64, SM_ = BM * 8, SB = 64 * BN * 2, STAGE = SA + SM_ + SB;
+  constexpr int B_N = BN / 8, B_WI = B_N / NL;  // B DMA instructions per loader wave per stage
+  static_assert(B_N % NL == 0 && B_WI >= 1, "B tile vs loader waves");
+  constexpr int CPITCH = BN * 2 + 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const unsigned tid = threadIdx.x, lane = tid & 63u;
+  const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const unsigned tiles = (unsigned)p.tiles_m * (unsigned)p.tiles_n;
+  const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
+  const unsigned b = lid / tiles, trem = lid - b * tiles;
+  const unsigned tile_m = trem / (unsigned)p.tiles_n, tile_n = trem - tile_m * (unsigned)p.tiles_n;
+  const int m0 = (int)tile_m * BM, n0 = (int)tile_n * BN;
+  const int nkt = p.K / 64;
+  half_t* C = p.C + (size_t)b * p.sC;
+
+  f4 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+  const unsigned g = lane >> 4, r = lane & 15u;
+  const unsigned wm = wave / WN, wn = wave % WN;  // consumer waves only
+
+  if (wave >= (unsigned)NC) {
+    // ------------------------------------------------------------------ loader wave
+    const unsigned lw = wave - NC;
+    const half_t* A = p.A + (size_t)b * p.sA;
+    const half_t* B = p.B + (size_t)b * p.sB;
+    const int mlast = p.Mrows - 1;
+    // A: load i of this wave = rows 8*(4*lw + i) + lane/8, dense chunk c = lane % 8 (k 8c .. 8c+7 of the stage)
+    const unsigned c8 = lane & 7u;
+    const half_t* a_src[4];
+    unsigned a_val_off[4], a_meta_off[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const unsigned row = 8u * (4u * lw + i) + (lane >> 3);
+      int gr = m0 + (int)row;
+      gr = gr < mlast ? gr : mlast;
+      a_src[i] = A + (size_t)gr * p.lda + 8u * c8;
+      a_val_off[i] = row * 64u + 16u * ((c8 >> 1) ^ a64_swz(row)) + 8u * (c8 & 1u);
+      a_meta_off[i] = SA + row * 8u + c8;
+    }
+    const char* b_src[B_WI];
+    unsigned b_loff[B_WI];
+#pragma unroll
+    for (int i = 0; i < B_WI; ++i) {
+      const unsigned j = lw + (unsigned)NL * i, panel = j >> 3, kr = 8u * (j & 7u) + (lane >> 3);
+      const unsigned cs = (lane & 7u) ^ b_swz(kr);
+      int gc = n0 + (int)(64u * panel + 8u * cs);
+      gc = gc <= p.N - 8 ? gc : p.N - 8;
+      b_src[i] = reinterpret_cast<const char*>(B + (size_t)kr * p.N + gc);
+      b_loff[i] = SA + SM_ + panel * 8192u + (j & 7u) * 1024u;
+    }
+    const size_t b_step = (size_t)64 * p.N * 2;
+
+    u4 ra[4];
+    auto load_a = [&](int kt) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const u4*>(a_src[i] + (size_t)kt * 64);
+    };
+    auto put_stage = [&](int kt, int buf) {  // B by DMA, A from the registers loaded one stage earlier
+      char* sb = smem + buf * STAGE;
+#pragma unroll
+      for (int i = 0; i < B_WI; ++i)
+        __builtin_amdgcn_global_load_lds((gptr_t*)(b_src[i] + (size_t)kt * b_step), (lptr_t*)(sb + b_loff[i]), 16, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const h8 v = __builtin_bit_cast(h8, ra[i]);
+        typedef unsigned short us8 __attribute__((ext_vector_type(8)));
+        const us8 e = __builtin_bit_cast(us8, v);
+        unsigned short out[4];
+        unsigned nib[2];
+#pragma unroll
+        for (unsigned s = 0; s < 2; ++s) {
+          const unsigned keep = strip_keepmask(key_of((uint16_t)e[4 * s]), key_of((uint16_t)e[4 * s + 1]),
+                                               key_of((uint16_t)e[4 * s + 2]), key_of((uint16_t)e[4 * s + 3]));
+          nib[s] = nibble_of(keep);
+          const unsigned p0 = nib[s] & 3u, p1 = nib[s] >> 2;
+          unsigned short a0 = e[4 * s], a1 = e[4 * s + 1];
+          a0 = p0 == 1 ? e[4 * s + 1] : a0;
+          a0 = p0 == 2 ? e[4 * s + 2] : a0;
+          a1 = p1 == 2 ? e[4 * s + 2] : a1;
+          a1 = p1 == 3 ? e[4 * s + 3] : a1;
+          out[2 * s] = a0;
+          out[2 * s + 1] = a1;
+        }
+        u2 packed = {(unsigned)out[0] | ((unsigned)out[1] << 16), (unsigned)out[2] | ((unsigned)out[3] << 16)};
+        *reinterpret_cast<u2*>(sb + a_val_off[i]) = packed;
+        *reinterpret_cast<unsigned char*>(sb + a_meta_off[i]) = (unsigned char)(nib[0] | (nib[1] << 4));
+      }
+    };
+
+    // the counted vmcnt below relies on issue order (B DMA of stage s, THEN the A loads of stage s+1):
+    // the empty asm statements keep the compiler from moving the plain loads across the DMA
+    load_a(0);
+    asm volatile("" ::: "memory");
+    put_stage(0, 0);
+    asm volatile("" ::: "memory");
+    if (nkt > 1) load_a(1);
+    for (int kt = 0; kt < nkt; ++kt) {
+      // stage kt is complete in LDS once this wave's ds_writes (lgkmcnt) and B DMA have landed; the
+      // four A loads of stage kt+1, issued after that DMA, may stay in flight (counted vmcnt)
+      if (kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (kt + 1 < nkt) {
+        put_stage(kt + 1, (kt + 1) & 1);  // consumes ra (stage kt+1); buffer freed by barrier kt
+        asm volatile("" ::: "memory");
+        if (kt + 2 < nkt) load_a(kt + 2);
+      }
+    }
+  } else {
+    // ------------------------------------------------------------------ consumer wave (as spmma_f16_pc_kernel)
+    int cur = 0;
+    for (int kt = 0; kt < nkt; ++kt) {
+      wait_dma_and_barrier<0>();
+      const char* As = smem + cur * STAGE;
+      const char* Ms = As + SA;
+      const char* Bs = Ms + SM_;
+      h8 af[FM];
+      int idx[FM];
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        const unsigned row = wm * TM + i * 16 + r;
+        af[i] = *reinterpret_cast<const h8*>(As + row * 64u + 16u * (g ^ a64_swz(row)));
+        idx[i] = (int)*reinterpret_cast<const unsigned short*>(Ms + row * 8u + 2u * g);
+      }
+      const unsigned bs_addr = (unsigned)(uintptr_t)(lds_char*)Bs;
+      s4 t0[2], t1[2], t2[2], t3[2];
+      auto issue = [&](int j, s4& v0, s4& v1, s4& v2, s4& v3) {
+        const unsigned col0 = wn * TN + j * 16, q = r >> 2, pp = r & 3u;
+        const unsigned a = bs_addr + b_off<64>(8u * g + q, col0 + 4u * pp);
+        asm volatile("ds_read_b64_tr_b16 %0, %4\n\tds_read_b64_tr_b16 %1, %4 offset:512\n\t"
+                     "ds_read_b64_tr_b16 %2, %4 offset:4096\n\tds_read_b64_tr_b16 %3, %4 offset:4608"
+                     : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3) : "v"(a) : "memory");
+      };
+      issue(0, t0[0], t1[0], t2[0], t3[0]);
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const int c = j & 1, n = c ^ 1;
+        if (j + 1 < FN) {
+          issue(j + 1, t0[n], t1[n], t2[n], t3[n]);
+          asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(t0[c]), "+v"(t1[c]), "+v"(t2[c]), "+v"(t3[c]) :: "memory");
+        } else {
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t0[c]), "+v"(t1[c]), "+v"(t2[c]), "+v"(t3[c]) :: "memory");
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        typedef short s16 __attribute__((ext_vector_type(16)));
+        const s16 all = {t0[c][0], t0[c][1], t0[c][2], t0[c][3], t1[c][0], t1[c][1], t1[c][2], t1[c][3],
+                         t2[c][0], t2[c][1], t2[c][2], t2[c][3], t3[c][0], t3[c][1], t3[c][2], t3[c][3]};
+        const h16 bf = __builtin_bit_cast(h16, all);
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+          acc[i][j] = __builtin_amdgcn_smfmac_f32_16x16x64_f16(af[i], bf, acc[i][j], idx[i], 0, 0);
+      }
+      cur ^= 1;
+    }
+  }
+  __syncthreads();
+
+  const bool c_vec = (reinterpret_cast<uintptr_t>(C) & 15u) == 0;
+  if (p.beta == 0.0f && c_vec) {
+    char* Cs = smem;
+    if (wave < (unsigned)NC) {
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+          const unsigned row = wm * TM + i * 16 + 4u * g, col = wn * TN + j * 16 + r;
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<half_t*>(Cs + (row + q) * CPITCH + col * 2) = (half_t)(p.alpha * acc[i][j][q]);
+        }
+    }
+    __syncthreads();
+    constexpr int NCH = BM * (BN / 8);
+    for (unsigned q = tid; q < (unsigned)NCH; q += 64u * NW) {
+      const unsigned row = q / (BN / 8), cn = q % (BN / 8);
+      const int gr = m0 + (int)row, gc = n0 + 8 * (int)cn;
+      if (gr >= p.Mrows || gc >= p.N) continue;
+      *reinterpret_cast<u4*>(C + (size_t)gr * p.N + gc) = *reinterpret_cast<const u4*>(Cs + row * CPITCH + cn * 16);
+    }
+  } else if (wave < (unsigned)NC) {
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const int gc = n0 + (int)(wn * TN + j * 16 + r);
+        if (gc >= p.N) continue;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int gr = m0 + (int)(wm * TM + i * 16 + 4u * g) + q;
+          if (gr >= p.Mrows) continue;
+          half_t* dst = C + (size_t)gr * p.N + gc;
+          float v = p.alpha * acc[i][j][q];
+          if (p.beta != 0.0f) v += p.beta * (float)*dst;
+          *dst = (half_t)v;
+        }
+      }
+  }
+}
+
+template <int BN, int WM, int WN>
+static int launch_fused(const FusedArgs& a0, hipStream_t st) {
+  FusedArgs a = a0;
+  a.tiles_m = (a.Mrows + 127) / 128;
+  a.tiles_n = (a.N + BN - 1) / BN;
+  const size_t nwg = (size_t)a.tiles_m * a.tiles_n * a.batch;
+  if (nwg == 0) return SM_STATUS_SUCCESS;
+  if (nwg > 0x7fffffffu) {
+    set_error("sm_spmma_fused_f16: grid too large");
+    return SM_STATUS_NOT_SUPPORTED;
+  }
+  constexpr size_t lds_main = 2 * ((size_t)128 * 72 + (size_t)64 * BN * 2);
+  constexpr size_t lds_epi = (size_t)128 * (BN * 2 + 16);
+  constexpr size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
+  spmma_f16_fused_kernel<BN, WM, WN, 2><<<dim3((unsigned)nwg), dim3(64 * (WM * WN + 4)), lds, st>>>(a);
+  return check_launch("spmma_f16_fused_kernel");
+}
+
+}  // namespace sm
+
+using namespace sm;
+
+extern "C" int sm_spmma_fused_f16(const void* A, const void* B, void* C, size_t m, size_t n, size_t k, size_t lda,
+                                  size_t batch, size_t strideA, size_t strideB, size_t strideC, float alpha, float beta,
+                                  sm_stream_t stream) {
+  if (!A || !B || !C || lda < k) {
+    set_error("sm_spmma_fused_f16: invalid argument");
+    return SM_STATUS_INVALID_VALUE;
+  }
+  if (m == 0 || n == 0 || batch == 0) return SM_STATUS_SUCCESS;
+  // whole 64-deep stages of 16-byte aligned rows only; anything else: sm_compress24_f16 + sm_spmma_f16
+  if (k % 64 != 0 || lda % 8 != 0 || strideA % 8 != 0 || n % 8 != 0 || strideB % 8 != 0 || !aligned16(A) || !aligned16(B)) {
+    set_error("sm_spmma_fused_f16: needs k %% 64 == 0, n %% 8 == 0 and 16-byte aligned rows (use the staged path)");
+    return SM_STATUS_NOT_SUPPORTED;
+  }
+  if (m * batch > 0x7fffffffull || n > 0x7fffffffull || k > 0x7fffffffull || lda > 0x7fffffffull) {
+    set_error("sm_spmma_fused_f16: dimension exceeds 2^31-1");
+    return SM_STATUS_NOT_SUPPORTED;
+  }
+  FusedArgs a = {};
+  a.A = (const half_t*)A; a.B = (const half_t*)B; a.C = (half_t*)C;
+  a.sA = strideA; a.sB = strideB; a.sC = strideC;
+  a.Mrows = (int)m; a.N = (int)n; a.K = (int)k; a.lda = (int)lda;
+  a.batch = (int)batch; a.alpha = alpha; a.beta = beta;
+  if (batch > 1 && strideB == 0 && strideA == m * lda && strideC == m * n) {
+    a.Mrows = (int)(m * batch);
+    a.batch = 1;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (n <= 64) return launch_fused<64, 4, 1>(a, st);
+  return launch_fused<128, 2, 2>(a, st);
+}

@@ -483,3 +483,44 @@ def test_cpp_drivers_cli_contract(gpu):
     assert "Incorrect pruning" not in out.stderr
     bad = run("spmma", 1, 2)
     assert bad.returncode != 0 and "Usage: ./spmma m n k b" in bad.stdout
+
+
+# ---------------------------------------------------------------------------------------------
+# (f-1) fused prune -> compress -> matmul
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(128, 64, 64, 1), (196, 512, 256, 2), (784, 256, 1024, 2), (130, 72, 192, 1), (96, 64, 128, 3),
+                                   (12544, 64, 576, 2), (3136, 128, 1152, 1), (300, 136, 320, 2)])
+@pytest.mark.parametrize("shared_b", [True, False])
+def test_fused_equals_staged(gpu, orc, shape, shared_b):
+    """sm_spmma_fused_f16(A) must be BIT-identical to sm_spmma_f16(sm_compress24_f16(A)): same kept values,
+    same position codes, same instruction sequence; and (tolerance) match the oracle."""
+    import torch
+    m, n, k, batch = shape
+    rng = np.random.default_rng(m * 3 + n + k * 5)
+    A = rand(rng, batch * m * k, np.float16, "ties" if m % 7 == 0 else "uniform")
+    nb = 1 if shared_b else batch
+    B = rand(rng, nb * k * n, np.float16)
+    strideB = 0 if shared_b else k * n
+    dA, dB = to_dev(A), to_dev(B)
+    blob = torch.empty(gpu.compress24_size(m, k, 2, batch), dtype=torch.uint8, device="cuda")
+    gpu.compress24(dA, m, k, k, batch, m * k, blob)
+    C1 = torch.zeros(batch * m * n, dtype=torch.float16, device="cuda")
+    gpu.spmma(blob, dB, C1, m, n, k, batch, strideB)
+    C2 = torch.full((batch * m * n,), 7.0, dtype=torch.float16, device="cuda")
+    gpu.spmma_fused(dA, dB, C2, m, n, k, batch=batch, strideB=strideB)
+    assert np.array_equal(bits(host(C1)), bits(host(C2))), "fused result differs from compress + spmma"
+    ob = orc.compress24(bits(A), m, k, k, batch)
+    Cref = np.zeros(batch * m * n, dtype=np.uint16)
+    orc.spmma(ob, bits(B), Cref, m, n, k, batch, strideB)
+    scale = np.stack([np.abs(A.astype(np.float64)).reshape(batch, m, k)[b] @ np.abs(B.astype(np.float64)).reshape(nb, k, n)[b if not shared_b else 0]
+                      for b in range(batch)]).reshape(-1)
+    check_close(host(C2), Cref.view(np.float16), scale, FP16_TOL, f"fused {shape}")
+
+
+def test_fused_rejects_what_it_cannot_take(gpu):
+    import torch
+    A = torch.zeros(16 * 147, dtype=torch.float16, device="cuda")
+    B = torch.zeros(147 * 64, dtype=torch.float16, device="cuda")
+    C = torch.zeros(16 * 64, dtype=torch.float16, device="cuda")
+    with pytest.raises(gpu.SparsifymeError):
+        gpu.spmma_fused(A, B, C, 16, 64, 147)   # k % 64 != 0: caller must use compress + spmma

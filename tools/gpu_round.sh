@@ -2,7 +2,7 @@
 # One GPU-box session: full GPU test-suite, bench, rocprof kernel stats, PMC traffic passes.
 # usage: bash tools/gpu_round.sh <tag>     (outputs under gpurun_out/<tag>_*)
 set -o pipefail
-tag=${1:-rXX}
+tag=${1:-rXX}; extra="${2:-}"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 timeout -k 10 900 python -m pytest tests -m gpu -q --timeout 300 > gpurun_out/${tag}_pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -3 gpurun_out/${tag}_pytest_gpu.log
 timeout -k 10 400 python bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err; echo "bench rc=$?"; cat gpurun_out/${tag}_bench.json

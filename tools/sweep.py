@@ -97,6 +97,16 @@ def main():
         def f_spmma():
             S = nxt(); sm.spmma(S["blob"], Bm, S["C"], m, n, k, b, 0)
 
+        fused_ok = k % 64 == 0 and n % 8 == 0 and args.dtype == "f16"
+
+        def f_fused():  # the whole path in one launch; shapes the fused kernel refuses run the staged pair
+            S = nxt()
+            if fused_ok:
+                sm.spmma_fused(S["A"], Bm, S["C"], m, n, k, batch=b)
+            else:
+                sm.compress24(S["A"], m, k, k, b, m * k, S["blob"])
+                sm.spmma(S["blob"], Bm, S["C"], m, n, k, b, 0)
+
         def f_compress():
             S = nxt(); sm.compress24(S["A"], m, k, k, b, m * k, S["blob"])
 
@@ -115,6 +125,7 @@ def main():
             ("gemm", f_gemm, flops, dense_bytes, peak),
             ("gemm_rm", f_gemm_rm, flops, dense_bytes, peak),
             ("spmma", f_spmma, flops, sp_bytes, 2 * peak if args.dtype == "f16" else peak),
+            ("fused", f_fused, flops, dense_bytes, 2 * peak),
             ("compress", f_compress, 0, b * m * k * (s + s / 2 + 1 / 8), 0),
             ("prune_s", f_prune_s, 0, 2 * b * m * k * s, 0),
             ("prune_t", f_prune_t, 0, 2 * b * m * k * s, 0),
