@@ -76,18 +76,13 @@ __global__ __launch_bounds__(64 * (WM * WN + 4)) void spmma_f16_fused_kernel(con
       a_val_off[i] = row * 64u + 16u * ((c8 >> 1) ^ a64_swz(row)) + 8u * (c8 & 1u);
       a_meta_off[i] = SA + row * 8u + c8;
     }
-    const char* b_src[B_WI];
-    unsigned b_loff[B_WI];
-#pragma unroll
-    for (int i = 0; i < B_WI; ++i) {
-      const unsigned j = lw + (unsigned)NL * i, panel = j >> 3, kr = 8u * (j & 7u) + (lane >> 3);
-      const unsigned cs = (lane & 7u) ^ b_swz(kr);
-      int gc = n0 + (int)(64u * panel + 8u * cs);
-      gc = gc <= p.N - 8 ? gc : p.N - 8;
-      b_src[i] = reinterpret_cast<const char*>(B + (size_t)kr * p.N + gc);
-      b_loff[i] = SA + SM_ + panel * 8192u + (j & 7u) * 1024u;
-    }
-    const size_t b_step = (size_t)64 * p.N * 2;
+    // B: DMA instruction i of this wave covers k-rows 8*lw + 32*(i&1) + lane/8 of panel i>>1 (64 columns);
+    // the chunk swizzle depends on bits 1 and 3 of the k-row only, i.e. not on i: addresses are rebuilt from
+    // two per-lane values at issue time instead of holding B_WI pointers in registers
+    const unsigned kr_lo = 8u * lw + (lane >> 3);
+    const unsigned b_cs = (lane & 7u) ^ b_swz(kr_lo);
+    const char* b_row0 = reinterpret_cast<const char*>(B + (size_t)kr_lo * p.N);
+    const size_t b_step = (size_t)64 * p.N * 2, b_half = (size_t)32 * p.N * 2;
 
     u4 ra[4];
     auto load_a = [&](int kt) {
@@ -97,8 +92,13 @@ __global__ __launch_bounds__(64 * (WM * WN + 4)) void spmma_f16_fused_kernel(con
     auto put_stage = [&](int kt, int buf) {  // B by DMA, A from the registers loaded one stage earlier
       char* sb = smem + buf * STAGE;
 #pragma unroll
-      for (int i = 0; i < B_WI; ++i)
-        __builtin_amdgcn_global_load_lds((gptr_t*)(b_src[i] + (size_t)kt * b_step), (lptr_t*)(sb + b_loff[i]), 16, 0, 0);
+      for (int i = 0; i < B_WI; ++i) {
+        int gc = n0 + (int)(64u * (unsigned)(i >> 1) + 8u * b_cs);
+        gc = gc <= p.N - 8 ? gc : p.N - 8;
+        const char* src = b_row0 + (size_t)kt * b_step + ((i & 1) ? b_half : 0) + (size_t)gc * 2;
+        __builtin_amdgcn_global_load_lds((gptr_t*)src,
+                                         (lptr_t*)(sb + SA + SM_ + (unsigned)(i >> 1) * 8192u + (lw + 4u * (i & 1)) * 1024u), 16, 0, 0);
+      }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const h8 v = __builtin_bit_cast(h8, ra[i]);
@@ -249,6 +249,12 @@ static int launch_fused(const FusedArgs& a0, hipStream_t st) {
   constexpr size_t lds_main = 2 * ((size_t)128 * 72 + (size_t)64 * BN * 2);
   constexpr size_t lds_epi = (size_t)128 * (BN * 2 + 16);
   constexpr size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
+  static bool attr_set = false;
+  if (lds > 64 * 1024 && !attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spmma_f16_fused_kernel<BN, WM, WN, 2>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
   spmma_f16_fused_kernel<BN, WM, WN, 2><<<dim3((unsigned)nwg), dim3(64 * (WM * WN + 4)), lds, st>>>(a);
   return check_launch("spmma_f16_fused_kernel");
 }
@@ -284,6 +290,10 @@ extern "C" int sm_spmma_fused_f16(const void* A, const void* B, void* C, size_t 
     a.batch = 1;
   }
   hipStream_t st = (hipStream_t)stream;
+  // One workgroup spans the whole N (up to 512), so every row of A is selected exactly once:
+  // 4 consumer waves for N <= 128, 8 (4 x 2, wave tile 32 x N/2) for N <= 512; wider N tiles N by 512.
   if (n <= 64) return launch_fused<64, 4, 1>(a, st);
-  return launch_fused<128, 2, 2>(a, st);
+  if (n <= 128) return launch_fused<128, 2, 2>(a, st);
+  if (n <= 256) return launch_fused<256, 4, 2>(a, st);
+  return launch_fused<512, 4, 2>(a, st);
 }
