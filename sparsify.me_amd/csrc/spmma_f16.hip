@@ -821,16 +821,19 @@ extern "C" int sm_spmma_f16(const void* blob, const void* B, void* C, size_t m, 
       sscanf(pc2_env, "%dx%d", &cfg2, &ns2);
       if (cfg2 >= 0) return spmma_f16_pc2_launch(a, cfg2, ns2, st);
     }
-    // 256 x 128 tiles with 128-deep stages pay when there are enough rows for ~100-400 such tiles, two or
-    // more n-tiles to share an A panel and a long K (profiles/sweep_r01_g.txt: 784x256x{1024,2304} b=32)
-    if (!pc2_env && !getenv("SM_SPMMA_PC") && !getenv("SM_SPMMA_CFG") && n >= 256 && n <= 256 && k >= 1024 &&
-        (size_t)a.Mrows >= 16384 && (size_t)a.Mrows <= 65536)
-      return spmma_f16_pc2_launch(a, 1, 2, st);
+    // 256 x 128 tiles (B lines amortised over twice the rows) pay with a long K and enough rows for >= 64 such
+    // tiles per n-tile (profiles/sweep_r01_*.txt: 784x256x{1024,2304}, 3136x128x1152 at b=32)
+    if (!pc2_env && !getenv("SM_SPMMA_PC") && !getenv("SM_SPMMA_CFG") && n >= 128 && n <= 256 && k >= 1024 &&
+        (size_t)a.Mrows >= 16384)
+      return launch_pc<256, 128, 4, 2, 4, 3>(a, st);
     static const char* pc_env = getenv("SM_SPMMA_PC");  // tuning aid: "<loaders>x<ring>", "0" = previous kernel
     // default: long K -> producer/consumer kernel (4 loader waves, ring of 3); short K -> the kernel
     // above with more tiles per CU (measured per shape on the ResNet tables, profiles/sweep_r01_*.txt)
     int nl = k >= 512 ? 4 : 0, pns = 3;
     if (pc_env) sscanf(pc_env, "%dx%d", &nl, &pns);
+    if (nl == 256 && n > 64) {  // tuning aid: 256 x 128 tiles, 8 consumer waves (64 x 64) + 4 loaders, 64-deep stages
+      return pns >= 3 ? launch_pc<256, 128, 4, 2, 4, 3>(a, st) : launch_pc<256, 128, 4, 2, 4, 2>(a, st);
+    }
     if (nl > 0) {
       if (n <= 64) {
         if (nl == 2) return pns >= 3 ? launch_pc<128, 64, 4, 1, 2, 3>(a, st) : launch_pc<128, 64, 4, 1, 2, 2>(a, st);
