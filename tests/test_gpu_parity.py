@@ -199,7 +199,9 @@ def test_mfma_lane_maps_with_identity_and_asymmetric_b(gpu, orc):
 
 
 SPMMA_SHAPES = [(128, 64, 128, 1), (196, 512, 256, 2), (130, 72, 200, 1), (784, 256, 1024, 1), (96, 64, 64, 3),
-                (12544, 64, 147, 1), (3136, 128, 576, 1), (17, 8, 4, 1), (300, 136, 320, 2)]
+                (12544, 64, 147, 1), (3136, 128, 576, 1), (17, 8, 4, 1), (300, 136, 320, 2),
+                # producer/consumer kernels (k >= 512) with row, column and batch tails; 256-row tiles (>= 16384 rows)
+                (200, 136, 576, 3), (130, 64, 1152, 2), (16400, 136, 1024, 1), (8200, 256, 1088, 2), (2, 8, 512, 1)]
 
 
 @pytest.mark.parametrize("shape", SPMMA_SHAPES)
