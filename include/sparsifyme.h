@@ -149,6 +149,32 @@ int sm_spmm_coo_f32(size_t A_num_rows, size_t A_num_cols, size_t A_nnz, size_t B
                     size_t num_batches, const int* rows, const int* cols, const float* vals,
                     const float* B, float* C, float alpha, float beta, sm_stream_t stream);
 
+/* Blocked-ELL with a caller-provided workspace of sm_spmm_bell_workspace_size() bytes (reusable across the
+ * batches of one stream): blocks are scattered into a dense A and multiplied on the fp32 matrix cores.
+ * workspace == NULL behaves as sm_spmm_bell_f32 (slow gather kernel). */
+int sm_spmm_bell_workspace_size(size_t rows, size_t cols, size_t* bytes /*host*/);
+int sm_spmm_bell_f32_ws(const float* values, const uint64_t* column_indices, size_t rows, size_t cols,
+                        size_t block_size, size_t ell_cols, const float* B, float* C, size_t n,
+                        float alpha, float beta, void* workspace, sm_stream_t stream);
+
+/* All batches of the reference's spmm() loop (spmm.hxx:90-101) in one submission: `values`, `column_indices` and `C`
+ * are HOST arrays of `batch` device pointers (every A has the same rows/cols/block_size/ell_cols, B is shared --
+ * exactly what the reference's driver builds).  Workspace: sm_spmm_bell_batched_workspace_size() bytes, required. */
+int sm_spmm_bell_batched_workspace_size(size_t rows, size_t cols, size_t batch, size_t* bytes /*host*/);
+int sm_spmm_bell_batched_f32(const float* const* values, const uint64_t* const* column_indices, size_t rows,
+                             size_t cols, size_t block_size, size_t ell_cols, const float* B, float* const* C,
+                             size_t n, size_t batch, float alpha, float beta, void* workspace, sm_stream_t stream);
+
+/* COO with a caller-provided workspace of sm_spmm_coo_workspace_size() bytes (the reference allocates its
+ * cuSPARSE buffer inside the call, spmm.hxx:183): row-sorted input runs as CSR, row-parallel, without
+ * atomics (bitwise reproducible); unsorted input falls back to the atomic kernel.  workspace == NULL
+ * behaves as sm_spmm_coo_f32. */
+int sm_spmm_coo_workspace_size(size_t A_num_rows, size_t* bytes /*host*/);
+int sm_spmm_coo_f32_ws(size_t A_num_rows, size_t A_num_cols, size_t A_nnz, size_t B_num_cols,
+                       size_t num_batches, const int* rows, const int* cols, const float* vals,
+                       const float* B, float* C, float alpha, float beta, void* workspace,
+                       sm_stream_t stream);
+
 /* ---- support: counter-based uniform fill (replaces the Thrust RNG transform of
  *      include/sparsify.me/util/gen.hxx:12-20); element i depends only on (seed, i). */
 int sm_fill_uniform_f16(void* out, size_t count, uint64_t seed, float lo, float hi, sm_stream_t stream);

@@ -35,8 +35,12 @@ struct Gemm32Args {
 constexpr int BK32 = 32;
 constexpr int APITCH = BK32 + 1;  // floats per A row in LDS: column reads by 16 rows x 2 k hit 32 distinct banks
 
-template <int BM, int BN, int WM, int WN, bool SPARSE>
+// MODE 0: dense A, B row-major [k][n];  MODE 1: A from the 2:4 blob;  MODE 2: dense A, B given K-MAJOR
+// ([n][k], ldb = row pitch in k): the form the Blocked-ELL path needs (its expanded A is row-major [m][k]
+// and plays the B role of the transposed product).
+template <int BM, int BN, int WM, int WN, int MODE>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const Gemm32Args p) {
+  constexpr bool SPARSE = MODE == 1, BKM = MODE == 2;
   static_assert(WM * WN == 4, "4 waves");
   constexpr int TM = BM / WM, TN = BN / WN, FM = TM / 16, FN = TN / 16;
   constexpr int BPITCH = BN + 16;  // the two k-rows a 32-lane half reads land on different bank halves
@@ -102,9 +106,15 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const Gemm32Args p) {
     }
 #pragma unroll
     for (int i = 0; i < B_CH; ++i) {
-      const unsigned q = tid + 256u * i, kr = q / (BN / 4), cn = q % (BN / 4);
-      const int gk = k0 + (int)kr;
-      rb[i] = load4(B + (size_t)gk * p.ldb, n0 + 4 * (int)cn, p.N, gk < p.K, b_vec);
+      if constexpr (BKM) {
+        const unsigned q = tid + 256u * i, nrow = q >> 3, ch = q & 7u;
+        const int gn = n0 + (int)nrow;
+        rb[i] = load4(B + (size_t)gn * p.ldb, k0 + 4 * (int)ch, p.K, gn < p.N, b_vec);
+      } else {
+        const unsigned q = tid + 256u * i, kr = q / (BN / 4), cn = q % (BN / 4);
+        const int gk = k0 + (int)kr;
+        rb[i] = load4(B + (size_t)gk * p.ldb, n0 + 4 * (int)cn, p.N, gk < p.K, b_vec);
+      }
     }
   };
   auto lstore = [&]() {
@@ -116,8 +126,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const Gemm32Args p) {
     }
 #pragma unroll
     for (int i = 0; i < B_CH; ++i) {
-      const unsigned q = tid + 256u * i, kr = q / (BN / 4), cn = q % (BN / 4);
-      *reinterpret_cast<f4*>(Bs + kr * BPITCH + 4 * cn) = rb[i];
+      if constexpr (BKM) {
+        const unsigned q = tid + 256u * i, nrow = q >> 3, ch = q & 7u;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) Bs[nrow * APITCH + 4 * ch + t] = rb[i][t];
+      } else {
+        const unsigned q = tid + 256u * i, kr = q / (BN / 4), cn = q % (BN / 4);
+        *reinterpret_cast<f4*>(Bs + kr * BPITCH + 4 * cn) = rb[i];
+      }
     }
   };
 
@@ -134,7 +150,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const Gemm32Args p) {
 #pragma unroll
       for (int i = 0; i < FM; ++i) af[i] = As[(wm * TM + i * 16 + (lane & 15u)) * APITCH + 4 * s + (lane >> 4)];
 #pragma unroll
-      for (int j = 0; j < FN; ++j) bf[j] = Bs[(4 * s + (lane >> 4)) * BPITCH + wn * TN + j * 16 + (lane & 15u)];
+      for (int j = 0; j < FN; ++j)
+        bf[j] = BKM ? Bs[(wn * TN + j * 16 + (lane & 15u)) * APITCH + 4 * s + (lane >> 4)]
+                    : Bs[(4 * s + (lane >> 4)) * BPITCH + wn * TN + j * 16 + (lane & 15u)];
 #pragma unroll
       for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -172,7 +190,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const Gemm32Args p) {
     }
 }
 
-template <int BM, int BN, int WM, int WN, bool SPARSE>
+template <int BM, int BN, int WM, int WN, int MODE>
 static int launch32(const Gemm32Args& a0, hipStream_t st) {
   Gemm32Args a = a0;
   a.tiles_m = (a.M + BM - 1) / BM;
@@ -183,16 +201,33 @@ static int launch32(const Gemm32Args& a0, hipStream_t st) {
     set_error("gemm_f32: grid too large");
     return SM_STATUS_NOT_SUPPORTED;
   }
-  constexpr size_t lds = ((size_t)BM * APITCH + (size_t)BK32 * (BN + 16)) * sizeof(float);
-  gemm_f32_kernel<BM, BN, WM, WN, SPARSE><<<dim3((unsigned)nwg), dim3(256), lds, st>>>(a);
+  constexpr size_t lds_b = (size_t)BK32 * (BN + 16) > (size_t)BN * APITCH ? (size_t)BK32 * (BN + 16) : (size_t)BN * APITCH;
+  constexpr size_t lds = ((size_t)BM * APITCH + lds_b) * sizeof(float);
+  gemm_f32_kernel<BM, BN, WM, WN, MODE><<<dim3((unsigned)nwg), dim3(256), lds, st>>>(a);
   return check_launch("gemm_f32_kernel");
 }
 
-template <bool SPARSE>
+template <int MODE>
 static int dispatch32(const Gemm32Args& a, hipStream_t st) {
-  if (a.N <= 64) return launch32<128, 64, 4, 1, SPARSE>(a, st);
-  if (a.M <= 64) return launch32<64, 128, 1, 4, SPARSE>(a, st);
-  return launch32<128, 128, 2, 2, SPARSE>(a, st);
+  if (a.N <= 64) return launch32<128, 64, 4, 1, MODE>(a, st);
+  if (a.M <= 64) return launch32<64, 128, 1, 4, MODE>(a, st);
+  return launch32<128, 128, 2, 2, MODE>(a, st);
+}
+
+// C^T[n x m] (row-major, ldc = m: i.e. column-major m x n C) = alpha * Bt[n x k] * Adense[m x k]^T + beta * C,
+// Bt = the column-major k x n B of the reference's SpMM (row-major n x k), Adense row-major m x k.
+// With Cptrs (a DEVICE array of `batch` C pointers) the grid covers all batches: Adense then holds `batch`
+// consecutive m x k matrices and Bcm is shared.
+int gemm_f32_colmajor_c_from_rowmajor_a(const float* Adense, const float* Bcm, float* Ccm, float* const* Cptrs,
+                                        size_t m, size_t n, size_t k, size_t batch, float alpha, float beta,
+                                        hipStream_t st) {
+  Gemm32Args a = {};
+  a.A = Bcm; a.B = Adense; a.C = Ccm; a.Cp = Cptrs;
+  a.sA = 0; a.sB = m * k; a.sC = 0;
+  a.M = (int)n; a.N = (int)m; a.K = (int)k;
+  a.lda = (int)k; a.ldb = (int)k; a.ldc = (int)m;
+  a.batch = (int)batch; a.alpha = alpha; a.beta = beta;
+  return dispatch32<2>(a, st);
 }
 
 // ---- fp64: plain FMA tiles, 64 x 64 outputs per 256-thread workgroup, 4 x 4 per thread ------------
@@ -272,7 +307,7 @@ int sm_gemm_rowmajor_f32(const float* A, const float* B, float* C, size_t m, siz
     a.M = (int)(m * batch);
     a.batch = 1;
   }
-  return dispatch32<false>(a, (hipStream_t)stream);
+  return dispatch32<0>(a, (hipStream_t)stream);
 }
 
 int sm_gemm_batched_f32(const float* const* A_ptrs, const float* const* B_ptrs, float* const* C_ptrs, size_t m, size_t n,
@@ -296,7 +331,7 @@ int sm_gemm_batched_f32(const float* const* A_ptrs, const float* const* B_ptrs, 
   a.M = (int)n; a.N = (int)m; a.K = (int)k;
   a.lda = (int)k; a.ldb = (int)m; a.ldc = (int)m;
   a.batch = (int)batch; a.alpha = alpha; a.beta = beta;
-  return dispatch32<false>(a, (hipStream_t)stream);
+  return dispatch32<0>(a, (hipStream_t)stream);
 }
 
 int sm_spmma_f32(const void* blob, const float* B, float* C, size_t m, size_t n, size_t k, size_t batch, size_t strideB,
@@ -324,7 +359,7 @@ int sm_spmma_f32(const void* blob, const float* B, float* C, size_t m, size_t n,
     a.M = (int)(m * batch);
     a.batch = 1;
   }
-  return dispatch32<true>(a, (hipStream_t)stream);
+  return dispatch32<1>(a, (hipStream_t)stream);
 }
 
 int sm_gemm_batched_f64(const double* const* A_ptrs, const double* const* B_ptrs, double* const* C_ptrs, size_t m, size_t n,

@@ -441,6 +441,55 @@ def test_spmm_bell_vs_oracle(gpu, orc):
                                         n, 1.5, 0.5, None)
         assert rc == 0
         assert np.allclose(host(dC), Cref, rtol=1e-5, atol=1e-5)
+        # workspace form: blocks scattered into a dense A, product on the fp32 matrix cores
+        import ctypes
+        nb = ctypes.c_size_t(0)
+        assert gpu.lib().sm_spmm_bell_workspace_size(rows, cols, ctypes.byref(nb)) == 0
+        assert nb.value >= rows * cols * 4
+        ws = torch.full((nb.value,), 0xFF, dtype=torch.uint8, device="cuda")  # stale workspace must not leak
+        dC2 = to_dev(C0.copy())
+        rc = gpu.lib().sm_spmm_bell_f32_ws(dV.data_ptr(), dI.data_ptr(), rows, cols, bs, ell_cols, dB.data_ptr(),
+                                           dC2.data_ptr(), n, 1.5, 0.5, ws.data_ptr(), None)
+        assert rc == 0
+        assert np.allclose(host(dC2), Cref, rtol=1e-4, atol=1e-4)
+
+
+def test_spmm_bell_batched_vs_oracle(gpu, orc):
+    """sm_spmm_bell_batched_f32: every batch of the reference's spmm() loop in one submission."""
+    import ctypes
+    import torch
+    rng = np.random.default_rng(14)
+    rows, cols, bs, n, batch = 136, 160, 2, 70, 5
+    ell_cols = cols // 2
+    bcols = ell_cols // bs
+    B = rng.uniform(-1, 1, cols * n).astype(np.float32)
+    dB = to_dev(B)
+    keep, refs, dCs = [], [], []
+    for b in range(batch):
+        ci = np.stack([np.sort(rng.choice(cols // bs, bcols, replace=False)) for _ in range(rows // bs)]).astype(np.uint64)
+        vals = rng.uniform(-1, 1, (rows, ell_cols)).astype(np.float32)
+        C0 = rng.uniform(-1, 1, rows * n).astype(np.float32)
+        Cref = C0.copy()
+        orc.spmm_bell(vals.reshape(-1), ci.reshape(-1), rows, cols, bs, ell_cols, B, Cref, n, 0.75, -2.0)
+        dV, dI, dC = to_dev(vals.reshape(-1)), to_dev(ci.reshape(-1).view(np.int64)), to_dev(C0.copy())
+        keep.append((dV, dI))
+        dCs.append(dC)
+        refs.append(Cref)
+    nb = ctypes.c_size_t(0)
+    assert gpu.lib().sm_spmm_bell_batched_workspace_size(rows, cols, batch, ctypes.byref(nb)) == 0
+    ws = torch.full((nb.value,), 0xFF, dtype=torch.uint8, device="cuda")
+    PtrArr = ctypes.c_void_p * batch
+    pv = PtrArr(*[v.data_ptr() for v, _ in keep])
+    pi = PtrArr(*[i.data_ptr() for _, i in keep])
+    pc = PtrArr(*[c.data_ptr() for c in dCs])
+    rc = gpu.lib().sm_spmm_bell_batched_f32(pv, pi, rows, cols, bs, ell_cols, dB.data_ptr(), pc, n, batch, 0.75, -2.0,
+                                            ws.data_ptr(), None)
+    assert rc == 0
+    for dC, Cref in zip(dCs, refs):
+        assert np.allclose(host(dC), Cref, rtol=1e-4, atol=1e-4)
+    # a missing workspace is an error, not a silent slow path
+    assert gpu.lib().sm_spmm_bell_batched_f32(pv, pi, rows, cols, bs, ell_cols, dB.data_ptr(), pc, n, batch, 1.0, 0.0,
+                                              None, None) != 0
 
 
 def test_spmm_coo_vs_oracle(gpu, orc):
@@ -460,6 +509,20 @@ def test_spmm_coo_vs_oracle(gpu, orc):
                                    dC.data_ptr(), 2.0, -1.0, None)
     assert rc == 0
     assert np.allclose(host(dC), Cref, rtol=1e-4, atol=1e-4)
+    # workspace form: row-sorted input -> CSR kernel (no atomics); shuffled input -> atomic fallback; same answer
+    import ctypes
+    nb = ctypes.c_size_t(0)
+    assert gpu.lib().sm_spmm_coo_workspace_size(rows, ctypes.byref(nb)) == 0
+    ws = torch.zeros(nb.value, dtype=torch.uint8, device="cuda")
+    order = np.lexsort((c, r))
+    perm = rng.permutation(r.size)
+    for idx in (order, perm):
+        dr2, dc2, dv2 = to_dev(r[idx].copy()), to_dev(c[idx].copy()), to_dev(v[idx].copy())
+        dC2 = to_dev(C0.copy())
+        rc = gpu.lib().sm_spmm_coo_f32_ws(rows, cols, r.size, n, batches, dr2.data_ptr(), dc2.data_ptr(), dv2.data_ptr(),
+                                          dB.data_ptr(), dC2.data_ptr(), 2.0, -1.0, ws.data_ptr(), None)
+        assert rc == 0
+        assert np.allclose(host(dC2), Cref, rtol=1e-4, atol=1e-4)
 
 
 # ---------------------------------------------------------------------------------------------
