@@ -18,9 +18,10 @@
  * 2:4 compressed blob (produced by sm_compress24_*, consumed by sm_spmma_* / sm_decompress24_*),
  * for `batch` row-major m x k matrices, M = batch*m rows:
  *   kc       = k rounded up to a multiple of 64
- *   values   : [M][kc/2] elements at byte 0 (kept pair of strip q at [R][2q], [R][2q+1])
- *   metadata : stage-major [kc/64][M][8] bytes at byte round_up(M*(kc/2)*elt, 256): plane s holds,
- *              for every row, the 8 bytes covering dense k 64s..64s+63; strip q's nibble
+ *   both sections are STAGE-major: plane s covers dense k 64s..64s+63 of every row
+ *   values   : [kc/64][M][32] elements at byte 0 (kept pair of strip q of row R at
+ *              [q/16][R][2(q%16)], [q/16][R][2(q%16)+1])
+ *   metadata : [kc/64][M][8] bytes at byte round_up(M*(kc/2)*elt, 256); strip q's nibble
  *              (p0 | p1 << 2, p0 < p1 kept positions) in bits 4*(q&1).. of byte [q/16][R][(q%16)/2]
  *   size     = sm_compress24_size()
  */

@@ -312,9 +312,10 @@ int sm_prune24_check_f32_ref(const float* A, size_t m, size_t k, size_t ld, int*
 /*
  * Compressed blob of a batch of `batch` row-major m x k matrices (M = batch*m rows in all):
  *   kc          = k rounded up to a multiple of 64
- *   values      : [M][kc/2] elements at byte 0; row R = b*m + i; the two kept elements of the
- *                 strip covering columns 4q..4q+3 sit at [R][2q], [R][2q+1] in k order;
- *                 strips at or beyond k hold +0
+ *   values      : [kc/64][M][32] elements at byte 0 (STAGE-major like the metadata, see val_index);
+ *                 row R = b*m + i; the two kept elements of the strip covering columns 4q..4q+3
+ *                 sit at [q/16][R][2(q%16)], [q/16][R][2(q%16)+1] in k order; strips at or
+ *                 beyond k hold +0
  *   metadata    : [kc/64][M][8] bytes (stage-major, see meta_index) at byte
  *                 meta_off = round_up(M*(kc/2)*elt, 256); byte [q/16][R][(q%16)/2] holds strip q's
  *                 nibble in bits 4*(q&1)..4*(q&1)+3;
@@ -333,6 +334,13 @@ static size_t round_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
  * [kc/64][M][8].  (A 128-row x 64-k tile of the matmul is then 1 KiB of contiguous metadata -- one
  * 8-cache-line DMA -- instead of 128 eight-byte pieces on 128 lines: profiles/stamp_r01.txt.) */
 static size_t meta_index(size_t M, size_t R, size_t q) { return ((q / 16) * M + R) * 8 + (q % 16) / 2; }
+
+/* Element index (values section) of the FIRST kept element of strip q of blob row R; the second follows it.
+ * Also stage-major: plane s = q / 16 holds the 32 kept elements of dense k 64s..64s+63 of every row,
+ * [kc/64][M][32].  (The 128-row x 64-k A tile of the fp16 matmul is then 8 KiB of contiguous values --
+ * 64 whole 128-byte lines -- instead of 128 half lines at a row pitch: the matmul is bound by the
+ * number of line requests its CU can issue, profiles/stamp_r01.txt.) */
+static size_t val_index(size_t M, size_t R, size_t q) { return ((q / 16) * M + R) * 32 + 2 * (q % 16); }
 
 int sm_compress24_layout(size_t m, size_t k, size_t elt_bytes, size_t batch, size_t* kc_out,
                          size_t* meta_off_out, size_t* total_out) {
@@ -374,8 +382,8 @@ int sm_compress24_size_ref(size_t m, size_t k, size_t elt_bytes, size_t batch, s
             }                                                                                    \
             nib = strip_select(key);                                                             \
           }                                                                                      \
-          vals[R * (kc / 2) + 2 * q] = v[nib & 3u];                                              \
-          vals[R * (kc / 2) + 2 * q + 1] = v[nib >> 2];                                          \
+          vals[val_index(M, R, q)] = v[nib & 3u];                                                \
+          vals[val_index(M, R, q) + 1] = v[nib >> 2];                                            \
           meta[meta_index(M, R, q)] |= (unsigned char)(nib << (4 * (q & 1)));                    \
         }                                                                                        \
       }                                                                                          \
@@ -404,8 +412,8 @@ int sm_compress24_f32_ref(const float* A, size_t m, size_t k, size_t ld, size_t 
         for (size_t q = 0; 4 * q < k; ++q) {                                                     \
           const unsigned nib = (meta[meta_index(m * batch, R, q)] >> (4 * (q & 1))) & 0xfu;      \
           const unsigned p0 = nib & 3u, p1 = nib >> 2;                                           \
-          if (4 * q + p0 < k) row[4 * q + p0] = vals[R * (kc / 2) + 2 * q];                      \
-          if (4 * q + p1 < k) row[4 * q + p1] = vals[R * (kc / 2) + 2 * q + 1];                  \
+          if (4 * q + p0 < k) row[4 * q + p0] = vals[val_index(m * batch, R, q)];                \
+          if (4 * q + p1 < k) row[4 * q + p1] = vals[val_index(m * batch, R, q) + 1];            \
         }                                                                                        \
       }                                                                                          \
     return SM_OK;                                                                                \
@@ -447,7 +455,7 @@ static int spmma_ref_impl(const void* blob, const void* B, void* C, size_t m, si
         for (int t = 0; t < 2; ++t) {
           const size_t kk = 4 * q + pos[t];
           if (kk >= k) continue;
-          const double a = ld(blob, R * (kc / 2) + 2 * q + (size_t)t);
+          const double a = ld(blob, val_index(m * batch, R, q) + (size_t)t);
           if (a == 0.0) continue; /* exact: a zero contributes nothing for finite B */
           const size_t brow = b * strideB + kk * n;
           for (size_t j = 0; j < n; ++j) acc[j] += a * ld(B, brow + j);

@@ -17,7 +17,7 @@ namespace sm {
 
 struct Gemm32Args {
   const float* A;      // dense A (row-major M x K, lda) -- or null when `vals` is set
-  const char* vals;    // 2:4 blob values  [Mtot][kc/2] floats
+  const char* vals;    // 2:4 blob values, stage-major [kc/64][Mtot][32] floats
   const char* meta;    // 2:4 blob metadata, stage-major [kc/64][Mtot][8 B]
   size_t Mtot;         // rows of the whole blob (m * batch)
   const float* B;
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const Gemm32Args p) {
         f4 v = {0.f, 0.f, 0.f, 0.f};
         if (gr < p.M && kk < p.kc) {
           const size_t R = row_base + (size_t)gr;
-          const float* vp = reinterpret_cast<const float*>(p.vals) + R * (size_t)(p.kc / 2) + kk / 2;
+          const float* vp = reinterpret_cast<const float*>(p.vals) + ((size_t)(kk >> 6) * p.Mtot + R) * 32 + ((kk & 63) >> 1);
           const float a0 = vp[0], a1 = vp[1];
           const unsigned mb = *reinterpret_cast<const unsigned char*>(p.meta + ((size_t)(kk >> 6) * p.Mtot + R) * 8 + ((kk >> 3) & 7));
           const unsigned nib = (mb >> (4 * ((kk >> 2) & 1))) & 0xfu, p0 = nib & 3u, p1 = nib >> 2;

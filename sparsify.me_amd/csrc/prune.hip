@@ -120,10 +120,6 @@ __global__ void sparsify_generic_kernel(VT* w, uint64_t* mask, size_t nblk, size
   }
 }
 
-// Metadata section: stage-major [kc/64][M][8 B] (oracle/sm_oracle.c: meta_index).  Byte of item `c8`
-// (8 dense k = 2 strips) of blob row R:
-__device__ __forceinline__ size_t meta_byte(size_t M, size_t R, size_t c8) { return ((c8 >> 3) * M + R) * 8 + (c8 & 7); }
-
 // ---------------------------------------------------------------------------------------------
 // element access helpers: 8 consecutive k of one row, vector path when aligned and in range
 // ---------------------------------------------------------------------------------------------
@@ -277,141 +273,116 @@ __global__ __launch_bounds__(256) void prune_check_kernel(const T* A, size_t m, 
 }
 
 // ---------------------------------------------------------------------------------------------
-// (a3) compress (K5, fused with the STRIP selection): item = 8 dense k of one blob row ->
-//      4 kept values (one 8- or 16-byte store) + 1 metadata byte (staged through LDS).
+// (a3) compress (K5, fused with the STRIP selection).  item = 8 dense k of one blob row -> 4 kept values
+//      (one 8- or 16-byte store) + 1 metadata byte.  Both blob sections are stage-major, so item
+//      it' = ((s * M + R) * 8 + j8)  (s = 64-k stage, R = blob row, j8 = item of the stage) owns values
+//      [4 it', 4 it' + 4) and metadata byte it': the OUTPUT is linear in it'.
 // ---------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void select_item(const Vec8<T>& v, unsigned valid_strips /*bit s: strip s in range*/, T out[4],
+                                            unsigned& mb) {
+  unsigned nib[2];
+#pragma unroll
+  for (unsigned s = 0; s < 2; ++s) {
+    // a strip wholly at or beyond k keeps the padding nibble 0x4 and zero values
+    const unsigned keep = ((valid_strips >> s) & 1u)
+                              ? strip_keepmask(key_of(v.e[4 * s]), key_of(v.e[4 * s + 1]), key_of(v.e[4 * s + 2]),
+                                               key_of(v.e[4 * s + 3]))
+                              : 3u;
+    nib[s] = nibble_of(keep);
+    // select the two kept values without dynamic register indexing
+    const unsigned p0 = nib[s] & 3u, p1 = nib[s] >> 2;
+    T a0 = v.e[4 * s], a1 = v.e[4 * s + 1];
+    a0 = p0 == 1 ? v.e[4 * s + 1] : a0;
+    a0 = p0 == 2 ? v.e[4 * s + 2] : a0;
+    a1 = p1 == 2 ? v.e[4 * s + 2] : a1;
+    a1 = p1 == 3 ? v.e[4 * s + 3] : a1;
+    out[2 * s] = a0;
+    out[2 * s + 1] = a1;
+  }
+  mb = nib[0] | (nib[1] << 4);
+}
+
+template <typename T>
+__device__ __forceinline__ void store_item(T* vals, size_t itp, const T out[4]) {
+  if constexpr (sizeof(T) == 2) {
+    *reinterpret_cast<u2*>(vals + itp * 4) = *reinterpret_cast<const u2*>(out);
+  } else {
+    *reinterpret_cast<u4*>(vals + itp * 4) = *reinterpret_cast<const u4*>(out);
+  }
+}
+
+// General form (any k, ld, batch stride, alignment): walks it' linearly, one division by M per item.
 template <typename T>
 __global__ __launch_bounds__(256) void compress_kernel(const T* A, size_t m, size_t k, size_t ld,
                                                        size_t strideA, size_t kc, size_t M, T* vals,
                                                        unsigned char* meta, bool vec_ok) {
-  __shared__ __attribute__((aligned(16))) unsigned char smeta[1024];
-  const size_t ipr = kc / 8;        // items per blob row
-  const size_t total = M * ipr;     // a multiple of 8 (kc % 64 == 0)
-  const bool flat = kc == k && ld == k && strideA == m * ld;
-  const size_t nchunk = (total + 1023) / 1024;
-  for (size_t chunk = blockIdx.x; chunk < nchunk; chunk += gridDim.x) {
-#pragma unroll
-    for (unsigned j = 0; j < 4; ++j) {
-      const size_t it = chunk * 1024 + j * 256 + threadIdx.x;
-      unsigned char mb = 0x44;
-      if (it < total) {
-        // flat: no padding columns and batches/rows back to back -> item `it` is input elements [8*it, 8*it+8)
-        const size_t R = flat ? 0 : it / ipr, c = flat ? 0 : (it - R * ipr) * 8;
-        T out[4] = {0, 0, 0, 0};
-        if (flat || c < k) {
-          const size_t b = flat ? 0 : R / m, i = R - b * m;
-          const size_t nvalid = flat ? 8 : (k - c < 8 ? k - c : 8);
-          Vec8<T> v;
-          load8(v, flat ? A + it * 8 : A + b * strideA + i * ld + c, nvalid, vec_ok);
-          unsigned nib[2];
-#pragma unroll
-          for (unsigned s = 0; s < 2; ++s) {
-            // a strip wholly at or beyond k keeps the padding nibble 0x4 and zero values
-            const unsigned keep = (flat || c + 4 * s < k)
-                                      ? strip_keepmask(key_of(v.e[4 * s]), key_of(v.e[4 * s + 1]),
-                                                       key_of(v.e[4 * s + 2]), key_of(v.e[4 * s + 3]))
-                                      : 3u;
-            nib[s] = nibble_of(keep);
-            // select the two kept values without dynamic register indexing
-            const unsigned p0 = nib[s] & 3u, p1 = nib[s] >> 2;
-            T a0 = v.e[4 * s], a1 = v.e[4 * s + 1];
-            a0 = p0 == 1 ? v.e[4 * s + 1] : a0;
-            a0 = p0 == 2 ? v.e[4 * s + 2] : a0;
-            a1 = p1 == 2 ? v.e[4 * s + 2] : a1;
-            a1 = p1 == 3 ? v.e[4 * s + 3] : a1;
-            out[2 * s] = a0;
-            out[2 * s + 1] = a1;
-          }
-          mb = (unsigned char)(nib[0] | (nib[1] << 4));
-        }
-        if constexpr (sizeof(T) == 2) {
-          *reinterpret_cast<u2*>(vals + it * 4) = *reinterpret_cast<const u2*>(out);
-        } else {
-          *reinterpret_cast<u4*>(vals + it * 4) = *reinterpret_cast<const u4*>(out);
-        }
-      }
-      smeta[j * 256 + threadIdx.x] = mb;
+  const size_t total = M * (kc / 8);  // a multiple of 8
+  for (size_t itp = blockIdx.x * (size_t)256 + threadIdx.x; itp < total; itp += (size_t)gridDim.x * 256) {
+    const size_t t = itp >> 3, s = t / M, R = t - s * M, c = (s * 8 + (itp & 7)) * 8;
+    T out[4] = {0, 0, 0, 0};
+    unsigned mb = 0x44;
+    if (c < k) {
+      const size_t b = R / m, i = R - b * m;
+      const size_t nvalid = k - c < 8 ? k - c : 8;
+      Vec8<T> v;
+      load8(v, A + b * strideA + i * ld + c, nvalid, vec_ok);
+      select_item(v, 1u | (c + 4 < k ? 2u : 0u), out, mb);
     }
-    __syncthreads();
-    {
-      // four consecutive items (same row: ipr is a multiple of 8) -> four consecutive metadata bytes
-      const size_t it4 = chunk * 1024 + threadIdx.x * 4;
-      if (it4 < total) {
-        const size_t R4 = it4 / ipr, c4 = it4 - R4 * ipr;
-        *reinterpret_cast<unsigned*>(meta + meta_byte(M, R4, c4)) = reinterpret_cast<const unsigned*>(smeta)[threadIdx.x];
-      }
-    }
-    __syncthreads();
+    store_item(vals, itp, out);
+    meta[itp] = (unsigned char)mb;
   }
 }
 
-// Fast path of compress: dense input with no padding columns, rows and batches back to back, 16-byte
-// aligned (every ResNet layer but k = 147).  No division, no LDS, no barrier: each lane issues its four
-// 16-byte loads up front (A is read exactly once: non-temporal), and the four metadata bytes of four
-// consecutive items -- held by the four lanes of a quad -- are gathered with DPP quad permutes so the quad's
-// first lane writes one dword.
-template <typename T, bool NT>
-__global__ __launch_bounds__(256) void compress_flat_kernel(const T* __restrict__ A, size_t total /*items of 8 dense k*/,
-                                                            size_t ipr /*items per row*/, size_t M,
-                                                            T* __restrict__ vals, unsigned char* __restrict__ meta) {
-  const bool small = total < 0xffffffffull;  // 32-bit division is a fraction of the 64-bit one
-  const size_t nchunk = (total + 1023) / 1024;
-  for (size_t chunk = blockIdx.x; chunk < nchunk; chunk += gridDim.x) {
-    const size_t it0 = chunk * 1024 + threadIdx.x;
-    Vec8<T> v[4];
+// Fast path of compress: dense input with no padding columns (k % 64 == 0), rows and batches back to back,
+// 16-byte aligned (every ResNet layer but k = 147).  No LDS, no barrier.  The work is cut into units of
+// 8 rows x 1 stage, numbered with the stage running fastest (unit U = row group * nstage + stage); a block
+// takes 4 * NLD consecutive units, unit NLD * wave + j being the j-th of the NLD 16-byte loads each lane issues up
+// front (A is read exactly once: non-temporal); lane l of a unit holds item j8 = l & 7 of row (l >> 3).
+// Reads are therefore runs of up to 2 KiB per row, writes 512 contiguous bytes of values + 64 contiguous
+// metadata bytes per unit; the four metadata bytes of a quad's lanes are gathered with DPP quad permutes so
+// its first lane writes one dword.  One 32-bit division per unit (wave-uniform).
+template <typename T, bool NT, int NLD>
+__global__ __launch_bounds__(256) void compress_flat_kernel(const T* __restrict__ A, size_t M, size_t k, unsigned nstage,
+                                                            unsigned nunits, T* __restrict__ vals,
+                                                            unsigned char* __restrict__ meta) {
+  const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  Vec8<T> v[NLD];
+  size_t itp[NLD];
+  bool ok[NLD];
 #pragma unroll
-    for (unsigned j = 0; j < 4; ++j) {
-      const size_t it = it0 + j * 256;
-      if (it < total) {
-        const u4* p = reinterpret_cast<const u4*>(A + it * 8);
-        if constexpr (sizeof(T) == 2) {
-          *reinterpret_cast<u4*>(v[j].e) = NT ? __builtin_nontemporal_load(p) : *p;
-        } else {
-          reinterpret_cast<u4*>(v[j].e)[0] = NT ? __builtin_nontemporal_load(p) : p[0];
-          reinterpret_cast<u4*>(v[j].e)[1] = NT ? __builtin_nontemporal_load(p + 1) : p[1];
-        }
+  for (unsigned j = 0; j < (unsigned)NLD; ++j) {
+    const unsigned U = blockIdx.x * (4u * NLD) + (unsigned)NLD * wave + j, rg = U / nstage, s = U - rg * nstage;
+    const size_t R = (size_t)rg * 8u + (lane >> 3);
+    ok[j] = U < nunits && R < M;
+    itp[j] = (((size_t)s * M + R) << 3) + (lane & 7u);
+    if (ok[j]) {
+      const u4* p = reinterpret_cast<const u4*>(A + R * k + (size_t)s * 64 + (lane & 7u) * 8);
+      if constexpr (sizeof(T) == 2) {
+        *reinterpret_cast<u4*>(v[j].e) = NT ? __builtin_nontemporal_load(p) : *p;
       } else {
-#pragma unroll
-        for (unsigned t = 0; t < 8; ++t) v[j].e[t] = 0;
+        reinterpret_cast<u4*>(v[j].e)[0] = NT ? __builtin_nontemporal_load(p) : p[0];
+        reinterpret_cast<u4*>(v[j].e)[1] = NT ? __builtin_nontemporal_load(p + 1) : p[1];
       }
+    } else {
+#pragma unroll
+      for (unsigned t = 0; t < 8; ++t) v[j].e[t] = 0;
     }
+  }
 #pragma unroll
-    for (unsigned j = 0; j < 4; ++j) {
-      const size_t it = it0 + j * 256;
-      T out[4];
-      unsigned nib[2];
-#pragma unroll
-      for (unsigned s = 0; s < 2; ++s) {
-        const unsigned keep = strip_keepmask(key_of(v[j].e[4 * s]), key_of(v[j].e[4 * s + 1]), key_of(v[j].e[4 * s + 2]),
-                                             key_of(v[j].e[4 * s + 3]));
-        nib[s] = nibble_of(keep);
-        const unsigned p0 = nib[s] & 3u, p1 = nib[s] >> 2;
-        T a0 = v[j].e[4 * s], a1 = v[j].e[4 * s + 1];
-        a0 = p0 == 1 ? v[j].e[4 * s + 1] : a0;
-        a0 = p0 == 2 ? v[j].e[4 * s + 2] : a0;
-        a1 = p1 == 2 ? v[j].e[4 * s + 2] : a1;
-        a1 = p1 == 3 ? v[j].e[4 * s + 3] : a1;
-        out[2 * s] = a0;
-        out[2 * s + 1] = a1;
-      }
-      const int mb = (int)(nib[0] | (nib[1] << 4));
-      // bytes of the quad's four lanes -> one dword (same value in all four lanes)
-      const unsigned b0 = (unsigned)__builtin_amdgcn_update_dpp(0, mb, 0x00, 0xf, 0xf, true);
-      const unsigned b1 = (unsigned)__builtin_amdgcn_update_dpp(0, mb, 0x55, 0xf, 0xf, true);
-      const unsigned b2 = (unsigned)__builtin_amdgcn_update_dpp(0, mb, 0xaa, 0xf, 0xf, true);
-      const unsigned b3 = (unsigned)__builtin_amdgcn_update_dpp(0, mb, 0xff, 0xf, 0xf, true);
-      if (it < total) {
-        if constexpr (sizeof(T) == 2) {
-          *reinterpret_cast<u2*>(vals + it * 4) = *reinterpret_cast<const u2*>(out);
-        } else {
-          *reinterpret_cast<u4*>(vals + it * 4) = *reinterpret_cast<const u4*>(out);
-        }
-        // total is a multiple of 8, so a quad is all in or all out
-        if ((threadIdx.x & 3u) == 0) {
-          const size_t R = small ? (size_t)((unsigned)it / (unsigned)ipr) : it / ipr;
-          *reinterpret_cast<unsigned*>(meta + meta_byte(M, R, it - R * ipr)) = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
-        }
-      }
+  for (unsigned j = 0; j < (unsigned)NLD; ++j) {
+    T out[4];
+    unsigned mbu;
+    select_item(v[j], 3u, out, mbu);
+    const int mb = (int)mbu;
+    // bytes of the quad's four lanes -> one dword (same value in all four lanes)
+    const unsigned b0 = (unsigned)__builtin_amdgcn_update_dpp(0, mb, 0x00, 0xf, 0xf, true);
+    const unsigned b1 = (unsigned)__builtin_amdgcn_update_dpp(0, mb, 0x55, 0xf, 0xf, true);
+    const unsigned b2 = (unsigned)__builtin_amdgcn_update_dpp(0, mb, 0xaa, 0xf, 0xf, true);
+    const unsigned b3 = (unsigned)__builtin_amdgcn_update_dpp(0, mb, 0xff, 0xf, 0xf, true);
+    if (ok[j]) {  // a quad shares its row and stage: all in or all out
+      store_item(vals, itp[j], out);
+      if ((lane & 3u) == 0) *reinterpret_cast<unsigned*>(meta + itp[j]) = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
     }
   }
 }
@@ -420,25 +391,24 @@ template <typename T>
 __global__ __launch_bounds__(256) void decompress_kernel(const T* vals, const unsigned char* meta, size_t m,
                                                          size_t k, size_t ld, size_t strideA, size_t kc,
                                                          size_t M, T* A, bool vec_ok) {
-  const size_t ipr = kc / 8;
-  const size_t total = M * ipr;
-  for (size_t it = blockIdx.x * (size_t)256 + threadIdx.x; it < total; it += (size_t)gridDim.x * 256) {
-    const size_t R = it / ipr, c = (it - R * ipr) * 8;
+  const size_t total = M * (kc / 8);
+  for (size_t itp = blockIdx.x * (size_t)256 + threadIdx.x; itp < total; itp += (size_t)gridDim.x * 256) {
+    const size_t t = itp >> 3, s = t / M, R = t - s * M, c = (s * 8 + (itp & 7)) * 8;
     if (c >= k) continue;
     const size_t b = R / m, i = R - b * m;
-    const unsigned mb = meta[meta_byte(M, R, it - R * ipr)];
+    const unsigned mb = meta[itp];
     T in[4];
     if constexpr (sizeof(T) == 2) {
-      *reinterpret_cast<u2*>(in) = *reinterpret_cast<const u2*>(vals + it * 4);
+      *reinterpret_cast<u2*>(in) = *reinterpret_cast<const u2*>(vals + itp * 4);
     } else {
-      *reinterpret_cast<u4*>(in) = *reinterpret_cast<const u4*>(vals + it * 4);
+      *reinterpret_cast<u4*>(in) = *reinterpret_cast<const u4*>(vals + itp * 4);
     }
     Vec8<T> v;
 #pragma unroll
-    for (unsigned s = 0; s < 2; ++s) {
-      const unsigned nib = (mb >> (4 * s)) & 0xfu, p0 = nib & 3u, p1 = nib >> 2;
+    for (unsigned s2 = 0; s2 < 2; ++s2) {
+      const unsigned nib = (mb >> (4 * s2)) & 0xfu, p0 = nib & 3u, p1 = nib >> 2;
 #pragma unroll
-      for (unsigned t = 0; t < 4; ++t) v.e[4 * s + t] = t == p0 ? in[2 * s] : (t == p1 ? in[2 * s + 1] : (T)0);
+      for (unsigned t2 = 0; t2 < 4; ++t2) v.e[4 * s2 + t2] = t2 == p0 ? in[2 * s2] : (t2 == p1 ? in[2 * s2 + 1] : (T)0);
     }
     const size_t nvalid = k - c < 8 ? k - c : 8;
     store8(v, A + b * strideA + i * ld + c, nvalid, vec_ok);
@@ -541,15 +511,20 @@ static int launch_compress(const void* A, size_t m, size_t k, size_t ld, size_t 
     return check_launch("hipMemsetAsync");
   const bool vec_ok = vec_ok_2d<T>(A, A, ld, strideA);
   const size_t items = L.M * (L.kc / 8);
-  const unsigned grid = stream_grid(ceil_div(items, 4), 256);
-  if (vec_ok && L.kc == k && ld == k && (batch == 1 || strideA == m * ld)) {
+  const size_t nunits = ceil_div(L.M, (size_t)8) * (L.kc / 64);
+  if (vec_ok && L.kc == k && ld == k && (batch == 1 || strideA == m * ld) && nunits < 0xfffffff0ull) {
     static const bool nt = !(getenv("SM_COMPRESS_NT") && atoi(getenv("SM_COMPRESS_NT")) == 0);
-    if (nt)
-      compress_flat_kernel<T, true><<<grid, 256, 0, st>>>((const T*)A, items, L.kc / 8, L.M, (T*)blob, (unsigned char*)blob + L.meta_off);
-    else
-      compress_flat_kernel<T, false><<<grid, 256, 0, st>>>((const T*)A, items, L.kc / 8, L.M, (T*)blob, (unsigned char*)blob + L.meta_off);
+    // two loads per lane (8 units per block) measured best on the ResNet-50 table (1.72 ms against 1.85 with 4,
+    // 2.00 with 8, 1.84 with 1: profiles/sweep_r01_i_compress.txt)
+    constexpr int NLD = 2;
+    const unsigned nstage = (unsigned)(L.kc / 64), grid = (unsigned)ceil_div(nunits, (size_t)(4 * NLD));
+    T* v = (T*)blob;
+    unsigned char* mt = (unsigned char*)blob + L.meta_off;
+    if (nt) compress_flat_kernel<T, true, NLD><<<grid, 256, 0, st>>>((const T*)A, L.M, k, nstage, (unsigned)nunits, v, mt);
+    else compress_flat_kernel<T, false, NLD><<<grid, 256, 0, st>>>((const T*)A, L.M, k, nstage, (unsigned)nunits, v, mt);
     return check_launch("compress_flat_kernel");
   }
+  const unsigned grid = stream_grid(items, 256);
   compress_kernel<T><<<grid, 256, 0, st>>>((const T*)A, m, k, ld, strideA, L.kc, L.M, (T*)blob,
                                            (unsigned char*)blob + L.meta_off, vec_ok);
   return check_launch("compress_kernel");

@@ -5,7 +5,7 @@
 namespace sm {
 
 struct SpmmaArgs {
-  const char* vals;   // [Mtot][kc/2] halves, row pitch kc bytes
+  const char* vals;   // stage-major [kc/64][Mtot][32] halves (64 B per row per plane)
   const char* meta;   // stage-major [kc/64][Mtot][8 B]
   size_t Mtot;        // rows of the whole blob (m * batch)
   const half_t* B;
@@ -25,8 +25,5 @@ struct SpmmaArgs {
 
 // 64-byte-row A image: 16-byte chunk c of row r lives at chunk c ^ ((-(r >> 2)) & 3).
 __device__ __forceinline__ unsigned a64_swz(unsigned row) { return (0u - (row >> 2)) & 3u; }
-
-// spmma_f16_pc.hip: producer/consumer kernels with BK = 128 stages.  cfg: 0 = 128x128, 1 = 256x128, 2 = 128x64.
-int spmma_f16_pc2_launch(const SpmmaArgs& a, int cfg, int ns, hipStream_t st);
 
 }  // namespace sm

@@ -1,7 +1,7 @@
 // spmma_f16.hip -- the 2:4 sparse x dense matmul on gfx950's native sparse matrix instruction
 // v_smfmac_f32_16x16x64_f16 (fp32 accumulate, one rounding to fp16).  Replaces cusparseLtMatmul as
 // include/sparsify.me/spmma.hxx:112-113 calls it: C[m x n] = alpha * A * B + beta * C, row-major,
-// A the compressed blob of sm_compress24_f16 (values [M][kc/2] + metadata [M][kc/8]).
+// A the compressed blob of sm_compress24_f16 (stage-major values [kc/64][M][32] + metadata [kc/64][M][8 B]).
 //
 // Per 128 dense k of a row the kernel moves 128 B of kept values + 16 B of metadata instead of the
 // dense kernel's 256 B, and issues half the matrix instructions: the hardware multiplies each kept
@@ -56,8 +56,8 @@ __global__ __launch_bounds__(256) void spmma_f16_kernel(const SpmmaArgs p) {
   const int m0 = (int)tile_m * BM, n0 = (int)tile_n * BN;
 
   const size_t row_base = (size_t)b * p.m;  // first blob row of this grid batch
-  const char* vals = p.vals + row_base * (size_t)p.kc;
-  const char* meta = p.meta + row_base * 8;  // + stage * Mtot * 8 per 64-k stage
+  const char* vals = p.vals + row_base * 64;  // + stage * Mtot * 64 per 64-k stage (stage-major values)
+  const char* meta = p.meta + row_base * 8;   // + stage * Mtot * 8 per 64-k stage
   const half_t* B = p.B + (size_t)b * p.sB;
   half_t* C = p.C + (size_t)b * p.sC;
 
@@ -72,13 +72,14 @@ __global__ __launch_bounds__(256) void spmma_f16_kernel(const SpmmaArgs p) {
   const bool b_vec = (p.N % 8 == 0) && ((reinterpret_cast<uintptr_t>(B) & 15u) == 0);
 
   auto gload = [&](int kt) {
-    const int vb0 = kt * 128;  // byte offset of this stage inside a value row (kc bytes per row)
 #pragma unroll
     for (int i = 0; i < A_CH; ++i) {
+      // a 128-k stage of this kernel = two 64-k planes of the blob, 64 bytes per row in each
       const unsigned q = tid + 256u * i, row = q >> 3, ch = q & 7u;
-      const int gr = m0 + (int)row, vb = vb0 + 16 * (int)ch;
+      const int gr = m0 + (int)row, st64 = kt * 2 + (int)(ch >> 2);
       u4 v = {0u, 0u, 0u, 0u};
-      if (gr < p.Mrows && vb < p.kc) v = *reinterpret_cast<const u4*>(vals + (size_t)gr * p.kc + vb);
+      if (gr < p.Mrows && st64 * 64 < p.kc)
+        v = *reinterpret_cast<const u4*>(vals + ((size_t)st64 * p.Mtot + (size_t)gr) * 64 + 16u * (ch & 3u));
       ra[i] = v;
     }
 #pragma unroll
@@ -262,7 +263,7 @@ __global__ __launch_bounds__(64 * WM * WN) void spmma_f16_dma_kernel(const Spmma
   const int m0 = (int)tile_m * BM, n0 = (int)tile_n * BN;
 
   const size_t row_base = (size_t)b * p.m;
-  const char* vals = p.vals + row_base * (size_t)p.kc;
+  const char* vals = p.vals + row_base * 64;  // plane of stage 0; + Mtot * 64 per stage (stage-major values)
   const char* meta = p.meta + row_base * 8;  // plane of stage 0; + Mtot * 8 per stage
   const half_t* B = p.B + (size_t)b * p.sB;
   half_t* C = p.C + (size_t)b * p.sC;
@@ -279,8 +280,8 @@ __global__ __launch_bounds__(64 * WM * WN) void spmma_f16_dma_kernel(const Spmma
       const unsigned row = 16u * t + (lane >> 2), cs = (lane & 3u) ^ a64_swz(row);
       int gr = m0 + (int)row;
       gr = gr < mlast ? gr : mlast;
-      src[i] = vals + (size_t)gr * p.kc + 16u * cs;
-      step[i] = 64;
+      src[i] = vals + (size_t)gr * 64 + 16u * cs;
+      step[i] = p.Mtot * 64;
       loff[i] = t * 1024u;
     } else if (t < (unsigned)(A_N + M_N)) {
       // lane moves the 16 bytes of tile rows 2*lane, 2*lane+1 (clamped to the batch's last row pair)
@@ -491,7 +492,7 @@ __global__ __launch_bounds__(64 * (WM * WN + NL)) void spmma_f16_pc_kernel(const
     // ------------------------------------------------------------------ loader wave
     const unsigned lw = wave - NC;
     const size_t row_base = (size_t)b * p.m;
-    const char* vals = p.vals + row_base * (size_t)p.kc;
+    const char* vals = p.vals + row_base * 64;  // plane of stage 0; + Mtot * 64 per stage (stage-major values)
     const char* meta = p.meta + row_base * 8;
     const half_t* B = p.B + (size_t)b * p.sB;
     const int mlast = p.Mrows - 1;
@@ -505,8 +506,8 @@ __global__ __launch_bounds__(64 * (WM * WN + NL)) void spmma_f16_pc_kernel(const
         const unsigned row = 16u * t + (lane >> 2), cs = (lane & 3u) ^ a64_swz(row);
         int gr = m0 + (int)row;
         gr = gr < mlast ? gr : mlast;
-        src[i] = vals + (size_t)gr * p.kc + 16u * cs;
-        step[i] = 64;
+        src[i] = vals + (size_t)gr * 64 + 16u * cs;
+        step[i] = p.Mtot * 64;
         loff[i] = t * 1024u;
       } else if (t < (unsigned)(A_N + M_N)) {
         const unsigned u = t - A_N;
@@ -815,15 +816,9 @@ extern "C" int sm_spmma_f16(const void* blob, const void* B, void* C, size_t m, 
     // tiles per CU overlap each other's latencies; with about one tile per CU the same tile is spread
     // over 8 or 16 waves so that every SIMD still holds several waves.  SM_SPMMA_CFG (tuning aid):
     // "<waves>x<ring>" forces a configuration.
-    static const char* pc2_env = getenv("SM_SPMMA_PC2");  // tuning aid: "<cfg>x<ring>" forces a 128-deep-stage kernel
-    if (pc2_env) {
-      int cfg2 = 0, ns2 = 2;
-      sscanf(pc2_env, "%dx%d", &cfg2, &ns2);
-      if (cfg2 >= 0) return spmma_f16_pc2_launch(a, cfg2, ns2, st);
-    }
     // 256 x 128 tiles (B lines amortised over twice the rows) pay with a long K and enough rows for >= 64 such
     // tiles per n-tile (profiles/sweep_r01_*.txt: 784x256x{1024,2304}, 3136x128x1152 at b=32)
-    if (!pc2_env && !getenv("SM_SPMMA_PC") && !getenv("SM_SPMMA_CFG") && n >= 128 && n <= 256 && k >= 1024 &&
+    if (!getenv("SM_SPMMA_PC") && !getenv("SM_SPMMA_CFG") && n >= 128 && n <= 256 && k >= 1024 &&
         (size_t)a.Mrows >= 16384)
       return launch_pc<256, 128, 4, 2, 4, 3>(a, st);
     static const char* pc_env = getenv("SM_SPMMA_PC");  // tuning aid: "<loaders>x<ring>", "0" = previous kernel

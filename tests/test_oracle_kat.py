@@ -241,10 +241,12 @@ def test_compress_layout_and_batches(orc):
     for b in range(batch):
         one = orc.compress24(bits(A[b * m * k:(b + 1) * m * k]), m, k, k, 1)
         kc1, mo1, _ = orc.compress24_layout(m, k, 2, 1)
-        assert np.array_equal(blob[b * m * kc:(b + 1) * m * kc], one[: m * kc])
-        # metadata is stage-major: plane s holds 8 bytes per row for dense k 64s..64s+63 of ALL rows
+        # both sections are stage-major: plane s holds, for ALL rows, the 32 kept halves (64 B) / the 8
+        # metadata bytes of dense k 64s..64s+63
         M = batch * m
         for s in range(kc // 64):
+            assert np.array_equal(blob[(s * M + b * m) * 64: (s * M + (b + 1) * m) * 64],
+                                  one[s * m * 64: (s + 1) * m * 64])
             assert np.array_equal(blob[meta_off + (s * M + b * m) * 8: meta_off + (s * M + (b + 1) * m) * 8],
                                   one[mo1 + s * m * 8: mo1 + (s + 1) * m * 8])
     D = orc.decompress24(blob, m, k, k, np.uint16, batch)
