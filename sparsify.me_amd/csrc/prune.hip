@@ -373,7 +373,16 @@ __global__ __launch_bounds__(256) void compress_flat_kernel(const T* __restrict_
   for (unsigned j = 0; j < (unsigned)NLD; ++j) {
     T out[4];
     unsigned mbu;
-    select_item(v[j], 3u, out, mbu);
+    if constexpr (sizeof(T) == 2) {  // composite-key selection, two strips of packed halves (select24.h)
+      const u4 d = *reinterpret_cast<const u4*>(v[j].e);
+      uint32_t k0, k1, n0, n1;
+      strip_select_f16(d[0], d[1], k0, n0);
+      strip_select_f16(d[2], d[3], k1, n1);
+      *reinterpret_cast<u2*>(out) = u2{k0, k1};
+      mbu = n0 | (n1 << 4);
+    } else {
+      select_item(v[j], 3u, out, mbu);
+    }
     const int mb = (int)mbu;
     // bytes of the quad's four lanes -> one dword (same value in all four lanes)
     const unsigned b0 = (unsigned)__builtin_amdgcn_update_dpp(0, mb, 0x00, 0xf, 0xf, true);

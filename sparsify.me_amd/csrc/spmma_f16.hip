@@ -824,7 +824,8 @@ extern "C" int sm_spmma_f16(const void* blob, const void* B, void* C, size_t m, 
     static const char* pc_env = getenv("SM_SPMMA_PC");  // tuning aid: "<loaders>x<ring>", "0" = previous kernel
     // default: long K -> producer/consumer kernel (4 loader waves, ring of 3); short K -> the kernel
     // above with more tiles per CU (measured per shape on the ResNet tables, profiles/sweep_r01_*.txt)
-    int nl = k >= 512 ? 4 : 0, pns = 3;
+    // (n <= 64 is HBM-bound at every K: the plain DMA kernel with more tiles per CU wins there)
+    int nl = (k >= 512 && n > 64) ? 4 : 0, pns = 3;
     if (pc_env) sscanf(pc_env, "%dx%d", &nl, &pns);
     if (nl == 256 && n > 64) {  // tuning aid: 256 x 128 tiles, 8 consumer waves (64 x 64) + 4 loaders, 64-deep stages
       return pns >= 3 ? launch_pc<256, 128, 4, 2, 4, 3>(a, st) : launch_pc<256, 128, 4, 2, 4, 2>(a, st);

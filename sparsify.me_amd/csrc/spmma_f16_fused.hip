@@ -101,26 +101,11 @@ __global__ __launch_bounds__(64 * (WM * WN + 4)) void spmma_f16_fused_kernel(con
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const h8 v = __builtin_bit_cast(h8, ra[i]);
-        typedef unsigned short us8 __attribute__((ext_vector_type(8)));
-        const us8 e = __builtin_bit_cast(us8, v);
-        unsigned short out[4];
-        unsigned nib[2];
-#pragma unroll
-        for (unsigned s = 0; s < 2; ++s) {
-          const unsigned keep = strip_keepmask(key_of((uint16_t)e[4 * s]), key_of((uint16_t)e[4 * s + 1]),
-                                               key_of((uint16_t)e[4 * s + 2]), key_of((uint16_t)e[4 * s + 3]));
-          nib[s] = nibble_of(keep);
-          const unsigned p0 = nib[s] & 3u, p1 = nib[s] >> 2;
-          unsigned short a0 = e[4 * s], a1 = e[4 * s + 1];
-          a0 = p0 == 1 ? e[4 * s + 1] : a0;
-          a0 = p0 == 2 ? e[4 * s + 2] : a0;
-          a1 = p1 == 2 ? e[4 * s + 2] : a1;
-          a1 = p1 == 3 ? e[4 * s + 3] : a1;
-          out[2 * s] = a0;
-          out[2 * s + 1] = a1;
-        }
-        u2 packed = {(unsigned)out[0] | ((unsigned)out[1] << 16), (unsigned)out[2] | ((unsigned)out[3] << 16)};
+        uint32_t k0, k1, n0, n1;
+        strip_select_f16(ra[i][0], ra[i][1], k0, n0);
+        strip_select_f16(ra[i][2], ra[i][3], k1, n1);
+        const u2 packed = {k0, k1};
+        const unsigned nib[2] = {n0, n1};
         *reinterpret_cast<u2*>(sb + a_val_off[i]) = packed;
         *reinterpret_cast<unsigned char*>(sb + a_meta_off[i]) = (unsigned char)(nib[0] | (nib[1] << 4));
       }
