@@ -45,8 +45,11 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the per-stage / denominator passes")
     ap.add_argument("--eager", action="store_true", help="launch from Python instead of replaying a hipGraph")
     ap.add_argument("--path", choices=["auto", "staged"], default="auto",
-                    help="auto: fused prune+compress+matmul kernel on the layers where it wins (n <= 128), the staged "
-                         "compress24 + spmma pair elsewhere; staged: the pair on every layer")
+                    help="auto: fused prune+compress+matmul kernel on the layers where it wins (n <= --fused-max-n), the "
+                         "staged compress24 + spmma pair elsewhere; staged: the pair on every layer")
+    ap.add_argument("--fused-max-n", type=int, default=256,
+                    help="auto path: widest n served by sm_spmma_fused_f16 (one workgroup spans up to 256 columns, so up "
+                         "to there A is loaded and selected once)")
     ap.add_argument("--streams", type=int, default=4,
                     help="HIP streams the independent layers of a step are spread over (fork/join inside the step)")
     args = ap.parse_args()
@@ -108,7 +111,7 @@ def main():
         sm.spmma(L["blob"], L["B"], L["C"], L["m"], L["n"], L["k"], L["b"], 0)
 
     def use_fused(L):
-        return args.path == "auto" and L["n"] <= 128 and L["k"] % 64 == 0
+        return args.path == "auto" and L["n"] <= args.fused_max_n and L["k"] % 64 == 0
 
     # (f-1) the fused kernel computes the same C bit for bit straight from the dense A (the 2:4 selection
     # and compaction happen in registers / LDS; no blob goes to HBM)
@@ -166,8 +169,8 @@ def main():
         "dtype": "f16", "data": "synthetic",
         "config": {"workload": "datasets/resnet50.csv: 49 conv layers as im2col GEMMs (m,n,k) at b=32, fp16; "
                                "step = per layer 2:4 prune+compress+matmul (path: " + args.path + ")",
-                   "path": args.path + (": sm_spmma_fused_f16 on %d layers (n <= 128), sm_compress24_f16 + sm_spmma_f16 on %d"
-                                        % (sum(use_fused(L) for L in layers), sum(not use_fused(L) for L in layers))
+                   "path": args.path + (": sm_spmma_fused_f16 on %d layers (n <= %d), sm_compress24_f16 + sm_spmma_f16 on %d"
+                                        % (sum(use_fused(L) for L in layers), args.fused_max_n, sum(not use_fused(L) for L in layers))
                                         if args.path == "auto" else ": sm_compress24_f16 + sm_spmma_f16 on every layer"),
                    "layers": len(layers), "batch": layers[0]["b"], "dense_equiv_gflop_per_step": flops / 1e9,
                    "launch": "eager" if args.eager else "hipGraph replay of one step", "streams": args.streams,

@@ -6,10 +6,13 @@
 // (the staged path moves m*k*s + 2 * (m*k*s/2 + m*k/8) bytes for the same result).
 //
 // Same producer/consumer skeleton as spmma_f16.hip's pc kernel (64-deep stages, one barrier per stage):
-//   loader waves (4): B tile by LDS-DMA; A tile by plain 16-byte loads (8 rows x 128 B per wave
-//     instruction: whole cache lines), one stage ahead in registers; per 8 loaded halves (two strips)
-//     the STRIP rule (select24.h) -> 4 kept halves + 1 metadata byte, written with ds_write_b64 / b8
-//     into exactly the LDS images the consumers of the staged kernel read;
+//   A loader waves (4): plain 16-byte loads (8 rows x 128 B per wave instruction: whole cache lines), PF
+//     stages ahead in registers; per 8 loaded halves (two strips) the STRIP rule (select24.h:
+//     strip_select_f16) -> 4 kept halves + 1 metadata byte, written with ds_write_b64 / b8 into exactly
+//     the LDS images the consumers of the staged kernel read (ring of 2);
+//   B loader waves (1-4): the B tile by LDS-DMA into its own ring of NSB stages.  They are separate waves
+//     because vmcnt retires in order per wave: a wave that waits for its B DMA also drains every older A
+//     load, which would cap the A data in flight at one stage (16 KiB per CU: latency-bound);
 //   consumer waves: unchanged (ds_read_b128 + ds_read_u16 + ds_read_b64_tr_b16 + v_smfmac).
 // The result is bit-identical to sm_spmma_f16(sm_compress24_f16(A), B): same kept values, same codes, same
 // instruction sequence on the same operands (tests/test_gpu_parity.py::test_fused_equals_staged).
@@ -28,6 +31,11 @@ struct FusedArgs {
   float alpha, beta;
 };
 
+// ---------------------------------------------------------------------------------------------
+// n <= 128: four loader waves do both jobs (B by DMA, A through registers one stage ahead), ring of 2.
+// Small LDS and 8 waves per workgroup keep 3-4 workgroups on a CU, which is what hides the latencies of
+// these HBM-bound shapes (profiles/sweep_r01_j_fused.txt: the split-loader kernel below is 1.2-1.7x slower here).
+// ---------------------------------------------------------------------------------------------
 template <int BN, int WM, int WN, int NS>
 __global__ __launch_bounds__(64 * (WM * WN + 4)) void spmma_f16_fused_kernel(const FusedArgs p) {
   constexpr int BM = 128, NL = 4, NC = WM * WN, NW = NC + NL;
@@ -244,6 +252,259 @@ static int launch_fused(const FusedArgs& a0, hipStream_t st) {
   return check_launch("spmma_f16_fused_kernel");
 }
 
+// ---------------------------------------------------------------------------------------------
+// 128 < n: 256-column tiles, split loader roles, deeper pipelines (one workgroup per CU)
+// ---------------------------------------------------------------------------------------------
+template <int BN, int WM, int WN, int NLB, int PF, int NSB>
+__global__ __launch_bounds__(64 * (WM * WN + 4 + NLB)) void spmma_f16_fused_wide_kernel(const FusedArgs p) {
+  constexpr int BM = 128, NLA = 4, NC = WM * WN, NW = NC + NLA + NLB;
+  static_assert(PF >= 1 && PF <= 3 && NSB >= 2 && NSB <= 4, "pipeline depths");
+  constexpr int TM = BM / WM, TN = BN / WN, FM = TM / 16, FN = TN / 16;
+  constexpr int SA = BM * 64, SM_ = BM * 8, ASTG = SA + SM_, SB = 64 * BN * 2;
+  constexpr int BRING = 2 * ASTG;               // LDS: [A+metadata stage] x 2 | [B stage] x NSB
+  constexpr int B_N = BN / 8, B_WI = B_N / NLB;  // B DMA instructions per stage / per B-loader wave
+  static_assert(B_N % NLB == 0 && B_WI >= 1 && (NSB - 2) * B_WI <= 63, "B tile vs loader waves");
+  constexpr int CPITCH = BN * 2 + 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const unsigned tid = threadIdx.x, lane = tid & 63u;
+  const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const unsigned tiles = (unsigned)p.tiles_m * (unsigned)p.tiles_n;
+  const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
+  const unsigned b = lid / tiles, trem = lid - b * tiles;
+  const unsigned tile_m = trem / (unsigned)p.tiles_n, tile_n = trem - tile_m * (unsigned)p.tiles_n;
+  const int m0 = (int)tile_m * BM, n0 = (int)tile_n * BN;
+  const int nkt = p.K / 64;
+  half_t* C = p.C + (size_t)b * p.sC;
+
+  f4 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+  const unsigned g = lane >> 4, r = lane & 15u;
+  const unsigned wm = wave / WN, wn = wave % WN;  // consumer waves only
+
+  if (wave >= (unsigned)(NC + NLA)) {
+    // ------------------------------------------------------------------ B loader wave: LDS-DMA only
+    // instruction j = lw + NLB * i of a stage covers k-rows 8 * (j & 7) + lane / 8 of panel j >> 3 (64 columns)
+    const unsigned lw = wave - (NC + NLA);
+    const char* Bb = reinterpret_cast<const char*>(p.B + (size_t)b * p.sB);
+    const char* b_src[B_WI];
+    unsigned b_dst[B_WI];
+#pragma unroll
+    for (int i = 0; i < B_WI; ++i) {
+      const unsigned j = lw + (unsigned)NLB * i, panel = j >> 3, grp = j & 7u, kr = 8u * grp + (lane >> 3);
+      const unsigned cs = (lane & 7u) ^ b_swz(kr);
+      int gc = n0 + (int)(64u * panel + 8u * cs);
+      gc = gc <= p.N - 8 ? gc : p.N - 8;
+      b_src[i] = Bb + ((size_t)kr * p.N + (size_t)gc) * 2;
+      b_dst[i] = BRING + panel * 8192u + grp * 1024u;
+    }
+    const size_t b_step = (size_t)64 * p.N * 2;
+    auto issue = [&](int kt, int buf) {
+#pragma unroll
+      for (int i = 0; i < B_WI; ++i)
+        __builtin_amdgcn_global_load_lds((gptr_t*)(b_src[i] + (size_t)kt * b_step), (lptr_t*)(smem + buf * SB + b_dst[i]), 16, 0, 0);
+    };
+#pragma unroll
+    for (int s = 0; s < NSB - 1; ++s)
+      if (s < nkt) issue(s, s);
+    int nb = NSB - 1;  // buffer of the next stage to issue
+    for (int kt = 0; kt < nkt; ++kt) {
+      // stage kt has landed once at most the NSB-2 younger stages are still in flight (fewer exist at the tail)
+      if (kt + NSB - 2 < nkt) wait_dma_and_barrier<(NSB - 2) * B_WI>();
+      else wait_dma_and_barrier<0>();
+      if (kt + NSB - 1 < nkt) {
+        issue(kt + NSB - 1, nb);  // the buffer stage kt-1 occupied: consumers left it before barrier kt
+        nb = nb + 1 == NSB ? 0 : nb + 1;
+      }
+    }
+  } else if (wave >= (unsigned)NC) {
+    // ------------------------------------------------------------------ A loader wave: load, select, ds_write
+    const unsigned lw = wave - NC;
+    const half_t* A = p.A + (size_t)b * p.sA;
+    const int mlast = p.Mrows - 1;
+    // load i of this wave = rows 8*(4*lw + i) + lane/8, dense chunk c = lane % 8 (k 8c .. 8c+7 of the stage)
+    const unsigned c8 = lane & 7u;
+    const half_t* a_src[4];
+    unsigned a_val_off[4], a_meta_off[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const unsigned row = 8u * (4u * lw + i) + (lane >> 3);
+      int gr = m0 + (int)row;
+      gr = gr < mlast ? gr : mlast;
+      a_src[i] = A + (size_t)gr * p.lda + 8u * c8;
+      a_val_off[i] = row * 64u + 16u * ((c8 >> 1) ^ a64_swz(row)) + 8u * (c8 & 1u);
+      a_meta_off[i] = SA + row * 8u + c8;
+    }
+    // PF stages of A stay in flight in registers (plain loads: the compiler's counted vmcnt guards each use).
+    // Its wait insertion takes the strictest count over all paths that reach a use, so the steady-state loop
+    // below is free of conditionals (every iteration issues its loads) and the last stages run in a peeled tail.
+    u4 ra[PF][4];
+    auto load_a = [&](int kt, u4 (&dst)[4]) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) dst[i] = __builtin_nontemporal_load(reinterpret_cast<const u4*>(a_src[i] + (size_t)kt * 64));
+      __builtin_amdgcn_sched_barrier(0);  // stages are issued in stage order on every path (the counted waits rely on it)
+    };
+    auto write_stage = [&](int kt, const u4 (&src)[4]) {
+      char* sb = smem + (kt & 1) * ASTG;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        uint32_t k0, k1, n0, n1;
+        strip_select_f16(src[i][0], src[i][1], k0, n0);
+        strip_select_f16(src[i][2], src[i][3], k1, n1);
+        *reinterpret_cast<u2*>(sb + a_val_off[i]) = u2{k0, k1};
+        *reinterpret_cast<unsigned char*>(sb + a_meta_off[i]) = (unsigned char)(n0 | (n1 << 4));
+      }
+    };
+    auto step = [&](int kt, u4 (&rr)[4], bool write, bool load) {
+      // stage kt is complete in LDS once this wave's ds_writes have landed; loads stay in flight
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);   // keep the next stage's selection (and its vmcnt wait) below the barrier
+      if (write) write_stage(kt + 1, rr);  // buffer (kt+1)&1: consumers left it before barrier kt
+      if (load) load_a(kt + 1 + PF, rr);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    int kt0 = 0;
+    if (nkt > 2 * PF) {
+#pragma unroll
+      for (int s = 0; s < PF; ++s) load_a(s, ra[s]);
+      write_stage(0, ra[0]);
+      load_a(PF, ra[0]);
+      for (; kt0 + 2 * PF < nkt; kt0 += PF) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) step(kt0 + u, ra[(u + 1) % PF], true, true);
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < PF; ++s)
+        if (s < nkt) load_a(s, ra[s]);
+      write_stage(0, ra[0]);
+      if (PF < nkt) load_a(PF, ra[0]);
+    }
+    for (; kt0 < nkt; kt0 += PF) {
+#pragma unroll
+      for (int u = 0; u < PF; ++u) {
+        const int kt = kt0 + u;
+        if (kt < nkt) step(kt, ra[(u + 1) % PF], kt + 1 < nkt, kt + 1 + PF < nkt);
+      }
+    }
+  } else {
+    // ------------------------------------------------------------------ consumer wave (as spmma_f16_pc_kernel)
+    int cb = 0;
+    for (int kt = 0; kt < nkt; ++kt) {
+      wait_dma_and_barrier<0>();
+      const char* As = smem + (kt & 1) * ASTG;
+      const char* Ms = As + SA;
+      const char* Bs = smem + BRING + cb * SB;
+      h8 af[FM];
+      int idx[FM];
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        const unsigned row = wm * TM + i * 16 + r;
+        af[i] = *reinterpret_cast<const h8*>(As + row * 64u + 16u * (g ^ a64_swz(row)));
+        idx[i] = (int)*reinterpret_cast<const unsigned short*>(Ms + row * 8u + 2u * g);
+      }
+      const unsigned bs_addr = (unsigned)(uintptr_t)(lds_char*)Bs;
+      s4 t0[2], t1[2], t2[2], t3[2];
+      auto issue = [&](int j, s4& v0, s4& v1, s4& v2, s4& v3) {
+        const unsigned col0 = wn * TN + j * 16, q = r >> 2, pp = r & 3u;
+        const unsigned a = bs_addr + b_off<64>(8u * g + q, col0 + 4u * pp);
+        asm volatile("ds_read_b64_tr_b16 %0, %4\n\tds_read_b64_tr_b16 %1, %4 offset:512\n\t"
+                     "ds_read_b64_tr_b16 %2, %4 offset:4096\n\tds_read_b64_tr_b16 %3, %4 offset:4608"
+                     : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3) : "v"(a) : "memory");
+      };
+      issue(0, t0[0], t1[0], t2[0], t3[0]);
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const int c = j & 1, n = c ^ 1;
+        if (j + 1 < FN) {
+          issue(j + 1, t0[n], t1[n], t2[n], t3[n]);
+          asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(t0[c]), "+v"(t1[c]), "+v"(t2[c]), "+v"(t3[c]) :: "memory");
+        } else {
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t0[c]), "+v"(t1[c]), "+v"(t2[c]), "+v"(t3[c]) :: "memory");
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        typedef short s16 __attribute__((ext_vector_type(16)));
+        const s16 all = {t0[c][0], t0[c][1], t0[c][2], t0[c][3], t1[c][0], t1[c][1], t1[c][2], t1[c][3],
+                         t2[c][0], t2[c][1], t2[c][2], t2[c][3], t3[c][0], t3[c][1], t3[c][2], t3[c][3]};
+        const h16 bf = __builtin_bit_cast(h16, all);
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+          acc[i][j] = __builtin_amdgcn_smfmac_f32_16x16x64_f16(af[i], bf, acc[i][j], idx[i], 0, 0);
+      }
+      cb = cb + 1 == NSB ? 0 : cb + 1;
+    }
+  }
+  __syncthreads();
+
+  const bool c_vec = (reinterpret_cast<uintptr_t>(C) & 15u) == 0;
+  if (p.beta == 0.0f && c_vec) {
+    char* Cs = smem;
+    if (wave < (unsigned)NC) {
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+          const unsigned row = wm * TM + i * 16 + 4u * g, col = wn * TN + j * 16 + r;
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<half_t*>(Cs + (row + q) * CPITCH + col * 2) = (half_t)(p.alpha * acc[i][j][q]);
+        }
+    }
+    __syncthreads();
+    constexpr int NCH = BM * (BN / 8);
+    for (unsigned q = tid; q < (unsigned)NCH; q += 64u * NW) {
+      const unsigned row = q / (BN / 8), cn = q % (BN / 8);
+      const int gr = m0 + (int)row, gc = n0 + 8 * (int)cn;
+      if (gr >= p.Mrows || gc >= p.N) continue;
+      *reinterpret_cast<u4*>(C + (size_t)gr * p.N + gc) = *reinterpret_cast<const u4*>(Cs + row * CPITCH + cn * 16);
+    }
+  } else if (wave < (unsigned)NC) {
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const int gc = n0 + (int)(wn * TN + j * 16 + r);
+        if (gc >= p.N) continue;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int gr = m0 + (int)(wm * TM + i * 16 + 4u * g) + q;
+          if (gr >= p.Mrows) continue;
+          half_t* dst = C + (size_t)gr * p.N + gc;
+          float v = p.alpha * acc[i][j][q];
+          if (p.beta != 0.0f) v += p.beta * (float)*dst;
+          *dst = (half_t)v;
+        }
+      }
+  }
+}
+
+template <int BN, int WM, int WN, int NLB, int PF, int NSB>
+static int launch_fused_wide(const FusedArgs& a0, hipStream_t st) {
+  FusedArgs a = a0;
+  a.tiles_m = (a.Mrows + 127) / 128;
+  a.tiles_n = (a.N + BN - 1) / BN;
+  const size_t nwg = (size_t)a.tiles_m * a.tiles_n * a.batch;
+  if (nwg == 0) return SM_STATUS_SUCCESS;
+  if (nwg > 0x7fffffffu) {
+    set_error("sm_spmma_fused_f16: grid too large");
+    return SM_STATUS_NOT_SUPPORTED;
+  }
+  constexpr size_t lds_main = 2 * (size_t)128 * 72 + (size_t)NSB * 64 * BN * 2;
+  constexpr size_t lds_epi = (size_t)128 * (BN * 2 + 16);
+  constexpr size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
+  static bool attr_set = false;
+  if (lds > 64 * 1024 && !attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spmma_f16_fused_wide_kernel<BN, WM, WN, NLB, PF, NSB>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  spmma_f16_fused_wide_kernel<BN, WM, WN, NLB, PF, NSB><<<dim3((unsigned)nwg), dim3(64 * (WM * WN + 4 + NLB)), lds, st>>>(a);
+  return check_launch("spmma_f16_fused_wide_kernel");
+}
+
 }  // namespace sm
 
 using namespace sm;
@@ -275,10 +536,17 @@ extern "C" int sm_spmma_fused_f16(const void* A, const void* B, void* C, size_t 
     a.batch = 1;
   }
   hipStream_t st = (hipStream_t)stream;
-  // One workgroup spans the whole N (up to 512), so every row of A is selected exactly once:
-  // 4 consumer waves for N <= 128, 8 (4 x 2, wave tile 32 x N/2) for N <= 512; wider N tiles N by 512.
-  if (n <= 64) return launch_fused<64, 4, 1>(a, st);
-  if (n <= 128) return launch_fused<128, 2, 2>(a, st);
-  if (n <= 256) return launch_fused<256, 4, 2>(a, st);
-  return launch_fused<512, 4, 2>(a, st);
+  // n <= 128: one workgroup spans the whole N (4 consumer waves, combined loaders).  Wider: 256-column tiles with
+  // 8 consumer waves (4 x 2, wave tile 32 x 128) and split loaders; for n <= 256 every row of A is still loaded
+  // and selected exactly once, beyond that once per 256 columns (callers with n >= 512 and a reusable A are
+  // better served by sm_compress24_f16 + sm_spmma_f16: bench.py --path auto decides per layer).
+  static const int wide_env = getenv("SM_FUSED_WIDE") ? atoi(getenv("SM_FUSED_WIDE")) : 0;  // tuning aid: force the wide kernel
+  if (!wide_env) {
+    if (n <= 64) return launch_fused<64, 4, 1>(a, st);
+    if (n <= 128) return launch_fused<128, 2, 2>(a, st);
+  }
+  static const int pf = getenv("SM_FUSED_PF") ? atoi(getenv("SM_FUSED_PF")) : 2;  // tuning aid: A stages in flight
+  if (pf >= 3) return launch_fused_wide<256, 4, 2, 4, 3, 3>(a, st);
+  if (pf == 1) return launch_fused_wide<256, 4, 2, 4, 1, 3>(a, st);
+  return launch_fused_wide<256, 4, 2, 4, 2, 3>(a, st);
 }
