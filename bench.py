@@ -223,7 +223,7 @@ def main():
         # roofline of the dominant kernel family of the timed step: algorithmic bytes (SURVEY.md 8(d),
         # DESIGN.md 4) / time of a single-stream pass that launches only that family on the layers it serves
         s = 2
-        fam = {"spmma_f16": dict(names=["spmma_f16_dma_kernel", "spmma_f16_pc_kernel", "spmma_f16_pc2_kernel", "spmma_f16_kernel"],
+        fam = {"spmma_f16": dict(names=["spmma_f16_dma_kernel", "spmma_f16_pc_kernel", "spmma_f16_kernel"],
                                  layers=[L for L in layers if not use_fused(L)],
                                  call=lambda L: sm.spmma(L["blob"], L["B"], L["C"], L["m"], L["n"], L["k"], L["b"], 0),
                                  bytes=lambda L: L["b"] * (L["m"] * L["k"] * s / 2 + L["m"] * L["k"] / 8 + L["m"] * L["n"] * s) + s * L["k"] * L["n"]),
@@ -231,7 +231,7 @@ def main():
                                 layers=[L for L in layers if not use_fused(L)],
                                 call=lambda L: sm.compress24(L["A"], L["m"], L["k"], L["k"], L["b"], L["m"] * L["k"], L["blob"]),
                                 bytes=lambda L: L["b"] * L["m"] * L["k"] * (s + s / 2 + 1 / 8)),
-               "spmma_f16_fused": dict(names=["spmma_f16_fused_kernel"],
+               "spmma_f16_fused": dict(names=["spmma_f16_fused_kernel", "spmma_f16_fused_wide_kernel"],
                                        layers=[L for L in layers if use_fused(L)],
                                        call=lambda L: sm.spmma_fused(L["A"], L["B"], L["C"], L["m"], L["n"], L["k"], batch=L["b"]),
                                        bytes=lambda L: L["b"] * s * (L["m"] * L["k"] + L["m"] * L["n"]) + s * L["k"] * L["n"])}

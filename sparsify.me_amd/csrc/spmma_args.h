@@ -23,6 +23,17 @@ struct SpmmaArgs {
 };
 
 
+#ifdef SM_STAMP
+__device__ __forceinline__ unsigned long long sm_stamp() {
+  unsigned long long t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  return t;
+}
+#define SM_T(...) __VA_ARGS__
+#else
+#define SM_T(...)
+#endif
+
 // 64-byte-row A image: 16-byte chunk c of row r lives at chunk c ^ ((-(r >> 2)) & 3).
 __device__ __forceinline__ unsigned a64_swz(unsigned row) { return (0u - (row >> 2)) & 3u; }
 

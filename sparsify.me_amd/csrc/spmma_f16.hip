@@ -22,16 +22,6 @@
 
 namespace sm {
 
-#ifdef SM_STAMP
-__device__ __forceinline__ unsigned long long sm_stamp() {
-  unsigned long long t;
-  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-  return t;
-}
-#define SM_T(...) __VA_ARGS__
-#else
-#define SM_T(...)
-#endif
 
 template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(256) void spmma_f16_kernel(const SpmmaArgs p) {

@@ -16,6 +16,9 @@
 //   consumer waves: unchanged (ds_read_b128 + ds_read_u16 + ds_read_b64_tr_b16 + v_smfmac).
 // The result is bit-identical to sm_spmma_f16(sm_compress24_f16(A), B): same kept values, same codes, same
 // instruction sequence on the same operands (tests/test_gpu_parity.py::test_fused_equals_staged).
+#include <cstdio>
+#include <vector>
+
 #include "select24.h"
 #include "spmma_args.h"
 
@@ -29,6 +32,9 @@ struct FusedArgs {
   int Mrows, N, K, lda;
   int batch, tiles_m, tiles_n;
   float alpha, beta;
+#ifdef SM_STAMP
+  unsigned long long* dbg;  // diagnostic build only: per-wave cycle sums (never in the product library)
+#endif
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -303,6 +309,9 @@ __global__ __launch_bounds__(64 * (WM * WN + 4 + NLB)) void spmma_f16_fused_wide
     }
     const size_t b_step = (size_t)64 * p.N * 2;
     auto issue = [&](int kt, int buf) {
+#if defined(SM_ABLATE) && (SM_ABLATE & 4)
+      return;  /* diagnostic timing builds only: 1 = no consumer compute, 2 = no selection, 4 = no B DMA, 8 = no A loads in the loop */
+#endif
 #pragma unroll
       for (int i = 0; i < B_WI; ++i)
         __builtin_amdgcn_global_load_lds((gptr_t*)(b_src[i] + (size_t)kt * b_step), (lptr_t*)(smem + buf * SB + b_dst[i]), 16, 0, 0);
@@ -311,15 +320,27 @@ __global__ __launch_bounds__(64 * (WM * WN + 4 + NLB)) void spmma_f16_fused_wide
     for (int s = 0; s < NSB - 1; ++s)
       if (s < nkt) issue(s, s);
     int nb = NSB - 1;  // buffer of the next stage to issue
+    SM_T(unsigned long long tb = 0, ti = 0, tv = 0, nlong = 0; unsigned long long s0 = sm_stamp(); unsigned long long sprev = s0;)
     for (int kt = 0; kt < nkt; ++kt) {
       // stage kt has landed once at most the NSB-2 younger stages are still in flight (fewer exist at the tail)
+#ifdef SM_STAMP
+      if (kt + NSB - 2 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSB - 2) * B_WI) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const unsigned long long sv = sm_stamp();
+      tv += sv - s0;
+      asm volatile("s_barrier" ::: "memory");
+#else
       if (kt + NSB - 2 < nkt) wait_dma_and_barrier<(NSB - 2) * B_WI>();
       else wait_dma_and_barrier<0>();
+#endif
+      SM_T(unsigned long long s1 = sm_stamp(); tb += s1 - s0;)
       if (kt + NSB - 1 < nkt) {
         issue(kt + NSB - 1, nb);  // the buffer stage kt-1 occupied: consumers left it before barrier kt
         nb = nb + 1 == NSB ? 0 : nb + 1;
       }
+      SM_T(s0 = sm_stamp(); ti += s0 - s1; { const unsigned long long busy = (s0 - s1) + (sv - sprev); nlong += busy > 2000 ? 1 : 0; sprev = s0; })
     }
+    SM_T(if (p.dbg && lane == 0) { unsigned long long* d = p.dbg + ((size_t)blockIdx.x * NW + wave) * 8; d[0] = tb; d[1] = ti; d[2] = tv; d[3] = 2; d[6] = nlong; })
   } else if (wave >= (unsigned)NC) {
     // ------------------------------------------------------------------ A loader wave: load, select, ds_write
     const unsigned lw = wave - NC;
@@ -352,21 +373,35 @@ __global__ __launch_bounds__(64 * (WM * WN + 4 + NLB)) void spmma_f16_fused_wide
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         uint32_t k0, k1, n0, n1;
+#if defined(SM_ABLATE) && (SM_ABLATE & 2)
+        k0 = src[i][0]; k1 = src[i][2]; n0 = 4; n1 = 4;
+#else
         strip_select_f16(src[i][0], src[i][1], k0, n0);
         strip_select_f16(src[i][2], src[i][3], k1, n1);
+#endif
         *reinterpret_cast<u2*>(sb + a_val_off[i]) = u2{k0, k1};
         *reinterpret_cast<unsigned char*>(sb + a_meta_off[i]) = (unsigned char)(n0 | (n1 << 4));
       }
     };
+    SM_T(unsigned long long tb = 0, tw = 0, ti = 0, tv = 0, tmax = 0, nlong = 0; unsigned long long s0 = 0;)
     auto step = [&](int kt, u4 (&rr)[4], bool write, bool load) {
       // stage kt is complete in LDS once this wave's ds_writes have landed; loads stay in flight
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);   // keep the next stage's selection (and its vmcnt wait) below the barrier
-      if (write) write_stage(kt + 1, rr);  // buffer (kt+1)&1: consumers left it before barrier kt
+      SM_T(unsigned long long s1 = sm_stamp(); tb += s1 - s0;)
+      if (write) {
+        SM_T(asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (PF - 1)) : "memory"); unsigned long long s1b = sm_stamp(); tv += s1b - s1;)
+        write_stage(kt + 1, rr);  // buffer (kt+1)&1: consumers left it before barrier kt
+      }
+      SM_T(__builtin_amdgcn_sched_barrier(0); unsigned long long s2 = sm_stamp(); tw += s2 - s1;)
+#if !(defined(SM_ABLATE) && (SM_ABLATE & 8))
       if (load) load_a(kt + 1 + PF, rr);
+#endif
       __builtin_amdgcn_sched_barrier(0);
+      SM_T(s0 = sm_stamp(); ti += s0 - s2; { const unsigned long long busy = s0 - s1; tmax = busy > tmax ? busy : tmax; nlong += busy > 2000 ? 1 : 0; })
     };
     int kt0 = 0;
+    SM_T(s0 = sm_stamp();)
     if (nkt > 2 * PF) {
 #pragma unroll
       for (int s = 0; s < PF; ++s) load_a(s, ra[s]);
@@ -390,11 +425,18 @@ __global__ __launch_bounds__(64 * (WM * WN + 4 + NLB)) void spmma_f16_fused_wide
         if (kt < nkt) step(kt, ra[(u + 1) % PF], kt + 1 < nkt, kt + 1 + PF < nkt);
       }
     }
+    SM_T(if (p.dbg && lane == 0) { unsigned long long* d = p.dbg + ((size_t)blockIdx.x * NW + wave) * 8; d[0] = tb; d[1] = tw; d[2] = ti; d[3] = 1; d[4] = tv; d[5] = tmax; d[6] = nlong; })
   } else {
     // ------------------------------------------------------------------ consumer wave (as spmma_f16_pc_kernel)
     int cb = 0;
+    SM_T(unsigned long long tb = 0, tc = 0, nlong = 0; unsigned long long s0 = sm_stamp();)
     for (int kt = 0; kt < nkt; ++kt) {
       wait_dma_and_barrier<0>();
+      SM_T(unsigned long long s1 = sm_stamp(); tb += s1 - s0;)
+#if defined(SM_ABLATE) && (SM_ABLATE & 1)
+      cb = cb + 1 == NSB ? 0 : cb + 1;
+      continue;
+#endif
       const char* As = smem + (kt & 1) * ASTG;
       const char* Ms = As + SA;
       const char* Bs = smem + BRING + cb * SB;
@@ -435,7 +477,9 @@ __global__ __launch_bounds__(64 * (WM * WN + 4 + NLB)) void spmma_f16_fused_wide
           acc[i][j] = __builtin_amdgcn_smfmac_f32_16x16x64_f16(af[i], bf, acc[i][j], idx[i], 0, 0);
       }
       cb = cb + 1 == NSB ? 0 : cb + 1;
+      SM_T(__builtin_amdgcn_sched_barrier(0); s0 = sm_stamp(); tc += s0 - s1; nlong += (s0 - s1) > 2000 ? 1 : 0;)
     }
+    SM_T(if (p.dbg && lane == 0) { unsigned long long* d = p.dbg + ((size_t)blockIdx.x * NW + wave) * 8; d[0] = tb; d[1] = tc; d[2] = 0; d[3] = 0; d[6] = nlong; })
   }
   __syncthreads();
 
@@ -501,6 +545,34 @@ static int launch_fused_wide(const FusedArgs& a0, hipStream_t st) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
+#ifdef SM_STAMP
+  {
+    constexpr int NWV = WM * WN + 4 + NLB;
+    static unsigned long long* dbg = nullptr;
+    static size_t cap = 0;
+    const size_t cnt = nwg * (size_t)NWV * 8;
+    if (cnt > cap) { if (dbg) (void)hipFree(dbg); (void)hipMalloc((void**)&dbg, cnt * 8); cap = cnt; }
+    (void)hipMemset(dbg, 0, cnt * 8);
+    a.dbg = dbg;
+    spmma_f16_fused_wide_kernel<BN, WM, WN, NLB, PF, NSB><<<dim3((unsigned)nwg), dim3(64 * NWV), lds, st>>>(a);
+    (void)hipDeviceSynchronize();
+    std::vector<unsigned long long> h(cnt);
+    (void)hipMemcpy(h.data(), dbg, cnt * 8, hipMemcpyDeviceToHost);
+    double LBl = 0, Cnl = 0, LA[6] = {0, 0, 0, 0, 0, 0}, LB[3] = {0, 0, 0}, Cn[2] = {0, 0}, na = 0, nbw = 0, nc = 0;
+    for (size_t i = 0; i < cnt / 8; ++i) {
+      const unsigned long long* d = &h[i * 8];
+      if (d[3] == 1) { LA[0] += d[0]; LA[1] += d[1]; LA[2] += d[2]; LA[3] += d[4]; LA[4] += d[5]; LA[5] += d[6]; na += 1; }
+      else if (d[3] == 2) { LB[0] += d[0]; LB[1] += d[1]; LB[2] += d[2]; LBl += d[6]; nbw += 1; }
+      else { Cn[0] += d[0]; Cn[1] += d[1]; Cnl += d[6]; nc += 1; }
+    }
+    const double nk = (double)(a.K / 64);
+    fprintf(stderr, "STAMP-FUSED-WIDE %dx%dx%d PF=%d NSB=%d tiles=%zu nkt=%d | A-loader per stage: barrier %.0f vmcnt-wait %.0f select+write(incl. wait) %.0f load-issue %.0f | B-loader: wait+barrier %.0f (vmcnt part %.0f) issue %.0f | consumer: barrier %.0f compute %.0f\n",
+            a.Mrows, a.N, a.K, PF, NSB, nwg, a.K / 64, LA[0] / na / nk, LA[3] / na / nk, LA[1] / na / nk, LA[2] / na / nk,
+            LB[0] / nbw / nk, LB[2] / nbw / nk, LB[1] / nbw / nk, Cn[0] / nc / nk, Cn[1] / nc / nk);
+    fprintf(stderr, "   A-loader busy per stage: mean of per-wave max %.0f, stages busier than 2000 cycles per wave %.1f of %d (B-loader %.1f, consumer %.1f)\n", LA[4] / na, LA[5] / na, a.K / 64, LBl / nbw, Cnl / nc);
+    return check_launch("spmma_f16_fused_wide_kernel");
+  }
+#endif
   spmma_f16_fused_wide_kernel<BN, WM, WN, NLB, PF, NSB><<<dim3((unsigned)nwg), dim3(64 * (WM * WN + 4 + NLB)), lds, st>>>(a);
   return check_launch("spmma_f16_fused_wide_kernel");
 }
@@ -545,7 +617,14 @@ extern "C" int sm_spmma_fused_f16(const void* A, const void* B, void* C, size_t 
     if (n <= 64) return launch_fused<64, 4, 1>(a, st);
     if (n <= 128) return launch_fused<128, 2, 2>(a, st);
   }
-  static const int pf = getenv("SM_FUSED_PF") ? atoi(getenv("SM_FUSED_PF")) : 2;  // tuning aid: A stages in flight
+  static const int pf = getenv("SM_FUSED_PF") ? atoi(getenv("SM_FUSED_PF")) : 2;    // tuning aids: A stages in flight,
+  static const int nsb = getenv("SM_FUSED_NSB") ? atoi(getenv("SM_FUSED_NSB")) : 3;  // B ring depth,
+  static const int wn4 = getenv("SM_FUSED_WN4") ? atoi(getenv("SM_FUSED_WN4")) : 0;  // consumer wave grid 2 x 4
+  if (wn4) {
+    if (nsb >= 4) return pf >= 3 ? launch_fused_wide<256, 2, 4, 4, 3, 4>(a, st) : launch_fused_wide<256, 2, 4, 4, 2, 4>(a, st);
+    return pf >= 3 ? launch_fused_wide<256, 2, 4, 4, 3, 3>(a, st) : launch_fused_wide<256, 2, 4, 4, 2, 3>(a, st);
+  }
+  if (nsb >= 4) return pf >= 3 ? launch_fused_wide<256, 4, 2, 4, 3, 4>(a, st) : launch_fused_wide<256, 4, 2, 4, 2, 4>(a, st);
   if (pf >= 3) return launch_fused_wide<256, 4, 2, 4, 3, 3>(a, st);
   if (pf == 1) return launch_fused_wide<256, 4, 2, 4, 1, 3>(a, st);
   return launch_fused_wide<256, 4, 2, 4, 2, 3>(a, st);

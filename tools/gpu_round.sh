@@ -6,7 +6,7 @@ tag=${1:-rXX}; extra="${2:-}"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 timeout -k 10 900 python -m pytest tests -m gpu -q --timeout 300 > gpurun_out/${tag}_pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -3 gpurun_out/${tag}_pytest_gpu.log
 timeout -k 10 400 python bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err; echo "bench rc=$?"; cat gpurun_out/${tag}_bench.json
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_prof -- python3 bench.py --eager --steps 5 --warmup 2 --no-cpu-baseline --no-extras > gpurun_out/${tag}_prof.log 2>&1; echo "rocprof stats rc=$?"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_prof -- python3 bench.py --eager --streams 1 --steps 5 --warmup 2 --no-cpu-baseline --no-extras > gpurun_out/${tag}_prof.log 2>&1; echo "rocprof stats rc=$?"
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/${tag}_pmc_fetch -- python3 bench.py --eager --steps 2 --warmup 1 --no-cpu-baseline --no-extras > gpurun_out/${tag}_pmc_fetch.log 2>&1; echo "pmc fetch rc=$?"
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/${tag}_pmc_write -- python3 bench.py --eager --steps 2 --warmup 1 --no-cpu-baseline --no-extras > gpurun_out/${tag}_pmc_write.log 2>&1; echo "pmc write rc=$?"
 python3 tools/pmc_traffic.py gpurun_out/${tag}_pmc_fetch gpurun_out/${tag}_pmc_write gpurun_out/${tag}_traffic.json

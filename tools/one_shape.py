@@ -20,6 +20,8 @@ for _ in range(reps):
         sm.spmma(blob, B, C, m, n, k, b, 0)
     elif stage == "gemm_rm":
         sm.gemm_rowmajor(A, B, C, m, n, k, batch=b)
+    elif stage == "fused":
+        sm.spmma_fused(A, B, C, m, n, k, batch=b)
     elif stage == "compress":
         sm.compress24(A, m, k, k, b, m * k, blob)
 torch.cuda.synchronize()
