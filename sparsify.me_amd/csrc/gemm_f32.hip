@@ -11,6 +11,10 @@
 // One register-staged, LDS-tiled kernel template serves the fp32 variants: 128 x BN tile, BK = 32,
 // 256 threads = 4 waves; the operands of the MFMA are swapped so a lane ends with four consecutive
 // columns of one row and stores them as one 16-byte access.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+
 #include "mma_tile.h"
 
 namespace sm {
@@ -207,11 +211,39 @@ static int launch32(const Gemm32Args& a0, hipStream_t st) {
   return check_launch("gemm_f32_kernel");
 }
 
+static int device_cu_count() {
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    if (cus <= 0) cus = 256;
+  }
+  return cus;
+}
+
+// Tile shape: the kernel is bound by the fp32 matrix pipe, not by operand traffic, so small tiles cost nothing per
+// flop (4096^3: 104.7 / 111.1 / 101.7 / 105.3 TF/s for 128x128 / 128x64 / 64x128 / 64x64) and win whenever the
+// tile count is not a large multiple of the CU count: 64 x 64 is the best shape on every ResNet-18 layer at
+// b = 32 (5.34 ms for the table against 8.25 / 6.01 / 7.18 ms, tools/f32_probe.py and tools/sweep.py
+// --dtype f32).  128 x 64 takes over once a CU gets >= 32 of the small tiles.
 template <int MODE>
 static int dispatch32(const Gemm32Args& a, hipStream_t st) {
-  if (a.N <= 64) return launch32<128, 64, 4, 1, MODE>(a, st);
-  if (a.M <= 64) return launch32<64, 128, 1, 4, MODE>(a, st);
-  return launch32<128, 128, 2, 2, MODE>(a, st);
+  struct Cand { int bm, bn; };
+  static const Cand cands[4] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
+  static const int force = getenv("SM_GEMM32_CFG") ? atoi(getenv("SM_GEMM32_CFG")) : -1;  // tuning aid: candidate index
+  const double cus = (double)device_cu_count();
+  const double small_tiles = (double)((a.M + 63) / 64) * (double)((a.N + 63) / 64) * a.batch;
+  int best = small_tiles / cus >= 32.0 ? 1 : 3;
+  if (force >= 0 && force < 4) best = force;
+  static const bool verbose = getenv("SM_GEMM32_VERBOSE") != nullptr;  // tuning aid
+  if (verbose) fprintf(stderr, "gemm_f32 %d x %d x %d b=%d on %d CUs -> tile %d x %d\n", a.M, a.N, a.K, a.batch, (int)cus, cands[best].bm, cands[best].bn);
+  switch (best) {
+    case 1: return launch32<128, 64, 4, 1, MODE>(a, st);
+    case 2: return launch32<64, 128, 1, 4, MODE>(a, st);
+    case 3: return launch32<64, 64, 2, 2, MODE>(a, st);
+    default: return launch32<128, 128, 2, 2, MODE>(a, st);
+  }
 }
 
 // C^T[n x m] (row-major, ldc = m: i.e. column-major m x n C) = alpha * Bt[n x k] * Adense[m x k]^T + beta * C,
