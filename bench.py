@@ -220,6 +220,20 @@ def main():
             "full_path_staged_gfs": gfs(t_staged), "full_path_staged_ms": t_staged * 1e3,
             "timed_path": args.path, "timed_path_ms": t_full * 1e3,
         }
+        # matrix-pipe view of the 2:4 matmul (north_star: "MFMA utilisation for the matmul against chip peak"):
+        # dense-equivalent rate of the matmul-only pass against 2 x the dense fp16 peak (v_smfmac does a 16x16x64
+        # product in the cycles of a dense 16x16x32), plus the PMC MfmaUtil per kernel when a profile is present
+        mfma = {"achieved_TFs": gfs(t_mul) / 1e3, "peak_TFs": 2.0 * 2500.0, "frac": gfs(t_mul) / 1e3 / 5000.0,
+                "peak": "2 x 2.5 PF/s dense fp16 (MI355X_MICROARCH.md); the v_smfmac issue rate measured on this chip "
+                        "is 3.4-3.8 PF/s dense-equivalent (profiles/mfma_rate_r01.txt)",
+                "pmc_mfma_util_percent": None}
+        mpath = os.path.join(ROOT, "profiles", "mfma_util_latest.json")  # tools/pmc_mfma.py, from a rocprofv3 --pmc pass
+        if os.path.exists(mpath):
+            try:
+                mfma["pmc_mfma_util_percent"] = {k: round(v["mfma_util_percent"], 2) for k, v in json.load(open(mpath)).items()}
+            except Exception:
+                pass
+        out["stages"]["matmul_mfma"] = mfma
         # roofline of the dominant kernel family of the timed step: algorithmic bytes (SURVEY.md 8(d),
         # DESIGN.md 4) / time of a single-stream pass that launches only that family on the layers it serves
         s = 2
