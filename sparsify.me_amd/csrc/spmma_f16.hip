@@ -22,6 +22,10 @@
 
 namespace sm {
 
+// 256 zero bytes in device memory: the B rows of a K tail (k % 64 != 0: stage rows at or beyond k) are DMA'd from
+// here, so the blob's zero padding meets zeros, never a clamped real row (0 * inf would poison finite outputs).
+__device__ __attribute__((aligned(256))) const unsigned char sm_zero_page[256] = {0};
+
 
 template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(256) void spmma_f16_kernel(const SpmmaArgs p) {
@@ -293,6 +297,8 @@ __global__ __launch_bounds__(64 * WM * WN) void spmma_f16_dma_kernel(const Spmma
     }
   }
 
+  const bool ktail = (p.K & 63) != 0;
+  const int nkt_last = p.kc / 64 - 1;
   auto stage = [&](int kt, int buf) {
     char* base = smem + buf * STAGE;
 #pragma unroll
@@ -301,6 +307,10 @@ __global__ __launch_bounds__(64 * WM * WN) void spmma_f16_dma_kernel(const Spmma
       if (t >= (unsigned)W) continue;
       gptr_t* g = (gptr_t*)(src[i] + (size_t)kt * step[i]);
       lptr_t* l = (lptr_t*)(base + loff[i]);
+      if (ktail && kt == nkt_last && t >= (unsigned)(A_N + M_N)) {  // B rows of the K tail: zeros
+        const unsigned kr = 8u * ((t - (unsigned)(A_N + M_N)) & 7u) + (lane >> 3);
+        if (kt * 64 + (int)kr >= p.K) g = (gptr_t*)(sm_zero_page + 16u * (lane & 7u));
+      }
       // A values and metadata are read exactly once (non-temporal: keep them from evicting B, which
       // every workgroup re-reads from L2); B uses the default policy.
       if (t < (unsigned)(A_N + M_N))
@@ -517,6 +527,7 @@ __global__ __launch_bounds__(64 * (WM * WN + NL)) void spmma_f16_pc_kernel(const
         loff[i] = SA + SM_ + panel * 8192u + (j & 7u) * 1024u;
       }
     }
+    const bool ktail = (p.K & 63) != 0;
     auto stage = [&](int kt, int buf) {
       char* base = smem + buf * STAGE;
 #pragma unroll
@@ -525,6 +536,10 @@ __global__ __launch_bounds__(64 * (WM * WN + NL)) void spmma_f16_pc_kernel(const
         if (t >= (unsigned)W) continue;
         gptr_t* gp = (gptr_t*)(src[i] + (size_t)kt * step[i]);
         lptr_t* lp = (lptr_t*)(base + loff[i]);
+        if (ktail && kt == nkt - 1 && t >= (unsigned)(A_N + M_N)) {  // B rows of the K tail: zeros
+          const unsigned kr = 8u * ((t - (unsigned)(A_N + M_N)) & 7u) + (lane >> 3);
+          if (kt * 64 + (int)kr >= p.K) gp = (gptr_t*)(sm_zero_page + 16u * (lane & 7u));
+        }
 #ifdef SM_ABLATE  /* diagnostic timing builds only: 1 = no metadata DMA, 2 = no A DMA, 4 = no B DMA */
         if ((SM_ABLATE & 1) && t >= (unsigned)A_N && t < (unsigned)(A_N + M_N)) continue;
         if ((SM_ABLATE & 2) && t < (unsigned)A_N) continue;
@@ -800,7 +815,7 @@ extern "C" int sm_spmma_f16(const void* blob, const void* B, void* C, size_t m, 
   }
   hipStream_t st = (hipStream_t)stream;
   // the metadata DMA moves 16-byte row pairs: batches and planes must start on even rows
-  const bool fast = (k % 64 == 0) && (n % 8 == 0) && n >= 8 && aligned16(B) && (strideB % 8 == 0) && (m % 2 == 0);
+  const bool fast = (n % 8 == 0) && n >= 8 && aligned16(B) && (strideB % 8 == 0) && (m % 2 == 0) && k >= 8;
   if (fast) {
     // Workgroup shape by how many tiles exist: with thousands of tiles 4 waves per tile and several
     // tiles per CU overlap each other's latencies; with about one tile per CU the same tile is spread

@@ -230,6 +230,37 @@ def test_spmma_f16_vs_oracle(gpu, orc, shape, shared_b):
     check_close(host(C), Cref.view(np.float16), scale, FP16_TOL, f"spmma {shape}")
 
 
+@pytest.mark.parametrize("shape", [(256, 64, 147), (130, 136, 71), (512, 256, 1099)])
+def test_spmma_k_tail_meets_zeros_not_a_clamped_row(gpu, orc, shape):
+    """k % 64 != 0 on the fast (LDS-DMA) kernels: the blob's zero padding must be multiplied with zeros.  B's last
+    valid row is +inf and never selected by A (column k-1 of A is zero, its strip holds larger values), so C is
+    finite -- unless a kernel fed the padded stage from a clamped real row (0 * inf = NaN)."""
+    import torch
+    m, n, k = shape
+    rng = np.random.default_rng(k)
+    A = rand(rng, m * k, np.float16).reshape(m, k)
+    A[:, k - 1] = 0
+    s0 = (k - 1) // 4 * 4
+    A[:, s0:k - 1] = np.where(np.abs(A[:, s0:k - 1]) < 0.25, np.float16(0.5), A[:, s0:k - 1])
+    if k - 1 - s0 < 2:   # fewer than two other columns in the last strip: the zero would be kept (as a stored 0)
+        pytest.skip("last strip too short for this construction")
+    B = rand(rng, k * n, np.float16).reshape(k, n)
+    B[k - 1, :] = np.inf
+    blob = torch.empty(gpu.compress24_size(m, k, 2), dtype=torch.uint8, device="cuda")
+    gpu.compress24(to_dev(A.reshape(-1)), m, k, k, 1, m * k, blob)
+    C = torch.zeros(m * n, dtype=torch.float16, device="cuda")
+    gpu.spmma(blob, to_dev(B.reshape(-1)), C, m, n, k)
+    got = host(C)
+    assert np.isfinite(got.astype(np.float32)).all(), "K tail multiplied the zero padding with a non-zero-page row"
+    ob = orc.compress24(bits(A.reshape(-1)), m, k, k)
+    Cref = np.zeros(m * n, dtype=np.uint16)
+    orc.spmma(ob, bits(B.reshape(-1)), Cref, m, n, k)
+    Bf = B.copy()
+    Bf[k - 1, :] = 0
+    scale = (np.abs(A.astype(np.float64)) @ np.abs(Bf.astype(np.float64))).reshape(-1)
+    check_close(got, Cref.view(np.float16), scale, FP16_TOL, f"spmma k tail {shape}")
+
+
 def test_spmma_alpha_beta(gpu, orc):
     import torch
     m, n, k = 140, 80, 192
