@@ -396,6 +396,55 @@ __global__ __launch_bounds__(256) void compress_flat_kernel(const T* __restrict_
   }
 }
 
+// fp16 rows whose byte length is not a multiple of 16 (k = 147: the 7 x 7 x 3 first layer), rows and batches back
+// to back: a block takes 32 rows; their bytes -- one contiguous span of the input -- are copied to LDS with aligned
+// 16-byte loads (coalesced whatever the row pitch), then thread (row = t / 8, j8 = t % 8) walks the stages, reads its
+// 8 halves with 2-byte LDS reads (zero beyond k: the padding semantics then fall out of the selection itself, a
+// strip of zeros keeps positions 0,1 = nibble 0x4) and stores like the fast path.  80 -> 46 us on 12544 x 147, b = 32.
+__global__ __launch_bounds__(256) void compress_rowspan_f16_kernel(const uint16_t* __restrict__ A, size_t M, size_t k,
+                                                                   size_t ld, unsigned nstage,
+                                                                   uint16_t* __restrict__ vals,
+                                                                   unsigned char* __restrict__ meta) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char span[];
+  const size_t R0 = (size_t)blockIdx.x * 32;
+  const unsigned rows = (unsigned)(M - R0 < 32 ? M - R0 : 32);
+  const size_t total = M * ld * 2;                 // bytes of the whole input
+  const size_t b0 = R0 * ld * 2, b1 = (R0 + rows) * ld * 2;
+  const size_t a0 = b0 & ~(size_t)15;              // A is 16-byte aligned (launcher)
+  const unsigned char* src = reinterpret_cast<const unsigned char*>(A);
+  for (size_t off = a0 + (size_t)threadIdx.x * 16; off < b1; off += 256 * 16) {
+    if (off + 16 <= total) {
+      *reinterpret_cast<u4*>(span + (off - a0)) = __builtin_nontemporal_load(reinterpret_cast<const u4*>(src + off));
+    } else {  // the last, partial chunk of the buffer: never read past its end
+      for (size_t i = off; i < total; i += 2)
+        *reinterpret_cast<uint16_t*>(span + (i - a0)) = *reinterpret_cast<const uint16_t*>(src + i);
+    }
+  }
+  __syncthreads();
+  const unsigned lane = threadIdx.x & 63u, row = threadIdx.x >> 3, j8 = threadIdx.x & 7u;
+  const bool ok = row < rows;
+  const unsigned char* rp = span + (b0 - a0) + (size_t)(ok ? row : 0) * ld * 2;
+  for (unsigned s = 0; s < nstage; ++s) {
+    const size_t c = ((size_t)s * 8 + j8) * 8;
+    uint16_t e[8];
+#pragma unroll
+    for (unsigned t = 0; t < 8; ++t) e[t] = (ok && c + t < k) ? *reinterpret_cast<const uint16_t*>(rp + (c + t) * 2) : (uint16_t)0;
+    uint32_t k0, k1, n0, n1;
+    strip_select_f16((uint32_t)e[0] | ((uint32_t)e[1] << 16), (uint32_t)e[2] | ((uint32_t)e[3] << 16), k0, n0);
+    strip_select_f16((uint32_t)e[4] | ((uint32_t)e[5] << 16), (uint32_t)e[6] | ((uint32_t)e[7] << 16), k1, n1);
+    const int mb = (int)(n0 | (n1 << 4));
+    const unsigned q0 = (unsigned)__builtin_amdgcn_update_dpp(0, mb, 0x00, 0xf, 0xf, true);
+    const unsigned q1 = (unsigned)__builtin_amdgcn_update_dpp(0, mb, 0x55, 0xf, 0xf, true);
+    const unsigned q2 = (unsigned)__builtin_amdgcn_update_dpp(0, mb, 0xaa, 0xf, 0xf, true);
+    const unsigned q3 = (unsigned)__builtin_amdgcn_update_dpp(0, mb, 0xff, 0xf, 0xf, true);
+    if (ok) {
+      const size_t itp = (((size_t)s * M + R0 + row) << 3) + j8;
+      *reinterpret_cast<u2*>(vals + itp * 4) = u2{k0, k1};
+      if ((lane & 3u) == 0) *reinterpret_cast<unsigned*>(meta + itp) = q0 | (q1 << 8) | (q2 << 16) | (q3 << 24);
+    }
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void decompress_kernel(const T* vals, const unsigned char* meta, size_t m,
                                                          size_t k, size_t ld, size_t strideA, size_t kc,
@@ -532,6 +581,16 @@ static int launch_compress(const void* A, size_t m, size_t k, size_t ld, size_t 
     if (nt) compress_flat_kernel<T, true, NLD><<<grid, 256, 0, st>>>((const T*)A, L.M, k, nstage, (unsigned)nunits, v, mt);
     else compress_flat_kernel<T, false, NLD><<<grid, 256, 0, st>>>((const T*)A, L.M, k, nstage, (unsigned)nunits, v, mt);
     return check_launch("compress_flat_kernel");
+  }
+  if constexpr (sizeof(T) == 2) {
+    // rows that are not whole 16-byte chunks (or k % 64 != 0), back to back: staged through LDS as one contiguous span
+    const size_t span_bytes = 32 * ld * 2 + 32;
+    if (aligned16(A) && (batch == 1 || strideA == m * ld) && span_bytes <= 48 * 1024 && L.kc / 64 <= 0xffffffu &&
+        ceil_div(L.M, (size_t)32) < 0x7fffffffull) {
+      compress_rowspan_f16_kernel<<<(unsigned)ceil_div(L.M, (size_t)32), 256, span_bytes, st>>>(
+          (const uint16_t*)A, L.M, k, ld, (unsigned)(L.kc / 64), (uint16_t*)blob, (unsigned char*)blob + L.meta_off);
+      return check_launch("compress_rowspan_f16_kernel");
+    }
   }
   const unsigned grid = stream_grid(items, 256);
   compress_kernel<T><<<grid, 256, 0, st>>>((const T*)A, m, k, ld, strideA, L.kc, L.M, (T*)blob,
