@@ -241,7 +241,7 @@ def main():
                                  layers=[L for L in layers if not use_fused(L)],
                                  call=lambda L: sm.spmma(L["blob"], L["B"], L["C"], L["m"], L["n"], L["k"], L["b"], 0),
                                  bytes=lambda L: L["b"] * (L["m"] * L["k"] * s / 2 + L["m"] * L["k"] / 8 + L["m"] * L["n"] * s) + s * L["k"] * L["n"]),
-               "compress": dict(names=["compress_flat_kernel", "compress_kernel"],
+               "compress": dict(names=["compress_flat_kernel", "compress_rowspan_f16_kernel", "compress_kernel"],
                                 layers=[L for L in layers if not use_fused(L)],
                                 call=lambda L: sm.compress24(L["A"], L["m"], L["k"], L["k"], L["b"], L["m"] * L["k"], L["blob"]),
                                 bytes=lambda L: L["b"] * L["m"] * L["k"] * (s + s / 2 + 1 / 8)),
