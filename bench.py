@@ -50,6 +50,9 @@ def main():
     ap.add_argument("--fused-max-n", type=int, default=256,
                     help="auto path: widest n served by sm_spmma_fused_f16 (one workgroup spans up to 256 columns, so up "
                          "to there A is loaded and selected once)")
+    ap.add_argument("--fused-max-k-wide", type=int, default=512,
+                    help="auto path: wider layers (n > --fused-max-n) are still fused when k <= this (the A-stationary "
+                         "kernel keeps the 2:4 image of a row panel in LDS across its column tiles); 0 = never")
     ap.add_argument("--streams", type=int, default=4,
                     help="HIP streams the independent layers of a step are spread over (fork/join inside the step)")
     args = ap.parse_args()
@@ -111,7 +114,7 @@ def main():
         sm.spmma(L["blob"], L["B"], L["C"], L["m"], L["n"], L["k"], L["b"], 0)
 
     def use_fused(L):
-        return args.path == "auto" and L["n"] <= args.fused_max_n and L["k"] % 64 == 0
+        return args.path == "auto" and L["k"] % 64 == 0 and (L["n"] <= args.fused_max_n or L["k"] <= args.fused_max_k_wide)
 
     # (f-1) the fused kernel computes the same C bit for bit straight from the dense A (the 2:4 selection
     # and compaction happen in registers / LDS; no blob goes to HBM)
@@ -169,8 +172,9 @@ def main():
         "dtype": "f16", "data": "synthetic",
         "config": {"workload": "datasets/resnet50.csv: 49 conv layers as im2col GEMMs (m,n,k) at b=32, fp16; "
                                "step = per layer 2:4 prune+compress+matmul (path: " + args.path + ")",
-                   "path": args.path + (": sm_spmma_fused_f16 on %d layers (n <= %d), sm_compress24_f16 + sm_spmma_f16 on %d"
-                                        % (sum(use_fused(L) for L in layers), args.fused_max_n, sum(not use_fused(L) for L in layers))
+                   "path": args.path + (": sm_spmma_fused_f16 on %d layers (n <= %d or k <= %d), sm_compress24_f16 + sm_spmma_f16 on %d"
+                                        % (sum(use_fused(L) for L in layers), args.fused_max_n, args.fused_max_k_wide,
+                                           sum(not use_fused(L) for L in layers))
                                         if args.path == "auto" else ": sm_compress24_f16 + sm_spmma_f16 on every layer"),
                    "layers": len(layers), "batch": layers[0]["b"], "dense_equiv_gflop_per_step": flops / 1e9,
                    "launch": "eager" if args.eager else "hipGraph replay of one step", "streams": args.streams,
@@ -245,7 +249,7 @@ def main():
                                 layers=[L for L in layers if not use_fused(L)],
                                 call=lambda L: sm.compress24(L["A"], L["m"], L["k"], L["k"], L["b"], L["m"] * L["k"], L["blob"]),
                                 bytes=lambda L: L["b"] * L["m"] * L["k"] * (s + s / 2 + 1 / 8)),
-               "spmma_f16_fused": dict(names=["spmma_f16_fused_kernel", "spmma_f16_fused_wide_kernel"],
+               "spmma_f16_fused": dict(names=["spmma_f16_fused_kernel", "spmma_f16_fused_wide_kernel", "spmma_f16_fused_astat_kernel"],
                                        layers=[L for L in layers if use_fused(L)],
                                        call=lambda L: sm.spmma_fused(L["A"], L["B"], L["C"], L["m"], L["n"], L["k"], batch=L["b"]),
                                        bytes=lambda L: L["b"] * s * (L["m"] * L["k"] + L["m"] * L["n"]) + s * L["k"] * L["n"])}

@@ -577,6 +577,255 @@ static int launch_fused_wide(const FusedArgs& a0, hipStream_t st) {
   return check_launch("spmma_f16_fused_wide_kernel");
 }
 
+// ---------------------------------------------------------------------------------------------
+// n > 256 with a short K (k <= 512): A-stationary.  The 2:4 image of the workgroup's 128 rows for the WHOLE K
+// (k/64 stages x 9 KiB) stays in LDS; all 16 waves build it first (every load of the panel in flight at once: a single
+// HBM latency), 4 of them then only attend the barriers, and the workgroup walks its column tiles re-using it: A is loaded and selected once per `nsplit` column range
+// instead of once per column tile, and from the second tile on a stage costs only the B tile's 128 line requests.
+// B streams through its own ring across tile boundaries (no drain); each consumer wave stores its own 32 x 64
+// piece of C through a wave-private LDS patch (no barrier in the epilogue), so the loaders keep prefetching the
+// next tile's B while C is written.  beta == 0 only (the caller falls back to the wide kernel otherwise).
+// ---------------------------------------------------------------------------------------------
+template <int NSB>
+__global__ __launch_bounds__(64 * 16) void spmma_f16_fused_astat_kernel(const FusedArgs p, int nsplit, int tiles_per_split) {
+  constexpr int BM = 128, BN = 128, WM = 4, WN = 2, NC = 8, NLA = 4, NLB = 4;
+  static_assert(NC + NLA + NLB == 16, "launch bounds");
+  constexpr int TM = BM / WM, TN = BN / WN, FM = TM / 16, FN = TN / 16;  // wave tile 32 x 64
+  constexpr int SA = BM * 64, SM_ = BM * 8, ASTG = SA + SM_, SB = 64 * BN * 2;
+  constexpr int B_N = BN / 8, B_WI = B_N / NLB;
+  static_assert((NSB - 2) * B_WI <= 63, "vmcnt range");
+  // wave-private C patch: 32 rows x 136 B.  34 dwords per row: the four 4-row groups a ds_write_b16 instruction
+  // touches (rows 4g + q) start 8 banks apart, each covering 8 banks: no conflict beyond the two halves of a dword
+  constexpr int WPITCH = TN * 2 + 8, WPATCH = TM * WPITCH;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const unsigned tid = threadIdx.x, lane = tid & 63u;
+  const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nkt = p.K / 64;
+  const unsigned per_batch = (unsigned)p.tiles_m * (unsigned)nsplit;
+  const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
+  const unsigned b = lid / per_batch, trem = lid - b * per_batch;
+  const unsigned tile_m = trem / (unsigned)nsplit, split = trem - tile_m * (unsigned)nsplit;
+  const int m0 = (int)tile_m * BM;
+  const int nt0 = (int)split * tiles_per_split;
+  const int nt1 = nt0 + tiles_per_split < p.tiles_n ? nt0 + tiles_per_split : p.tiles_n;
+  const int T = (nt1 - nt0) * nkt;  // stage iterations of this workgroup (>= nkt: the launcher never makes empty splits)
+  char* const Bring = smem + nkt * ASTG;
+  char* const Cpatch = Bring + NSB * SB;
+  half_t* C = p.C + (size_t)b * p.sC;
+
+  // B loader state (waves NC+NLA ..): set up first so that their ring prologue is in flight during phase 1
+  const bool is_b = wave >= (unsigned)(NC + NLA);
+  const unsigned lwb = is_b ? wave - (NC + NLA) : 0u;
+  const char* Bb = reinterpret_cast<const char*>(p.B + (size_t)b * p.sB);
+  unsigned b_kr[B_WI], b_col[B_WI], b_dst[B_WI];
+#pragma unroll
+  for (int i = 0; i < B_WI; ++i) {
+    const unsigned j = lwb + (unsigned)NLB * i, panel = j >> 3, grp = j & 7u, kr = 8u * grp + (lane >> 3);
+    b_kr[i] = kr;
+    b_col[i] = 64u * panel + 8u * ((lane & 7u) ^ b_swz(kr));
+    b_dst[i] = panel * 8192u + grp * 1024u;
+  }
+  const size_t row_bytes = (size_t)p.N * 2;
+  int i_nt = nt0, i_kt = 0, i_buf = 0;  // the next B stage to issue
+  auto issue_b = [&]() {
+#pragma unroll
+    for (int i = 0; i < B_WI; ++i) {
+      int gc = i_nt * BN + (int)b_col[i];
+      gc = gc <= p.N - 8 ? gc : p.N - 8;
+      const char* src = Bb + (size_t)(i_kt * 64 + (int)b_kr[i]) * row_bytes + (size_t)gc * 2;
+      __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)(Bring + i_buf * SB + b_dst[i]), 16, 0, 0);
+    }
+    i_buf = i_buf + 1 == NSB ? 0 : i_buf + 1;
+    if (++i_kt == nkt) { i_kt = 0; ++i_nt; }
+  };
+  if (is_b) {
+#pragma unroll
+    for (int s = 0; s < NSB - 1; ++s)
+      if (s < T) issue_b();
+  }
+
+  // ---- phase 1, all 16 waves: the 2:4 image of the row panel for the whole K.  Wave w owns rows 8w .. 8w+7: one
+  // 16-byte load per lane and stage, all stages in flight at once (K <= 512: at most 8 loads), then selection.
+  {
+    const half_t* A = p.A + (size_t)b * p.sA;
+    const unsigned row = 8u * wave + (lane >> 3), c8 = lane & 7u;
+    int gr = m0 + (int)row;
+    gr = gr < p.Mrows - 1 ? gr : p.Mrows - 1;
+    const half_t* a_src = A + (size_t)gr * p.lda + 8u * c8;
+    const unsigned a_val_off = row * 64u + 16u * ((c8 >> 1) ^ a64_swz(row)) + 8u * (c8 & 1u);
+    const unsigned a_meta_off = SA + row * 8u + c8;
+    u4 ra[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+      if (s < nkt) ra[s] = __builtin_nontemporal_load(reinterpret_cast<const u4*>(a_src + (size_t)s * 64));
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+      if (s < nkt) {
+        uint32_t k0, k1, n0, n1;
+        strip_select_f16(ra[s][0], ra[s][1], k0, n0);
+        strip_select_f16(ra[s][2], ra[s][3], k1, n1);
+        char* sb = smem + s * ASTG;
+        *reinterpret_cast<u2*>(sb + a_val_off) = u2{k0, k1};
+        *reinterpret_cast<unsigned char*>(sb + a_meta_off) = (unsigned char)(n0 | (n1 << 4));
+      }
+  }
+  __syncthreads();  // the image is complete (and the B prologue has landed)
+  if (wave >= (unsigned)NC && !is_b) {  // 4 of the 16 waves were only needed for phase 1: they just keep the barrier count
+    // (letting them write C out of the consumers' patches was tried: no gain, the consumers' 32 ds_write_b16 per tile
+    // and the stage barriers, not the store queue, set the tile's time)
+    for (int it = 0; it < T; ++it) asm volatile("s_barrier" ::: "memory");
+    return;
+  }
+
+  if (is_b) {
+    // ------------------------------------------------------------------ B loader wave
+    SM_T(unsigned long long tv = 0, tb = 0, ti = 0; unsigned long long s0 = sm_stamp();)
+    for (int it = 0; it < T; ++it) {
+#ifdef SM_STAMP
+      if (it + NSB - 2 < T) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSB - 2) * B_WI) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const unsigned long long sv = sm_stamp();
+      tv += sv - s0;
+      asm volatile("s_barrier" ::: "memory");
+      const unsigned long long s1 = sm_stamp();
+      tb += s1 - sv;
+#else
+      if (it + NSB - 2 < T) wait_dma_and_barrier<(NSB - 2) * B_WI>();
+      else wait_dma_and_barrier<0>();
+#endif
+      if (it + NSB - 1 < T) issue_b();
+      SM_T(s0 = sm_stamp(); ti += s0 - s1;)
+    }
+    SM_T(if (p.dbg && lane == 0) { unsigned long long* d = p.dbg + ((size_t)blockIdx.x * 16 + wave) * 8; d[0] = tv; d[1] = tb; d[2] = ti; d[3] = 2; d[4] = (unsigned long long)T; })
+  } else {
+    // ------------------------------------------------------------------ consumer wave
+    const unsigned g = lane >> 4, r = lane & 15u;
+    const unsigned wm = wave / WN, wn = wave % WN;
+    char* const patch = Cpatch + wave * WPATCH;
+    f4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+    int cb = 0, kt = 0, nt = nt0;
+    SM_T(unsigned long long tb = 0, tc = 0, te = 0; unsigned long long s0 = sm_stamp();)
+    for (int it = 0; it < T; ++it) {
+      asm volatile("s_barrier" ::: "memory");  // (no vmcnt: this wave's C stores of the previous tile may still be in flight)
+      SM_T(unsigned long long s1 = sm_stamp(); tb += s1 - s0;)
+      const char* As = smem + kt * ASTG;
+      const char* Ms = As + SA;
+      const char* Bs = Bring + cb * SB;
+      h8 af[FM];
+      int idx[FM];
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        const unsigned row = wm * TM + i * 16 + r;
+        af[i] = *reinterpret_cast<const h8*>(As + row * 64u + 16u * (g ^ a64_swz(row)));
+        idx[i] = (int)*reinterpret_cast<const unsigned short*>(Ms + row * 8u + 2u * g);
+      }
+      const unsigned bs_addr = (unsigned)(uintptr_t)(lds_char*)Bs;
+      s4 t0[2], t1[2], t2[2], t3[2];
+      auto issue = [&](int j, s4& v0, s4& v1, s4& v2, s4& v3) {
+        const unsigned col0 = wn * TN + j * 16, q = r >> 2, pp = r & 3u;
+        const unsigned a = bs_addr + b_off<64>(8u * g + q, col0 + 4u * pp);
+        asm volatile("ds_read_b64_tr_b16 %0, %4\n\tds_read_b64_tr_b16 %1, %4 offset:512\n\t"
+                     "ds_read_b64_tr_b16 %2, %4 offset:4096\n\tds_read_b64_tr_b16 %3, %4 offset:4608"
+                     : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3) : "v"(a) : "memory");
+      };
+      issue(0, t0[0], t1[0], t2[0], t3[0]);
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const int c = j & 1, n = c ^ 1;
+        if (j + 1 < FN) {
+          issue(j + 1, t0[n], t1[n], t2[n], t3[n]);
+          asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(t0[c]), "+v"(t1[c]), "+v"(t2[c]), "+v"(t3[c]) :: "memory");
+        } else {
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t0[c]), "+v"(t1[c]), "+v"(t2[c]), "+v"(t3[c]) :: "memory");
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        typedef short s16 __attribute__((ext_vector_type(16)));
+        const s16 all = {t0[c][0], t0[c][1], t0[c][2], t0[c][3], t1[c][0], t1[c][1], t1[c][2], t1[c][3],
+                         t2[c][0], t2[c][1], t2[c][2], t2[c][3], t3[c][0], t3[c][1], t3[c][2], t3[c][3]};
+        const h16 bf = __builtin_bit_cast(h16, all);
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+          acc[i][j] = __builtin_amdgcn_smfmac_f32_16x16x64_f16(af[i], bf, acc[i][j], idx[i], 0, 0);
+      }
+      cb = cb + 1 == NSB ? 0 : cb + 1;
+      SM_T(__builtin_amdgcn_sched_barrier(0); s0 = sm_stamp(); tc += s0 - s1;)
+      if (++kt == nkt) {
+        // ---- this column tile is done: C piece of this wave through its private LDS patch, 16-byte row pieces out
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int j = 0; j < FN; ++j) {
+            const unsigned lr = i * 16 + 4u * g, lc = j * 16 + r;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              *reinterpret_cast<half_t*>(patch + (lr + q) * WPITCH + lc * 2) = (half_t)(p.alpha * acc[i][j][q]);
+              acc[i][j][q] = 0.f;
+            }
+          }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // same wave wrote and reads: no barrier
+        const int gc = nt * BN + (int)(wn * TN) + 8 * (int)(lane & 7u);
+#pragma unroll
+        for (int s = 0; s < TM / 8; ++s) {
+          const unsigned lr = 8u * s + (lane >> 3);
+          const int gr = m0 + (int)(wm * TM + lr);
+          if (gr < p.Mrows && gc < p.N) {
+            const u2 lo = *reinterpret_cast<const u2*>(patch + lr * WPITCH + 16u * (lane & 7u));  // rows are 8-byte aligned
+            const u2 hi = *reinterpret_cast<const u2*>(patch + lr * WPITCH + 16u * (lane & 7u) + 8u);
+            *reinterpret_cast<u4*>(C + (size_t)gr * p.N + gc) = u4{lo[0], lo[1], hi[0], hi[1]};
+          }
+        }
+        kt = 0;
+        ++nt;
+        SM_T(__builtin_amdgcn_sched_barrier(0); { const unsigned long long s2 = sm_stamp(); te += s2 - s0; s0 = s2; })
+      }
+    }
+    SM_T(if (p.dbg && lane == 0) { unsigned long long* d = p.dbg + ((size_t)blockIdx.x * 16 + wave) * 8; d[0] = tb; d[1] = tc; d[2] = te; d[3] = 0; d[4] = (unsigned long long)T; })
+  }
+}
+
+static size_t astat_lds_bytes(int nkt, int nsb) { return (size_t)nkt * (128 * 72) + (size_t)nsb * 64 * 128 * 2 + 8 * 32 * (64 * 2 + 8); }
+
+static int launch_fused_astat(const FusedArgs& a0, hipStream_t st) {
+  FusedArgs a = a0;
+  a.tiles_m = (a.Mrows + 127) / 128;
+  a.tiles_n = (a.N + 127) / 128;
+  // split the column range of a row panel over several workgroups until 3/4 of the CUs have one (a split re-selects
+  // its A panel, so no more than needed: 784 x 1024 x 256, b = 32: 29 / 33 / 41 us with 1 / 2 / 4 splits); >= 2 tiles
+  // per split
+  int dev = 0, cus = 256;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+    cus = prop.multiProcessorCount;
+  const size_t panels = (size_t)a.tiles_m * a.batch;
+  static const int nsplit_env = getenv("SM_FUSED_NSPLIT") ? atoi(getenv("SM_FUSED_NSPLIT")) : 0;  // tuning aid
+  int nsplit = 1;
+  while (!nsplit_env && panels * nsplit * 4 < (size_t)3 * cus && (a.tiles_n + 2 * nsplit - 1) / (2 * nsplit) >= 2) nsplit *= 2;
+  if (nsplit_env > 0) nsplit = nsplit_env < a.tiles_n ? nsplit_env : a.tiles_n;
+  int tps = (a.tiles_n + nsplit - 1) / nsplit;
+  nsplit = (a.tiles_n + tps - 1) / tps;  // no empty splits
+  const size_t nwg = panels * nsplit;
+  if (nwg == 0) return SM_STATUS_SUCCESS;
+  if (nwg > 0x7fffffffu) {
+    set_error("sm_spmma_fused_f16: grid too large");
+    return SM_STATUS_NOT_SUPPORTED;
+  }
+  constexpr int NSB = 3;  // (a ring of 4 measured the same)
+  const size_t lds = astat_lds_bytes(a.K / 64, NSB);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spmma_f16_fused_astat_kernel<NSB>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
+    attr_set = true;
+  }
+  spmma_f16_fused_astat_kernel<NSB><<<dim3((unsigned)nwg), dim3(64 * 16), lds, st>>>(a, nsplit, tps);
+  return check_launch("spmma_f16_fused_astat_kernel");
+}
+
 }  // namespace sm
 
 using namespace sm;
@@ -617,6 +866,11 @@ extern "C" int sm_spmma_fused_f16(const void* A, const void* B, void* C, size_t 
     if (n <= 64) return launch_fused<64, 4, 1>(a, st);
     if (n <= 128) return launch_fused<128, 2, 2>(a, st);
   }
+  // n > 256, short K, plain store: A-stationary (the 2:4 image of a row panel stays in LDS across column tiles)
+  static const int astat_env = getenv("SM_FUSED_ASTAT") ? atoi(getenv("SM_FUSED_ASTAT")) : 1;  // tuning aid: 0 = off
+  if (astat_env && n > 256 && k <= 512 && beta == 0.0f && aligned16(C) && (strideC % 8 == 0) &&
+      astat_lds_bytes((int)(k / 64), 3) <= 160 * 1024)
+    return launch_fused_astat(a, st);
   static const int pf = getenv("SM_FUSED_PF") ? atoi(getenv("SM_FUSED_PF")) : 2;    // tuning aids: A stages in flight,
   static const int nsb = getenv("SM_FUSED_NSB") ? atoi(getenv("SM_FUSED_NSB")) : 3;  // B ring depth,
   static const int wn4 = getenv("SM_FUSED_WN4") ? atoi(getenv("SM_FUSED_WN4")) : 0;  // consumer wave grid 2 x 4

@@ -585,7 +585,11 @@ def test_cpp_drivers_cli_contract(gpu):
 # (f-1) fused prune -> compress -> matmul
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("shape", [(128, 64, 64, 1), (196, 512, 256, 2), (784, 256, 1024, 2), (130, 72, 192, 1), (96, 64, 128, 3),
-                                   (12544, 64, 576, 2), (3136, 128, 1152, 1), (300, 136, 320, 2)])
+                                   (12544, 64, 576, 2), (3136, 128, 1152, 1), (300, 136, 320, 2),
+                                   # A-stationary kernel (n > 256, k <= 512): column tails, row tails, single stage, 8 stages
+                                   (300, 520, 128, 2), (784, 1024, 256, 1), (130, 2048, 512, 1), (4000, 264, 64, 1),
+                                   # wide kernel beyond its one-tile range (n > 256, k > 512)
+                                   (260, 520, 576, 1)])
 @pytest.mark.parametrize("shared_b", [True, False])
 def test_fused_equals_staged(gpu, orc, shape, shared_b):
     """sm_spmma_fused_f16(A) must be BIT-identical to sm_spmma_f16(sm_compress24_f16(A)): same kept values,
