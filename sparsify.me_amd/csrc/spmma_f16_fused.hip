@@ -629,6 +629,9 @@ __global__ __launch_bounds__(64 * 16) void spmma_f16_fused_astat_kernel(const Fu
   const size_t row_bytes = (size_t)p.N * 2;
   int i_nt = nt0, i_kt = 0, i_buf = 0;  // the next B stage to issue
   auto issue_b = [&]() {
+#if defined(SM_ABLATE) && (SM_ABLATE & 4)
+    if (nkt > 0) { i_buf = i_buf + 1 == NSB ? 0 : i_buf + 1; if (++i_kt == nkt) { i_kt = 0; ++i_nt; } return; }
+#endif
 #pragma unroll
     for (int i = 0; i < B_WI; ++i) {
       int gc = i_nt * BN + (int)b_col[i];
@@ -713,6 +716,9 @@ __global__ __launch_bounds__(64 * 16) void spmma_f16_fused_astat_kernel(const Fu
     for (int it = 0; it < T; ++it) {
       asm volatile("s_barrier" ::: "memory");  // (no vmcnt: this wave's C stores of the previous tile may still be in flight)
       SM_T(unsigned long long s1 = sm_stamp(); tb += s1 - s0;)
+#if defined(SM_ABLATE) && (SM_ABLATE & 1)
+      if (nkt > 0) { cb = cb + 1 == NSB ? 0 : cb + 1; if (++kt == nkt) { kt = 0; ++nt; } continue; }
+#endif
       const char* As = smem + kt * ASTG;
       const char* Ms = As + SA;
       const char* Bs = Bring + cb * SB;
@@ -754,6 +760,10 @@ __global__ __launch_bounds__(64 * 16) void spmma_f16_fused_astat_kernel(const Fu
       }
       cb = cb + 1 == NSB ? 0 : cb + 1;
       SM_T(__builtin_amdgcn_sched_barrier(0); s0 = sm_stamp(); tc += s0 - s1;)
+#if defined(SM_ABLATE) && (SM_ABLATE & 16)
+      if (++kt == nkt) { kt = 0; ++nt; }
+      if (nkt > 0) continue;
+#endif
       if (++kt == nkt) {
         // ---- this column tile is done: C piece of this wave through its private LDS patch, 16-byte row pieces out
 #pragma unroll
