@@ -46,6 +46,55 @@ __device__ __forceinline__ s4 b_read_tr(const char* Bs, unsigned kr0, unsigned c
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(lds_char*)addr);
 }
 
+// 64-byte-row A image: 16-byte chunk c of row r lives at chunk c ^ ((-(r >> 2)) & 3).
+__device__ __forceinline__ unsigned a64_swz(unsigned row) { return (0u - (row >> 2)) & 3u; }
+
+// One 64-deep stage of the 2:4 matmul for one consumer wave (wave tile 16*FM x 16*FN at rows row0.., columns col0..
+// of the workgroup tile): A fragments + index halfwords from the 64-byte-row image `As` / its metadata `Ms`, B
+// fragments from the row-major [64][BN] image `Bs` through ds_read_b64_tr_b16, FM x FN v_smfmac_f32_16x16x64_f16.
+// The transposing reads are issued by hand (inline asm, counted lgkmcnt): the compiler would drain the in-flight DMA
+// (vmcnt(0)) in front of the intrinsic form; fragment j+1's four reads are in flight while fragment j's SMFMACs run.
+template <int FM, int FN>
+__device__ __forceinline__ void smfmac_stage(const char* As, const char* Ms, const char* Bs, unsigned row0, unsigned col0,
+                                             unsigned lane, f4 (&acc)[FM][FN]) {
+  const unsigned g = lane >> 4, r = lane & 15u;
+  h8 af[FM];
+  int idx[FM];
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+    const unsigned row = row0 + i * 16 + r;
+    af[i] = *reinterpret_cast<const h8*>(As + row * 64u + 16u * (g ^ a64_swz(row)));
+    idx[i] = (int)*reinterpret_cast<const unsigned short*>(Ms + row * 8u + 2u * g);
+  }
+  const unsigned bs_addr = (unsigned)(uintptr_t)(lds_char*)Bs;
+  s4 t0[2], t1[2], t2[2], t3[2];
+  auto issue = [&](int j, s4& v0, s4& v1, s4& v2, s4& v3) {
+    const unsigned c0 = col0 + j * 16, q = r >> 2, pp = r & 3u;
+    const unsigned a = bs_addr + b_off<64>(8u * g + q, c0 + 4u * pp);
+    asm volatile("ds_read_b64_tr_b16 %0, %4\n\tds_read_b64_tr_b16 %1, %4 offset:512\n\t"
+                 "ds_read_b64_tr_b16 %2, %4 offset:4096\n\tds_read_b64_tr_b16 %3, %4 offset:4608"
+                 : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3) : "v"(a) : "memory");
+  };
+  issue(0, t0[0], t1[0], t2[0], t3[0]);
+#pragma unroll
+  for (int j = 0; j < FN; ++j) {
+    const int c = j & 1, n = c ^ 1;
+    if (j + 1 < FN) {
+      issue(j + 1, t0[n], t1[n], t2[n], t3[n]);
+      asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(t0[c]), "+v"(t1[c]), "+v"(t2[c]), "+v"(t3[c]) :: "memory");
+    } else {
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t0[c]), "+v"(t1[c]), "+v"(t2[c]), "+v"(t3[c]) :: "memory");
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    typedef short s16 __attribute__((ext_vector_type(16)));
+    const s16 all = {t0[c][0], t0[c][1], t0[c][2], t0[c][3], t1[c][0], t1[c][1], t1[c][2], t1[c][3],
+                     t2[c][0], t2[c][1], t2[c][2], t2[c][3], t3[c][0], t3[c][1], t3[c][2], t3[c][3]};
+    const h16 bf = __builtin_bit_cast(h16, all);
+#pragma unroll
+    for (int i = 0; i < FM; ++i) acc[i][j] = __builtin_amdgcn_smfmac_f32_16x16x64_f16(af[i], bf, acc[i][j], idx[i], 0, 0);
+  }
+}
+
 // XCD-aware bijective remap of a linear workgroup id: blocks that share an XCD (ids equal mod 8)
 // receive a contiguous range of logical ids, so tiles that re-read the same operand panel sit on
 // one L2 (speed only; any placement is correct).

@@ -34,7 +34,5 @@ __device__ __forceinline__ unsigned long long sm_stamp() {
 #define SM_T(...)
 #endif
 
-// 64-byte-row A image: 16-byte chunk c of row r lives at chunk c ^ ((-(r >> 2)) & 3).
-__device__ __forceinline__ unsigned a64_swz(unsigned row) { return (0u - (row >> 2)) & 3u; }
 
 }  // namespace sm

@@ -347,44 +347,7 @@ __global__ __launch_bounds__(64 * WM * WN) void spmma_f16_dma_kernel(const Spmma
     const char* As = smem + cur * STAGE;
     const char* Ms = As + SA;
     const char* Bs = Ms + SM_;
-    h8 af[FM];
-    int idx[FM];
-#pragma unroll
-    for (int i = 0; i < FM; ++i) {
-      const unsigned row = wm * TM + i * 16 + r;
-      af[i] = *reinterpret_cast<const h8*>(As + row * 64u + 16u * (g ^ a64_swz(row)));
-      idx[i] = (int)*reinterpret_cast<const unsigned short*>(Ms + row * 8u + 2u * g);
-    }
-    // B fragments by hand-issued transposed reads (the compiler would drain the in-flight DMA in
-    // front of the intrinsic form): fragment j+1's four reads are issued before fragment j's wait.
-    const unsigned bs_addr = (unsigned)(uintptr_t)(lds_char*)Bs;
-    s4 t0[2], t1[2], t2[2], t3[2];
-    auto issue = [&](int j, s4& v0, s4& v1, s4& v2, s4& v3) {
-      const unsigned col0 = wn * TN + j * 16, q = r >> 2, pp = r & 3u;
-      const unsigned a = bs_addr + b_off<64>(8u * g + q, col0 + 4u * pp);
-      asm volatile("ds_read_b64_tr_b16 %0, %4\n\tds_read_b64_tr_b16 %1, %4 offset:512\n\t"
-                   "ds_read_b64_tr_b16 %2, %4 offset:4096\n\tds_read_b64_tr_b16 %3, %4 offset:4608"
-                   : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3) : "v"(a) : "memory");
-    };
-    issue(0, t0[0], t1[0], t2[0], t3[0]);
-#pragma unroll
-    for (int j = 0; j < FN; ++j) {
-      const int c = j & 1, n = c ^ 1;
-      if (j + 1 < FN) {
-        issue(j + 1, t0[n], t1[n], t2[n], t3[n]);
-        asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(t0[c]), "+v"(t1[c]), "+v"(t2[c]), "+v"(t3[c]) :: "memory");
-      } else {
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t0[c]), "+v"(t1[c]), "+v"(t2[c]), "+v"(t3[c]) :: "memory");
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      typedef short s16 __attribute__((ext_vector_type(16)));
-      const s16 all = {t0[c][0], t0[c][1], t0[c][2], t0[c][3], t1[c][0], t1[c][1], t1[c][2], t1[c][3],
-                       t2[c][0], t2[c][1], t2[c][2], t2[c][3], t3[c][0], t3[c][1], t3[c][2], t3[c][3]};
-      const h16 bf = __builtin_bit_cast(h16, all);
-#pragma unroll
-      for (int i = 0; i < FM; ++i)
-        acc[i][j] = __builtin_amdgcn_smfmac_f32_16x16x64_f16(af[i], bf, acc[i][j], idx[i], 0, 0);
-    }
+    smfmac_stage<FM, FN>(As, Ms, Bs, wm * TM, wn * TN, lane, acc);
     cur = cur + 1 == NS ? 0 : cur + 1;
     fill = fill + 1 == NS ? 0 : fill + 1;
     SM_T(__builtin_amdgcn_sched_barrier(0); st0 = sm_stamp(); tc += st0 - st2;)
@@ -582,42 +545,7 @@ __global__ __launch_bounds__(64 * (WM * WN + NL)) void spmma_f16_pc_kernel(const
       const char* As = smem + cur * STAGE;
       const char* Ms = As + SA;
       const char* Bs = Ms + SM_;
-      h8 af[FM];
-      int idx[FM];
-#pragma unroll
-      for (int i = 0; i < FM; ++i) {
-        const unsigned row = wm * TM + i * 16 + r;
-        af[i] = *reinterpret_cast<const h8*>(As + row * 64u + 16u * (g ^ a64_swz(row)));
-        idx[i] = (int)*reinterpret_cast<const unsigned short*>(Ms + row * 8u + 2u * g);
-      }
-      const unsigned bs_addr = (unsigned)(uintptr_t)(lds_char*)Bs;
-      s4 t0[2], t1[2], t2[2], t3[2];
-      auto issue = [&](int j, s4& v0, s4& v1, s4& v2, s4& v3) {
-        const unsigned col0 = wn * TN + j * 16, q = r >> 2, pp = r & 3u;
-        const unsigned a = bs_addr + b_off<64>(8u * g + q, col0 + 4u * pp);
-        asm volatile("ds_read_b64_tr_b16 %0, %4\n\tds_read_b64_tr_b16 %1, %4 offset:512\n\t"
-                     "ds_read_b64_tr_b16 %2, %4 offset:4096\n\tds_read_b64_tr_b16 %3, %4 offset:4608"
-                     : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3) : "v"(a) : "memory");
-      };
-      issue(0, t0[0], t1[0], t2[0], t3[0]);
-#pragma unroll
-      for (int j = 0; j < FN; ++j) {
-        const int c = j & 1, n = c ^ 1;
-        if (j + 1 < FN) {
-          issue(j + 1, t0[n], t1[n], t2[n], t3[n]);
-          asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(t0[c]), "+v"(t1[c]), "+v"(t2[c]), "+v"(t3[c]) :: "memory");
-        } else {
-          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t0[c]), "+v"(t1[c]), "+v"(t2[c]), "+v"(t3[c]) :: "memory");
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        typedef short s16 __attribute__((ext_vector_type(16)));
-        const s16 all = {t0[c][0], t0[c][1], t0[c][2], t0[c][3], t1[c][0], t1[c][1], t1[c][2], t1[c][3],
-                         t2[c][0], t2[c][1], t2[c][2], t2[c][3], t3[c][0], t3[c][1], t3[c][2], t3[c][3]};
-        const h16 bf = __builtin_bit_cast(h16, all);
-#pragma unroll
-        for (int i = 0; i < FM; ++i)
-          acc[i][j] = __builtin_amdgcn_smfmac_f32_16x16x64_f16(af[i], bf, acc[i][j], idx[i], 0, 0);
-      }
+      smfmac_stage<FM, FN>(As, Ms, Bs, wm * TM, wn * TN, lane, acc);
       cur = cur + 1 == NS ? 0 : cur + 1;
       SM_T(__builtin_amdgcn_sched_barrier(0); s0 = sm_stamp(); tc += s0 - s1;)
     }
