@@ -95,6 +95,59 @@ __device__ __forceinline__ void smfmac_stage(const char* As, const char* Ms, con
   }
 }
 
+// Epilogue of the 2:4 matmul kernels, called by EVERY thread of the workgroup after its last barrier: the SMFMAC
+// result map leaves 4 consecutive ROWS of one column per lane, so with beta == 0 and a 16-byte aligned C the tile is
+// transposed through LDS (`smem`, BM x (2 BN + 16) bytes, aliasing the stage buffers) and written as 16-byte row
+// pieces by all NT threads; otherwise (beta != 0, misaligned C) each accumulator wave stores its elements itself,
+// reading C once: one rounding of alpha * acc + beta * C to fp16 either way.  `has_acc`: this wave holds a tile
+// (loader waves of the producer/consumer kernels do not); row0/col0: its tile inside the workgroup tile.
+template <int BM, int BN, int FM, int FN, int NT>
+__device__ __forceinline__ void store_c_tile(char* smem, half_t* C, const f4 (&acc)[FM][FN], bool has_acc, unsigned row0,
+                                             unsigned col0, int m0, int n0, int Mrows, int N, float alpha, float beta,
+                                             unsigned tid) {
+  constexpr int CPITCH = BN * 2 + 16;
+  const unsigned lane = tid & 63u, g = lane >> 4, r = lane & 15u;
+  const bool c_vec = (reinterpret_cast<uintptr_t>(C) & 15u) == 0 && (N % 8 == 0);
+  if (beta == 0.0f && c_vec) {
+    if (has_acc) {
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+          const unsigned row = row0 + i * 16 + 4u * g, col = col0 + j * 16 + r;
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<half_t*>(smem + (row + q) * CPITCH + col * 2) = (half_t)(alpha * acc[i][j][q]);
+        }
+    }
+    __syncthreads();
+    constexpr int NCH = BM * (BN / 8);
+    for (unsigned q = tid; q < (unsigned)NCH; q += (unsigned)NT) {
+      const unsigned row = q / (BN / 8), cn = q % (BN / 8);
+      const int gr = m0 + (int)row, gc = n0 + 8 * (int)cn;
+      if (gr >= Mrows || gc >= N) continue;  // N % 8 == 0: a chunk is all in or all out
+      *reinterpret_cast<u4*>(C + (size_t)gr * N + gc) = *reinterpret_cast<const u4*>(smem + row * CPITCH + cn * 16);
+    }
+  } else if (has_acc) {
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const int gc = n0 + (int)(col0 + j * 16 + r);
+        if (gc >= N) continue;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int gr = m0 + (int)(row0 + i * 16 + 4u * g) + q;
+          if (gr >= Mrows) continue;
+          half_t* dst = C + (size_t)gr * N + gc;
+          float v = alpha * acc[i][j][q];
+          if (beta != 0.0f) v += beta * (float)*dst;
+          *dst = (half_t)v;
+        }
+      }
+  }
+}
+
 // XCD-aware bijective remap of a linear workgroup id: blocks that share an XCD (ids equal mod 8)
 // receive a contiguous range of logical ids, so tiles that re-read the same operand panel sit on
 // one L2 (speed only; any placement is correct).

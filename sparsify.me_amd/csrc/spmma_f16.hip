@@ -243,7 +243,6 @@ __global__ __launch_bounds__(64 * WM * WN) void spmma_f16_dma_kernel(const Spmma
   constexpr int SL = (W + NW - 1) / NW;  // slots per wave
   constexpr int LPS = W / NW;            // least DMA instructions any wave issues per stage (vmcnt unit)
   static_assert(LPS >= 1, "every wave must issue at least one DMA per stage");
-  constexpr int CPITCH = BN * 2 + 16;
   constexpr int NT_A = SM_NT_A;  // cache policy bits of the A-side DMA (2 = nt)
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -333,7 +332,6 @@ __global__ __launch_bounds__(64 * WM * WN) void spmma_f16_dma_kernel(const Spmma
 #pragma unroll
   for (int s = 0; s < NS - 1; ++s)
     if (s < nkt) stage(s, s);
-  const unsigned g = lane >> 4, r = lane & 15u;
   int cur = 0, fill = NS - 1;  // buffer of stage kt, buffer of stage kt+NS-1
   SM_T(unsigned long long tw = 0, ti = 0, tc = 0; unsigned long long st0 = sm_stamp(); const unsigned long long tstart = st0;)
   for (int kt = 0; kt < nkt; ++kt) {
@@ -355,46 +353,7 @@ __global__ __launch_bounds__(64 * WM * WN) void spmma_f16_dma_kernel(const Spmma
   __syncthreads();  // nothing is in flight here: the last NS-1 iterations issued no DMA
   SM_T(const unsigned long long tloop = sm_stamp();)
 
-  // ---- epilogue (lane holds C[rows 4*(lane>>4) + r][col lane&15] of each fragment)
-  const bool c_vec = (reinterpret_cast<uintptr_t>(C) & 15u) == 0;
-  if (p.beta == 0.0f && c_vec) {
-    char* Cs = smem;
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-      for (int j = 0; j < FN; ++j) {
-        const unsigned row = wm * TM + i * 16 + 4u * g, col = wn * TN + j * 16 + r;
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          *reinterpret_cast<half_t*>(Cs + (row + q) * CPITCH + col * 2) = (half_t)(p.alpha * acc[i][j][q]);
-      }
-    __syncthreads();
-    constexpr int C_CH = BM * (BN / 8) / (64 * NW);
-#pragma unroll
-    for (int i = 0; i < C_CH; ++i) {
-      const unsigned q = tid + 64u * NW * i, row = q / (BN / 8), cn = q % (BN / 8);
-      const int gr = m0 + (int)row, gc = n0 + 8 * (int)cn;
-      if (gr >= p.Mrows || gc >= p.N) continue;  // N % 8 == 0: a chunk is all in or all out
-      *reinterpret_cast<u4*>(C + (size_t)gr * p.N + gc) = *reinterpret_cast<const u4*>(Cs + row * CPITCH + cn * 16);
-    }
-  } else {
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-      for (int j = 0; j < FN; ++j) {
-        const int gc = n0 + (int)(wn * TN + j * 16 + r);
-        if (gc >= p.N) continue;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int gr = m0 + (int)(wm * TM + i * 16 + 4u * g) + q;
-          if (gr >= p.Mrows) continue;
-          half_t* dst = C + (size_t)gr * p.N + gc;
-          float v = p.alpha * acc[i][j][q];
-          if (p.beta != 0.0f) v += p.beta * (float)*dst;
-          *dst = (half_t)v;
-        }
-      }
-  }
+  store_c_tile<BM, BN, FM, FN, 64 * NW>(smem, C, acc, true, wm * TM, wn * TN, m0, n0, p.Mrows, p.N, p.alpha, p.beta, tid);
 #ifdef SM_STAMP
   if (p.dbg && lane == 0) {
     const unsigned long long tend = sm_stamp();
@@ -430,7 +389,6 @@ __global__ __launch_bounds__(64 * (WM * WN + NL)) void spmma_f16_pc_kernel(const
   constexpr int LPS = W / NL;            // least any loader wave issues per stage: the vmcnt unit (a wave
                                          // with one more then waits slightly longer than it must -- safe)
   static_assert(LPS >= 1, "loader waves");
-  constexpr int CPITCH = BN * 2 + 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const unsigned tid = threadIdx.x, lane = tid & 63u;
@@ -448,7 +406,6 @@ __global__ __launch_bounds__(64 * (WM * WN + NL)) void spmma_f16_pc_kernel(const
   for (int i = 0; i < FM; ++i)
 #pragma unroll
     for (int j = 0; j < FN; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
-  const unsigned g = lane >> 4, r = lane & 15u;
   const unsigned wm = wave / WN, wn = wave % WN;  // meaningful for consumer waves only
 
   if (wave >= (unsigned)NC) {
@@ -554,46 +511,7 @@ __global__ __launch_bounds__(64 * (WM * WN + NL)) void spmma_f16_pc_kernel(const
   __syncthreads();  // both roles; nothing is in flight (the last NS-1 loader iterations issued no DMA)
 
   // ---- epilogue: consumers stage their fragments, every wave (loaders too) stores 16-byte row pieces
-  const bool c_vec = (reinterpret_cast<uintptr_t>(C) & 15u) == 0;
-  if (p.beta == 0.0f && c_vec) {
-    char* Cs = smem;
-    if (wave < (unsigned)NC) {
-#pragma unroll
-      for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j) {
-          const unsigned row = wm * TM + i * 16 + 4u * g, col = wn * TN + j * 16 + r;
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-            *reinterpret_cast<half_t*>(Cs + (row + q) * CPITCH + col * 2) = (half_t)(p.alpha * acc[i][j][q]);
-        }
-    }
-    __syncthreads();
-    constexpr int NCH = BM * (BN / 8);
-    for (unsigned q = tid; q < (unsigned)NCH; q += 64u * NW) {
-      const unsigned row = q / (BN / 8), cn = q % (BN / 8);
-      const int gr = m0 + (int)row, gc = n0 + 8 * (int)cn;
-      if (gr >= p.Mrows || gc >= p.N) continue;
-      *reinterpret_cast<u4*>(C + (size_t)gr * p.N + gc) = *reinterpret_cast<const u4*>(Cs + row * CPITCH + cn * 16);
-    }
-  } else if (wave < (unsigned)NC) {
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-      for (int j = 0; j < FN; ++j) {
-        const int gc = n0 + (int)(wn * TN + j * 16 + r);
-        if (gc >= p.N) continue;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int gr = m0 + (int)(wm * TM + i * 16 + 4u * g) + q;
-          if (gr >= p.Mrows) continue;
-          half_t* dst = C + (size_t)gr * p.N + gc;
-          float v = p.alpha * acc[i][j][q];
-          if (p.beta != 0.0f) v += p.beta * (float)*dst;
-          *dst = (half_t)v;
-        }
-      }
-  }
+  store_c_tile<BM, BN, FM, FN, 64 * NW>(smem, C, acc, wave < (unsigned)NC, wm * TM, wn * TN, m0, n0, p.Mrows, p.N, p.alpha, p.beta, tid);
 }
 
 template <int BM, int BN, int WM, int WN, int NL, int NS>

@@ -50,7 +50,6 @@ __global__ __launch_bounds__(64 * (WM * WN + 4)) void spmma_f16_fused_kernel(con
   constexpr int SA = BM * 64, SM_ = BM * 8, SB = 64 * BN * 2, STAGE = SA + SM_ + SB;
   constexpr int B_N = BN / 8, B_WI = B_N / NL;  // B DMA instructions per loader wave per stage
   static_assert(B_N % NL == 0 && B_WI >= 1, "B tile vs loader waves");
-  constexpr int CPITCH = BN * 2 + 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const unsigned tid = threadIdx.x, lane = tid & 63u;
@@ -68,7 +67,6 @@ __global__ __launch_bounds__(64 * (WM * WN + 4)) void spmma_f16_fused_kernel(con
   for (int i = 0; i < FM; ++i)
 #pragma unroll
     for (int j = 0; j < FN; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
-  const unsigned g = lane >> 4, r = lane & 15u;
   const unsigned wm = wave / WN, wn = wave % WN;  // consumer waves only
 
   if (wave >= (unsigned)NC) {
@@ -157,46 +155,7 @@ __global__ __launch_bounds__(64 * (WM * WN + 4)) void spmma_f16_fused_kernel(con
   }
   __syncthreads();
 
-  const bool c_vec = (reinterpret_cast<uintptr_t>(C) & 15u) == 0;
-  if (p.beta == 0.0f && c_vec) {
-    char* Cs = smem;
-    if (wave < (unsigned)NC) {
-#pragma unroll
-      for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j) {
-          const unsigned row = wm * TM + i * 16 + 4u * g, col = wn * TN + j * 16 + r;
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-            *reinterpret_cast<half_t*>(Cs + (row + q) * CPITCH + col * 2) = (half_t)(p.alpha * acc[i][j][q]);
-        }
-    }
-    __syncthreads();
-    constexpr int NCH = BM * (BN / 8);
-    for (unsigned q = tid; q < (unsigned)NCH; q += 64u * NW) {
-      const unsigned row = q / (BN / 8), cn = q % (BN / 8);
-      const int gr = m0 + (int)row, gc = n0 + 8 * (int)cn;
-      if (gr >= p.Mrows || gc >= p.N) continue;
-      *reinterpret_cast<u4*>(C + (size_t)gr * p.N + gc) = *reinterpret_cast<const u4*>(Cs + row * CPITCH + cn * 16);
-    }
-  } else if (wave < (unsigned)NC) {
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-      for (int j = 0; j < FN; ++j) {
-        const int gc = n0 + (int)(wn * TN + j * 16 + r);
-        if (gc >= p.N) continue;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int gr = m0 + (int)(wm * TM + i * 16 + 4u * g) + q;
-          if (gr >= p.Mrows) continue;
-          half_t* dst = C + (size_t)gr * p.N + gc;
-          float v = p.alpha * acc[i][j][q];
-          if (p.beta != 0.0f) v += p.beta * (float)*dst;
-          *dst = (half_t)v;
-        }
-      }
-  }
+  store_c_tile<BM, BN, FM, FN, 64 * NW>(smem, C, acc, wave < (unsigned)NC, wm * TM, wn * TN, m0, n0, p.Mrows, p.N, p.alpha, p.beta, tid);
 }
 
 template <int BN, int WM, int WN>
@@ -235,7 +194,6 @@ __global__ __launch_bounds__(64 * (WM * WN + 4 + NLB)) void spmma_f16_fused_wide
   constexpr int BRING = 2 * ASTG;               // LDS: [A+metadata stage] x 2 | [B stage] x NSB
   constexpr int B_N = BN / 8, B_WI = B_N / NLB;  // B DMA instructions per stage / per B-loader wave
   static_assert(B_N % NLB == 0 && B_WI >= 1 && (NSB - 2) * B_WI <= 63, "B tile vs loader waves");
-  constexpr int CPITCH = BN * 2 + 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const unsigned tid = threadIdx.x, lane = tid & 63u;
@@ -253,7 +211,6 @@ __global__ __launch_bounds__(64 * (WM * WN + 4 + NLB)) void spmma_f16_fused_wide
   for (int i = 0; i < FM; ++i)
 #pragma unroll
     for (int j = 0; j < FN; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
-  const unsigned g = lane >> 4, r = lane & 15u;
   const unsigned wm = wave / WN, wn = wave % WN;  // consumer waves only
 
   if (wave >= (unsigned)(NC + NLA)) {
@@ -413,46 +370,7 @@ __global__ __launch_bounds__(64 * (WM * WN + 4 + NLB)) void spmma_f16_fused_wide
   }
   __syncthreads();
 
-  const bool c_vec = (reinterpret_cast<uintptr_t>(C) & 15u) == 0;
-  if (p.beta == 0.0f && c_vec) {
-    char* Cs = smem;
-    if (wave < (unsigned)NC) {
-#pragma unroll
-      for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j) {
-          const unsigned row = wm * TM + i * 16 + 4u * g, col = wn * TN + j * 16 + r;
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-            *reinterpret_cast<half_t*>(Cs + (row + q) * CPITCH + col * 2) = (half_t)(p.alpha * acc[i][j][q]);
-        }
-    }
-    __syncthreads();
-    constexpr int NCH = BM * (BN / 8);
-    for (unsigned q = tid; q < (unsigned)NCH; q += 64u * NW) {
-      const unsigned row = q / (BN / 8), cn = q % (BN / 8);
-      const int gr = m0 + (int)row, gc = n0 + 8 * (int)cn;
-      if (gr >= p.Mrows || gc >= p.N) continue;
-      *reinterpret_cast<u4*>(C + (size_t)gr * p.N + gc) = *reinterpret_cast<const u4*>(Cs + row * CPITCH + cn * 16);
-    }
-  } else if (wave < (unsigned)NC) {
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-      for (int j = 0; j < FN; ++j) {
-        const int gc = n0 + (int)(wn * TN + j * 16 + r);
-        if (gc >= p.N) continue;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int gr = m0 + (int)(wm * TM + i * 16 + 4u * g) + q;
-          if (gr >= p.Mrows) continue;
-          half_t* dst = C + (size_t)gr * p.N + gc;
-          float v = p.alpha * acc[i][j][q];
-          if (p.beta != 0.0f) v += p.beta * (float)*dst;
-          *dst = (half_t)v;
-        }
-      }
-  }
+  store_c_tile<BM, BN, FM, FN, 64 * NW>(smem, C, acc, wave < (unsigned)NC, wm * TM, wn * TN, m0, n0, p.Mrows, p.N, p.alpha, p.beta, tid);
 }
 
 template <int BN, int WM, int WN, int NLB, int PF, int NSB>
