@@ -687,7 +687,8 @@ extern "C" int sm_spmma_fused_f16(const void* A, const void* B, void* C, size_t 
   static const int wide_env = getenv("SM_FUSED_WIDE") ? atoi(getenv("SM_FUSED_WIDE")) : 0;  // tuning aid: force the wide kernel
   if (!wide_env) {
     if (n <= 64) return launch_fused<64, 4, 1>(a, st);
-    if (n <= 128) return launch_fused<128, 2, 2>(a, st);
+    // (a single stage per tile, k = 64: two 128-column tiles with 2-3 workgroups per CU beat one 256-column tile)
+    if (n <= 128 || (n <= 256 && k <= 64)) return launch_fused<128, 2, 2>(a, st);
   }
   // n > 256, short K, plain store: A-stationary (the 2:4 image of a row panel stays in LDS across column tiles)
   static const int astat_env = getenv("SM_FUSED_ASTAT") ? atoi(getenv("SM_FUSED_ASTAT")) : 1;  // tuning aid: 0 = off
