@@ -12,3 +12,6 @@ timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv 
 python3 tools/pmc_traffic.py gpurun_out/${tag}_pmc_fetch gpurun_out/${tag}_pmc_write gpurun_out/${tag}_traffic.json
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/${tag}_pmc_mfma -- python3 bench.py --eager --streams 1 --steps 2 --warmup 1 --no-cpu-baseline --no-extras > gpurun_out/${tag}_pmc_mfma.log 2>&1; echo "pmc mfma rc=$?"
 python3 tools/pmc_mfma.py gpurun_out/${tag}_pmc_mfma gpurun_out/${tag}_mfma.json
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/${tag}_prune_fetch -- python3 tools/prune_profile.py 2 > gpurun_out/${tag}_prune_fetch.log 2>&1; echo "prune pmc fetch rc=$?"
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/${tag}_prune_write -- python3 tools/prune_profile.py 2 > gpurun_out/${tag}_prune_write.log 2>&1; echo "prune pmc write rc=$?"
+python3 tools/pmc_traffic.py gpurun_out/${tag}_prune_fetch gpurun_out/${tag}_prune_write gpurun_out/${tag}_prune_hbm.json

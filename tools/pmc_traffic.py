@@ -25,9 +25,24 @@ def per_kernel(d, counter):
     return {k: (sum(v) / len(v), len(v)) for k, v in acc.items()}
 
 
+def durations(d):
+    """average End-Start (ns) per kernel over the dispatches of a pass (the PMC rows carry the timestamps)"""
+    acc, seen = collections.defaultdict(list), set()
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            key = (f, r["Dispatch_Id"])
+            if key in seen:
+                continue
+            seen.add(key)
+            name = r["Kernel_Name"].split("(")[0].replace("void ", "").strip().split("<")[0].split("::")[-1]
+            acc[name].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
+    return {k: sum(v) / len(v) for k, v in acc.items()}
+
+
 def main():
     fdir, wdir, out = sys.argv[1:4]
     fetch, write = per_kernel(fdir, "FETCH_SIZE"), per_kernel(wdir, "WRITE_SIZE")
+    dur = durations(fdir)
     res = {}
     for k in sorted(set(fetch) | set(write)):
         f, nf = fetch.get(k, (0.0, 0))
@@ -35,9 +50,13 @@ def main():
         res[k] = {"launches_profiled": max(nf, nw), "FETCH_SIZE_KiB_avg": f, "WRITE_SIZE_KiB_avg": w,
                   "hbm_bytes_per_launch": (2.0 * f + w) * 1024.0,
                   "correction": "2 x FETCH_SIZE (gfx950 counts 128-B requests at 64 B) + WRITE_SIZE, KiB -> B"}
+        if dur.get(k):
+            res[k]["avg_duration_us_in_pmc_pass"] = dur[k] / 1e3
+            res[k]["hbm_GBs"] = res[k]["hbm_bytes_per_launch"] / dur[k]
     json.dump(res, open(out, "w"), indent=1)
     for k, v in res.items():
-        print(f"{k:32s} launches {v['launches_profiled']:5d}  hbm {v['hbm_bytes_per_launch'] / 1e6:10.2f} MB/launch")
+        print(f"{k:32s} launches {v['launches_profiled']:5d}  hbm {v['hbm_bytes_per_launch'] / 1e6:10.2f} MB/launch"
+              + (f"  {v['hbm_GBs']:8.1f} GB/s" if "hbm_GBs" in v else ""))
 
 
 if __name__ == "__main__":
