@@ -7,6 +7,8 @@
 // Dense operands are column-major as the reference declares them.  Both kernels are HBM/L2-bound
 // gathers: lanes run along the rows of C (contiguous in column-major), every lane walks its own row
 // of A, and the B column it needs is small enough to stay in L1/L2.
+#include <cstdlib>
+
 #include "sm_common.h"
 
 namespace sm {
@@ -154,6 +156,115 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(size_t A_rows, size_t A_c
     }
 }
 
+// CSR with the dense operand in LDS.  Column j of column-major B_b (A_cols floats, contiguous) and column j of C_b are
+// one sparse matrix-vector product; the batches only add columns (A is shared and the batch strides of B and C are
+// exactly A_cols * n and A_rows * n), so the whole call is ONE product with NV = n * batches vectors.  A workgroup
+// stages J = 8, 16 or 32 of those vectors in LDS, interleaved [A_cols][J], and its sixteen waves walk the rows: lanes
+// (e = lane / (J/4), q = lane % (J/4)) take non-zero e of the 256/J the wave reads per step -- column index and value
+// coalesced -- and the four vectors 4q .. 4q+3 with one ds_read_b128; partial sums are folded over e with xor-shuffles.  B is read from
+// HBM exactly once, A comes from L2 (it is re-read by every workgroup), the gather happens in LDS: 0.6 TF/s -> see
+// DESIGN.md for the measured rate against the thread-per-row kernel above, whose B gather went to global memory at a
+// stride of A_cols floats.
+constexpr int LDS_WAVES = 16;
+template <int J>  // vectors per workgroup: 8, 16 or 32 (LDS = A_cols * J * 4 bytes)
+__global__ __launch_bounds__(64 * LDS_WAVES) void spmm_csr_lds_kernel(size_t A_rows, size_t A_cols, size_t NV,
+                                                                      const int* __restrict__ ws,
+                                                                      const int* __restrict__ colsidx,
+                                                                      const float* __restrict__ vals,
+                                                                      const float* __restrict__ B, float* __restrict__ C,
+                                                                      float alpha, float beta) {
+  constexpr int QL = J / 4;    // lanes across the vectors (one 16-byte LDS read = four vectors each)
+  constexpr int EL = 64 / QL;  // non-zeros a wave takes per step
+  if (ws[0] != 0) return;  // unsorted input: the atomic kernel handles it
+  extern __shared__ __attribute__((aligned(16))) float Xs[];  // [A_cols][J]
+  const int* row_ptr = ws + 1;
+  const size_t v0 = (size_t)blockIdx.x * J;
+  const unsigned tid = threadIdx.x, lane = tid & 63u;
+  const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // stage: a thread gathers element c of four vectors (each global read runs along c: coalesced) into one 16-byte store
+  // (four iterations -- sixteen loads -- in flight per thread: the staging is a pure latency chain otherwise)
+  const size_t n_it = A_cols * QL;
+  for (size_t i0 = tid; i0 < n_it; i0 += 4 * 64 * LDS_WAVES) {
+    f4 x[4];
+#pragma unroll
+    for (unsigned u = 0; u < 4; ++u) {
+      const size_t i = i0 + u * 64 * LDS_WAVES;
+      const size_t c = i / QL;
+      const unsigned h = (unsigned)(i % QL);
+#pragma unroll
+      for (unsigned t = 0; t < 4; ++t) {
+        const size_t v = v0 + 4u * h + t;
+        x[u][t] = (i < n_it && v < NV) ? B[v * A_cols + c] : 0.0f;
+      }
+    }
+#pragma unroll
+    for (unsigned u = 0; u < 4; ++u) {
+      const size_t i = i0 + u * 64 * LDS_WAVES;
+      if (i < n_it) *reinterpret_cast<f4*>(Xs + (i / QL) * J + 4u * (unsigned)(i % QL)) = x[u];
+    }
+  }
+  __syncthreads();
+  const unsigned e = lane / QL, q = lane % QL;
+  // blockIdx.y splits the rows (each split stages the same vectors again: B comes from L2 then)
+  const size_t rows_per = (A_rows + gridDim.y - 1) / gridDim.y, r_begin = blockIdx.y * rows_per;
+  const size_t r_end = r_begin + rows_per < A_rows ? r_begin + rows_per : A_rows;
+  for (size_t r = r_begin + wave; r < r_end; r += LDS_WAVES) {
+    const int e0 = row_ptr[r], e1 = row_ptr[r + 1];  // wave-uniform: scalar loads
+    f4 acc = {0.f, 0.f, 0.f, 0.f};
+    // four steps of EL non-zeros per round: all eight global loads of a round are issued before the first use
+    // (prefetching the next round -- or the next row's first -- during the current one measured 10 % slower)
+    for (int base = e0; base < e1; base += 4 * EL) {
+      int ci[4];
+      float av[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = base + EL * u + (int)e;
+        const bool ok = i < e1;
+        ci[u] = ok ? colsidx[i] : 0;
+        av[u] = ok ? vals[i] : 0.0f;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const size_t c = (size_t)ci[u] < A_cols ? (size_t)ci[u] : 0;
+        const float a = (size_t)ci[u] < A_cols ? av[u] : 0.0f;
+        const f4 x = *reinterpret_cast<const f4*>(Xs + c * J + 4u * q);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = fmaf(a, x[t], acc[t]);
+      }
+    }
+#pragma unroll
+    for (int off = QL; off < 64; off <<= 1)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[t] += __shfl_xor(acc[t], off, 64);
+    if (e == 0) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const size_t v = v0 + 4u * q + t;
+        if (v < NV) {
+          float* d = C + v * A_rows + r;
+          *d = beta != 0.0f ? alpha * acc[t] + beta * *d : alpha * acc[t];
+        }
+      }
+    }
+  }
+}
+
+template <int J>
+static void launch_csr_lds(size_t A_rows, size_t A_cols, size_t nv, const int* ws, const int* cols, const float* vals,
+                           const float* B, float* C, float alpha, float beta, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_csr_lds_kernel<J>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)(144 * 1024));
+    attr_set = true;
+  }
+  // enough workgroups for the chip: split the rows when there are few vector groups (>= 256 rows per split)
+  const size_t groups = ceil_div(nv, (size_t)J);
+  size_t rsplit = 1;
+  while (groups * rsplit < 1024 && A_rows / (rsplit * 2) >= 256) rsplit *= 2;
+  spmm_csr_lds_kernel<J><<<dim3((unsigned)groups, (unsigned)rsplit), 64 * LDS_WAVES, A_cols * J * sizeof(float), st>>>(A_rows, A_cols, nv, ws, cols, vals, B, C, alpha, beta);
+}
+
 // atomic fallback gated on the flag (runs only when the rows were NOT sorted)
 __global__ __launch_bounds__(256) void scale_if_unsorted_kernel(const int* ws, float* C, size_t count, float beta) {
   if (ws[0] == 0) return;
@@ -161,17 +272,17 @@ __global__ __launch_bounds__(256) void scale_if_unsorted_kernel(const int* ws, f
     C[i] = beta != 0.0f ? beta * C[i] : 0.0f;
 }
 __global__ __launch_bounds__(256) void spmm_coo_if_unsorted_kernel(const int* ws, size_t A_rows, size_t A_cols, size_t nnz,
-                                                                   size_t n, const int* __restrict__ rows,
+                                                                   size_t nv, const int* __restrict__ rows,
                                                                    const int* __restrict__ colsidx,
                                                                    const float* __restrict__ vals,
                                                                    const float* __restrict__ B, float* C, float alpha) {
-  if (ws[0] == 0) return;
-  const size_t e = blockIdx.x * (size_t)256 + threadIdx.x;
-  if (e >= nnz) return;
-  const size_t b = blockIdx.y / n, j = blockIdx.y % n;
-  const size_t r = (size_t)rows[e], c = (size_t)colsidx[e];
-  if (r >= A_rows || c >= A_cols) return;
-  atomicAdd(C + b * A_rows * n + j * A_rows + r, alpha * vals[e] * B[b * A_cols * n + j * A_cols + c]);
+  if (ws[0] == 0) return;  // sorted input was served by the CSR kernel: this (small, grid-stride) launch costs nothing
+  for (size_t v = blockIdx.y; v < nv; v += gridDim.y)
+    for (size_t e = blockIdx.x * (size_t)256 + threadIdx.x; e < nnz; e += (size_t)gridDim.x * 256) {
+      const size_t r = (size_t)rows[e], c = (size_t)colsidx[e];
+      if (r >= A_rows || c >= A_cols) continue;
+      atomicAdd(C + v * A_rows + r, alpha * vals[e] * B[v * A_cols + c]);
+    }
 }
 
 }  // namespace sm
@@ -315,12 +426,26 @@ int sm_spmm_coo_f32_ws(size_t A_num_rows, size_t A_num_cols, size_t A_nnz, size_
   int* ws = (int*)workspace;
   if (hipMemsetAsync(ws, 0, sizeof(int), st) != hipSuccess) return check_launch("hipMemsetAsync");
   coo_rowptr_kernel<<<(unsigned)ceil_div(A_num_rows + 1, 256), 256, 0, st>>>(rows, A_nnz, A_num_rows, ws);
-  dim3 grid((unsigned)ceil_div(A_num_rows, 256), (unsigned)ceil_div(B_num_cols, CSR_J), (unsigned)num_batches);
-  spmm_csr_kernel<<<grid, dim3(256), 0, st>>>(A_num_rows, A_num_cols, B_num_cols, ws, cols, vals, B, C, alpha, beta);
-  scale_if_unsorted_kernel<<<stream_grid(count, 256), 256, 0, st>>>(ws, C, count, beta);
+  const size_t nv = B_num_cols * num_batches, col_bytes = A_num_cols * sizeof(float);
+  static const int lds_env = getenv("SM_SPMM_LDS") ? atoi(getenv("SM_SPMM_LDS")) : -1;  // tuning aid: 0 = off, 8/16/32 = J
+  // as many vectors per workgroup as keep two workgroups on a CU (72 KB each): more FMAs per loaded non-zero
+  int J = col_bytes * 32 <= 72 * 1024 ? 32 : (col_bytes * 16 <= 144 * 1024 ? 16 : 8);
+  if (lds_env == 8 || lds_env == 16 || lds_env == 32) J = lds_env;
+  if (lds_env != 0 && col_bytes * J <= 144 * 1024 && ceil_div(nv, (size_t)J) <= 0x7fffffffull) {
+    if (J == 32) launch_csr_lds<32>(A_num_rows, A_num_cols, nv, ws, cols, vals, B, C, alpha, beta, st);
+    else if (J == 16) launch_csr_lds<16>(A_num_rows, A_num_cols, nv, ws, cols, vals, B, C, alpha, beta, st);
+    else launch_csr_lds<8>(A_num_rows, A_num_cols, nv, ws, cols, vals, B, C, alpha, beta, st);
+  } else {
+    dim3 grid((unsigned)ceil_div(A_num_rows, 256), (unsigned)ceil_div(B_num_cols, CSR_J), (unsigned)num_batches);
+    spmm_csr_kernel<<<grid, dim3(256), 0, st>>>(A_num_rows, A_num_cols, B_num_cols, ws, cols, vals, B, C, alpha, beta);
+  }
+  scale_if_unsorted_kernel<<<(unsigned)(ceil_div(count, (size_t)256) < 1024 ? ceil_div(count, (size_t)256) : 1024), 256, 0, st>>>(ws, C, count, beta);
   if (A_nnz) {
-    dim3 g2((unsigned)ceil_div(A_nnz, 256), (unsigned)(B_num_cols * num_batches));
-    spmm_coo_if_unsorted_kernel<<<g2, dim3(256), 0, st>>>(ws, A_num_rows, A_num_cols, A_nnz, B_num_cols, rows, cols, vals, B, C, alpha);
+    // a capped grid with grid-stride loops: when the input is sorted (the flag is clear) these blocks exit at once,
+    // and millions of empty blocks would cost more than the product itself
+    const size_t gx = ceil_div(A_nnz, (size_t)256), gy = B_num_cols * num_batches;
+    dim3 g2((unsigned)(gx < 64 ? gx : 64), (unsigned)(gy < 64 ? gy : 64));
+    spmm_coo_if_unsorted_kernel<<<g2, dim3(256), 0, st>>>(ws, A_num_rows, A_num_cols, A_nnz, B_num_cols * num_batches, rows, cols, vals, B, C, alpha);
   }
   return check_launch("spmm_csr_kernel");
 }
