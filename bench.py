@@ -55,6 +55,9 @@ def main():
                          "kernel keeps the 2:4 image of a row panel in LDS across its column tiles); 0 = never")
     ap.add_argument("--streams", type=int, default=4,
                     help="HIP streams the independent layers of a step are spread over (fork/join inside the step)")
+    ap.add_argument("--rehearse-gloo", action="store_true",
+                    help="multi-rank rehearsal on a ONE-GPU box: gloo backend, every rank on cuda:0 (control flow only; "
+                         "the ranks share the device, so the numbers mean nothing)")
     args = ap.parse_args()
 
     import torch
@@ -67,8 +70,12 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.rehearse_gloo:
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", torch.cuda.current_device())
@@ -147,21 +154,24 @@ def main():
             sys.stderr.write(f"bench: hipGraph capture failed ({e}); launching eagerly\n")
             return fn
 
-    def timed(run, steps, warmup):
+    def timed(run, steps, warmup, collective=True):
+        """collective=False: rank-local timing (the per-stage / per-family passes only rank 0 runs: a distributed
+        barrier there would pair with the other ranks' final barrier and hang the job)."""
+        sync = barrier if collective else torch.cuda.synchronize
         for _ in range(warmup):
             run()
-        barrier()
+        sync()
         t0 = time.perf_counter()
         for _ in range(steps):
             run()
         torch.cuda.synchronize()
         wall = time.perf_counter() - t0
-        barrier()
+        sync()
         return wall
 
     run_full = make_runner(step_full)
     wall = timed(run_full, args.steps, args.warmup)
-    tot_flops, wall_max = mg.rollup(flops * args.steps, wall, dev)
+    tot_flops, wall_max = mg.rollup(flops * args.steps, wall, None if args.rehearse_gloo else dev)
     ms_per_step = wall_max / args.steps * 1e3
     value = tot_flops / wall_max / 1e9
 
@@ -185,7 +195,7 @@ def main():
         R = max(5, args.steps)
 
         def sec_per_call(fn):
-            return timed(make_runner(fn), R, 2) / R
+            return timed(make_runner(fn), R, 2, collective=False) / R
 
         def spmma_only():
             forked(lambda L: sm.spmma(L["blob"], L["B"], L["C"], L["m"], L["n"], L["k"], L["b"], 0))
