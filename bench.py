@@ -180,8 +180,9 @@ def main():
         "value": value, "unit": "GF/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f16", "data": "synthetic",
-        "config": {"workload": "datasets/resnet50.csv: 49 conv layers as im2col GEMMs (m,n,k) at b=32, fp16; "
-                               "step = per layer 2:4 prune+compress+matmul (path: " + args.path + ")",
+        "config": {"workload": "datasets/%s: %d conv layers as im2col GEMMs (m,n,k) at b=%d, fp16; "
+                               "step = per layer 2:4 prune+compress+matmul (path: %s)"
+                               % (os.path.basename(args.table), len(layers), layers[0]["b"], args.path),
                    "path": args.path + (": sm_spmma_fused_f16 on %d layers (n <= %d or k <= %d), sm_compress24_f16 + sm_spmma_f16 on %d"
                                         % (sum(use_fused(L) for L in layers), args.fused_max_n, args.fused_max_k_wide,
                                            sum(not use_fused(L) for L in layers))
