@@ -98,7 +98,8 @@ std::vector<float> spmma(type_t* dA,
 // Extension of this build (no reference counterpart): the same result as spmma()
 // -- C = alpha * prune_2:4(A) * B + beta * C -- in ONE kernel straight from the dense A: nothing is pruned in
 // place, no blob is built, A is read from HBM once.  fp16 only; needs k % 64 == 0, n % 8 == 0.  Returns the
-// elapsed milliseconds; falls back to nothing -- an unsupported shape prints the library's message.
+// elapsed milliseconds.  A shape the fused kernels cannot take (SM_STATUS_NOT_SUPPORTED) runs as sm_compress24 +
+// sm_spmma with a temporary blob: the same C bit for bit, so callers need no shape logic.
 template <typename type_t>
 float spmma_fused(type_t* dA, type_t* dB, type_t* dC, std::size_t m, std::size_t n, std::size_t k, std::size_t batch_size,
                   float alpha = 1.0f, float beta = 0.0f) {
@@ -106,7 +107,16 @@ float spmma_fused(type_t* dA, type_t* dB, type_t* dC, std::size_t m, std::size_t
   if (batch_size == 0) batch_size = 1;
   util::timer_t timer;
   timer.begin();
-  const int rc = sm_spmma_fused_f16(dA, dB, dC, m, n, k, k, batch_size, m * k, k * n, m * n, alpha, beta, nullptr);
+  int rc = sm_spmma_fused_f16(dA, dB, dC, m, n, k, k, batch_size, m * k, k * n, m * n, alpha, beta, nullptr);
+  if (rc == SM_STATUS_NOT_SUPPORTED) {
+    std::size_t compressed_size = 0;
+    (void)sm_compress24_size(m, k, sizeof(type_t), batch_size, &compressed_size);
+    device_vector<unsigned char> compressed(compressed_size);
+    rc = sm_compress24_f16(dA, m, k, k, batch_size, m * k, compressed.data().get(), nullptr);
+    if (rc == SM_STATUS_SUCCESS)
+      rc = sm_spmma_f16(compressed.data().get(), dB, dC, m, n, k, batch_size, k * n, m * n, alpha, beta, nullptr);
+    (void)hipStreamSynchronize(nullptr);  // the blob is released when this scope ends
+  }
   const float ms = timer.end();
   if (rc != SM_STATUS_SUCCESS) std::cerr << "sparsifyme::spmma_fused: " << sm_last_error() << std::endl;
   return ms;
