@@ -380,6 +380,10 @@ def test_full_size_properties_resnet50(gpu, orc, shape):
     C2 = torch.empty_like(C)
     gpu.spmma(blob, dB * 2, C2, m, n, k, batch)
     assert torch.equal((C * 2).view(torch.int16), C2.view(torch.int16)), "spmma not linear in B"
+    if k % 64 == 0 and n % 8 == 0:  # the fused kernels (narrow / wide / A-stationary by shape) at full size: same bits
+        C3 = torch.full_like(C, 3.0)
+        gpu.spmma_fused(dA, dB, C3, m, n, k, batch=batch)
+        assert torch.equal(C3.view(torch.int16), C.view(torch.int16)), "fused != compress + spmma at full size"
     Cd = torch.empty_like(C)
     gpu.gemm_rowmajor(P, dB, Cd, m, n, k, batch=batch)
     assert (C.float() - Cd.float()).abs().max().item() <= 4 * 2.0 ** -11 * Cd.float().abs().max().item()
