@@ -234,6 +234,10 @@ def main():
             "speedup_full_vs_dense_rowmajor": t_drm / t_full, "speedup_full_vs_dense_batched": t_dcm / t_full,
             "full_path_staged_gfs": gfs(t_staged), "full_path_staged_ms": t_staged * 1e3,
             "timed_path": args.path, "timed_path_ms": t_full * 1e3,
+            # what 2:4 can buy on these shapes when both products are HBM-bound (they are: DESIGN.md 4.2): the ratio of
+            # the algorithmic bytes, dense (A + B + C) over sparse (9/16 A + B + C)
+            "hbm_bound_speedup_ceiling": sum(L["b"] * 2.0 * (L["m"] * L["k"] + L["m"] * L["n"]) + 2.0 * L["k"] * L["n"] for L in layers)
+            / sum(L["b"] * (L["m"] * L["k"] * (1.0 + 1.0 / 8) + 2.0 * L["m"] * L["n"]) + 2.0 * L["k"] * L["n"] for L in layers),
         }
         # matrix-pipe view of the 2:4 matmul (north_star: "MFMA utilisation for the matmul against chip peak"):
         # dense-equivalent rate of the matmul-only pass against 2 x the dense fp16 peak (v_smfmac does a 16x16x64

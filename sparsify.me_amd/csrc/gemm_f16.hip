@@ -337,8 +337,12 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_dma_kernel(const GemmAr
   }
   __syncthreads();
 
-  // ---- epilogue: lane holds C[row lane&15][cols 4*(lane>>4) .. +3] of each fragment
-  const bool c_vec = (p.ldc % 8 == 0) && ((reinterpret_cast<uintptr_t>(C) & 15u) == 0);
+  // ---- epilogue: lane holds C[row lane&15][cols 4*(lane>>4) .. +3] of each fragment.
+  // N % 8 == 4 (the reference's column-major layout with m = 196): the B loads of the last, half-valid 8-column chunk
+  // were clamped to columns N-8 .. N-1, so that chunk of the tile holds THOSE outputs: it is stored at N-8 as well
+  // (the four columns it shares with its neighbour are written twice with the same values), or, element by element,
+  // only its upper four columns.  A 16-byte store needs dword alignment only.
+  const bool c_vec = (p.ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(C) & 7u) == 0);
   if (p.beta == 0.0f && c_vec) {
     char* Cs = smem;
 #pragma unroll
@@ -356,8 +360,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_dma_kernel(const GemmAr
 #pragma unroll
     for (int i = 0; i < C_CH; ++i) {
       const unsigned q = tid + 64u * NW * i, row = q / (BN / 8), cn = q % (BN / 8);
-      const int gr = m0 + (int)row, gc = n0 + 8 * (int)cn;
+      const int gr = m0 + (int)row;
+      int gc = n0 + 8 * (int)cn;
       if (gr >= p.M || gc >= p.N) continue;
+      gc = gc <= p.N - 8 ? gc : p.N - 8;
       *reinterpret_cast<u4*>(C + (size_t)gr * p.ldc + gc) = *reinterpret_cast<const u4*>(Cs + row * CPITCH + cn * 16);
     }
   } else {
@@ -366,8 +372,13 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_dma_kernel(const GemmAr
 #pragma unroll
       for (int j = 0; j < FN; ++j) {
         const int gr = m0 + (int)(wm * TM + i * 16 + r);
-        const int gc = n0 + (int)(wn * TN + j * 16 + 4u * g);
+        int gc = n0 + (int)(wn * TN + j * 16 + 4u * g);
         if (gr >= p.M) continue;
+        const int chunk0 = gc & ~7;  // first column of this lane's 8-column chunk
+        if (chunk0 < p.N && chunk0 > p.N - 8) {  // the clamped chunk: its lower half duplicates the neighbour's columns
+          if ((gc & 4) == 0) continue;
+          gc -= chunk0 - (p.N - 8);
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           if (gc + q >= p.N) continue;
@@ -437,9 +448,10 @@ static int launch_gemm_f16(const GemmArgs& a, hipStream_t st) {
   };
   const int vec = aligned_to(8) ? 8 : (aligned_to(4) ? 4 : 1);
   // pointer-array batches: per-batch base alignment is the caller's (hipMalloc gives 256 B);
-  // DMA fast path: whole 64-deep K stages, whole 8-column chunks, rows on 8-byte boundaries (a
+  // DMA fast path: whole 64-deep K stages, N a multiple of 4 (a half-valid last chunk is served from columns
+  // N-8 .. N-1, see the kernel's epilogue), rows on 8-byte boundaries (a
   // 16-byte global access needs only dword alignment; the LDS side is aligned by construction)
-  const bool fast = (a.K % 64 == 0) && (a.N % 8 == 0) && a.N >= 8 && (a.lda % 4 == 0) && (a.ldb % 4 == 0) &&
+  const bool fast = (a.K % 64 == 0) && (a.N % 4 == 0) && a.N >= 8 && (a.lda % 4 == 0) && (a.ldb % 4 == 0) &&
                     (a.sA % 4 == 0) && (a.sB % 4 == 0) && (a.Ap || (reinterpret_cast<uintptr_t>(a.A) & 7u) == 0) &&
                     (a.Bp || (reinterpret_cast<uintptr_t>(a.B) & 7u) == 0);
   if (fast) {

@@ -296,26 +296,31 @@ def test_gemm_rowmajor_f16_vs_oracle(gpu, orc, shape):
     check_close(host(C), Cref.view(np.float16), scale, FP16_TOL, f"gemm_rowmajor {shape}")
 
 
-@pytest.mark.parametrize("shape", [(128, 64, 64, 2), (196, 512, 256, 2), (130, 72, 200, 3), (3136, 128, 576, 2), (12544, 64, 147, 1)])
-def test_gemm_batched_column_major_f16_vs_oracle(gpu, orc, shape):
+@pytest.mark.parametrize("shape", [(128, 64, 64, 2), (196, 512, 256, 2), (130, 72, 200, 3), (3136, 128, 576, 2), (12544, 64, 147, 1),
+                                   # m % 8 == 4 on the LDS-DMA kernel (half-valid last chunk served from columns m-8 .. m-1)
+                                   (44, 72, 128, 3), (196, 64, 64, 1), (1100, 136, 192, 2)])
+@pytest.mark.parametrize("ab", [(1.0, 0.0), (0.5, -2.0)])
+def test_gemm_batched_column_major_f16_vs_oracle(gpu, orc, shape, ab):
     """The reference's call: column-major, lda=m ldb=k ldc=m, device arrays of pointers, one shared B
     repeated `batch` times (examples/gemm.cu:40,60,86)."""
     import torch
     m, n, k, batch = shape
+    alpha, beta = ab
     rng = np.random.default_rng(m + 2 * n + 3 * k)
     As = [rand(rng, m * k, np.float16) for _ in range(batch)]
     Bsh = rand(rng, k * n, np.float16)
+    C0 = [rand(rng, m * n, np.float16) for _ in range(batch)]
     dAs = [to_dev(a) for a in As]
     dB = to_dev(Bsh)
-    dCs = [torch.zeros(m * n, dtype=torch.float16, device="cuda") for _ in range(batch)]
+    dCs = [to_dev(c.copy()) for c in C0]
     ptr = lambda ts: torch.tensor([t.data_ptr() for t in ts], dtype=torch.int64, device="cuda")
-    gpu.gemm_batched(ptr(dAs), ptr([dB] * batch), ptr(dCs), m, n, k, batch, "f16")
-    Cs = [np.zeros(m * n, dtype=np.uint16) for _ in range(batch)]
-    orc.gemm_batched([bits(a) for a in As], [bits(Bsh)] * batch, Cs, m, n, k)
+    gpu.gemm_batched(ptr(dAs), ptr([dB] * batch), ptr(dCs), m, n, k, batch, "f16", alpha, beta)
+    Cs = [bits(c.copy()) for c in C0]
+    orc.gemm_batched([bits(a) for a in As], [bits(Bsh)] * batch, Cs, m, n, k, alpha, beta)
     Bm = np.abs(Bsh.astype(np.float64)).reshape(n, k).T            # column-major k x n
     for b in range(batch):
         Am = np.abs(As[b].astype(np.float64)).reshape(k, m).T      # column-major m x k
-        scale = (Am @ Bm).T.reshape(-1)                            # column-major m x n
+        scale = abs(alpha) * (Am @ Bm).T.reshape(-1) + abs(beta) * np.abs(C0[b].astype(np.float64))  # column-major m x n
         check_close(host(dCs[b]), Cs[b].view(np.float16), scale, FP16_TOL, f"gemm_batched {shape} batch {b}")
 
 
