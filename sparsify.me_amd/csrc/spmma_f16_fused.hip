@@ -185,6 +185,33 @@ static int launch_fused(const FusedArgs& a0, hipStream_t st) {
 // ---------------------------------------------------------------------------------------------
 // 128 < n: 256-column tiles, split loader roles, deeper pipelines (one workgroup per CU)
 // ---------------------------------------------------------------------------------------------
+// The B tile's LDS-DMA, shared by the B loader waves of the wide kernel and -- when it has none (NLB = 0) -- by its
+// consumer waves: instruction j = bw + NBW * i of a stage covers k-rows 8 * (j & 7) + lane / 8 of panel j >> 3.
+template <int BN, int NBW>
+struct BTileDma {
+  static constexpr int B_WI = (BN / 8) / NBW;
+  const char* src[B_WI];
+  unsigned dst[B_WI];
+  size_t step;
+  __device__ __forceinline__ void setup(const half_t* B, int N, int n0, unsigned bw, unsigned lane, unsigned ring_off) {
+#pragma unroll
+    for (int i = 0; i < B_WI; ++i) {
+      const unsigned j = bw + (unsigned)NBW * i, panel = j >> 3, grp = j & 7u, kr = 8u * grp + (lane >> 3);
+      const unsigned cs = (lane & 7u) ^ b_swz(kr);
+      int gc = n0 + (int)(64u * panel + 8u * cs);
+      gc = gc <= N - 8 ? gc : N - 8;
+      src[i] = reinterpret_cast<const char*>(B) + ((size_t)kr * N + (size_t)gc) * 2;
+      dst[i] = ring_off + panel * 8192u + grp * 1024u;
+    }
+    step = (size_t)64 * N * 2;
+  }
+  __device__ __forceinline__ void issue(char* smem, int kt, unsigned buf_off) const {
+#pragma unroll
+    for (int i = 0; i < B_WI; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t*)(src[i] + (size_t)kt * step), (lptr_t*)(smem + buf_off + dst[i]), 16, 0, 0);
+  }
+};
+
 template <int BN, int WM, int WN, int NLB, int PF, int NSB>
 __global__ __launch_bounds__(64 * (WM * WN + 4 + NLB)) void spmma_f16_fused_wide_kernel(const FusedArgs p) {
   constexpr int BM = 128, NLA = 4, NC = WM * WN, NW = NC + NLA + NLB;
@@ -192,8 +219,9 @@ __global__ __launch_bounds__(64 * (WM * WN + 4 + NLB)) void spmma_f16_fused_wide
   constexpr int TM = BM / WM, TN = BN / WN, FM = TM / 16, FN = TN / 16;
   constexpr int SA = BM * 64, SM_ = BM * 8, ASTG = SA + SM_, SB = 64 * BN * 2;
   constexpr int BRING = 2 * ASTG;               // LDS: [A+metadata stage] x 2 | [B stage] x NSB
-  constexpr int B_N = BN / 8, B_WI = B_N / NLB;  // B DMA instructions per stage / per B-loader wave
-  static_assert(B_N % NLB == 0 && B_WI >= 1 && (NSB - 2) * B_WI <= 63, "B tile vs loader waves");
+  constexpr int NBW = NLB > 0 ? NLB : WM * WN;   // waves that issue the B DMA: the B loaders, or the consumers themselves
+  constexpr int B_N = BN / 8, B_WI = B_N / NBW;  // B DMA instructions per stage / per issuing wave
+  static_assert(B_N % NBW == 0 && B_WI >= 1 && (NSB - 2) * B_WI <= 63, "B tile vs issuing waves");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const unsigned tid = threadIdx.x, lane = tid & 63u;
@@ -213,30 +241,15 @@ __global__ __launch_bounds__(64 * (WM * WN + 4 + NLB)) void spmma_f16_fused_wide
     for (int j = 0; j < FN; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
   const unsigned wm = wave / WN, wn = wave % WN;  // consumer waves only
 
-  if (wave >= (unsigned)(NC + NLA)) {
+  if (NLB > 0 && wave >= (unsigned)(NC + NLA)) {
     // ------------------------------------------------------------------ B loader wave: LDS-DMA only
-    // instruction j = lw + NLB * i of a stage covers k-rows 8 * (j & 7) + lane / 8 of panel j >> 3 (64 columns)
-    const unsigned lw = wave - (NC + NLA);
-    const char* Bb = reinterpret_cast<const char*>(p.B + (size_t)b * p.sB);
-    const char* b_src[B_WI];
-    unsigned b_dst[B_WI];
-#pragma unroll
-    for (int i = 0; i < B_WI; ++i) {
-      const unsigned j = lw + (unsigned)NLB * i, panel = j >> 3, grp = j & 7u, kr = 8u * grp + (lane >> 3);
-      const unsigned cs = (lane & 7u) ^ b_swz(kr);
-      int gc = n0 + (int)(64u * panel + 8u * cs);
-      gc = gc <= p.N - 8 ? gc : p.N - 8;
-      b_src[i] = Bb + ((size_t)kr * p.N + (size_t)gc) * 2;
-      b_dst[i] = BRING + panel * 8192u + grp * 1024u;
-    }
-    const size_t b_step = (size_t)64 * p.N * 2;
+    BTileDma<BN, NBW> bd;
+    bd.setup(p.B + (size_t)b * p.sB, p.N, n0, wave - (NC + NLA), lane, BRING);
     auto issue = [&](int kt, int buf) {
 #if defined(SM_ABLATE) && (SM_ABLATE & 4)
       return;  /* diagnostic timing builds only: 1 = no consumer compute, 2 = no selection, 4 = no B DMA, 8 = no A loads in the loop */
 #endif
-#pragma unroll
-      for (int i = 0; i < B_WI; ++i)
-        __builtin_amdgcn_global_load_lds((gptr_t*)(b_src[i] + (size_t)kt * b_step), (lptr_t*)(smem + buf * SB + b_dst[i]), 16, 0, 0);
+      bd.issue(smem, kt, (unsigned)(buf * SB));
     };
 #pragma unroll
     for (int s = 0; s < NSB - 1; ++s)
@@ -351,9 +364,29 @@ __global__ __launch_bounds__(64 * (WM * WN + 4 + NLB)) void spmma_f16_fused_wide
   } else {
     // ------------------------------------------------------------------ consumer wave (as spmma_f16_pc_kernel)
     int cb = 0;
+    // without B loader waves (n <= 128: eight waves per workgroup keep three workgroups on a CU) the consumers issue
+    // the B tile's DMA themselves -- they have no other vector-memory traffic, so the counted vmcnt stays theirs --
+    // and the loader waves only carry A, two stages ahead
+    BTileDma<BN, NBW> bd;
+    int nb = NSB - 1;
+    if (NLB == 0) {
+      bd.setup(p.B + (size_t)b * p.sB, p.N, n0, wave, lane, BRING);
+#pragma unroll
+      for (int s = 0; s < NSB - 1; ++s)
+        if (s < nkt) bd.issue(smem, s, (unsigned)(s * SB));
+    }
     SM_T(unsigned long long tb = 0, tc = 0, nlong = 0; unsigned long long s0 = sm_stamp();)
     for (int kt = 0; kt < nkt; ++kt) {
-      wait_dma_and_barrier<0>();
+      if (NLB == 0) {
+        if (kt + NSB - 2 < nkt) wait_dma_and_barrier<(NSB - 2) * B_WI>();
+        else wait_dma_and_barrier<0>();
+        if (kt + NSB - 1 < nkt) {
+          bd.issue(smem, kt + NSB - 1, (unsigned)(nb * SB));
+          nb = nb + 1 == NSB ? 0 : nb + 1;
+        }
+      } else {
+        wait_dma_and_barrier<0>();
+      }
       SM_T(unsigned long long s1 = sm_stamp(); tb += s1 - s0;)
 #if defined(SM_ABLATE) && (SM_ABLATE & 1)
       cb = cb + 1 == NSB ? 0 : cb + 1;
@@ -688,7 +721,11 @@ extern "C" int sm_spmma_fused_f16(const void* A, const void* B, void* C, size_t 
   if (!wide_env) {
     if (n <= 64) return launch_fused<64, 4, 1>(a, st);
     // (a single stage per tile, k = 64: two 128-column tiles with 2-3 workgroups per CU beat one 256-column tile)
-    if (n <= 128 || (n <= 256 && k <= 64)) return launch_fused<128, 2, 2>(a, st);
+    if (k <= 64 && n <= 256) return launch_fused<128, 2, 2>(a, st);
+    // 64 < n <= 128, more than one stage: the split-loader kernel without B loader waves (the consumers issue B's DMA,
+    // the four loader waves carry A two stages ahead), 3-8 % faster than the combined loaders here; for n <= 64 the
+    // combined kernel's third workgroup per CU (71 against 86 VGPRs) wins
+    if (n <= 128) return launch_fused_wide<128, 2, 2, 0, 2, 3>(a, st);
   }
   // n > 256, short K, plain store: A-stationary (the 2:4 image of a row panel stays in LDS across column tiles)
   static const int astat_env = getenv("SM_FUSED_ASTAT") ? atoi(getenv("SM_FUSED_ASTAT")) : 1;  // tuning aid: 0 = off
