@@ -264,7 +264,7 @@ def main():
                                 layers=[L for L in layers if not use_fused(L)],
                                 call=lambda L: sm.compress24(L["A"], L["m"], L["k"], L["k"], L["b"], L["m"] * L["k"], L["blob"]),
                                 bytes=lambda L: L["b"] * L["m"] * L["k"] * (s + s / 2 + 1 / 8)),
-               "spmma_f16_fused": dict(names=["spmma_f16_fused_kernel", "spmma_f16_fused_wide_kernel", "spmma_f16_fused_astat_kernel"],
+               "spmma_f16_fused": dict(names=["spmma_f16_fused_direct_kernel", "spmma_f16_fused_wide_kernel", "spmma_f16_fused_astat_kernel"],
                                        layers=[L for L in layers if use_fused(L)],
                                        call=lambda L: sm.spmma_fused(L["A"], L["B"], L["C"], L["m"], L["n"], L["k"], batch=L["b"]),
                                        bytes=lambda L: L["b"] * s * (L["m"] * L["k"] + L["m"] * L["n"]) + s * L["k"] * L["n"])}

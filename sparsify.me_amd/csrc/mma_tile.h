@@ -13,6 +13,7 @@
 //                             16-bit); lane i receives {blk[0][i], blk[1][i], blk[2][i], blk[3][i]}.
 #pragma once
 #include "sm_common.h"
+#include "select24.h"
 
 namespace sm {
 
@@ -65,6 +66,58 @@ __device__ __forceinline__ void smfmac_stage(const char* As, const char* Ms, con
     const unsigned row = row0 + i * 16 + r;
     af[i] = *reinterpret_cast<const h8*>(As + row * 64u + 16u * (g ^ a64_swz(row)));
     idx[i] = (int)*reinterpret_cast<const unsigned short*>(Ms + row * 8u + 2u * g);
+  }
+  const unsigned bs_addr = (unsigned)(uintptr_t)(lds_char*)Bs;
+  s4 t0[2], t1[2], t2[2], t3[2];
+  auto issue = [&](int j, s4& v0, s4& v1, s4& v2, s4& v3) {
+    const unsigned c0 = col0 + j * 16, q = r >> 2, pp = r & 3u;
+    const unsigned a = bs_addr + b_off<64>(8u * g + q, c0 + 4u * pp);
+    asm volatile("ds_read_b64_tr_b16 %0, %4\n\tds_read_b64_tr_b16 %1, %4 offset:512\n\t"
+                 "ds_read_b64_tr_b16 %2, %4 offset:4096\n\tds_read_b64_tr_b16 %3, %4 offset:4608"
+                 : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3) : "v"(a) : "memory");
+  };
+  issue(0, t0[0], t1[0], t2[0], t3[0]);
+#pragma unroll
+  for (int j = 0; j < FN; ++j) {
+    const int c = j & 1, n = c ^ 1;
+    if (j + 1 < FN) {
+      issue(j + 1, t0[n], t1[n], t2[n], t3[n]);
+      asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(t0[c]), "+v"(t1[c]), "+v"(t2[c]), "+v"(t3[c]) :: "memory");
+    } else {
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t0[c]), "+v"(t1[c]), "+v"(t2[c]), "+v"(t3[c]) :: "memory");
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    typedef short s16 __attribute__((ext_vector_type(16)));
+    const s16 all = {t0[c][0], t0[c][1], t0[c][2], t0[c][3], t1[c][0], t1[c][1], t1[c][2], t1[c][3],
+                     t2[c][0], t2[c][1], t2[c][2], t2[c][3], t3[c][0], t3[c][1], t3[c][2], t3[c][3]};
+    const h16 bf = __builtin_bit_cast(h16, all);
+#pragma unroll
+    for (int i = 0; i < FM; ++i) acc[i][j] = __builtin_amdgcn_smfmac_f32_16x16x64_f16(af[i], bf, acc[i][j], idx[i], 0, 0);
+  }
+}
+
+// The same stage straight from the DENSE A: `Araw` is the [rows][128 B] image of 64 dense k per row (chunk c of row r
+// at chunk c ^ (r & 7), a_off), and the lane that would read 8 compressed halves + 4 nibbles reads its 16 dense halves
+// (two ds_read_b128) and selects in registers (select24.h): four strips -> the A operand and the index halfword of
+// v_smfmac_f32_16x16x64_f16.  No compressed image, no metadata, no selecting loader waves.
+template <int FM, int FN>
+__device__ __forceinline__ void smfmac_stage_dense_a(const char* Araw, const char* Bs, unsigned row0, unsigned col0,
+                                                     unsigned lane, f4 (&acc)[FM][FN]) {
+  const unsigned g = lane >> 4, r = lane & 15u;
+  h8 af[FM];
+  int idx[FM];
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+    const unsigned row = row0 + i * 16 + r;
+    const u4 lo = *reinterpret_cast<const u4*>(Araw + a_off(row, 2u * g));
+    const u4 hi = *reinterpret_cast<const u4*>(Araw + a_off(row, 2u * g + 1u));
+    uint32_t k0, k1, k2, k3, n0, n1, n2, n3;
+    strip_select_f16(lo[0], lo[1], k0, n0);
+    strip_select_f16(lo[2], lo[3], k1, n1);
+    strip_select_f16(hi[0], hi[1], k2, n2);
+    strip_select_f16(hi[2], hi[3], k3, n3);
+    af[i] = __builtin_bit_cast(h8, u4{k0, k1, k2, k3});
+    idx[i] = (int)(n0 | (n1 << 4) | (n2 << 8) | (n3 << 12));
   }
   const unsigned bs_addr = (unsigned)(uintptr_t)(lds_char*)Bs;
   s4 t0[2], t1[2], t2[2], t3[2];

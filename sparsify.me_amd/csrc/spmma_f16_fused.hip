@@ -38,18 +38,19 @@ struct FusedArgs {
 };
 
 // ---------------------------------------------------------------------------------------------
-// n <= 128: four loader waves do both jobs (B by DMA, A through registers one stage ahead), ring of 2.
-// Small LDS and 8 waves per workgroup keep 3-4 workgroups on a CU, which is what hides the latencies of
-// these HBM-bound shapes (profiles/sweep_r01_j_fused.txt: the split-loader kernel below is 1.2-1.7x slower here).
+// n <= 128, DIRECT form: no loader waves and no compressed image at all.  The dense A tile (128 rows x 128 B per 64-k
+// stage) and the B tile reach LDS by LDS-DMA issued by the four compute waves themselves (ring of NS stages, counted
+// vmcnt, one barrier per stage: the structure of spmma_f16_dma_kernel); wave w owns rows 32w .. 32w+31 and ALL columns,
+// so every row of A is selected exactly once -- by the lane that feeds it to the SMFMAC (smfmac_stage_dense_a).
+// The data in flight are LDS buffers, not registers: 2 x 24 KiB per workgroup, two workgroups per CU at n = 64.
 // ---------------------------------------------------------------------------------------------
-template <int BN, int WM, int WN, int NS>
-__global__ __launch_bounds__(64 * (WM * WN + 4)) void spmma_f16_fused_kernel(const FusedArgs p) {
-  constexpr int BM = 128, NL = 4, NC = WM * WN, NW = NC + NL;
-  static_assert(NS == 2, "the loader keeps exactly one stage of A in registers");
-  constexpr int TM = BM / WM, TN = BN / WN, FM = TM / 16, FN = TN / 16;
-  constexpr int SA = BM * 64, SM_ = BM * 8, SB = 64 * BN * 2, STAGE = SA + SM_ + SB;
-  constexpr int B_N = BN / 8, B_WI = B_N / NL;  // B DMA instructions per loader wave per stage
-  static_assert(B_N % NL == 0 && B_WI >= 1, "B tile vs loader waves");
+template <int BN, int NS>
+__global__ __launch_bounds__(256) void spmma_f16_fused_direct_kernel(const FusedArgs p) {
+  constexpr int BM = 128, NW = 4, TM = 32, FM = 2, FN = BN / 16;
+  constexpr int SA = BM * 128, SB = 64 * BN * 2, STAGE = SA + SB;
+  constexpr int A_N = BM / 8, B_N = BN / 8, W = A_N + B_N;  // 1 KiB DMA wave-instructions per stage
+  static_assert(W % NW == 0, "equal DMA share per wave");
+  constexpr int SL = W / NW;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const unsigned tid = threadIdx.x, lane = tid & 63u;
@@ -60,106 +61,83 @@ __global__ __launch_bounds__(64 * (WM * WN + 4)) void spmma_f16_fused_kernel(con
   const unsigned tile_m = trem / (unsigned)p.tiles_n, tile_n = trem - tile_m * (unsigned)p.tiles_n;
   const int m0 = (int)tile_m * BM, n0 = (int)tile_n * BN;
   const int nkt = p.K / 64;
+  const half_t* A = p.A + (size_t)b * p.sA;
+  const half_t* B = p.B + (size_t)b * p.sB;
   half_t* C = p.C + (size_t)b * p.sC;
+  const int mlast = p.Mrows - 1;
+
+  const char* src[SL];
+  size_t step[SL];
+  unsigned loff[SL];
+#pragma unroll
+  for (int i = 0; i < SL; ++i) {
+    const unsigned t = wave + (unsigned)NW * i;
+    if (t < (unsigned)A_N) {  // 8 rows x 128 B: lane -> row 8t + lane/8, LDS chunk lane%8 holds source chunk (lane%8) ^ (row&7)
+      const unsigned row = 8u * t + (lane >> 3), cs = (lane & 7u) ^ (row & 7u);
+      int gr = m0 + (int)row;
+      gr = gr < mlast ? gr : mlast;
+      src[i] = reinterpret_cast<const char*>(A + (size_t)gr * p.lda) + 16u * cs;
+      step[i] = 128;
+      loff[i] = t * 1024u;
+    } else {
+      const unsigned j = t - A_N, panel = j >> 3, kr = 8u * (j & 7u) + (lane >> 3);
+      const unsigned cs = (lane & 7u) ^ b_swz(kr);
+      int gc = n0 + (int)(64u * panel + 8u * cs);
+      gc = gc <= p.N - 8 ? gc : p.N - 8;
+      src[i] = reinterpret_cast<const char*>(B + (size_t)kr * p.N + gc);
+      step[i] = (size_t)64 * p.N * 2;
+      loff[i] = SA + panel * 8192u + (j & 7u) * 1024u;
+    }
+  }
+  auto stage = [&](int kt, int buf) {
+    char* base = smem + buf * STAGE;
+#pragma unroll
+    for (int i = 0; i < SL; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t*)(src[i] + (size_t)kt * step[i]), (lptr_t*)(base + loff[i]), 16, 0, 0);
+  };
 
   f4 acc[FM][FN];
 #pragma unroll
   for (int i = 0; i < FM; ++i)
 #pragma unroll
     for (int j = 0; j < FN; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
-  const unsigned wm = wave / WN, wn = wave % WN;  // consumer waves only
 
-  if (wave >= (unsigned)NC) {
-    // ------------------------------------------------------------------ loader wave
-    const unsigned lw = wave - NC;
-    const half_t* A = p.A + (size_t)b * p.sA;
-    const half_t* B = p.B + (size_t)b * p.sB;
-    const int mlast = p.Mrows - 1;
-    // A: load i of this wave = rows 8*(4*lw + i) + lane/8, dense chunk c = lane % 8 (k 8c .. 8c+7 of the stage)
-    const unsigned c8 = lane & 7u;
-    const half_t* a_src[4];
-    unsigned a_val_off[4], a_meta_off[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const unsigned row = 8u * (4u * lw + i) + (lane >> 3);
-      int gr = m0 + (int)row;
-      gr = gr < mlast ? gr : mlast;
-      a_src[i] = A + (size_t)gr * p.lda + 8u * c8;
-      a_val_off[i] = row * 64u + 16u * ((c8 >> 1) ^ a64_swz(row)) + 8u * (c8 & 1u);
-      a_meta_off[i] = SA + row * 8u + c8;
-    }
-    // B: DMA instruction i of this wave covers k-rows 8*lw + 32*(i&1) + lane/8 of panel i>>1 (64 columns);
-    // the chunk swizzle depends on bits 1 and 3 of the k-row only, i.e. not on i: addresses are rebuilt from
-    // two per-lane values at issue time instead of holding B_WI pointers in registers
-    const unsigned kr_lo = 8u * lw + (lane >> 3);
-    const unsigned b_cs = (lane & 7u) ^ b_swz(kr_lo);
-    const char* b_row0 = reinterpret_cast<const char*>(B + (size_t)kr_lo * p.N);
-    const size_t b_step = (size_t)64 * p.N * 2, b_half = (size_t)32 * p.N * 2;
-
-    u4 ra[4];
-    auto load_a = [&](int kt) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const u4*>(a_src[i] + (size_t)kt * 64);
-    };
-    auto put_stage = [&](int kt, int buf) {  // B by DMA, A from the registers loaded one stage earlier
-      char* sb = smem + buf * STAGE;
-#pragma unroll
-      for (int i = 0; i < B_WI; ++i) {
-        int gc = n0 + (int)(64u * (unsigned)(i >> 1) + 8u * b_cs);
-        gc = gc <= p.N - 8 ? gc : p.N - 8;
-        const char* src = b_row0 + (size_t)kt * b_step + ((i & 1) ? b_half : 0) + (size_t)gc * 2;
-        __builtin_amdgcn_global_load_lds((gptr_t*)src,
-                                         (lptr_t*)(sb + SA + SM_ + (unsigned)(i >> 1) * 8192u + (lw + 4u * (i & 1)) * 1024u), 16, 0, 0);
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        uint32_t k0, k1, n0, n1;
-        strip_select_f16(ra[i][0], ra[i][1], k0, n0);
-        strip_select_f16(ra[i][2], ra[i][3], k1, n1);
-        const u2 packed = {k0, k1};
-        const unsigned nib[2] = {n0, n1};
-        *reinterpret_cast<u2*>(sb + a_val_off[i]) = packed;
-        *reinterpret_cast<unsigned char*>(sb + a_meta_off[i]) = (unsigned char)(nib[0] | (nib[1] << 4));
-      }
-    };
-
-    // the counted vmcnt below relies on issue order (B DMA of stage s, THEN the A loads of stage s+1):
-    // the empty asm statements keep the compiler from moving the plain loads across the DMA
-    load_a(0);
-    asm volatile("" ::: "memory");
-    put_stage(0, 0);
-    asm volatile("" ::: "memory");
-    if (nkt > 1) load_a(1);
-    for (int kt = 0; kt < nkt; ++kt) {
-      // stage kt is complete in LDS once this wave's ds_writes (lgkmcnt) and B DMA have landed; the
-      // four A loads of stage kt+1, issued after that DMA, may stay in flight (counted vmcnt)
-      if (kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      if (kt + 1 < nkt) {
-        put_stage(kt + 1, (kt + 1) & 1);  // consumes ra (stage kt+1); buffer freed by barrier kt
-        asm volatile("" ::: "memory");
-        if (kt + 2 < nkt) load_a(kt + 2);
-      }
-    }
-  } else {
-    // ------------------------------------------------------------------ consumer wave (as spmma_f16_pc_kernel)
-    int cur = 0;
-    for (int kt = 0; kt < nkt; ++kt) {
-      wait_dma_and_barrier<0>();
-      const char* As = smem + cur * STAGE;
-      const char* Ms = As + SA;
-      const char* Bs = Ms + SM_;
-      smfmac_stage<FM, FN>(As, Ms, Bs, wm * TM, wn * TN, lane, acc);
-      cur ^= 1;
-    }
+  for (int s = 0; s < NS - 1; ++s)
+    if (s < nkt) stage(s, s);
+  int cur = 0, fill = NS - 1;
+  SM_T(unsigned long long tv = 0, tb = 0, ti = 0, tc = 0; unsigned long long s0 = sm_stamp(); const unsigned long long sstart = s0;)
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int ahead = (nkt - 1 - kt) < (NS - 2) ? (nkt - 1 - kt) : (NS - 2);
+#ifdef SM_STAMP
+    if (NS >= 4 && ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * SL) : "memory");
+    else if (NS >= 3 && ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SL) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long sv = sm_stamp(); tv += sv - s0;
+    asm volatile("s_barrier" ::: "memory");
+    const unsigned long long sb = sm_stamp(); tb += sb - sv;
+#else
+    if (NS >= 4 && ahead == 2) wait_dma_and_barrier<2 * SL>();
+    else if (NS >= 3 && ahead == 1) wait_dma_and_barrier<SL>();
+    else wait_dma_and_barrier<0>();
+#endif
+    if (kt + NS - 1 < nkt) stage(kt + NS - 1, fill);
+    SM_T(const unsigned long long si = sm_stamp(); ti += si - sb;)
+    const char* As = smem + cur * STAGE;
+    smfmac_stage_dense_a<FM, FN>(As, As + SA, wave * TM, 0, lane, acc);
+    cur = cur + 1 == NS ? 0 : cur + 1;
+    fill = fill + 1 == NS ? 0 : fill + 1;
+    SM_T(__builtin_amdgcn_sched_barrier(0); s0 = sm_stamp(); tc += s0 - si;)
   }
   __syncthreads();
-
-  store_c_tile<BM, BN, FM, FN, 64 * NW>(smem, C, acc, wave < (unsigned)NC, wm * TM, wn * TN, m0, n0, p.Mrows, p.N, p.alpha, p.beta, tid);
+  SM_T(const unsigned long long sloop = sm_stamp();)
+  store_c_tile<BM, BN, FM, FN, 64 * NW>(smem, C, acc, true, wave * TM, 0, m0, n0, p.Mrows, p.N, p.alpha, p.beta, tid);
+  SM_T(if (p.dbg && lane == 0) { unsigned long long* d = p.dbg + ((size_t)blockIdx.x * NW + wave) * 8; const unsigned long long se = sm_stamp();
+        d[0] = tv; d[1] = tb; d[2] = ti; d[3] = tc; d[4] = sloop - sstart; d[5] = se - sloop; })
 }
 
-template <int BN, int WM, int WN>
-static int launch_fused(const FusedArgs& a0, hipStream_t st) {
+template <int BN, int NS>
+static int launch_fused_direct(const FusedArgs& a0, hipStream_t st) {
   FusedArgs a = a0;
   a.tiles_m = (a.Mrows + 127) / 128;
   a.tiles_n = (a.N + BN - 1) / BN;
@@ -169,22 +147,40 @@ static int launch_fused(const FusedArgs& a0, hipStream_t st) {
     set_error("sm_spmma_fused_f16: grid too large");
     return SM_STATUS_NOT_SUPPORTED;
   }
-  constexpr size_t lds_main = 2 * ((size_t)128 * 72 + (size_t)64 * BN * 2);
+  constexpr size_t lds_main = (size_t)NS * (128 * 128 + 64 * BN * 2);
   constexpr size_t lds_epi = (size_t)128 * (BN * 2 + 16);
   constexpr size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
   static bool attr_set = false;
   if (lds > 64 * 1024 && !attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spmma_f16_fused_kernel<BN, WM, WN, 2>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spmma_f16_fused_direct_kernel<BN, NS>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  spmma_f16_fused_kernel<BN, WM, WN, 2><<<dim3((unsigned)nwg), dim3(64 * (WM * WN + 4)), lds, st>>>(a);
-  return check_launch("spmma_f16_fused_kernel");
+#ifdef SM_STAMP
+  {
+    static unsigned long long* dbg = nullptr;
+    static size_t cap = 0;
+    const size_t cnt = nwg * 4 * 8;
+    if (cnt > cap) { if (dbg) (void)hipFree(dbg); (void)hipMalloc((void**)&dbg, cnt * 8); cap = cnt; }
+    (void)hipMemset(dbg, 0, cnt * 8);
+    a.dbg = dbg;
+    spmma_f16_fused_direct_kernel<BN, NS><<<dim3((unsigned)nwg), dim3(256), lds, st>>>(a);
+    (void)hipDeviceSynchronize();
+    std::vector<unsigned long long> h(cnt);
+    (void)hipMemcpy(h.data(), dbg, cnt * 8, hipMemcpyDeviceToHost);
+    double t[6] = {0, 0, 0, 0, 0, 0};
+    for (size_t i = 0; i < cnt / 8; ++i)
+      for (int j = 0; j < 6; ++j) t[j] += (double)h[i * 8 + j];
+    const double nwv = (double)(cnt / 8), nk = (double)(a.K / 64);
+    fprintf(stderr, "STAMP-FUSED-DIRECT %dx%dx%d NS=%d tiles=%zu nkt=%d | per wave per stage: vmcnt-wait %.0f barrier %.0f dma-issue %.0f compute %.0f | loop %.0f epilogue %.0f cycles per tile\n",
+            a.Mrows, a.N, a.K, NS, nwg, a.K / 64, t[0] / nwv / nk, t[1] / nwv / nk, t[2] / nwv / nk, t[3] / nwv / nk, t[4] / nwv, t[5] / nwv);
+    return check_launch("spmma_f16_fused_direct_kernel");
+  }
+#endif
+  spmma_f16_fused_direct_kernel<BN, NS><<<dim3((unsigned)nwg), dim3(256), lds, st>>>(a);
+  return check_launch("spmma_f16_fused_direct_kernel");
 }
 
-// ---------------------------------------------------------------------------------------------
-// 128 < n: 256-column tiles, split loader roles, deeper pipelines (one workgroup per CU)
-// ---------------------------------------------------------------------------------------------
 // The B tile's LDS-DMA, shared by the B loader waves of the wide kernel and -- when it has none (NLB = 0) -- by its
 // consumer waves: instruction j = bw + NBW * i of a stage covers k-rows 8 * (j & 7) + lane / 8 of panel j >> 3.
 template <int BN, int NBW>
@@ -713,34 +709,22 @@ extern "C" int sm_spmma_fused_f16(const void* A, const void* B, void* C, size_t 
     a.batch = 1;
   }
   hipStream_t st = (hipStream_t)stream;
-  // n <= 128: one workgroup spans the whole N (4 consumer waves, combined loaders).  Wider: 256-column tiles with
-  // 8 consumer waves (4 x 2, wave tile 32 x 128) and split loaders; for n <= 256 every row of A is still loaded
-  // and selected exactly once, beyond that once per 256 columns (callers with n >= 512 and a reusable A are
-  // better served by sm_compress24_f16 + sm_spmma_f16: bench.py --path auto decides per layer).
+  // n <= 128 (and n <= 256 with a single stage): the direct kernel -- dense A by LDS-DMA, selection in the consumer's
+  // registers, ring of 2 so that three workgroups share a CU.  SM_FUSED_DIRECT=3 (tuning aid): ring of 3.
+  static const int direct_env = getenv("SM_FUSED_DIRECT") ? atoi(getenv("SM_FUSED_DIRECT")) : 2;
   static const int wide_env = getenv("SM_FUSED_WIDE") ? atoi(getenv("SM_FUSED_WIDE")) : 0;  // tuning aid: force the wide kernel
-  if (!wide_env) {
-    if (n <= 64) return launch_fused<64, 4, 1>(a, st);
-    // (a single stage per tile, k = 64: two 128-column tiles with 2-3 workgroups per CU beat one 256-column tile)
-    if (k <= 64 && n <= 256) return launch_fused<128, 2, 2>(a, st);
-    // 64 < n <= 128, more than one stage: the split-loader kernel without B loader waves (the consumers issue B's DMA,
-    // the four loader waves carry A two stages ahead), 3-8 % faster than the combined loaders here; for n <= 64 the
-    // combined kernel's third workgroup per CU (71 against 86 VGPRs) wins
-    if (n <= 128) return launch_fused_wide<128, 2, 2, 0, 2, 3>(a, st);
+  if (!wide_env && (n <= 128 || (n <= 256 && k <= 64))) {
+    if (n <= 64) return direct_env >= 3 ? launch_fused_direct<64, 3>(a, st) : launch_fused_direct<64, 2>(a, st);
+    return direct_env >= 3 ? launch_fused_direct<128, 3>(a, st) : launch_fused_direct<128, 2>(a, st);
   }
   // n > 256, short K, plain store: A-stationary (the 2:4 image of a row panel stays in LDS across column tiles)
   static const int astat_env = getenv("SM_FUSED_ASTAT") ? atoi(getenv("SM_FUSED_ASTAT")) : 1;  // tuning aid: 0 = off
   if (astat_env && n > 256 && k <= 512 && beta == 0.0f && aligned16(C) && (strideC % 8 == 0) &&
       astat_lds_bytes((int)(k / 64), 3) <= 160 * 1024)
     return launch_fused_astat(a, st);
-  static const int pf = getenv("SM_FUSED_PF") ? atoi(getenv("SM_FUSED_PF")) : 2;    // tuning aids: A stages in flight,
-  static const int nsb = getenv("SM_FUSED_NSB") ? atoi(getenv("SM_FUSED_NSB")) : 3;  // B ring depth,
-  static const int wn4 = getenv("SM_FUSED_WN4") ? atoi(getenv("SM_FUSED_WN4")) : 0;  // consumer wave grid 2 x 4
-  if (wn4) {
-    if (nsb >= 4) return pf >= 3 ? launch_fused_wide<256, 2, 4, 4, 3, 4>(a, st) : launch_fused_wide<256, 2, 4, 4, 2, 4>(a, st);
-    return pf >= 3 ? launch_fused_wide<256, 2, 4, 4, 3, 3>(a, st) : launch_fused_wide<256, 2, 4, 4, 2, 3>(a, st);
-  }
-  if (nsb >= 4) return pf >= 3 ? launch_fused_wide<256, 4, 2, 4, 3, 4>(a, st) : launch_fused_wide<256, 4, 2, 4, 2, 4>(a, st);
-  if (pf >= 3) return launch_fused_wide<256, 4, 2, 4, 3, 3>(a, st);
-  if (pf == 1) return launch_fused_wide<256, 4, 2, 4, 1, 3>(a, st);
+  // wider: 256-column tiles, 8 consumer waves (wave tile 32 x 128), split loaders; for n <= 256 every row of A is loaded
+  // and selected exactly once, beyond that once per 256 columns (callers with n >= 512, a long K and a reusable A are
+  // better served by sm_compress24_f16 + sm_spmma_f16: bench.py --path auto decides per layer).  Three A stages in
+  // flight, a B ring of 4 and a 2 x 4 consumer grid all measured within noise of this configuration.
   return launch_fused_wide<256, 4, 2, 4, 2, 3>(a, st);
 }
