@@ -28,8 +28,8 @@ __device__ __forceinline__ unsigned nibble_of(unsigned keep) {
 
 // fp16 strip in one pass (23 VALU ops against ~60 for the mask form above): element i of the strip becomes the
 // 32-bit composite key (|x_i| << 16) | (3 - i) -- all four distinct, larger = kept earlier, equal magnitudes
-// ordered by the lower index -- and the two largest fall out of a 7-op max/min tree:
-//   p,q = max,min(K0,K1)   r,s = max,min(K2,K3)   first = max(p,r)   second = max3(min(p,r), q, s).
+// ordered by the lower index -- and the two largest fall out of five instructions:
+//   m = max3(K0,K1,K2)   med = med3(K0,K1,K2)   first = max(m,K3)   second = max(min(m,K3), med).
 // Their low two bits name the kept positions; one v_perm_b32 with a computed selector then pulls the two kept
 // halves (sign and all) out of the strip's two dwords in position order.
 //   d0 = {x1:x0}, d1 = {x3:x2}  ->  kept = {x[p1]:x[p0]},  nib = p0 | p1 << 2   (p0 < p1)
@@ -39,11 +39,14 @@ __device__ __forceinline__ void strip_select_f16(uint32_t d0, uint32_t d1, uint3
   const uint32_t a0 = d0 & 0x7fff7fffu, a1 = d1 & 0x7fff7fffu;
   const uint32_t K0 = (a0 << 16) | 3u, K1 = (a0 & 0xffff0000u) | 2u;
   const uint32_t K2 = (a1 << 16) | 1u, K3 = a1 & 0xffff0000u;
-  const uint32_t p = K0 > K1 ? K0 : K1, q = K0 > K1 ? K1 : K0;
-  const uint32_t r = K2 > K3 ? K2 : K3, s = K2 > K3 ? K3 : K2;
-  const uint32_t first = p > r ? p : r, t = p > r ? r : p;
-  uint32_t second = t > q ? t : q;
-  second = second > s ? second : s;
+  // first = max of the four; second = max(min(m, K3), med3(K0, K1, K2)) with m = max3(K0, K1, K2): if m >= K3 the
+  // runner-up is K3 or the median of the three, otherwise it is m itself (>= that median).  Five instructions.
+  const uint32_t m01 = K0 > K1 ? K0 : K1, n01 = K0 > K1 ? K1 : K0;
+  const uint32_t m = m01 > K2 ? m01 : K2;          // max(max(K0,K1),K2): v_max3_u32
+  const uint32_t c01 = m01 < K2 ? m01 : K2;        // min(max(K0,K1),K2)
+  const uint32_t med = n01 > c01 ? n01 : c01;      // max(min(K0,K1), min(max(K0,K1),K2)): v_med3_u32
+  const uint32_t first = m > K3 ? m : K3, lo = m > K3 ? K3 : m;
+  const uint32_t second = lo > med ? lo : med;
   const uint32_t a = first & 3u, b = second & 3u;       // 3 - position
   const uint32_t A = a > b ? a : b, B = a > b ? b : a;  // p0 = 3 - A < p1 = 3 - B
   const uint32_t sel = 0x07060706u - (A | (B << 16)) * 0x0202u;  // < 2^24: v_mul_u32_u24
