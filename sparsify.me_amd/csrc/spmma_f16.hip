@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256) void spmma_f16_kernel(const SpmmaArgs p) {
       const u4 v = *reinterpret_cast<const u4*>(Cs + row * CPITCH + cn * 16);
       half_t* dst = C + (size_t)gr * p.N + gc;
       if (gc + 8 <= p.N) {
-        *reinterpret_cast<u4*>(dst) = v;
+        __builtin_nontemporal_store(v, reinterpret_cast<u4*>(dst));
       } else {
         const h8 e = __builtin_bit_cast(h8, v);
 #pragma unroll

@@ -628,7 +628,7 @@ __global__ __launch_bounds__(64 * 16) void spmma_f16_fused_astat_kernel(const Fu
           if (gr < p.Mrows && gc < p.N) {
             const u2 lo = *reinterpret_cast<const u2*>(patch + lr * WPITCH + 16u * (lane & 7u));  // rows are 8-byte aligned
             const u2 hi = *reinterpret_cast<const u2*>(patch + lr * WPITCH + 16u * (lane & 7u) + 8u);
-            *reinterpret_cast<u4*>(C + (size_t)gr * p.N + gc) = u4{lo[0], lo[1], hi[0], hi[1]};
+            __builtin_nontemporal_store(u4{lo[0], lo[1], hi[0], hi[1]}, reinterpret_cast<u4*>(C + (size_t)gr * p.N + gc));
           }
         }
         kt = 0;
