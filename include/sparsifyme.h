@@ -120,7 +120,10 @@ int sm_spmma_fused_f16(const void* A, const void* B, void* C, size_t m, size_t n
 
 /* ---- (a5) dense batched GEMM: replaces cublas{H,S,D}gemmBatched (gemm.hxx:80-81, 133-134,
  *      186-187).  COLUMN-major, lda = m, ldb = k, ldc = m as the reference passes them;
- *      A_ptrs/B_ptrs/C_ptrs are device arrays of `batch` device pointers (examples/gemm.cu:65-90). */
+ *      A_ptrs/B_ptrs/C_ptrs are device arrays of `batch` device pointers (examples/gemm.cu:65-90).
+ *      ta / tb (gemm.hxx:33-34): SM_OP_N or SM_OP_T; a transposed operand is read as its stored k x m
+ *      (n x k) form through the same leading dimension, which must cover a stored column (m >= k for
+ *      ta = T, k >= n for tb = T; SM_STATUS_INVALID_VALUE otherwise, as the vendor BLAS). */
 int sm_gemm_batched_f16(const void* const* A_ptrs, const void* const* B_ptrs, void* const* C_ptrs,
                         size_t m, size_t n, size_t k, size_t batch, int ta, int tb, float alpha,
                         float beta, sm_stream_t stream);

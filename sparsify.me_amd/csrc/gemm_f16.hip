@@ -57,7 +57,10 @@ __device__ __forceinline__ u4 load_chunk(const half_t* rowp, int col, int limit,
   return __builtin_bit_cast(u4, e);
 }
 
-template <int BM, int BN, int WM, int WN, int VEC>
+// TA: the A operand is given M-contiguous (element (r, kk) at A[kk * lda + r]); TB: the B operand is given K-contiguous
+// (element (kk, c) at B[c * ldb + kk]) -- the transposed operands of sm_gemm_batched_f16.  The 16-byte chunks then run
+// along the contiguous direction and are scattered into the same LDS images with 2-byte writes.
+template <int BM, int BN, int WM, int WN, int VEC, bool TA = false, bool TB = false>
 __global__ __launch_bounds__(256) void gemm_f16_kernel(const GemmArgs p) {
   static_assert(WM * WN == 4, "4 waves");
   constexpr int TM = BM / WM, TN = BN / WN, FM = TM / 16, FN = TN / 16;
@@ -91,27 +94,53 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(const GemmArgs p) {
   auto gload = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < A_CH; ++i) {
-      const unsigned q = tid + 256u * i, row = q >> 3, ch = q & 7u;
-      const int gr = m0 + (int)row;
-      ra[i] = load_chunk<VEC>(A + (size_t)gr * p.lda, k0 + 8 * (int)ch, p.K, gr < p.M);
+      if constexpr (TA) {
+        const unsigned q = tid + 256u * i, kk = q / (BM / 8), rc = q % (BM / 8);
+        const int gk = k0 + (int)kk;
+        ra[i] = load_chunk<VEC>(A + (size_t)gk * p.lda, m0 + 8 * (int)rc, p.M, gk < p.K);
+      } else {
+        const unsigned q = tid + 256u * i, row = q >> 3, ch = q & 7u;
+        const int gr = m0 + (int)row;
+        ra[i] = load_chunk<VEC>(A + (size_t)gr * p.lda, k0 + 8 * (int)ch, p.K, gr < p.M);
+      }
     }
 #pragma unroll
     for (int i = 0; i < B_CH; ++i) {
-      const unsigned q = tid + 256u * i, kr = q / (BN / 8), cn = q % (BN / 8);
-      const int gk = k0 + (int)kr;
-      rb[i] = load_chunk<VEC>(B + (size_t)gk * p.ldb, n0 + 8 * (int)cn, p.N, gk < p.K);
+      if constexpr (TB) {
+        const unsigned q = tid + 256u * i, col = q >> 3, kc = q & 7u;
+        const int gn = n0 + (int)col;
+        rb[i] = load_chunk<VEC>(B + (size_t)gn * p.ldb, k0 + 8 * (int)kc, p.K, gn < p.N);
+      } else {
+        const unsigned q = tid + 256u * i, kr = q / (BN / 8), cn = q % (BN / 8);
+        const int gk = k0 + (int)kr;
+        rb[i] = load_chunk<VEC>(B + (size_t)gk * p.ldb, n0 + 8 * (int)cn, p.N, gk < p.K);
+      }
     }
   };
   auto lstore = [&]() {
 #pragma unroll
     for (int i = 0; i < A_CH; ++i) {
-      const unsigned q = tid + 256u * i, row = q >> 3, ch = q & 7u;
-      *reinterpret_cast<u4*>(As + a_off(row, ch)) = ra[i];
+      if constexpr (TA) {
+        const unsigned q = tid + 256u * i, kk = q / (BM / 8), rc = q % (BM / 8);
+        const h8 e = __builtin_bit_cast(h8, ra[i]);
+#pragma unroll
+        for (unsigned t = 0; t < 8; ++t) *reinterpret_cast<half_t*>(As + a_off(8u * rc + t, kk >> 3) + 2u * (kk & 7u)) = e[t];
+      } else {
+        const unsigned q = tid + 256u * i, row = q >> 3, ch = q & 7u;
+        *reinterpret_cast<u4*>(As + a_off(row, ch)) = ra[i];
+      }
     }
 #pragma unroll
     for (int i = 0; i < B_CH; ++i) {
-      const unsigned q = tid + 256u * i, kr = q / (BN / 8), cn = q % (BN / 8);
-      *reinterpret_cast<u4*>(Bs + b_off<64>(kr, 8u * cn)) = rb[i];
+      if constexpr (TB) {
+        const unsigned q = tid + 256u * i, col = q >> 3, kc = q & 7u;
+        const h8 e = __builtin_bit_cast(h8, rb[i]);
+#pragma unroll
+        for (unsigned t = 0; t < 8; ++t) *reinterpret_cast<half_t*>(Bs + b_off<64>(8u * kc + t, col)) = e[t];
+      } else {
+        const unsigned q = tid + 256u * i, kr = q / (BN / 8), cn = q % (BN / 8);
+        *reinterpret_cast<u4*>(Bs + b_off<64>(kr, 8u * cn)) = rb[i];
+      }
     }
   };
 
@@ -415,7 +444,7 @@ static int launch_dma(const GemmArgs& a0, hipStream_t st) {
   return check_launch("gemm_f16_dma_kernel");
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool TA = false, bool TB = false>
 static int launch_cfg(const GemmArgs& a0, int vec, hipStream_t st) {
   GemmArgs a = a0;
   a.tiles_m = (a.M + BM - 1) / BM;
@@ -430,23 +459,26 @@ static int launch_cfg(const GemmArgs& a0, int vec, hipStream_t st) {
   constexpr size_t lds_epi = (size_t)BM * (BN * 2 + 16);
   constexpr size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
   if (vec == 8)
-    gemm_f16_kernel<BM, BN, WM, WN, 8><<<dim3((unsigned)nwg), dim3(256), lds, st>>>(a);
-  else if (vec == 4)
+    gemm_f16_kernel<BM, BN, WM, WN, 8, TA, TB><<<dim3((unsigned)nwg), dim3(256), lds, st>>>(a);
+  else if (vec == 4 && !TA && !TB)
     gemm_f16_kernel<BM, BN, WM, WN, 4><<<dim3((unsigned)nwg), dim3(256), lds, st>>>(a);
   else
-    gemm_f16_kernel<BM, BN, WM, WN, 1><<<dim3((unsigned)nwg), dim3(256), lds, st>>>(a);
+    gemm_f16_kernel<BM, BN, WM, WN, 1, TA, TB><<<dim3((unsigned)nwg), dim3(256), lds, st>>>(a);
   return check_launch("gemm_f16_kernel");
 }
 
 // Tile choice: the streamed dimension gets the long tile edge; narrow problems get a tile as wide
 // as they are, so the big operand is read from HBM exactly once.
-static int launch_gemm_f16(const GemmArgs& a, hipStream_t st) {
+static int launch_gemm_f16(const GemmArgs& a, hipStream_t st, bool ta = false, bool tb = false) {
   auto aligned_to = [&](unsigned halves) {
     const uintptr_t mask = halves * 2u - 1u;
     return (a.lda % halves == 0) && (a.ldb % halves == 0) && (a.sA % halves == 0) && (a.sB % halves == 0) &&
            (a.Ap || (reinterpret_cast<uintptr_t>(a.A) & mask) == 0) && (a.Bp || (reinterpret_cast<uintptr_t>(a.B) & mask) == 0);
   };
   const int vec = aligned_to(8) ? 8 : (aligned_to(4) ? 4 : 1);
+  if (ta && tb) return launch_cfg<128, 128, 2, 2, true, true>(a, vec, st);
+  if (ta) return launch_cfg<128, 128, 2, 2, true, false>(a, vec, st);
+  if (tb) return launch_cfg<128, 128, 2, 2, false, true>(a, vec, st);
   // pointer-array batches: per-batch base alignment is the caller's (hipMalloc gives 256 B);
   // DMA fast path: whole 64-deep K stages, N a multiple of 4 (a half-valid last chunk is served from columns
   // N-8 .. N-1, see the kernel's epilogue), rows on 8-byte boundaries (a
@@ -503,9 +535,16 @@ int sm_gemm_batched_f16(const void* const* A_ptrs, const void* const* B_ptrs, vo
     set_error("sm_gemm_batched_f16: null pointer array");
     return SM_STATUS_INVALID_VALUE;
   }
-  if (ta != SM_OP_N || tb != SM_OP_N) {
-    set_error("sm_gemm_batched_f16: transposed operands are not implemented (no reference driver passes them)");
-    return SM_STATUS_NOT_SUPPORTED;
+  if ((ta != SM_OP_N && ta != SM_OP_T) || (tb != SM_OP_N && tb != SM_OP_T)) {
+    set_error("sm_gemm_batched_f16: operation must be SM_OP_N or SM_OP_T");
+    return SM_STATUS_INVALID_VALUE;
+  }
+  // the reference passes lda = m, ldb = k whatever the flags (gemm.hxx:80-81); a transposed operand is then read as
+  // its k x m (n x k) stored form through that same leading dimension, which the vendor BLAS accepts only when it
+  // covers a stored column: lda >= k for op(A) = T, ldb >= n for op(B) = T
+  if ((ta == SM_OP_T && m < k) || (tb == SM_OP_T && k < n)) {
+    set_error("sm_gemm_batched_f16: leading dimension (lda = m, ldb = k) shorter than a column of the transposed operand");
+    return SM_STATUS_INVALID_VALUE;
   }
   if (m == 0 || n == 0 || batch == 0) return SM_STATUS_SUCCESS;
   if (m > 0x7fffffffull || n > 0x7fffffffull || k > 0x7fffffffull || batch > 0x7fffffffull) {
@@ -520,7 +559,9 @@ int sm_gemm_batched_f16(const void* const* A_ptrs, const void* const* B_ptrs, vo
   a.M = (int)n; a.N = (int)m; a.K = (int)k;
   a.lda = (int)k; a.ldb = (int)m; a.ldc = (int)m;
   a.batch = (int)batch; a.alpha = alpha; a.beta = beta;
-  return launch_gemm_f16(a, (hipStream_t)stream);
+  // op(B) = T: the row-major view's A operand (n x k) arrives n-contiguous; op(A) = T: its B operand (k x m) arrives
+  // k-contiguous.  The leading dimensions stay (ldb = k, lda = m), as the reference passes them.
+  return launch_gemm_f16(a, (hipStream_t)stream, tb == SM_OP_T, ta == SM_OP_T);
 }
 
 }  // extern "C"

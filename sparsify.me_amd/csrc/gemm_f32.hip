@@ -42,9 +42,12 @@ constexpr int APITCH = BK32 + 1;  // floats per A row in LDS: column reads by 16
 // MODE 0: dense A, B row-major [k][n];  MODE 1: A from the 2:4 blob;  MODE 2: dense A, B given K-MAJOR
 // ([n][k], ldb = row pitch in k): the form the Blocked-ELL path needs (its expanded A is row-major [m][k]
 // and plays the B role of the transposed product).
-template <int BM, int BN, int WM, int WN, int MODE>
+// ATR (dense modes only): A given M-CONTIGUOUS (element (r, kk) at A[kk * lda + r]) -- with MODE 2 the two transposed
+// operand forms of sm_gemm_batched_f32.
+template <int BM, int BN, int WM, int WN, int MODE, bool ATR = false>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const Gemm32Args p) {
   constexpr bool SPARSE = MODE == 1, BKM = MODE == 2;
+  static_assert(!(ATR && SPARSE), "the blob is row-major by construction");
   static_assert(WM * WN == 4, "4 waves");
   constexpr int TM = BM / WM, TN = BN / WN, FM = TM / 16, FN = TN / 16;
   constexpr int BPITCH = BN + 16;  // the two k-rows a 32-lane half reads land on different bank halves
@@ -91,7 +94,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const Gemm32Args p) {
     for (int i = 0; i < A_CH; ++i) {
       const unsigned q = tid + 256u * i, row = q >> 3, ch = q & 7u;  // 8 strips of 4 dense k per row
       const int gr = m0 + (int)row, kk = k0 + 4 * (int)ch;
-      if constexpr (SPARSE) {
+      if constexpr (ATR) {
+        const unsigned kr = q / (BM / 4), rc = q % (BM / 4);  // 4 consecutive rows of one k
+        const int gk = k0 + (int)kr;
+        ra[i] = load4(A + (size_t)gk * p.lda, m0 + 4 * (int)rc, p.M, gk < p.K, a_vec);
+      } else if constexpr (SPARSE) {
         // expand one strip: two kept values + their nibble -> four dense k
         f4 v = {0.f, 0.f, 0.f, 0.f};
         if (gr < p.M && kk < p.kc) {
@@ -125,8 +132,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const Gemm32Args p) {
 #pragma unroll
     for (int i = 0; i < A_CH; ++i) {
       const unsigned q = tid + 256u * i, row = q >> 3, ch = q & 7u;
+      if constexpr (ATR) {
+        const unsigned kr = q / (BM / 4), rc = q % (BM / 4);
 #pragma unroll
-      for (int t = 0; t < 4; ++t) As[row * APITCH + 4 * ch + t] = ra[i][t];
+        for (int t = 0; t < 4; ++t) As[(4 * rc + t) * APITCH + kr] = ra[i][t];
+      } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) As[row * APITCH + 4 * ch + t] = ra[i][t];
+      }
     }
 #pragma unroll
     for (int i = 0; i < B_CH; ++i) {
@@ -194,7 +207,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const Gemm32Args p) {
     }
 }
 
-template <int BM, int BN, int WM, int WN, int MODE>
+template <int BM, int BN, int WM, int WN, int MODE, bool ATR = false>
 static int launch32(const Gemm32Args& a0, hipStream_t st) {
   Gemm32Args a = a0;
   a.tiles_m = (a.M + BM - 1) / BM;
@@ -207,7 +220,7 @@ static int launch32(const Gemm32Args& a0, hipStream_t st) {
   }
   constexpr size_t lds_b = (size_t)BK32 * (BN + 16) > (size_t)BN * APITCH ? (size_t)BK32 * (BN + 16) : (size_t)BN * APITCH;
   constexpr size_t lds = ((size_t)BM * APITCH + lds_b) * sizeof(float);
-  gemm_f32_kernel<BM, BN, WM, WN, MODE><<<dim3((unsigned)nwg), dim3(256), lds, st>>>(a);
+  gemm_f32_kernel<BM, BN, WM, WN, MODE, ATR><<<dim3((unsigned)nwg), dim3(256), lds, st>>>(a);
   return check_launch("gemm_f32_kernel");
 }
 
@@ -268,6 +281,7 @@ struct Gemm64Args {
   const double* const* Bp;
   double* const* Cp;
   int M, N, K, lda, ldb, ldc;  // row-major view (see sm_gemm_batched_f64)
+  int ta, tb;                  // 1: A given M-contiguous / B given K-contiguous (the transposed operands)
   double alpha, beta;
 };
 __global__ __launch_bounds__(256) void gemm_f64_kernel(const Gemm64Args p) {
@@ -281,11 +295,13 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(const Gemm64Args p) {
   for (int k0 = 0; k0 < p.K; k0 += 16) {
     for (unsigned q = tid; q < 64 * 16; q += 256) {
       const int r = q >> 4, c = q & 15;
-      As[r][c] = (m0 + r < p.M && k0 + c < p.K) ? A[(size_t)(m0 + r) * p.lda + k0 + c] : 0.0;
+      As[r][c] = (m0 + r < p.M && k0 + c < p.K)
+                     ? (p.ta ? A[(size_t)(k0 + c) * p.lda + m0 + r] : A[(size_t)(m0 + r) * p.lda + k0 + c]) : 0.0;
     }
     for (unsigned q = tid; q < 16 * 64; q += 256) {
       const int r = q >> 6, c = q & 63;
-      Bs[r][c] = (k0 + r < p.K && n0 + c < p.N) ? B[(size_t)(k0 + r) * p.ldb + n0 + c] : 0.0;
+      Bs[r][c] = (k0 + r < p.K && n0 + c < p.N)
+                     ? (p.tb ? B[(size_t)(n0 + c) * p.ldb + k0 + r] : B[(size_t)(k0 + r) * p.ldb + n0 + c]) : 0.0;
     }
     __syncthreads();
 #pragma unroll
@@ -348,9 +364,13 @@ int sm_gemm_batched_f32(const float* const* A_ptrs, const float* const* B_ptrs, 
     set_error("sm_gemm_batched_f32: null pointer array");
     return SM_STATUS_INVALID_VALUE;
   }
-  if (ta != SM_OP_N || tb != SM_OP_N) {
-    set_error("sm_gemm_batched_f32: transposed operands are not implemented (no reference driver passes them)");
-    return SM_STATUS_NOT_SUPPORTED;
+  if ((ta != SM_OP_N && ta != SM_OP_T) || (tb != SM_OP_N && tb != SM_OP_T)) {
+    set_error("sm_gemm_batched_f32: operation must be SM_OP_N or SM_OP_T");
+    return SM_STATUS_INVALID_VALUE;
+  }
+  if ((ta == SM_OP_T && m < k) || (tb == SM_OP_T && k < n)) {  // see sm_gemm_batched_f16
+    set_error("sm_gemm_batched_f32: leading dimension (lda = m, ldb = k) shorter than a column of the transposed operand");
+    return SM_STATUS_INVALID_VALUE;
   }
   if (m == 0 || n == 0 || batch == 0) return SM_STATUS_SUCCESS;
   if (m > 0x7fffffffull || n > 0x7fffffffull || k > 0x7fffffffull || batch > 0x7fffffffull) {
@@ -363,6 +383,10 @@ int sm_gemm_batched_f32(const float* const* A_ptrs, const float* const* B_ptrs, 
   a.M = (int)n; a.N = (int)m; a.K = (int)k;
   a.lda = (int)k; a.ldb = (int)m; a.ldc = (int)m;
   a.batch = (int)batch; a.alpha = alpha; a.beta = beta;
+  // op(B) = T: the row-major view's A operand arrives n-contiguous (ATR); op(A) = T: its B operand k-contiguous (MODE 2)
+  if (tb == SM_OP_T) return ta == SM_OP_T ? launch32<64, 64, 2, 2, 2, true>(a, (hipStream_t)stream)
+                                          : launch32<64, 64, 2, 2, 0, true>(a, (hipStream_t)stream);
+  if (ta == SM_OP_T) return dispatch32<2>(a, (hipStream_t)stream);
   return dispatch32<0>(a, (hipStream_t)stream);
 }
 
@@ -400,9 +424,13 @@ int sm_gemm_batched_f64(const double* const* A_ptrs, const double* const* B_ptrs
     set_error("sm_gemm_batched_f64: null pointer array");
     return SM_STATUS_INVALID_VALUE;
   }
-  if (ta != SM_OP_N || tb != SM_OP_N) {
-    set_error("sm_gemm_batched_f64: transposed operands are not implemented (no reference driver passes them)");
-    return SM_STATUS_NOT_SUPPORTED;
+  if ((ta != SM_OP_N && ta != SM_OP_T) || (tb != SM_OP_N && tb != SM_OP_T)) {
+    set_error("sm_gemm_batched_f64: operation must be SM_OP_N or SM_OP_T");
+    return SM_STATUS_INVALID_VALUE;
+  }
+  if ((ta == SM_OP_T && m < k) || (tb == SM_OP_T && k < n)) {  // see sm_gemm_batched_f16
+    set_error("sm_gemm_batched_f64: leading dimension (lda = m, ldb = k) shorter than a column of the transposed operand");
+    return SM_STATUS_INVALID_VALUE;
   }
   if (m == 0 || n == 0 || batch == 0) return SM_STATUS_SUCCESS;
   if (m > 0x7fffffffull || n > 0x7fffffffull || k > 0x7fffffffull || batch > 65535) {
@@ -413,6 +441,7 @@ int sm_gemm_batched_f64(const double* const* A_ptrs, const double* const* B_ptrs
   a.Ap = B_ptrs; a.Bp = A_ptrs; a.Cp = C_ptrs;  // transposed view, as for fp32
   a.M = (int)n; a.N = (int)m; a.K = (int)k;
   a.lda = (int)k; a.ldb = (int)m; a.ldc = (int)m;
+  a.ta = tb == SM_OP_T; a.tb = ta == SM_OP_T;  // roles swap with the operands
   a.alpha = alpha; a.beta = beta;
   dim3 grid((unsigned)ceil_div(a.N, 64), (unsigned)ceil_div(a.M, 64), (unsigned)batch);
   gemm_f64_kernel<<<grid, dim3(256), 0, (hipStream_t)stream>>>(a);

@@ -464,6 +464,50 @@ def test_gemm_batched_column_major_f32_f64(gpu, orc, sfx, dtype, tol, shape):
         check_close(host(dCs[b]), Cs[b], scale, tol, f"gemm_batched_{sfx} {shape} batch {b}")
 
 
+@pytest.mark.parametrize("sfx,dtype,tol", [("f16", np.float16, FP16_TOL), ("f32", np.float32, FP32_TOL), ("f64", np.float64, 1e-12)])
+@pytest.mark.parametrize("tatb", [(1, 0), (0, 1), (1, 1)])
+@pytest.mark.parametrize("shape", [(128, 64, 64, 2), (200, 72, 136, 2), (131, 35, 77, 3), (264, 128, 192, 1)])
+def test_gemm_batched_transposed_operands(gpu, orc, sfx, dtype, tol, tatb, shape):
+    """transpose_a / transpose_b of batched::gemm (gemm.hxx:33-34): the stored operand is read through the leading
+    dimensions the reference always passes (lda = m, ldb = k; gemm.hxx:80-81), as the oracle does."""
+    import torch
+    m, n, k, batch = shape
+    ta, tb = tatb
+    alpha, beta = 0.75, -0.5
+    rng = np.random.default_rng(m + 2 * n + 3 * k + 7 * ta + 11 * tb)
+    na = m * m if ta else m * k          # op(A)[i][l] = A[i * lda + l], lda = m >= k
+    nb = k * k if tb else k * n          # op(B)[l][j] = B[l * ldb + j], ldb = k >= n
+    As = [rand(rng, na, dtype) for _ in range(batch)]
+    Bs = [rand(rng, nb, dtype) for _ in range(batch)]
+    C0 = [rand(rng, m * n, dtype) for _ in range(batch)]
+    dAs, dBs = [to_dev(a) for a in As], [to_dev(b) for b in Bs]
+    dCs = [to_dev(c.copy()) for c in C0]
+    ptr = lambda ts: torch.tensor([t.data_ptr() for t in ts], dtype=torch.int64, device="cuda")
+    gpu.gemm_batched(ptr(dAs), ptr(dBs), ptr(dCs), m, n, k, batch, sfx, alpha, beta, ta=ta, tb=tb)
+    view = (lambda x: bits(x)) if sfx == "f16" else (lambda x: x)
+    Cs = [view(c.copy()) for c in C0]
+    orc.gemm_batched([view(a) for a in As], [view(b) for b in Bs], Cs, m, n, k, alpha, beta, ta=ta, tb=tb)
+    for b in range(batch):
+        a64, b64 = np.abs(As[b].astype(np.float64)), np.abs(Bs[b].astype(np.float64))
+        opA = a64.reshape(m, m)[:, :k] if ta else a64.reshape(k, m).T          # m x k
+        opB = b64.reshape(k, k)[:, :n] if tb else b64.reshape(n, k).T          # k x n
+        scale = abs(alpha) * (opA @ opB).T.reshape(-1) + abs(beta) * np.abs(C0[b].astype(np.float64))
+        got = host(dCs[b])
+        want = Cs[b].view(np.float16) if sfx == "f16" else Cs[b]
+        check_close(got, want, scale, tol, f"gemm_batched_{sfx} ta={ta} tb={tb} {shape} batch {b}")
+
+
+def test_gemm_batched_transposed_rejects_short_leading_dimension(gpu):
+    """lda = m < k with op(A) = T (or ldb = k < n with op(B) = T) is what the vendor BLAS rejects as an invalid
+    leading dimension; the C ABI reports it instead of reading overlapping columns."""
+    import torch
+    z = torch.zeros(4, dtype=torch.int64, device="cuda")
+    L = gpu.lib()
+    assert L.sm_gemm_batched_f32(z.data_ptr(), z.data_ptr(), z.data_ptr(), 8, 8, 16, 1, 1, 0, 1.0, 0.0, None) == 1  # SM_STATUS_INVALID_VALUE
+    assert L.sm_gemm_batched_f16(z.data_ptr(), z.data_ptr(), z.data_ptr(), 32, 16, 8, 1, 0, 1, 1.0, 0.0, None) == 1  # SM_STATUS_INVALID_VALUE
+    assert L.sm_gemm_batched_f64(z.data_ptr(), z.data_ptr(), z.data_ptr(), 8, 8, 8, 1, 2, 0, 1.0, 0.0, None) == 1  # SM_STATUS_INVALID_VALUE
+
+
 def test_spmm_bell_vs_oracle(gpu, orc):
     import torch
     rng = np.random.default_rng(4)
