@@ -34,6 +34,12 @@ struct spmma_fns<float> {
   static int mul(void* blob, float* B, float* C, std::size_t m, std::size_t n, std::size_t k, std::size_t b, float al, float be) {
     return sm_spmma_f32(blob, B, C, m, n, k, b, k * n, m * n, al, be, nullptr);
   }
+  static int prune_on(float* A, std::size_t m, std::size_t k, hipStream_t st) { return sm_prune24_f32(A, A, m, k, k, SM_PRUNE_TILE, st); }
+  static int compress_on(float* A, std::size_t m, std::size_t k, std::size_t b, void* blob, hipStream_t st) { return sm_compress24_f32(A, m, k, k, b, m * k, blob, st); }
+  static int mul_on(const void* blob, float* B, float* C, std::size_t m, std::size_t n, std::size_t k, std::size_t b, std::size_t sB, float al,
+                    float be, hipStream_t st) {
+    return sm_spmma_f32(blob, B, C, m, n, k, b, sB, m * n, al, be, st);
+  }
 };
 struct spmma_fns_f16 {
   static int prune(void* A, std::size_t m, std::size_t k) { return sm_prune24_f16(A, A, m, k, k, SM_PRUNE_TILE, nullptr); }
@@ -41,6 +47,12 @@ struct spmma_fns_f16 {
   static int compress(void* A, std::size_t m, std::size_t k, std::size_t b, void* blob) { return sm_compress24_f16(A, m, k, k, b, m * k, blob, nullptr); }
   static int mul(void* blob, void* B, void* C, std::size_t m, std::size_t n, std::size_t k, std::size_t b, float al, float be) {
     return sm_spmma_f16(blob, B, C, m, n, k, b, k * n, m * n, al, be, nullptr);
+  }
+  static int prune_on(void* A, std::size_t m, std::size_t k, hipStream_t st) { return sm_prune24_f16(A, A, m, k, k, SM_PRUNE_TILE, st); }
+  static int compress_on(void* A, std::size_t m, std::size_t k, std::size_t b, void* blob, hipStream_t st) { return sm_compress24_f16(A, m, k, k, b, m * k, blob, st); }
+  static int mul_on(const void* blob, void* B, void* C, std::size_t m, std::size_t n, std::size_t k, std::size_t b, std::size_t sB, float al,
+                    float be, hipStream_t st) {
+    return sm_spmma_f16(blob, B, C, m, n, k, b, sB, m * n, al, be, st);
   }
 };
 template <>
@@ -121,6 +133,46 @@ float spmma_fused(type_t* dA, type_t* dB, type_t* dC, std::size_t m, std::size_t
   if (rc != SM_STATUS_SUCCESS) std::cerr << "sparsifyme::spmma_fused: " << sm_last_error() << std::endl;
   return ms;
 }
+
+// Extension of this build ("cached-plan API"): the reference builds handle, descriptors, plan
+// and the compressed blob inside every spmma() call and times the allocation (spmma.hxx:51-80,101).  A plan owns the
+// blob for one (m, k, batch) operand: compress() once (optionally pruning A in place first, as spmma() does), then
+// multiply() any number of times against different B / C -- nothing is allocated, synchronised or re-compressed in the
+// loop, and every call only enqueues on the caller's stream.  The results are those of spmma() bit for bit.
+template <typename type_t>
+class spmma_plan_t {
+ public:
+  spmma_plan_t(std::size_t m, std::size_t k, std::size_t batch_size = 1) : m_(m), k_(k), batch_(batch_size ? batch_size : 1) {
+    std::size_t bytes = 0;
+    (void)sm_compress24_size(m_, k_, sizeof(type_t), batch_, &bytes);
+    blob_.resize(bytes);
+  }
+  std::size_t compressed_bytes() const { return blob_.size(); }
+  const void* compressed() const { return blob_.data().get(); }
+
+  // A: batch contiguous m x k matrices, row-major.  prune_in_place = true reproduces spmma(): A is pruned in place with
+  // the TILE rule and compressed; false leaves A untouched and keeps the two largest magnitudes of every 1 x 4 strip.
+  int compress(type_t* dA, bool prune_in_place = false, hipStream_t stream = nullptr) {
+    using fns = detail::spmma_fns<type_t>;
+    int rc = SM_STATUS_SUCCESS;
+    if (prune_in_place) rc = fns::prune_on(dA, m_ * batch_, k_, stream);
+    if (rc == SM_STATUS_SUCCESS) rc = fns::compress_on(dA, m_, k_, batch_, blob_.data().get(), stream);
+    ready_ = rc == SM_STATUS_SUCCESS;
+    return rc;
+  }
+  // C_b = alpha * A_b(2:4) * B_b + beta * C_b for every batch; strideB = 0 shares one B (the reference drivers' case).
+  int multiply(type_t* dB, type_t* dC, std::size_t n, float alpha = 1.0f, float beta = 0.0f, hipStream_t stream = nullptr,
+               std::ptrdiff_t strideB = -1) {
+    using fns = detail::spmma_fns<type_t>;
+    if (!ready_) return SM_STATUS_INVALID_VALUE;
+    return fns::mul_on(blob_.data().get(), dB, dC, m_, n, k_, batch_, strideB < 0 ? k_ * n : (std::size_t)strideB, alpha, beta, stream);
+  }
+
+ private:
+  std::size_t m_, k_, batch_;
+  device_vector<unsigned char> blob_;
+  bool ready_ = false;
+};
 
 namespace batched {}  // namespace batched
 }  // namespace sparsifyme
