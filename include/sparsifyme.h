@@ -184,6 +184,26 @@ int sm_spmm_coo_f32_ws(size_t A_num_rows, size_t A_num_cols, size_t A_nnz, size_
 int sm_fill_uniform_f16(void* out, size_t count, uint64_t seed, float lo, float hi, sm_stream_t stream);
 int sm_fill_uniform_f32(float* out, size_t count, uint64_t seed, float lo, float hi, sm_stream_t stream);
 
+/* ---- bfloat16 forms (extension; SURVEY.md 8(f) rank 2: the vendor call behind spmma.hxx:40-113 lists bf16 among its
+ *      2:4 types, examples/libcusparse_lt/include/cusparseLt.h:164-169).  Same arguments, blob layout and rules as the
+ *      _f16 entry points: the selection looks at magnitude bit patterns only, so prune (STRIP), check, compress and
+ *      decompress ARE the fp16 kernels; the TILE rule (sums of magnitudes), the matmuls (v_smfmac_f32_16x16x64_bf16 /
+ *      v_mfma_f32_16x16x32_bf16, fp32 accumulate) and the final round-to-nearest-even have their own code. */
+int sm_prune24_bf16(const void* A_in, void* A_out, size_t m, size_t k, size_t ld, int alg, sm_stream_t stream);
+int sm_prune24_check_bf16(const void* A, size_t m, size_t k, size_t ld, int* d_valid, sm_stream_t stream);
+int sm_compress24_bf16(const void* A, size_t m, size_t k, size_t ld, size_t batch, size_t strideA, void* blob,
+                       sm_stream_t stream);
+int sm_decompress24_bf16(const void* blob, size_t m, size_t k, size_t ld, size_t batch, size_t strideA, void* A,
+                         sm_stream_t stream);
+int sm_spmma_bf16(const void* blob, const void* B, void* C, size_t m, size_t n, size_t k, size_t batch,
+                  size_t strideB, size_t strideC, float alpha, float beta, sm_stream_t stream);
+int sm_spmma_fused_bf16(const void* A, const void* B, void* C, size_t m, size_t n, size_t k, size_t lda, size_t batch,
+                        size_t strideA, size_t strideB, size_t strideC, float alpha, float beta, sm_stream_t stream);
+int sm_gemm_rowmajor_bf16(const void* A, const void* B, void* C, size_t m, size_t n, size_t k, size_t lda,
+                          size_t batch, size_t strideA, size_t strideB, size_t strideC, float alpha, float beta,
+                          sm_stream_t stream);
+int sm_fill_uniform_bf16(void* out, size_t count, uint64_t seed, float lo, float hi, sm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -94,6 +94,22 @@ static uint16_t f2h(float f) {
   return (uint16_t)(sign | q);
 }
 
+/* bfloat16 (the upper half of an IEEE binary32) <-> fp32, round to nearest even; a NaN keeps its sign and upper
+ * payload bits and is made quiet, infinities and the exponent range carry over unchanged. */
+static float bf2f(uint16_t h) {
+  const uint32_t bits = (uint32_t)h << 16;
+  float f;
+  memcpy(&f, &bits, 4);
+  return f;
+}
+static uint16_t f2bf(float f) {
+  uint32_t x;
+  memcpy(&x, &f, 4);
+  if ((x & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((x >> 16) | 0x0040u);
+  x += 0x7fffu + ((x >> 16) & 1u); /* ties to even; a carry into the exponent (up to inf) is the right result */
+  return (uint16_t)(x >> 16);
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* (a1) positional sparsify -- restates include/sparsify.me/sparsify.hxx:32-81                 */
 /* ------------------------------------------------------------------------------------------ */
@@ -216,6 +232,10 @@ static inline float mag16(uint16_t v) {
   uint32_t k = key16(v);
   return k > 0x7c00u ? INFINITY : h2f((uint16_t)k);
 }
+static inline float magbf(uint16_t v) {
+  uint32_t k = key16(v);
+  return k > 0x7f80u ? INFINITY : bf2f((uint16_t)k);
+}
 static inline float mag32(uint32_t v) {
   uint32_t k = key32(v);
   if (k > 0x7f800000u) return INFINITY;
@@ -274,6 +294,9 @@ static inline float mag32(uint32_t v) {
 
 DEFINE_PRUNE(sm_prune24_f16_ref, uint16_t, key16, mag16)
 DEFINE_PRUNE(sm_prune24_f32_bits_ref, uint32_t, key32, mag32)
+/* bfloat16 (extension of the build): magnitudes order by bit pattern exactly as fp16's do, so
+ * the STRIP rule is the same function of the bits; the TILE rule sums bfloat16 magnitudes */
+DEFINE_PRUNE(sm_prune24_bf16_ref, uint16_t, key16, magbf)
 
 int sm_prune24_f32_ref(const float* A_in, float* A_out, size_t m, size_t k, size_t ld, int alg) {
   return sm_prune24_f32_bits_ref((const uint32_t*)A_in, (uint32_t*)A_out, m, k, ld, alg);
@@ -476,6 +499,12 @@ int sm_spmma_f16_ref(const void* blob, const uint16_t* B, uint16_t* C, size_t m,
                      size_t batch, size_t strideB, size_t strideC, float alpha, float beta) {
   return spmma_ref_impl(blob, B, C, m, n, k, batch, strideB, strideC, alpha, beta, 2, ld16, st16);
 }
+static double ldbf(const void* p, size_t i) { return (double)bf2f(((const uint16_t*)p)[i]); }
+static void stbf(void* p, size_t i, double v) { ((uint16_t*)p)[i] = f2bf((float)v); }
+int sm_spmma_bf16_ref(const void* blob, const uint16_t* B, uint16_t* C, size_t m, size_t n, size_t k,
+                      size_t batch, size_t strideB, size_t strideC, float alpha, float beta) {
+  return spmma_ref_impl(blob, B, C, m, n, k, batch, strideB, strideC, alpha, beta, 2, ldbf, stbf);
+}
 int sm_spmma_f32_ref(const void* blob, const float* B, float* C, size_t m, size_t n, size_t k,
                      size_t batch, size_t strideB, size_t strideC, float alpha, float beta) {
   return spmma_ref_impl(blob, B, C, m, n, k, batch, strideB, strideC, alpha, beta, 4, ld32, st32);
@@ -562,6 +591,11 @@ int sm_gemm_rowmajor_f16_ref(const uint16_t* A, const uint16_t* B, uint16_t* C, 
                              size_t k, size_t lda, size_t batch, size_t strideA, size_t strideB,
                              size_t strideC, float alpha, float beta) {
   return gemm_rm_impl(A, B, C, m, n, k, lda, batch, strideA, strideB, strideC, alpha, beta, ld16, st16);
+}
+int sm_gemm_rowmajor_bf16_ref(const uint16_t* A, const uint16_t* B, uint16_t* C, size_t m, size_t n,
+                              size_t k, size_t lda, size_t batch, size_t strideA, size_t strideB,
+                              size_t strideC, float alpha, float beta) {
+  return gemm_rm_impl(A, B, C, m, n, k, lda, batch, strideA, strideB, strideC, alpha, beta, ldbf, stbf);
 }
 int sm_gemm_rowmajor_f32_ref(const float* A, const float* B, float* C, size_t m, size_t n, size_t k,
                              size_t lda, size_t batch, size_t strideA, size_t strideB,
@@ -686,6 +720,12 @@ int sm_cpu_spmma_f32(const float* A, const float* B, float* C, size_t m, size_t 
 void sm_widen_f16(const uint16_t* in, float* out, size_t count) {
 #pragma omp parallel for schedule(static)
   for (long long i = 0; i < (long long)count; ++i) out[i] = h2f(in[i]);
+}
+void sm_widen_bf16(const uint16_t* in, float* out, size_t count) {
+  for (size_t i = 0; i < count; ++i) out[i] = bf2f(in[i]);
+}
+void sm_narrow_bf16(const float* in, uint16_t* out, size_t count) {
+  for (size_t i = 0; i < count; ++i) out[i] = f2bf(in[i]);
 }
 void sm_narrow_f16(const float* in, uint16_t* out, size_t count) {
 #pragma omp parallel for schedule(static)

@@ -60,10 +60,11 @@ def sparsify_positional(weights, mask, m, n, sparsity_factor=0.5, blk_m=2, blk_n
                                          _sz(blk_m), _sz(blk_n), ctypes.c_float(sparsity_factor)), "sparsify_positional")
 
 
-def prune24(A, m, k, ld, alg=STRIP):
-    """Returns the pruned copy of row-major A (shape-agnostic flat buffer of >= (m-1)*ld + k elements)."""
+def prune24(A, m, k, ld, alg=STRIP, bf16=False):
+    """Returns the pruned copy of row-major A (shape-agnostic flat buffer of >= (m-1)*ld + k elements).
+    bf16=True: the uint16 bit patterns are bfloat16 (matters for the TILE rule only)."""
     out = A.copy()
-    fn = getattr(lib(), "sm_prune24_%s_ref" % _sfx(A))
+    fn = getattr(lib(), "sm_prune24_%s_ref" % ("bf16" if bf16 else _sfx(A)))
     _ok(fn(_p(A), _p(out), _sz(m), _sz(k), _sz(ld), ctypes.c_int(alg)), "prune24")
     return out
 
@@ -104,10 +105,10 @@ def decompress24(blob, m, k, ld, dtype, batch=1, strideA=None):
     return A
 
 
-def spmma(blob, B, C, m, n, k, batch=1, strideB=0, strideC=None, alpha=1.0, beta=0.0):
-    """C updated in place (fp64 accumulation)."""
+def spmma(blob, B, C, m, n, k, batch=1, strideB=0, strideC=None, alpha=1.0, beta=0.0, bf16=False):
+    """C updated in place (fp64 accumulation).  bf16=True: B, C and the blob's values are bfloat16 bit patterns."""
     strideC = m * n if strideC is None else strideC
-    fn = getattr(lib(), "sm_spmma_%s_ref" % _sfx(B))
+    fn = getattr(lib(), "sm_spmma_%s_ref" % ("bf16" if bf16 else _sfx(B)))
     _ok(fn(_p(blob), _p(B), _p(C), _sz(m), _sz(n), _sz(k), _sz(batch), _sz(strideB), _sz(strideC),
            ctypes.c_float(alpha), ctypes.c_float(beta)), "spmma")
     return C
@@ -125,11 +126,11 @@ def gemm_batched(As, Bs, Cs, m, n, k, alpha=1.0, beta=0.0, ta=0, tb=0):
     return Cs
 
 
-def gemm_rowmajor(A, B, C, m, n, k, lda=None, batch=1, strideA=None, strideB=0, strideC=None, alpha=1.0, beta=0.0):
+def gemm_rowmajor(A, B, C, m, n, k, lda=None, batch=1, strideA=None, strideB=0, strideC=None, alpha=1.0, beta=0.0, bf16=False):
     lda = k if lda is None else lda
     strideA = m * lda if strideA is None else strideA
     strideC = m * n if strideC is None else strideC
-    fn = getattr(lib(), "sm_gemm_rowmajor_%s_ref" % _sfx(A))
+    fn = getattr(lib(), "sm_gemm_rowmajor_%s_ref" % ("bf16" if bf16 else _sfx(A)))
     _ok(fn(_p(A), _p(B), _p(C), _sz(m), _sz(n), _sz(k), _sz(lda), _sz(batch), _sz(strideA), _sz(strideB),
            _sz(strideC), ctypes.c_float(alpha), ctypes.c_float(beta)), "gemm_rowmajor")
     return C

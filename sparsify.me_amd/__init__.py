@@ -70,6 +70,10 @@ _SIGS = {
     "sm_fill_uniform_f16": [_c_ptr, _c_size, ctypes.c_uint64, _c_f, _c_f, _c_ptr],
     "sm_fill_uniform_f32": [_c_ptr, _c_size, ctypes.c_uint64, _c_f, _c_f, _c_ptr],
 }
+# bfloat16 forms: same signatures as their _f16 counterparts
+for _name in ("sm_prune24", "sm_prune24_check", "sm_compress24", "sm_decompress24", "sm_spmma", "sm_spmma_fused",
+              "sm_gemm_rowmajor", "sm_fill_uniform"):
+    _SIGS[_name + "_bf16"] = _SIGS[_name + "_f16"]
 _RET = {"sm_version": ctypes.c_char_p, "sm_last_error": ctypes.c_char_p}
 
 # every symbol include/sparsifyme.h declares (checked by tests/test_abi.py without a GPU)
@@ -124,7 +128,7 @@ def _t():
     if _torch is None:
         import torch
         _torch = torch
-        _SFX = {torch.float16: "f16", torch.float32: "f32", torch.float64: "f64"}
+        _SFX = {torch.float16: "f16", torch.bfloat16: "bf16", torch.float32: "f32", torch.float64: "f64"}
     return _torch
 
 
@@ -224,8 +228,9 @@ def spmma_fused(A, B, C, m, n, k, lda=None, batch=1, strideA=None, strideB=0, st
     lda = k if lda is None else lda
     strideA = m * lda if strideA is None else strideA
     strideC = m * n if strideC is None else strideC
-    _check(lib().sm_spmma_fused_f16(_dev(A), _dev(B), _dev(C), m, n, k, lda, batch, strideA, strideB, strideC,
-                                    float(alpha), float(beta), _stream()), "sm_spmma_fused_f16")
+    fn = getattr(lib(), "sm_spmma_fused_" + _sfx(A))
+    _check(fn(_dev(A), _dev(B), _dev(C), m, n, k, lda, batch, strideA, strideB, strideC, float(alpha), float(beta), _stream()),
+           "sm_spmma_fused")
 
 
 def gemm_batched(A_ptrs, B_ptrs, C_ptrs, m, n, k, batch, dtype_suffix, alpha=1.0, beta=0.0, ta=0, tb=0):

@@ -77,6 +77,9 @@ int sm_device_check(void) {
 int sm_fill_uniform_f16(void* out, size_t count, uint64_t seed, float lo, float hi, sm_stream_t s) {
   return sm::launch_fill<_Float16>(out, count, seed, lo, hi, (hipStream_t)s);
 }
+int sm_fill_uniform_bf16(void* out, size_t count, uint64_t seed, float lo, float hi, sm_stream_t s) {
+  return sm::launch_fill<__bf16>(out, count, seed, lo, hi, (hipStream_t)s);
+}
 int sm_fill_uniform_f32(float* out, size_t count, uint64_t seed, float lo, float hi, sm_stream_t s) {
   return sm::launch_fill<float>(out, count, seed, lo, hi, (hipStream_t)s);
 }

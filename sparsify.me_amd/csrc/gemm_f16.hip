@@ -60,7 +60,7 @@ __device__ __forceinline__ u4 load_chunk(const half_t* rowp, int col, int limit,
 // TA: the A operand is given M-contiguous (element (r, kk) at A[kk * lda + r]); TB: the B operand is given K-contiguous
 // (element (kk, c) at B[c * ldb + kk]) -- the transposed operands of sm_gemm_batched_f16.  The 16-byte chunks then run
 // along the contiguous direction and are scattered into the same LDS images with 2-byte writes.
-template <int BM, int BN, int WM, int WN, int VEC, bool TA = false, bool TB = false>
+template <int BM, int BN, int WM, int WN, int VEC, bool TA = false, bool TB = false, bool BF = false>
 __global__ __launch_bounds__(256) void gemm_f16_kernel(const GemmArgs p) {
   static_assert(WM * WN == 4, "4 waves");
   constexpr int TM = BM / WM, TN = BN / WN, FM = TM / 16, FN = TN / 16;
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(const GemmArgs p) {
         for (int j = 0; j < FN; ++j)
           // operands swapped: D = B^T-fragment x A^T-fragment = (A*B)^T tile, i.e. this lane holds
           // C[row (lane&15)][cols 4*(lane>>4) .. +3] of fragment (i, j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
+          acc[i][j] = mfma16<BF>(bf[j], af[i], acc[i][j]);
     }
     __syncthreads();
   }
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(const GemmArgs p) {
         const unsigned row = wm * TM + i * 16 + (lane & 15u), col = wn * TN + j * 16 + 4u * (lane >> 4);
         h4 o;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = (half_t)(p.alpha * acc[i][j][r]);
+        for (int r = 0; r < 4; ++r) o[r] = to_elt<BF>(p.alpha * acc[i][j][r]);
         *reinterpret_cast<h4*>(Cs + row * CPITCH + col * 2) = o;
       }
     __syncthreads();
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(const GemmArgs p) {
         if (p.beta == 0.0f && c8 && gc + 4 <= p.N) {  // four consecutive n of one row: one 8-byte store
           h4 o;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) o[r] = (half_t)(p.alpha * acc[i][j][r]);
+          for (int r = 0; r < 4; ++r) o[r] = to_elt<BF>(p.alpha * acc[i][j][r]);
           *reinterpret_cast<h4*>(C + (size_t)gr * p.ldc + gc) = o;
           continue;
         }
@@ -232,8 +232,8 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(const GemmArgs p) {
           if (gc + r >= p.N) continue;
           half_t* dst = C + (size_t)gr * p.ldc + gc + r;
           float v = p.alpha * acc[i][j][r];
-          if (p.beta != 0.0f) v += p.beta * (float)*dst;
-          *dst = (half_t)v;
+          if (p.beta != 0.0f) v += p.beta * to_f32<BF>(*dst);
+          *dst = to_elt<BF>(v);
         }
       }
   }
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(const GemmArgs p) {
 // lane-linear for the DMA with the swizzle on the per-lane source address.  Edge rows / columns are
 // clamped to the last valid one (their products land in outputs that are never stored).
 // ---------------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, int NS>
+template <int BM, int BN, int WM, int WN, int NS, bool BF = false>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_dma_kernel(const GemmArgs p) {
   constexpr int NW = WM * WN;
   static_assert(NW == 4 || NW == 8 || NW == 16, "4, 8 or 16 waves");
@@ -358,7 +358,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_dma_kernel(const GemmAr
         const h8 bf = __builtin_bit_cast(h8, both);
 #pragma unroll
         for (int i = 0; i < FM; ++i)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf, af[i], acc[i][j], 0, 0, 0);  // swapped: C^T layout
+          acc[i][j] = mfma16<BF>(bf, af[i], acc[i][j]);  // swapped: C^T layout
       }
     }
     cur = cur + 1 == NS ? 0 : cur + 1;
@@ -381,7 +381,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_dma_kernel(const GemmAr
         const unsigned row = wm * TM + i * 16 + r, col = wn * TN + j * 16 + 4u * g;
         h4 o;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) o[q] = (half_t)(p.alpha * acc[i][j][q]);
+        for (int q = 0; q < 4; ++q) o[q] = to_elt<BF>(p.alpha * acc[i][j][q]);
         *reinterpret_cast<h4*>(Cs + row * CPITCH + col * 2) = o;
       }
     __syncthreads();
@@ -413,14 +413,14 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_dma_kernel(const GemmAr
           if (gc + q >= p.N) continue;
           half_t* dst = C + (size_t)gr * p.ldc + gc + q;
           float v = p.alpha * acc[i][j][q];
-          if (p.beta != 0.0f) v += p.beta * (float)*dst;
-          *dst = (half_t)v;
+          if (p.beta != 0.0f) v += p.beta * to_f32<BF>(*dst);
+          *dst = to_elt<BF>(v);
         }
       }
   }
 }
 
-template <int BM, int BN, int WM, int WN, int NS>
+template <int BM, int BN, int WM, int WN, int NS, bool BF = false>
 static int launch_dma(const GemmArgs& a0, hipStream_t st) {
   GemmArgs a = a0;
   a.tiles_m = (a.M + BM - 1) / BM;
@@ -436,15 +436,15 @@ static int launch_dma(const GemmArgs& a0, hipStream_t st) {
   constexpr size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
   static bool attr_set = false;
   if (lds > 64 * 1024 && !attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16_dma_kernel<BM, BN, WM, WN, NS>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16_dma_kernel<BM, BN, WM, WN, NS, BF>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  gemm_f16_dma_kernel<BM, BN, WM, WN, NS><<<dim3((unsigned)nwg), dim3(64 * WM * WN), lds, st>>>(a);
+  gemm_f16_dma_kernel<BM, BN, WM, WN, NS, BF><<<dim3((unsigned)nwg), dim3(64 * WM * WN), lds, st>>>(a);
   return check_launch("gemm_f16_dma_kernel");
 }
 
-template <int BM, int BN, int WM, int WN, bool TA = false, bool TB = false>
+template <int BM, int BN, int WM, int WN, bool TA = false, bool TB = false, bool BF = false>
 static int launch_cfg(const GemmArgs& a0, int vec, hipStream_t st) {
   GemmArgs a = a0;
   a.tiles_m = (a.M + BM - 1) / BM;
@@ -459,16 +459,17 @@ static int launch_cfg(const GemmArgs& a0, int vec, hipStream_t st) {
   constexpr size_t lds_epi = (size_t)BM * (BN * 2 + 16);
   constexpr size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
   if (vec == 8)
-    gemm_f16_kernel<BM, BN, WM, WN, 8, TA, TB><<<dim3((unsigned)nwg), dim3(256), lds, st>>>(a);
+    gemm_f16_kernel<BM, BN, WM, WN, 8, TA, TB, BF><<<dim3((unsigned)nwg), dim3(256), lds, st>>>(a);
   else if (vec == 4 && !TA && !TB)
-    gemm_f16_kernel<BM, BN, WM, WN, 4><<<dim3((unsigned)nwg), dim3(256), lds, st>>>(a);
+    gemm_f16_kernel<BM, BN, WM, WN, 4, false, false, BF><<<dim3((unsigned)nwg), dim3(256), lds, st>>>(a);
   else
-    gemm_f16_kernel<BM, BN, WM, WN, 1, TA, TB><<<dim3((unsigned)nwg), dim3(256), lds, st>>>(a);
+    gemm_f16_kernel<BM, BN, WM, WN, 1, TA, TB, BF><<<dim3((unsigned)nwg), dim3(256), lds, st>>>(a);
   return check_launch("gemm_f16_kernel");
 }
 
 // Tile choice: the streamed dimension gets the long tile edge; narrow problems get a tile as wide
 // as they are, so the big operand is read from HBM exactly once.
+template <bool BF = false>
 static int launch_gemm_f16(const GemmArgs& a, hipStream_t st, bool ta = false, bool tb = false) {
   auto aligned_to = [&](unsigned halves) {
     const uintptr_t mask = halves * 2u - 1u;
@@ -476,9 +477,11 @@ static int launch_gemm_f16(const GemmArgs& a, hipStream_t st, bool ta = false, b
            (a.Ap || (reinterpret_cast<uintptr_t>(a.A) & mask) == 0) && (a.Bp || (reinterpret_cast<uintptr_t>(a.B) & mask) == 0);
   };
   const int vec = aligned_to(8) ? 8 : (aligned_to(4) ? 4 : 1);
-  if (ta && tb) return launch_cfg<128, 128, 2, 2, true, true>(a, vec, st);
-  if (ta) return launch_cfg<128, 128, 2, 2, true, false>(a, vec, st);
-  if (tb) return launch_cfg<128, 128, 2, 2, false, true>(a, vec, st);
+  if constexpr (!BF) {  // transposed operands: batched::gemm only, which has no bfloat16 form
+    if (ta && tb) return launch_cfg<128, 128, 2, 2, true, true>(a, vec, st);
+    if (ta) return launch_cfg<128, 128, 2, 2, true, false>(a, vec, st);
+    if (tb) return launch_cfg<128, 128, 2, 2, false, true>(a, vec, st);
+  }
   // pointer-array batches: per-batch base alignment is the caller's (hipMalloc gives 256 B);
   // DMA fast path: whole 64-deep K stages, N a multiple of 4 (a half-valid last chunk is served from columns
   // N-8 .. N-1, see the kernel's epilogue), rows on 8-byte boundaries (a
@@ -487,13 +490,13 @@ static int launch_gemm_f16(const GemmArgs& a, hipStream_t st, bool ta = false, b
                     (a.sA % 4 == 0) && (a.sB % 4 == 0) && (a.Ap || (reinterpret_cast<uintptr_t>(a.A) & 7u) == 0) &&
                     (a.Bp || (reinterpret_cast<uintptr_t>(a.B) & 7u) == 0);
   if (fast) {
-    if (a.N <= 64) return launch_dma<128, 64, 4, 1, 2>(a, st);
-    if (a.M <= 64) return launch_dma<64, 128, 1, 4, 2>(a, st);
-    return launch_dma<128, 128, 2, 2, 2>(a, st);
+    if (a.N <= 64) return launch_dma<128, 64, 4, 1, 2, BF>(a, st);
+    if (a.M <= 64) return launch_dma<64, 128, 1, 4, 2, BF>(a, st);
+    return launch_dma<128, 128, 2, 2, 2, BF>(a, st);
   }
-  if (a.N <= 64) return launch_cfg<128, 64, 4, 1>(a, vec, st);
-  if (a.M <= 64) return launch_cfg<64, 128, 1, 4>(a, vec, st);
-  return launch_cfg<128, 128, 2, 2>(a, vec, st);
+  if (a.N <= 64) return launch_cfg<128, 64, 4, 1, false, false, BF>(a, vec, st);
+  if (a.M <= 64) return launch_cfg<64, 128, 1, 4, false, false, BF>(a, vec, st);
+  return launch_cfg<128, 128, 2, 2, false, false, BF>(a, vec, st);
 }
 
 }  // namespace sm
@@ -502,16 +505,19 @@ using namespace sm;
 
 extern "C" {
 
-int sm_gemm_rowmajor_f16(const void* A, const void* B, void* C, size_t m, size_t n, size_t k, size_t lda,
-                         size_t batch, size_t strideA, size_t strideB, size_t strideC, float alpha, float beta,
-                         sm_stream_t stream) {
+}  // extern "C"
+
+template <bool BF>
+static int gemm_rowmajor16(const void* A, const void* B, void* C, size_t m, size_t n, size_t k, size_t lda,
+                           size_t batch, size_t strideA, size_t strideB, size_t strideC, float alpha, float beta,
+                           sm_stream_t stream) {
   if (!A || !B || !C || lda < k) {
-    set_error("sm_gemm_rowmajor_f16: invalid argument");
+    set_error("sm_gemm_rowmajor_{f16,bf16}: invalid argument");
     return SM_STATUS_INVALID_VALUE;
   }
   if (m == 0 || n == 0 || batch == 0) return SM_STATUS_SUCCESS;
   if (m * batch > 0x7fffffffull || n > 0x7fffffffull || k > 0x7fffffffull || lda > 0x7fffffffull) {
-    set_error("sm_gemm_rowmajor_f16: dimension exceeds 2^31-1");
+    set_error("sm_gemm_rowmajor_{f16,bf16}: dimension exceeds 2^31-1");
     return SM_STATUS_NOT_SUPPORTED;
   }
   GemmArgs a = {};
@@ -525,7 +531,21 @@ int sm_gemm_rowmajor_f16(const void* A, const void* B, void* C, size_t m, size_t
     a.M = (int)(m * batch);
     a.batch = 1;
   }
-  return launch_gemm_f16(a, (hipStream_t)stream);
+  return launch_gemm_f16<BF>(a, (hipStream_t)stream);
+}
+
+extern "C" {
+
+int sm_gemm_rowmajor_f16(const void* A, const void* B, void* C, size_t m, size_t n, size_t k, size_t lda,
+                         size_t batch, size_t strideA, size_t strideB, size_t strideC, float alpha, float beta,
+                         sm_stream_t stream) {
+  return gemm_rowmajor16<false>(A, B, C, m, n, k, lda, batch, strideA, strideB, strideC, alpha, beta, stream);
+}
+/* bfloat16 form of the same kernels (v_mfma_f32_16x16x32_bf16): the dense denominator of sm_spmma_bf16 */
+int sm_gemm_rowmajor_bf16(const void* A, const void* B, void* C, size_t m, size_t n, size_t k, size_t lda,
+                          size_t batch, size_t strideA, size_t strideB, size_t strideC, float alpha, float beta,
+                          sm_stream_t stream) {
+  return gemm_rowmajor16<true>(A, B, C, m, n, k, lda, batch, strideA, strideB, strideC, alpha, beta, stream);
 }
 
 int sm_gemm_batched_f16(const void* const* A_ptrs, const void* const* B_ptrs, void* const* C_ptrs, size_t m,

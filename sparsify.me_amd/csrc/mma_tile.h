@@ -50,12 +50,38 @@ __device__ __forceinline__ s4 b_read_tr(const char* Bs, unsigned kr0, unsigned c
 // 64-byte-row A image: 16-byte chunk c of row r lives at chunk c ^ ((-(r >> 2)) & 3).
 __device__ __forceinline__ unsigned a64_swz(unsigned row) { return (0u - (row >> 2)) & 3u; }
 
+// ---- the two 16-bit element types.  Kernels keep `half_t` as the 16-bit storage type and take `bool BF`: false =
+//      IEEE fp16, true = bfloat16 (same blob, same selection -- it only looks at the magnitude bits -- other matrix
+//      instruction and other rounding at the end).  Conversions round to nearest even, once.
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x16 __attribute__((ext_vector_type(16)));
+template <bool BF>
+__device__ __forceinline__ half_t to_elt(float x) {
+  if constexpr (BF) return __builtin_bit_cast(half_t, (__bf16)x);  // v_cvt_pk_bf16_f32
+  else return (half_t)x;
+}
+template <bool BF>
+__device__ __forceinline__ float to_f32(half_t x) {
+  if constexpr (BF) return __builtin_bit_cast(float, (uint32_t)__builtin_bit_cast(unsigned short, x) << 16);
+  else return (float)x;
+}
+template <bool BF>
+__device__ __forceinline__ f4 smfmac16(h8 a, h16 b, f4 c, int idx) {
+  if constexpr (BF) return __builtin_amdgcn_smfmac_f32_16x16x64_bf16(__builtin_bit_cast(bf8, a), __builtin_bit_cast(bf16x16, b), c, idx, 0, 0);
+  else return __builtin_amdgcn_smfmac_f32_16x16x64_f16(a, b, c, idx, 0, 0);
+}
+template <bool BF>
+__device__ __forceinline__ f4 mfma16(h8 a, h8 b, f4 c) {
+  if constexpr (BF) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8, a), __builtin_bit_cast(bf8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+
 // One 64-deep stage of the 2:4 matmul for one consumer wave (wave tile 16*FM x 16*FN at rows row0.., columns col0..
 // of the workgroup tile): A fragments + index halfwords from the 64-byte-row image `As` / its metadata `Ms`, B
 // fragments from the row-major [64][BN] image `Bs` through ds_read_b64_tr_b16, FM x FN v_smfmac_f32_16x16x64_f16.
 // The transposing reads are issued by hand (inline asm, counted lgkmcnt): the compiler would drain the in-flight DMA
 // (vmcnt(0)) in front of the intrinsic form; fragment j+1's four reads are in flight while fragment j's SMFMACs run.
-template <int FM, int FN>
+template <int FM, int FN, bool BF = false>
 __device__ __forceinline__ void smfmac_stage(const char* As, const char* Ms, const char* Bs, unsigned row0, unsigned col0,
                                              unsigned lane, f4 (&acc)[FM][FN]) {
   const unsigned g = lane >> 4, r = lane & 15u;
@@ -92,7 +118,7 @@ __device__ __forceinline__ void smfmac_stage(const char* As, const char* Ms, con
                      t2[c][0], t2[c][1], t2[c][2], t2[c][3], t3[c][0], t3[c][1], t3[c][2], t3[c][3]};
     const h16 bf = __builtin_bit_cast(h16, all);
 #pragma unroll
-    for (int i = 0; i < FM; ++i) acc[i][j] = __builtin_amdgcn_smfmac_f32_16x16x64_f16(af[i], bf, acc[i][j], idx[i], 0, 0);
+    for (int i = 0; i < FM; ++i) acc[i][j] = smfmac16<BF>(af[i], bf, acc[i][j], idx[i]);
   }
 }
 
@@ -100,7 +126,7 @@ __device__ __forceinline__ void smfmac_stage(const char* As, const char* Ms, con
 // at chunk c ^ (r & 7), a_off), and the lane that would read 8 compressed halves + 4 nibbles reads its 16 dense halves
 // (two ds_read_b128) and selects in registers (select24.h): four strips -> the A operand and the index halfword of
 // v_smfmac_f32_16x16x64_f16.  No compressed image, no metadata, no selecting loader waves.
-template <int FM, int FN>
+template <int FM, int FN, bool BF = false>
 __device__ __forceinline__ void smfmac_stage_dense_a(const char* Araw, const char* Bs, unsigned row0, unsigned col0,
                                                      unsigned lane, f4 (&acc)[FM][FN]) {
   const unsigned g = lane >> 4, r = lane & 15u;
@@ -144,7 +170,7 @@ __device__ __forceinline__ void smfmac_stage_dense_a(const char* Araw, const cha
                      t2[c][0], t2[c][1], t2[c][2], t2[c][3], t3[c][0], t3[c][1], t3[c][2], t3[c][3]};
     const h16 bf = __builtin_bit_cast(h16, all);
 #pragma unroll
-    for (int i = 0; i < FM; ++i) acc[i][j] = __builtin_amdgcn_smfmac_f32_16x16x64_f16(af[i], bf, acc[i][j], idx[i], 0, 0);
+    for (int i = 0; i < FM; ++i) acc[i][j] = smfmac16<BF>(af[i], bf, acc[i][j], idx[i]);
   }
 }
 
@@ -154,7 +180,7 @@ __device__ __forceinline__ void smfmac_stage_dense_a(const char* Araw, const cha
 // pieces by all NT threads; otherwise (beta != 0, misaligned C) each accumulator wave stores its elements itself,
 // reading C once: one rounding of alpha * acc + beta * C to fp16 either way.  `has_acc`: this wave holds a tile
 // (loader waves of the producer/consumer kernels do not); row0/col0: its tile inside the workgroup tile.
-template <int BM, int BN, int FM, int FN, int NT>
+template <int BM, int BN, int FM, int FN, int NT, bool BF = false>
 __device__ __forceinline__ void store_c_tile(char* smem, half_t* C, const f4 (&acc)[FM][FN], bool has_acc, unsigned row0,
                                              unsigned col0, int m0, int n0, int Mrows, int N, float alpha, float beta,
                                              unsigned tid) {
@@ -170,7 +196,7 @@ __device__ __forceinline__ void store_c_tile(char* smem, half_t* C, const f4 (&a
           const unsigned row = row0 + i * 16 + 4u * g, col = col0 + j * 16 + r;
 #pragma unroll
           for (int q = 0; q < 4; ++q)
-            *reinterpret_cast<half_t*>(smem + (row + q) * CPITCH + col * 2) = (half_t)(alpha * acc[i][j][q]);
+            *reinterpret_cast<half_t*>(smem + (row + q) * CPITCH + col * 2) = to_elt<BF>(alpha * acc[i][j][q]);
         }
     }
     __syncthreads();
@@ -196,8 +222,8 @@ __device__ __forceinline__ void store_c_tile(char* smem, half_t* C, const f4 (&a
           if (gr >= Mrows) continue;
           half_t* dst = C + (size_t)gr * N + gc;
           float v = alpha * acc[i][j][q];
-          if (beta != 0.0f) v += beta * (float)*dst;
-          *dst = (half_t)v;
+          if (beta != 0.0f) v += beta * to_f32<BF>(*dst);
+          *dst = to_elt<BF>(v);
         }
       }
   }

@@ -18,10 +18,22 @@ __device__ __forceinline__ float mag_of(uint16_t v) {
   if (k > 0x7c00u) return __builtin_inff();
   return (float)__builtin_bit_cast(_Float16, k);
 }
+// bfloat16 magnitude (the TILE rule adds magnitudes; the STRIP rule, compress and check only compare bit patterns and
+// are shared with fp16 as they are)
+__device__ __forceinline__ float mag_of_bf16(uint16_t v) {
+  const uint32_t k = v & 0x7fffu;
+  if (k > 0x7f80u) return __builtin_inff();
+  return __builtin_bit_cast(float, k << 16);
+}
 __device__ __forceinline__ float mag_of(uint32_t v) {
   const uint32_t k = v & 0x7fffffffu;
   if (k > 0x7f800000u) return __builtin_inff();
   return __builtin_bit_cast(float, k);
+}
+template <bool BF, typename T>
+__device__ __forceinline__ float mag_sel(T v) {
+  if constexpr (BF) return mag_of_bf16(v);
+  else return mag_of(v);
 }
 
 // TILE rule: 16-bit keep mask (bit 4*r + c) of the best of the 90 candidates.
@@ -228,7 +240,7 @@ __global__ __launch_bounds__(256) void prune_strip_kernel(const T* A_in, T* A_ou
 // ---------------------------------------------------------------------------------------------
 // (a2) prune TILE: item = one 4x4 tile (K3 of SURVEY.md 2.2, the variant spmma.hxx:86 asks for)
 // ---------------------------------------------------------------------------------------------
-template <typename T>
+template <typename T, bool BF = false>
 __global__ __launch_bounds__(256) void prune_tile_kernel(const T* A_in, T* A_out, size_t m, size_t k,
                                                          size_t ld, bool vec_ok) {
   const size_t tpr = (k + 3) / 4, trows = (m + 3) / 4;
@@ -254,7 +266,7 @@ __global__ __launch_bounds__(256) void prune_tile_kernel(const T* A_in, T* A_out
         for (unsigned t = 0; t < 4; ++t) v[r][t] = (rv && t < ncol) ? p[t] : (T)0;
       }
 #pragma unroll
-      for (unsigned t = 0; t < 4; ++t) mag[r][t] = mag_of(v[r][t]);
+      for (unsigned t = 0; t < 4; ++t) mag[r][t] = mag_sel<BF>(v[r][t]);
     }
     const unsigned keep = tile_keepmask(mag);
 #pragma unroll
@@ -282,7 +294,7 @@ __global__ __launch_bounds__(256) void prune_tile_kernel(const T* A_in, T* A_out
 // Fast path of TILE: 4 rows x 8 columns (two tiles) per thread, 16-byte (fp16) / 2 x 16-byte (fp32) accesses, the
 // adds of both tiles packed (tile_keepmask2).  Needs k % 8 == 0 and aligned rows; row tails (m % 4) are zero-filled
 // on load and skipped on store.
-template <typename T>
+template <typename T, bool BF = false>
 __global__ __launch_bounds__(256) void prune_tile2_kernel(const T* __restrict__ A_in, T* __restrict__ A_out, size_t m,
                                                           size_t k, size_t ld) {
   const size_t ppr = k / 8, trows = (m + 3) / 4;
@@ -301,7 +313,7 @@ __global__ __launch_bounds__(256) void prune_tile2_kernel(const T* __restrict__ 
         for (unsigned t = 0; t < 8; ++t) v[r].e[t] = 0;
       }
 #pragma unroll
-      for (unsigned t = 0; t < 4; ++t) mag[r][t] = f2{mag_of(v[r].e[t]), mag_of(v[r].e[4 + t])};
+      for (unsigned t = 0; t < 4; ++t) mag[r][t] = f2{mag_sel<BF>(v[r].e[t]), mag_sel<BF>(v[r].e[4 + t])};
     }
     unsigned keep0, keep1;
     tile_keepmask2(mag, keep0, keep1);
@@ -592,7 +604,7 @@ static bool vec_ok_2d(const void* a, const void* b, size_t ld, size_t stride) {
   return aligned16(a) && aligned16(b) && ld % per16 == 0 && stride % per16 == 0;
 }
 
-template <typename T>
+template <typename T, bool BF = false>
 static int launch_prune(const void* A_in, void* A_out, size_t m, size_t k, size_t ld, int alg, hipStream_t st) {
   if (!A_in || !A_out || ld < k || (alg != SM_PRUNE_TILE && alg != SM_PRUNE_STRIP)) {
     set_error("sm_prune24: invalid argument");
@@ -611,10 +623,10 @@ static int launch_prune(const void* A_in, void* A_out, size_t m, size_t k, size_
   // fp16 is bound by the rule's arithmetic (two tiles per thread with packed adds: 3.76 -> 3.20 ms on the ResNet-50
   // table); fp32 moves twice the bytes for the same arithmetic and stays on the one-tile kernel (5.1 TB/s)
   if (sizeof(T) == 2 && k % 8 == 0 && vec_ok_2d<T>(A_in, A_out, ld, 0)) {
-    prune_tile2_kernel<T><<<stream_grid(ceil_div(m, 4) * (k / 8), 256), 256, 0, st>>>((const T*)A_in, (T*)A_out, m, k, ld);
+    prune_tile2_kernel<T, BF><<<stream_grid(ceil_div(m, 4) * (k / 8), 256), 256, 0, st>>>((const T*)A_in, (T*)A_out, m, k, ld);
     return check_launch("prune_tile2_kernel");
   }
-  prune_tile_kernel<T><<<stream_grid(ceil_div(m, 4) * ceil_div(k, 4), 256), 256, 0, st>>>((const T*)A_in, (T*)A_out, m, k, ld, vec_ok);
+  prune_tile_kernel<T, BF><<<stream_grid(ceil_div(m, 4) * ceil_div(k, 4), 256), 256, 0, st>>>((const T*)A_in, (T*)A_out, m, k, ld, vec_ok);
   return check_launch("prune_tile_kernel");
 }
 
@@ -725,6 +737,21 @@ int sm_sparsify_positional_f64(double* w, uint64_t* mask, size_t m, size_t n, fl
 
 int sm_prune24_f16(const void* A_in, void* A_out, size_t m, size_t k, size_t ld, int alg, sm_stream_t s) {
   return launch_prune<uint16_t>(A_in, A_out, m, k, ld, alg, (hipStream_t)s);
+}
+/* bfloat16 (extension): the STRIP rule, the check, compress and decompress look at magnitude
+ * BIT PATTERNS only, which order bfloat16 exactly as they order fp16 -- those entry points run the fp16 kernels as
+ * they are; the TILE rule adds magnitudes and has its own instantiation. */
+int sm_prune24_bf16(const void* A_in, void* A_out, size_t m, size_t k, size_t ld, int alg, sm_stream_t s) {
+  return launch_prune<uint16_t, true>(A_in, A_out, m, k, ld, alg, (hipStream_t)s);
+}
+int sm_prune24_check_bf16(const void* A, size_t m, size_t k, size_t ld, int* d_valid, sm_stream_t s) {
+  return launch_check<uint16_t>(A, m, k, ld, d_valid, (hipStream_t)s);
+}
+int sm_compress24_bf16(const void* A, size_t m, size_t k, size_t ld, size_t batch, size_t strideA, void* blob, sm_stream_t s) {
+  return launch_compress<uint16_t>(A, m, k, ld, batch, strideA, blob, (hipStream_t)s);
+}
+int sm_decompress24_bf16(const void* blob, size_t m, size_t k, size_t ld, size_t batch, size_t strideA, void* A, sm_stream_t s) {
+  return launch_decompress<uint16_t>(blob, m, k, ld, batch, strideA, A, (hipStream_t)s);
 }
 int sm_prune24_f32(const float* A_in, float* A_out, size_t m, size_t k, size_t ld, int alg, sm_stream_t s) {
   return launch_prune<uint32_t>(A_in, A_out, m, k, ld, alg, (hipStream_t)s);

@@ -27,7 +27,7 @@ namespace sm {
 __device__ __attribute__((aligned(256))) const unsigned char sm_zero_page[256] = {0};
 
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool BF = false>
 __global__ __launch_bounds__(256) void spmma_f16_kernel(const SpmmaArgs p) {
   static_assert(WM * WN == 4, "4 waves");
   constexpr int TM = BM / WM, TN = BN / WN, FM = TM / 16, FN = TN / 16;
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void spmma_f16_kernel(const SpmmaArgs p) {
         for (int i = 0; i < FM; ++i)
 #pragma unroll
           for (int j = 0; j < FN; ++j)
-            acc[i][j] = __builtin_amdgcn_smfmac_f32_16x16x64_f16(af[i], bf[j], acc[i][j], idx[i], 0, 0);
+            acc[i][j] = smfmac16<BF>(af[i], bf[j], acc[i][j], idx[i]);
       }
     }
     __syncthreads();
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256) void spmma_f16_kernel(const SpmmaArgs p) {
         const unsigned row = wm * TM + i * 16 + 4u * (lane >> 4), col = wn * TN + j * 16 + (lane & 15u);
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          *reinterpret_cast<half_t*>(Cs + (row + r) * CPITCH + col * 2) = (half_t)(p.alpha * acc[i][j][r]);
+          *reinterpret_cast<half_t*>(Cs + (row + r) * CPITCH + col * 2) = to_elt<BF>(p.alpha * acc[i][j][r]);
       }
     __syncthreads();
     constexpr int C_CH = BM * (BN / 8) / 256;
@@ -209,8 +209,8 @@ __global__ __launch_bounds__(256) void spmma_f16_kernel(const SpmmaArgs p) {
           if (gr >= p.Mrows) continue;
           half_t* dst = C + (size_t)gr * p.N + gc;
           float v = p.alpha * acc[i][j][r];
-          if (p.beta != 0.0f) v += p.beta * (float)*dst;
-          *dst = (half_t)v;
+          if (p.beta != 0.0f) v += p.beta * to_f32<BF>(*dst);
+          *dst = to_elt<BF>(v);
         }
       }
   }
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(256) void spmma_f16_kernel(const SpmmaArgs p) {
 // ---------------------------------------------------------------------------------------------
 
 
-template <int BM, int BN, int WM, int WN, int NS>
+template <int BM, int BN, int WM, int WN, int NS, bool BF = false>
 __global__ __launch_bounds__(64 * WM * WN) void spmma_f16_dma_kernel(const SpmmaArgs p) {
   constexpr int NW = WM * WN;  // waves per workgroup: 4 for big grids, 8 / 16 when few tiles exist
   static_assert(NW == 4 || NW == 8 || NW == 16, "4, 8 or 16 waves");
@@ -345,7 +345,7 @@ __global__ __launch_bounds__(64 * WM * WN) void spmma_f16_dma_kernel(const Spmma
     const char* As = smem + cur * STAGE;
     const char* Ms = As + SA;
     const char* Bs = Ms + SM_;
-    smfmac_stage<FM, FN>(As, Ms, Bs, wm * TM, wn * TN, lane, acc);
+    smfmac_stage<FM, FN, BF>(As, Ms, Bs, wm * TM, wn * TN, lane, acc);
     cur = cur + 1 == NS ? 0 : cur + 1;
     fill = fill + 1 == NS ? 0 : fill + 1;
     SM_T(__builtin_amdgcn_sched_barrier(0); st0 = sm_stamp(); tc += st0 - st2;)
@@ -353,7 +353,7 @@ __global__ __launch_bounds__(64 * WM * WN) void spmma_f16_dma_kernel(const Spmma
   __syncthreads();  // nothing is in flight here: the last NS-1 iterations issued no DMA
   SM_T(const unsigned long long tloop = sm_stamp();)
 
-  store_c_tile<BM, BN, FM, FN, 64 * NW>(smem, C, acc, true, wm * TM, wn * TN, m0, n0, p.Mrows, p.N, p.alpha, p.beta, tid);
+  store_c_tile<BM, BN, FM, FN, 64 * NW, BF>(smem, C, acc, true, wm * TM, wn * TN, m0, n0, p.Mrows, p.N, p.alpha, p.beta, tid);
 #ifdef SM_STAMP
   if (p.dbg && lane == 0) {
     const unsigned long long tend = sm_stamp();
@@ -376,7 +376,7 @@ __global__ __launch_bounds__(64 * WM * WN) void spmma_f16_dma_kernel(const Spmma
 //   consumer:                                 barrier kt | compute stage kt
 // so the transfer of stages kt+1 .. kt+NS-1 runs under the compute of stage kt.
 // ---------------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, int NL, int NS>
+template <int BM, int BN, int WM, int WN, int NL, int NS, bool BF = false>
 __global__ __launch_bounds__(64 * (WM * WN + NL)) void spmma_f16_pc_kernel(const SpmmaArgs p) {
   constexpr int NC = WM * WN, NW = NC + NL;
   static_assert(NS >= 2 && NS <= 4, "ring depth");
@@ -502,7 +502,7 @@ __global__ __launch_bounds__(64 * (WM * WN + NL)) void spmma_f16_pc_kernel(const
       const char* As = smem + cur * STAGE;
       const char* Ms = As + SA;
       const char* Bs = Ms + SM_;
-      smfmac_stage<FM, FN>(As, Ms, Bs, wm * TM, wn * TN, lane, acc);
+      smfmac_stage<FM, FN, BF>(As, Ms, Bs, wm * TM, wn * TN, lane, acc);
       cur = cur + 1 == NS ? 0 : cur + 1;
       SM_T(__builtin_amdgcn_sched_barrier(0); s0 = sm_stamp(); tc += s0 - s1;)
     }
@@ -511,10 +511,10 @@ __global__ __launch_bounds__(64 * (WM * WN + NL)) void spmma_f16_pc_kernel(const
   __syncthreads();  // both roles; nothing is in flight (the last NS-1 loader iterations issued no DMA)
 
   // ---- epilogue: consumers stage their fragments, every wave (loaders too) stores 16-byte row pieces
-  store_c_tile<BM, BN, FM, FN, 64 * NW>(smem, C, acc, wave < (unsigned)NC, wm * TM, wn * TN, m0, n0, p.Mrows, p.N, p.alpha, p.beta, tid);
+  store_c_tile<BM, BN, FM, FN, 64 * NW, BF>(smem, C, acc, wave < (unsigned)NC, wm * TM, wn * TN, m0, n0, p.Mrows, p.N, p.alpha, p.beta, tid);
 }
 
-template <int BM, int BN, int WM, int WN, int NL, int NS>
+template <int BM, int BN, int WM, int WN, int NL, int NS, bool BF = false>
 static int launch_pc(const SpmmaArgs& a0, hipStream_t st) {
   SpmmaArgs a = a0;
   a.tiles_m = (a.Mrows + BM - 1) / BM;
@@ -530,7 +530,7 @@ static int launch_pc(const SpmmaArgs& a0, hipStream_t st) {
   constexpr size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
   static bool attr_set = false;
   if (lds > 64 * 1024 && !attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spmma_f16_pc_kernel<BM, BN, WM, WN, NL, NS>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spmma_f16_pc_kernel<BM, BN, WM, WN, NL, NS, BF>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
@@ -542,7 +542,7 @@ static int launch_pc(const SpmmaArgs& a0, hipStream_t st) {
     static size_t cap = 0;
     if (cnt > cap) { if (dbg) (void)hipFree(dbg); (void)hipMalloc((void**)&dbg, cnt * 8); cap = cnt; }
     a.dbg = dbg;
-    spmma_f16_pc_kernel<BM, BN, WM, WN, NL, NS><<<dim3((unsigned)nwg), dim3(64 * NWV), lds, st>>>(a);
+    spmma_f16_pc_kernel<BM, BN, WM, WN, NL, NS, BF><<<dim3((unsigned)nwg), dim3(64 * NWV), lds, st>>>(a);
     (void)hipDeviceSynchronize();
     std::vector<unsigned long long> h(cnt);
     (void)hipMemcpy(h.data(), dbg, cnt * 8, hipMemcpyDeviceToHost);
@@ -558,11 +558,11 @@ static int launch_pc(const SpmmaArgs& a0, hipStream_t st) {
     return check_launch("spmma_f16_pc_kernel");
   }
 #endif
-  spmma_f16_pc_kernel<BM, BN, WM, WN, NL, NS><<<dim3((unsigned)nwg), dim3(64 * (WM * WN + NL)), lds, st>>>(a);
+  spmma_f16_pc_kernel<BM, BN, WM, WN, NL, NS, BF><<<dim3((unsigned)nwg), dim3(64 * (WM * WN + NL)), lds, st>>>(a);
   return check_launch("spmma_f16_pc_kernel");
 }
 
-template <int BM, int BN, int WM, int WN, int NS>
+template <int BM, int BN, int WM, int WN, int NS, bool BF = false>
 static int launch_dma(const SpmmaArgs& a0, hipStream_t st) {
   SpmmaArgs a = a0;
   a.tiles_m = (a.Mrows + BM - 1) / BM;
@@ -578,7 +578,7 @@ static int launch_dma(const SpmmaArgs& a0, hipStream_t st) {
   constexpr size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
   static bool attr_set = false;
   if (lds > 64 * 1024 && !attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spmma_f16_dma_kernel<BM, BN, WM, WN, NS>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spmma_f16_dma_kernel<BM, BN, WM, WN, NS, BF>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
@@ -589,7 +589,7 @@ static int launch_dma(const SpmmaArgs& a0, hipStream_t st) {
     static size_t cap = 0;
     if (cnt > cap) { if (dbg) (void)hipFree(dbg); (void)hipMalloc((void**)&dbg, cnt * 8); cap = cnt; }
     a.dbg = dbg;
-    spmma_f16_dma_kernel<BM, BN, WM, WN, NS><<<dim3((unsigned)nwg), dim3(64 * WM * WN), lds, st>>>(a);
+    spmma_f16_dma_kernel<BM, BN, WM, WN, NS, BF><<<dim3((unsigned)nwg), dim3(64 * WM * WN), lds, st>>>(a);
     (void)hipDeviceSynchronize();
     std::vector<unsigned long long> h(cnt);
     (void)hipMemcpy(h.data(), dbg, cnt * 8, hipMemcpyDeviceToHost);
@@ -607,11 +607,11 @@ static int launch_dma(const SpmmaArgs& a0, hipStream_t st) {
     return check_launch("spmma_f16_dma_kernel");
   }
 #endif
-  spmma_f16_dma_kernel<BM, BN, WM, WN, NS><<<dim3((unsigned)nwg), dim3(64 * WM * WN), lds, st>>>(a);
+  spmma_f16_dma_kernel<BM, BN, WM, WN, NS, BF><<<dim3((unsigned)nwg), dim3(64 * WM * WN), lds, st>>>(a);
   return check_launch("spmma_f16_dma_kernel");
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool BF = false>
 static int launch_cfg(const SpmmaArgs& a0, hipStream_t st) {
   SpmmaArgs a = a0;
   a.tiles_m = (a.Mrows + BM - 1) / BM;
@@ -625,7 +625,7 @@ static int launch_cfg(const SpmmaArgs& a0, hipStream_t st) {
   constexpr size_t lds_main = (size_t)BM * 144 + (size_t)(BN / 64) * 128 * 128;
   constexpr size_t lds_epi = (size_t)BM * (BN * 2 + 16);
   constexpr size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
-  spmma_f16_kernel<BM, BN, WM, WN><<<dim3((unsigned)nwg), dim3(256), lds, st>>>(a);
+  spmma_f16_kernel<BM, BN, WM, WN, BF><<<dim3((unsigned)nwg), dim3(256), lds, st>>>(a);
   return check_launch("spmma_f16_kernel");
 }
 
@@ -633,15 +633,17 @@ static int launch_cfg(const SpmmaArgs& a0, hipStream_t st) {
 
 using namespace sm;
 
-extern "C" int sm_spmma_f16(const void* blob, const void* B, void* C, size_t m, size_t n, size_t k, size_t batch,
-                            size_t strideB, size_t strideC, float alpha, float beta, sm_stream_t stream) {
+// BF = false: fp16, true: bfloat16 -- same blob layout, same kernels, other matrix instruction and final rounding
+template <bool BF>
+static int spmma16(const void* blob, const void* B, void* C, size_t m, size_t n, size_t k, size_t batch,
+                   size_t strideB, size_t strideC, float alpha, float beta, sm_stream_t stream) {
   if (!blob || !B || !C || !aligned16(blob)) {
-    set_error("sm_spmma_f16: invalid argument (blob must be 16-byte aligned)");
+    set_error("sm_spmma_{f16,bf16}: invalid argument (blob must be 16-byte aligned)");
     return SM_STATUS_INVALID_VALUE;
   }
   if (m == 0 || n == 0 || batch == 0) return SM_STATUS_SUCCESS;
   if (m * batch > 0x7fffffffull || n > 0x7fffffffull || k > 0x7fffffffull) {
-    set_error("sm_spmma_f16: dimension exceeds 2^31-1");
+    set_error("sm_spmma_{f16,bf16}: dimension exceeds 2^31-1");
     return SM_STATUS_NOT_SUPPORTED;
   }
   const BlobLayout L = blob_layout(m, k, 2, batch);
@@ -671,7 +673,7 @@ extern "C" int sm_spmma_f16(const void* blob, const void* B, void* C, size_t m, 
     // tiles per n-tile (profiles/sweep_r01_*.txt: 784x256x{1024,2304}, 3136x128x1152 at b=32)
     if (!getenv("SM_SPMMA_PC") && !getenv("SM_SPMMA_CFG") && n >= 128 && n <= 256 && k >= 1024 &&
         (size_t)a.Mrows >= 16384)
-      return launch_pc<256, 128, 4, 2, 4, 3>(a, st);
+      return launch_pc<256, 128, 4, 2, 4, 3, BF>(a, st);
     static const char* pc_env = getenv("SM_SPMMA_PC");  // tuning aid: "<loaders>x<ring>", "0" = previous kernel
     // default: long K -> producer/consumer kernel (4 loader waves, ring of 3); short K -> the kernel
     // above with more tiles per CU (measured per shape on the ResNet tables, profiles/sweep_r01_*.txt)
@@ -679,15 +681,15 @@ extern "C" int sm_spmma_f16(const void* blob, const void* B, void* C, size_t m, 
     int nl = (k >= 512 && n > 64) ? 4 : 0, pns = 3;
     if (pc_env) sscanf(pc_env, "%dx%d", &nl, &pns);
     if (nl == 256 && n > 64) {  // tuning aid: 256 x 128 tiles, 8 consumer waves (64 x 64) + 4 loaders, 64-deep stages
-      return pns >= 3 ? launch_pc<256, 128, 4, 2, 4, 3>(a, st) : launch_pc<256, 128, 4, 2, 4, 2>(a, st);
+      return pns >= 3 ? launch_pc<256, 128, 4, 2, 4, 3, BF>(a, st) : launch_pc<256, 128, 4, 2, 4, 2, BF>(a, st);
     }
     if (nl > 0) {
       if (n <= 64) {
-        if (nl == 2) return pns >= 3 ? launch_pc<128, 64, 4, 1, 2, 3>(a, st) : launch_pc<128, 64, 4, 1, 2, 2>(a, st);
-        return pns >= 4 ? launch_pc<128, 64, 4, 1, 4, 4>(a, st) : (pns == 3 ? launch_pc<128, 64, 4, 1, 4, 3>(a, st) : launch_pc<128, 64, 4, 1, 4, 2>(a, st));
+        if (nl == 2) return pns >= 3 ? launch_pc<128, 64, 4, 1, 2, 3, BF>(a, st) : launch_pc<128, 64, 4, 1, 2, 2, BF>(a, st);
+        return pns >= 4 ? launch_pc<128, 64, 4, 1, 4, 4, BF>(a, st) : (pns == 3 ? launch_pc<128, 64, 4, 1, 4, 3, BF>(a, st) : launch_pc<128, 64, 4, 1, 4, 2, BF>(a, st));
       }
-      if (nl == 2) return pns >= 3 ? launch_pc<128, 128, 2, 2, 2, 3>(a, st) : launch_pc<128, 128, 2, 2, 2, 2>(a, st);
-      return pns >= 4 ? launch_pc<128, 128, 2, 2, 4, 4>(a, st) : (pns == 3 ? launch_pc<128, 128, 2, 2, 4, 3>(a, st) : launch_pc<128, 128, 2, 2, 4, 2>(a, st));
+      if (nl == 2) return pns >= 3 ? launch_pc<128, 128, 2, 2, 2, 3, BF>(a, st) : launch_pc<128, 128, 2, 2, 2, 2, BF>(a, st);
+      return pns >= 4 ? launch_pc<128, 128, 2, 2, 4, 4, BF>(a, st) : (pns == 3 ? launch_pc<128, 128, 2, 2, 4, 3, BF>(a, st) : launch_pc<128, 128, 2, 2, 4, 2, BF>(a, st));
     }
     static const char* cfg_env = getenv("SM_SPMMA_CFG");
     const size_t Mr = (size_t)a.Mrows;
@@ -697,17 +699,26 @@ extern "C" int sm_spmma_f16(const void* blob, const void* B, void* C, size_t m, 
       nw = tiles >= 1024 ? 4 : 8;
       ns = 2;
       if (cfg_env) sscanf(cfg_env, "%dx%d", &nw, &ns);
-      if (nw >= 8) return ns >= 3 ? launch_dma<128, 64, 4, 2, 3>(a, st) : launch_dma<128, 64, 4, 2, 2>(a, st);
-      return ns >= 3 ? launch_dma<128, 64, 4, 1, 3>(a, st) : launch_dma<128, 64, 4, 1, 2>(a, st);
+      if (nw >= 8) return ns >= 3 ? launch_dma<128, 64, 4, 2, 3, BF>(a, st) : launch_dma<128, 64, 4, 2, 2, BF>(a, st);
+      return ns >= 3 ? launch_dma<128, 64, 4, 1, 3, BF>(a, st) : launch_dma<128, 64, 4, 1, 2, BF>(a, st);
     }
     const size_t tiles = ceil_div(Mr, 128) * ceil_div(n, 128) * a.batch;
     nw = tiles >= 1024 ? 4 : (tiles >= 512 ? 8 : 16);
     ns = (tiles < 512 && k >= 1024) ? 3 : 2;
     if (cfg_env) sscanf(cfg_env, "%dx%d", &nw, &ns);
-    if (nw >= 16) return ns >= 3 ? launch_dma<128, 128, 4, 4, 3>(a, st) : launch_dma<128, 128, 4, 4, 2>(a, st);
-    if (nw >= 8) return ns >= 3 ? launch_dma<128, 128, 2, 4, 3>(a, st) : launch_dma<128, 128, 2, 4, 2>(a, st);
-    return ns >= 3 ? launch_dma<128, 128, 2, 2, 3>(a, st) : launch_dma<128, 128, 2, 2, 2>(a, st);
+    if (nw >= 16) return ns >= 3 ? launch_dma<128, 128, 4, 4, 3, BF>(a, st) : launch_dma<128, 128, 4, 4, 2, BF>(a, st);
+    if (nw >= 8) return ns >= 3 ? launch_dma<128, 128, 2, 4, 3, BF>(a, st) : launch_dma<128, 128, 2, 4, 2, BF>(a, st);
+    return ns >= 3 ? launch_dma<128, 128, 2, 2, 3, BF>(a, st) : launch_dma<128, 128, 2, 2, 2, BF>(a, st);
   }
-  if (n <= 64) return launch_cfg<128, 64, 4, 1>(a, st);
-  return launch_cfg<128, 128, 2, 2>(a, st);
+  if (n <= 64) return launch_cfg<128, 64, 4, 1, BF>(a, st);
+  return launch_cfg<128, 128, 2, 2, BF>(a, st);
+}
+
+extern "C" int sm_spmma_f16(const void* blob, const void* B, void* C, size_t m, size_t n, size_t k, size_t batch,
+                            size_t strideB, size_t strideC, float alpha, float beta, sm_stream_t stream) {
+  return spmma16<false>(blob, B, C, m, n, k, batch, strideB, strideC, alpha, beta, stream);
+}
+extern "C" int sm_spmma_bf16(const void* blob, const void* B, void* C, size_t m, size_t n, size_t k, size_t batch,
+                             size_t strideB, size_t strideC, float alpha, float beta, sm_stream_t stream) {
+  return spmma16<true>(blob, B, C, m, n, k, batch, strideB, strideC, alpha, beta, stream);
 }

@@ -44,7 +44,7 @@ struct FusedArgs {
 // so every row of A is selected exactly once -- by the lane that feeds it to the SMFMAC (smfmac_stage_dense_a).
 // The data in flight are LDS buffers, not registers: 2 x 24 KiB per workgroup, two workgroups per CU at n = 64.
 // ---------------------------------------------------------------------------------------------
-template <int BN, int NS>
+template <int BN, int NS, bool BF = false>
 __global__ __launch_bounds__(256) void spmma_f16_fused_direct_kernel(const FusedArgs p) {
   constexpr int BM = 128, NW = 4, TM = 32, FM = 2, FN = BN / 16;
   constexpr int SA = BM * 128, SB = 64 * BN * 2, STAGE = SA + SB;
@@ -124,19 +124,19 @@ __global__ __launch_bounds__(256) void spmma_f16_fused_direct_kernel(const Fused
     if (kt + NS - 1 < nkt) stage(kt + NS - 1, fill);
     SM_T(const unsigned long long si = sm_stamp(); ti += si - sb;)
     const char* As = smem + cur * STAGE;
-    smfmac_stage_dense_a<FM, FN>(As, As + SA, wave * TM, 0, lane, acc);
+    smfmac_stage_dense_a<FM, FN, BF>(As, As + SA, wave * TM, 0, lane, acc);
     cur = cur + 1 == NS ? 0 : cur + 1;
     fill = fill + 1 == NS ? 0 : fill + 1;
     SM_T(__builtin_amdgcn_sched_barrier(0); s0 = sm_stamp(); tc += s0 - si;)
   }
   __syncthreads();
   SM_T(const unsigned long long sloop = sm_stamp();)
-  store_c_tile<BM, BN, FM, FN, 64 * NW>(smem, C, acc, true, wave * TM, 0, m0, n0, p.Mrows, p.N, p.alpha, p.beta, tid);
+  store_c_tile<BM, BN, FM, FN, 64 * NW, BF>(smem, C, acc, true, wave * TM, 0, m0, n0, p.Mrows, p.N, p.alpha, p.beta, tid);
   SM_T(if (p.dbg && lane == 0) { unsigned long long* d = p.dbg + ((size_t)blockIdx.x * NW + wave) * 8; const unsigned long long se = sm_stamp();
         d[0] = tv; d[1] = tb; d[2] = ti; d[3] = tc; d[4] = sloop - sstart; d[5] = se - sloop; })
 }
 
-template <int BN, int NS>
+template <int BN, int NS, bool BF = false>
 static int launch_fused_direct(const FusedArgs& a0, hipStream_t st) {
   FusedArgs a = a0;
   a.tiles_m = (a.Mrows + 127) / 128;
@@ -152,7 +152,7 @@ static int launch_fused_direct(const FusedArgs& a0, hipStream_t st) {
   constexpr size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
   static bool attr_set = false;
   if (lds > 64 * 1024 && !attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spmma_f16_fused_direct_kernel<BN, NS>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spmma_f16_fused_direct_kernel<BN, NS, BF>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
@@ -164,7 +164,7 @@ static int launch_fused_direct(const FusedArgs& a0, hipStream_t st) {
     if (cnt > cap) { if (dbg) (void)hipFree(dbg); (void)hipMalloc((void**)&dbg, cnt * 8); cap = cnt; }
     (void)hipMemset(dbg, 0, cnt * 8);
     a.dbg = dbg;
-    spmma_f16_fused_direct_kernel<BN, NS><<<dim3((unsigned)nwg), dim3(256), lds, st>>>(a);
+    spmma_f16_fused_direct_kernel<BN, NS, BF><<<dim3((unsigned)nwg), dim3(256), lds, st>>>(a);
     (void)hipDeviceSynchronize();
     std::vector<unsigned long long> h(cnt);
     (void)hipMemcpy(h.data(), dbg, cnt * 8, hipMemcpyDeviceToHost);
@@ -177,7 +177,7 @@ static int launch_fused_direct(const FusedArgs& a0, hipStream_t st) {
     return check_launch("spmma_f16_fused_direct_kernel");
   }
 #endif
-  spmma_f16_fused_direct_kernel<BN, NS><<<dim3((unsigned)nwg), dim3(256), lds, st>>>(a);
+  spmma_f16_fused_direct_kernel<BN, NS, BF><<<dim3((unsigned)nwg), dim3(256), lds, st>>>(a);
   return check_launch("spmma_f16_fused_direct_kernel");
 }
 
@@ -208,7 +208,7 @@ struct BTileDma {
   }
 };
 
-template <int BN, int WM, int WN, int NLB, int PF, int NSB>
+template <int BN, int WM, int WN, int NLB, int PF, int NSB, bool BF = false>
 __global__ __launch_bounds__(64 * (WM * WN + 4 + NLB)) void spmma_f16_fused_wide_kernel(const FusedArgs p) {
   constexpr int BM = 128, NLA = 4, NC = WM * WN, NW = NC + NLA + NLB;
   static_assert(PF >= 1 && PF <= 3 && NSB >= 2 && NSB <= 4, "pipeline depths");
@@ -391,7 +391,7 @@ __global__ __launch_bounds__(64 * (WM * WN + 4 + NLB)) void spmma_f16_fused_wide
       const char* As = smem + (kt & 1) * ASTG;
       const char* Ms = As + SA;
       const char* Bs = smem + BRING + cb * SB;
-      smfmac_stage<FM, FN>(As, Ms, Bs, wm * TM, wn * TN, lane, acc);
+      smfmac_stage<FM, FN, BF>(As, Ms, Bs, wm * TM, wn * TN, lane, acc);
       cb = cb + 1 == NSB ? 0 : cb + 1;
       SM_T(__builtin_amdgcn_sched_barrier(0); s0 = sm_stamp(); tc += s0 - s1; nlong += (s0 - s1) > 2000 ? 1 : 0;)
     }
@@ -399,10 +399,10 @@ __global__ __launch_bounds__(64 * (WM * WN + 4 + NLB)) void spmma_f16_fused_wide
   }
   __syncthreads();
 
-  store_c_tile<BM, BN, FM, FN, 64 * NW>(smem, C, acc, wave < (unsigned)NC, wm * TM, wn * TN, m0, n0, p.Mrows, p.N, p.alpha, p.beta, tid);
+  store_c_tile<BM, BN, FM, FN, 64 * NW, BF>(smem, C, acc, wave < (unsigned)NC, wm * TM, wn * TN, m0, n0, p.Mrows, p.N, p.alpha, p.beta, tid);
 }
 
-template <int BN, int WM, int WN, int NLB, int PF, int NSB>
+template <int BN, int WM, int WN, int NLB, int PF, int NSB, bool BF = false>
 static int launch_fused_wide(const FusedArgs& a0, hipStream_t st) {
   FusedArgs a = a0;
   a.tiles_m = (a.Mrows + 127) / 128;
@@ -418,7 +418,7 @@ static int launch_fused_wide(const FusedArgs& a0, hipStream_t st) {
   constexpr size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
   static bool attr_set = false;
   if (lds > 64 * 1024 && !attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spmma_f16_fused_wide_kernel<BN, WM, WN, NLB, PF, NSB>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spmma_f16_fused_wide_kernel<BN, WM, WN, NLB, PF, NSB, BF>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
@@ -431,7 +431,7 @@ static int launch_fused_wide(const FusedArgs& a0, hipStream_t st) {
     if (cnt > cap) { if (dbg) (void)hipFree(dbg); (void)hipMalloc((void**)&dbg, cnt * 8); cap = cnt; }
     (void)hipMemset(dbg, 0, cnt * 8);
     a.dbg = dbg;
-    spmma_f16_fused_wide_kernel<BN, WM, WN, NLB, PF, NSB><<<dim3((unsigned)nwg), dim3(64 * NWV), lds, st>>>(a);
+    spmma_f16_fused_wide_kernel<BN, WM, WN, NLB, PF, NSB, BF><<<dim3((unsigned)nwg), dim3(64 * NWV), lds, st>>>(a);
     (void)hipDeviceSynchronize();
     std::vector<unsigned long long> h(cnt);
     (void)hipMemcpy(h.data(), dbg, cnt * 8, hipMemcpyDeviceToHost);
@@ -450,7 +450,7 @@ static int launch_fused_wide(const FusedArgs& a0, hipStream_t st) {
     return check_launch("spmma_f16_fused_wide_kernel");
   }
 #endif
-  spmma_f16_fused_wide_kernel<BN, WM, WN, NLB, PF, NSB><<<dim3((unsigned)nwg), dim3(64 * (WM * WN + 4 + NLB)), lds, st>>>(a);
+  spmma_f16_fused_wide_kernel<BN, WM, WN, NLB, PF, NSB, BF><<<dim3((unsigned)nwg), dim3(64 * (WM * WN + 4 + NLB)), lds, st>>>(a);
   return check_launch("spmma_f16_fused_wide_kernel");
 }
 
@@ -463,7 +463,7 @@ static int launch_fused_wide(const FusedArgs& a0, hipStream_t st) {
 // piece of C through a wave-private LDS patch (no barrier in the epilogue), so the loaders keep prefetching the
 // next tile's B while C is written.  beta == 0 only (the caller falls back to the wide kernel otherwise).
 // ---------------------------------------------------------------------------------------------
-template <int NSB>
+template <int NSB, bool BF = false>
 __global__ __launch_bounds__(64 * 16) void spmma_f16_fused_astat_kernel(const FusedArgs p, int nsplit, int tiles_per_split) {
   constexpr int BM = 128, BN = 128, WM = 4, WN = 2, NC = 8, NLA = 4, NLB = 4;
   static_assert(NC + NLA + NLB == 16, "launch bounds");
@@ -599,7 +599,7 @@ __global__ __launch_bounds__(64 * 16) void spmma_f16_fused_astat_kernel(const Fu
       const char* As = smem + kt * ASTG;
       const char* Ms = As + SA;
       const char* Bs = Bring + cb * SB;
-      smfmac_stage<FM, FN>(As, Ms, Bs, wm * TM, wn * TN, lane, acc);
+      smfmac_stage<FM, FN, BF>(As, Ms, Bs, wm * TM, wn * TN, lane, acc);
       cb = cb + 1 == NSB ? 0 : cb + 1;
       SM_T(__builtin_amdgcn_sched_barrier(0); s0 = sm_stamp(); tc += s0 - s1;)
 #if defined(SM_ABLATE) && (SM_ABLATE & 16)
@@ -615,7 +615,7 @@ __global__ __launch_bounds__(64 * 16) void spmma_f16_fused_astat_kernel(const Fu
             const unsigned lr = i * 16 + 4u * g, lc = j * 16 + r;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-              *reinterpret_cast<half_t*>(patch + (lr + q) * WPITCH + lc * 2) = (half_t)(p.alpha * acc[i][j][q]);
+              *reinterpret_cast<half_t*>(patch + (lr + q) * WPITCH + lc * 2) = to_elt<BF>(p.alpha * acc[i][j][q]);
               acc[i][j][q] = 0.f;
             }
           }
@@ -642,6 +642,7 @@ __global__ __launch_bounds__(64 * 16) void spmma_f16_fused_astat_kernel(const Fu
 
 static size_t astat_lds_bytes(int nkt, int nsb) { return (size_t)nkt * (128 * 72) + (size_t)nsb * 64 * 128 * 2 + 8 * 32 * (64 * 2 + 8); }
 
+template <bool BF = false>
 static int launch_fused_astat(const FusedArgs& a0, hipStream_t st) {
   FusedArgs a = a0;
   a.tiles_m = (a.Mrows + 127) / 128;
@@ -670,11 +671,11 @@ static int launch_fused_astat(const FusedArgs& a0, hipStream_t st) {
   const size_t lds = astat_lds_bytes(a.K / 64, NSB);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spmma_f16_fused_astat_kernel<NSB>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spmma_f16_fused_astat_kernel<NSB, BF>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
     attr_set = true;
   }
-  spmma_f16_fused_astat_kernel<NSB><<<dim3((unsigned)nwg), dim3(64 * 16), lds, st>>>(a, nsplit, tps);
+  spmma_f16_fused_astat_kernel<NSB, BF><<<dim3((unsigned)nwg), dim3(64 * 16), lds, st>>>(a, nsplit, tps);
   return check_launch("spmma_f16_fused_astat_kernel");
 }
 
@@ -682,21 +683,22 @@ static int launch_fused_astat(const FusedArgs& a0, hipStream_t st) {
 
 using namespace sm;
 
-extern "C" int sm_spmma_fused_f16(const void* A, const void* B, void* C, size_t m, size_t n, size_t k, size_t lda,
-                                  size_t batch, size_t strideA, size_t strideB, size_t strideC, float alpha, float beta,
-                                  sm_stream_t stream) {
+template <bool BF>
+static int spmma_fused16(const void* A, const void* B, void* C, size_t m, size_t n, size_t k, size_t lda,
+                         size_t batch, size_t strideA, size_t strideB, size_t strideC, float alpha, float beta,
+                         sm_stream_t stream) {
   if (!A || !B || !C || lda < k) {
-    set_error("sm_spmma_fused_f16: invalid argument");
+    set_error("sm_spmma_fused_{f16,bf16}: invalid argument");
     return SM_STATUS_INVALID_VALUE;
   }
   if (m == 0 || n == 0 || batch == 0) return SM_STATUS_SUCCESS;
   // whole 64-deep stages of 16-byte aligned rows only; anything else: sm_compress24_f16 + sm_spmma_f16
   if (k % 64 != 0 || lda % 8 != 0 || strideA % 8 != 0 || n % 8 != 0 || strideB % 8 != 0 || !aligned16(A) || !aligned16(B)) {
-    set_error("sm_spmma_fused_f16: needs k %% 64 == 0, n %% 8 == 0 and 16-byte aligned rows (use the staged path)");
+    set_error("sm_spmma_fused_{f16,bf16}: needs k %% 64 == 0, n %% 8 == 0 and 16-byte aligned rows (use the staged path)");
     return SM_STATUS_NOT_SUPPORTED;
   }
   if (m * batch > 0x7fffffffull || n > 0x7fffffffull || k > 0x7fffffffull || lda > 0x7fffffffull) {
-    set_error("sm_spmma_fused_f16: dimension exceeds 2^31-1");
+    set_error("sm_spmma_fused_{f16,bf16}: dimension exceeds 2^31-1");
     return SM_STATUS_NOT_SUPPORTED;
   }
   FusedArgs a = {};
@@ -714,17 +716,28 @@ extern "C" int sm_spmma_fused_f16(const void* A, const void* B, void* C, size_t 
   static const int direct_env = getenv("SM_FUSED_DIRECT") ? atoi(getenv("SM_FUSED_DIRECT")) : 2;
   static const int wide_env = getenv("SM_FUSED_WIDE") ? atoi(getenv("SM_FUSED_WIDE")) : 0;  // tuning aid: force the wide kernel
   if (!wide_env && (n <= 128 || (n <= 256 && k <= 64))) {
-    if (n <= 64) return direct_env >= 3 ? launch_fused_direct<64, 3>(a, st) : launch_fused_direct<64, 2>(a, st);
-    return direct_env >= 3 ? launch_fused_direct<128, 3>(a, st) : launch_fused_direct<128, 2>(a, st);
+    if (n <= 64) return direct_env >= 3 ? launch_fused_direct<64, 3, BF>(a, st) : launch_fused_direct<64, 2, BF>(a, st);
+    return direct_env >= 3 ? launch_fused_direct<128, 3, BF>(a, st) : launch_fused_direct<128, 2, BF>(a, st);
   }
   // n > 256, short K, plain store: A-stationary (the 2:4 image of a row panel stays in LDS across column tiles)
   static const int astat_env = getenv("SM_FUSED_ASTAT") ? atoi(getenv("SM_FUSED_ASTAT")) : 1;  // tuning aid: 0 = off
   if (astat_env && n > 256 && k <= 512 && beta == 0.0f && aligned16(C) && (strideC % 8 == 0) &&
       astat_lds_bytes((int)(k / 64), 3) <= 160 * 1024)
-    return launch_fused_astat(a, st);
+    return launch_fused_astat<BF>(a, st);
   // wider: 256-column tiles, 8 consumer waves (wave tile 32 x 128), split loaders; for n <= 256 every row of A is loaded
   // and selected exactly once, beyond that once per 256 columns (callers with n >= 512, a long K and a reusable A are
   // better served by sm_compress24_f16 + sm_spmma_f16: bench.py --path auto decides per layer).  Three A stages in
   // flight, a B ring of 4 and a 2 x 4 consumer grid all measured within noise of this configuration.
-  return launch_fused_wide<256, 4, 2, 4, 2, 3>(a, st);
+  return launch_fused_wide<256, 4, 2, 4, 2, 3, BF>(a, st);
+}
+
+extern "C" int sm_spmma_fused_f16(const void* A, const void* B, void* C, size_t m, size_t n, size_t k, size_t lda,
+                                  size_t batch, size_t strideA, size_t strideB, size_t strideC, float alpha, float beta,
+                                  sm_stream_t stream) {
+  return spmma_fused16<false>(A, B, C, m, n, k, lda, batch, strideA, strideB, strideC, alpha, beta, stream);
+}
+extern "C" int sm_spmma_fused_bf16(const void* A, const void* B, void* C, size_t m, size_t n, size_t k, size_t lda,
+                                   size_t batch, size_t strideA, size_t strideB, size_t strideC, float alpha, float beta,
+                                   sm_stream_t stream) {
+  return spmma_fused16<true>(A, B, C, m, n, k, lda, batch, strideA, strideB, strideC, alpha, beta, stream);
 }

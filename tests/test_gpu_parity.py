@@ -675,6 +675,112 @@ def test_fused_equals_staged(gpu, orc, shape, shared_b):
     check_close(host(C2), Cref.view(np.float16), scale, FP16_TOL, f"fused {shape}")
 
 
+# ---------------------------------------------------------------------------------------------
+# (f-2) bfloat16 forms of the 2:4 path
+# ---------------------------------------------------------------------------------------------
+def bf16_bits(rng, n, kind="uniform"):
+    """n random bfloat16 values as uint16 bit patterns (torch's CPU conversion, round to nearest even)."""
+    import torch
+    x = rng.integers(-3, 4, n).astype(np.float32) if kind == "ties" else rng.uniform(-1, 1, n).astype(np.float32)
+    return torch.from_numpy(x).to(torch.bfloat16).view(torch.int16).numpy().view(np.uint16).copy()
+
+
+def bf16_dev(b):
+    import torch
+    return torch.from_numpy(b.view(np.int16)).cuda().view(torch.bfloat16)
+
+
+def bf16_host(t):
+    import torch
+    torch.cuda.synchronize()
+    return t.view(torch.int16).cpu().numpy().view(np.uint16)
+
+
+def bf16_f64(b):
+    return (b.astype(np.uint32) << 16).view(np.float32).astype(np.float64)
+
+
+@pytest.mark.parametrize("shape", [(4, 4), (7, 10), (196, 512), (130, 147), (784, 64), (33, 8)])
+@pytest.mark.parametrize("alg", ["TILE", "STRIP"])
+def test_prune24_bf16_vs_oracle(gpu, orc, shape, alg):
+    import torch
+    m, k = shape
+    rng = np.random.default_rng(m * 7 + k)
+    for kind in ("uniform", "ties"):
+        A = bf16_bits(rng, m * k, kind)
+        dA = bf16_dev(A)
+        out = torch.empty_like(dA)
+        gpu.prune24(dA, out, m, k, k, getattr(gpu, "PRUNE_" + alg))
+        want = orc.prune24(A, m, k, k, getattr(orc, alg), bf16=True)
+        assert np.array_equal(bf16_host(out), want), f"prune24 bf16 {alg} {shape} {kind}"
+        valid = torch.full((1,), 7, dtype=torch.int32, device="cuda")
+        gpu.prune24_check(out, m, k, k, valid)
+        assert int(host(valid)[0]) == 0
+
+
+@pytest.mark.parametrize("shape", [(128, 64, 64, 1), (196, 512, 256, 2), (784, 256, 1024, 2), (130, 72, 200, 3), (12544, 64, 147, 1),
+                                   (3136, 128, 1152, 1), (300, 520, 128, 2), (131, 35, 77, 2)])
+@pytest.mark.parametrize("ab", [(1.0, 0.0), (0.5, -2.0)])
+def test_spmma_bf16_vs_oracle(gpu, orc, shape, ab):
+    """compress (bit-exact, the fp16 kernels on the same bits) + 2:4 matmul on v_smfmac_f32_16x16x64_bf16, and the
+    bf16 dense kernel on the pruned operand."""
+    import torch
+    m, n, k, batch = shape
+    alpha, beta = ab
+    rng = np.random.default_rng(m + 3 * n + 5 * k)
+    A, B, C0 = bf16_bits(rng, batch * m * k), bf16_bits(rng, k * n), bf16_bits(rng, batch * m * n)
+    dA, dB = bf16_dev(A), bf16_dev(B)
+    blob = torch.empty(gpu.compress24_size(m, k, 2, batch), dtype=torch.uint8, device="cuda")
+    gpu.compress24(dA, m, k, k, batch, m * k, blob)
+    ob = orc.compress24(A, m, k, k, batch)
+    assert np.array_equal(host(blob), ob)
+    back = torch.empty_like(dA)
+    gpu.decompress24(blob, m, k, k, batch, m * k, back)
+    pruned = orc.prune24(A, batch * m, k, k, orc.STRIP, bf16=True)
+    assert np.array_equal(bf16_host(back), pruned)
+    dC = bf16_dev(C0.copy())
+    gpu.spmma(blob, dB, dC, m, n, k, batch, 0, alpha=alpha, beta=beta)
+    Cref = C0.copy()
+    orc.spmma(ob, B, Cref, m, n, k, batch, 0, alpha=alpha, beta=beta, bf16=True)
+    scale = abs(alpha) * (np.abs(bf16_f64(A)).reshape(batch * m, k) @ np.abs(bf16_f64(B)).reshape(k, n)).reshape(-1) \
+        + abs(beta) * np.abs(bf16_f64(C0))
+    check_close(bf16_f64(bf16_host(dC)), bf16_f64(Cref), scale, FP16_TOL, f"spmma_bf16 {shape}")
+    # dense bf16 kernel on the pruned operand: the same products
+    dC2 = bf16_dev(C0.copy())
+    gpu.gemm_rowmajor(bf16_dev(pruned), dB, dC2, m, n, k, batch=batch, alpha=alpha, beta=beta)
+    check_close(bf16_f64(bf16_host(dC2)), bf16_f64(Cref), scale, FP16_TOL, f"gemm_rowmajor_bf16 {shape}")
+
+
+@pytest.mark.parametrize("shape", [(128, 64, 64, 1), (196, 512, 256, 2), (784, 256, 1024, 2), (12544, 64, 576, 1), (3136, 128, 1152, 1),
+                                   (300, 520, 128, 2), (784, 1024, 256, 1), (260, 520, 576, 1)])
+def test_fused_bf16_equals_staged(gpu, orc, shape):
+    import torch
+    m, n, k, batch = shape
+    rng = np.random.default_rng(m * 3 + n + k * 5)
+    A, B = bf16_bits(rng, batch * m * k, "ties" if m % 7 == 0 else "uniform"), bf16_bits(rng, k * n)
+    dA, dB = bf16_dev(A), bf16_dev(B)
+    blob = torch.empty(gpu.compress24_size(m, k, 2, batch), dtype=torch.uint8, device="cuda")
+    gpu.compress24(dA, m, k, k, batch, m * k, blob)
+    C1 = torch.zeros(batch * m * n, dtype=torch.bfloat16, device="cuda")
+    gpu.spmma(blob, dB, C1, m, n, k, batch, 0)
+    C2 = torch.full((batch * m * n,), 7.0, dtype=torch.bfloat16, device="cuda")
+    gpu.spmma_fused(dA, dB, C2, m, n, k, batch=batch)
+    assert np.array_equal(bf16_host(C1), bf16_host(C2)), "fused bf16 result differs from compress + spmma"
+    Cref = np.zeros(batch * m * n, dtype=np.uint16)
+    orc.spmma(orc.compress24(A, m, k, k, batch), B, Cref, m, n, k, batch, 0, bf16=True)
+    scale = (np.abs(bf16_f64(A)).reshape(batch * m, k) @ np.abs(bf16_f64(B)).reshape(k, n)).reshape(-1)
+    check_close(bf16_f64(bf16_host(C2)), bf16_f64(Cref), scale, FP16_TOL, f"fused bf16 {shape}")
+
+
+def test_fill_uniform_bf16(gpu):
+    import torch
+    x = torch.empty(1 << 16, dtype=torch.bfloat16, device="cuda")
+    y = torch.empty(1 << 16, dtype=torch.float32, device="cuda")
+    gpu.fill_uniform(x, 42, -1.0, 3.0)
+    gpu.fill_uniform(y, 42, -1.0, 3.0)
+    assert torch.equal(x, y.to(torch.bfloat16))     # same counter-based stream, rounded once to nearest even
+
+
 def test_fused_rejects_what_it_cannot_take(gpu):
     import torch
     A = torch.zeros(16 * 147, dtype=torch.float16, device="cuda")

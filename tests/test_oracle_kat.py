@@ -311,6 +311,67 @@ def test_fp16_conversions_roundtrip(orc):
         assert np.array_equal(h, x.astype(np.float16).view(np.uint16))
 
 
+def test_bf16_conversions_and_rules(orc):
+    """bfloat16 in the oracle: conversions agree with torch's CPU bfloat16 (an independent implementation of round to
+    nearest even), the STRIP rule is the fp16 function of the bits, the TILE rule keeps 2 per row and column with a
+    maximal kept magnitude, and the bf16 matmul refs equal an fp64 matmul of the widened operands rounded once."""
+    import ctypes
+    import torch
+    rng = np.random.default_rng(11)
+    x = np.concatenate([rng.uniform(-3e38, 3e38, 5000), rng.uniform(-1, 1, 20000), rng.uniform(-1e-38, 1e-38, 2000),
+                        np.array([1.0, 1.00390625, 1.005859375, 1.001953125, 3.3895313892515355e38, 3.4e38, 0.0, -0.0, np.inf, -np.inf])]).astype(np.float32)
+    h = np.zeros(x.size, dtype=np.uint16)
+    orc.lib().sm_narrow_bf16(x.ctypes.data_as(ctypes.c_void_p), h.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(x.size))
+    want = torch.from_numpy(x).to(torch.bfloat16).view(torch.int16).numpy().view(np.uint16)
+    assert np.array_equal(h, want)
+    allb = np.arange(0, 1 << 16, dtype=np.uint16)
+    f = np.zeros(allb.size, dtype=np.float32)
+    orc.lib().sm_widen_bf16(allb.ctypes.data_as(ctypes.c_void_p), f.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(allb.size))
+    assert np.array_equal(f.view(np.uint32), allb.astype(np.uint32) << 16)
+    # STRIP: same bits in, same bits out as the fp16 rule
+    m, k = 37, 52
+    Ab = rng.integers(0, 1 << 16, m * k).astype(np.uint16)
+    assert np.array_equal(orc.prune24(Ab, m, k, k, orc.STRIP, bf16=True), orc.prune24(Ab, m, k, k, orc.STRIP))
+    # TILE on bf16 magnitudes: valid pattern, never worse than STRIP's kept sum when STRIP happens to be column-valid
+    A = torch.from_numpy(rng.uniform(-4, 4, (16, 16)).astype(np.float32)).to(torch.bfloat16)
+    Abits = A.view(torch.int16).numpy().view(np.uint16).reshape(-1).copy()
+    P = orc.prune24(Abits, 16, 16, 16, orc.TILE, bf16=True).reshape(16, 16)
+    nz = P != 0
+    mag = np.abs(A.to(torch.float32).numpy().astype(np.float64))
+    for r0 in range(0, 16, 4):
+        for c0 in range(0, 16, 4):
+            t = nz[r0:r0 + 4, c0:c0 + 4]
+            assert (t.sum(0) == 2).all() and (t.sum(1) == 2).all()
+            # brute force over the 90 patterns
+            import itertools
+            pairs = list(itertools.combinations(range(4), 2))
+            best = -1.0
+            for combo in itertools.product(pairs, repeat=4):
+                cols = np.zeros(4, int)
+                for pr in combo:
+                    cols[list(pr)] += 1
+                if (cols == 2).all():
+                    best = max(best, sum(mag[r0 + r, c0 + c] for r, pr in enumerate(combo) for c in pr))
+            assert abs((mag[r0:r0 + 4, c0:c0 + 4] * t).sum() - best) <= 1e-6 * best
+    # matmul refs
+    m, n, k = 9, 7, 24
+    Af = torch.from_numpy(rng.uniform(-1, 1, (m, k)).astype(np.float32)).to(torch.bfloat16)
+    Bf = torch.from_numpy(rng.uniform(-1, 1, (k, n)).astype(np.float32)).to(torch.bfloat16)
+    ab = Af.view(torch.int16).numpy().view(np.uint16).reshape(-1).copy()
+    bb = Bf.view(torch.int16).numpy().view(np.uint16).reshape(-1).copy()
+    C = np.zeros(m * n, dtype=np.uint16)
+    orc.gemm_rowmajor(ab, bb, C, m, n, k, bf16=True)
+    want = torch.from_numpy((Af.to(torch.float64).numpy() @ Bf.to(torch.float64).numpy()).astype(np.float32)).to(torch.bfloat16)
+    got = torch.from_numpy(C.view(np.int16)).view(torch.bfloat16)
+    assert (got.to(torch.float32) - want.reshape(-1).to(torch.float32)).abs().max() <= 2.0 ** -7 * max(1.0, float(want.to(torch.float32).abs().max()))  # at most 1 ulp (double rounding)
+    blob = orc.compress24(ab, m, k, k)
+    pr = orc.prune24(ab, m, k, k, orc.STRIP, bf16=True)
+    C1, C2 = np.zeros(m * n, dtype=np.uint16), np.zeros(m * n, dtype=np.uint16)
+    orc.spmma(blob, bb, C1, m, n, k, bf16=True)
+    orc.gemm_rowmajor(pr, bb, C2, m, n, k, bf16=True)
+    assert np.array_equal(C1, C2)
+
+
 def test_bell_and_coo_restatements(orc):
     rng = np.random.default_rng(2)
     rows, cols, bs, n = 8, 12, 2, 5

@@ -28,7 +28,7 @@ def main():
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--out", default=None)
     ap.add_argument("--only", default=None, help="comma list of stages to run")
-    ap.add_argument("--dtype", default="f16", choices=["f16", "f32"])
+    ap.add_argument("--dtype", default="f16", choices=["f16", "bf16", "f32"])
     ap.add_argument("--hot", action="store_true", help="one buffer set per shape (cache-resident for small layers)")
     args = ap.parse_args()
     import torch
@@ -56,10 +56,11 @@ def main():
     tot = {}
     hdr = ("m", "n", "k", "b", "cnt", "stage", "ms", "effTF/s", "GB/s", "roof_us", "frac")
     print("%6s %5s %5s %3s %3s %-10s %9s %9s %8s %8s %6s" % hdr)
-    tdt = torch.float16 if args.dtype == "f16" else torch.float32
-    peak = MFMA_F16 if args.dtype == "f16" else 157.3e12
+    h16 = args.dtype in ("f16", "bf16")
+    tdt = {"f16": torch.float16, "bf16": torch.bfloat16, "f32": torch.float32}[args.dtype]
+    peak = MFMA_F16 if h16 else 157.3e12
     for (m, n, k, b), cnt in uniq:
-        s = 2 if args.dtype == "f16" else 4
+        s = 2 if h16 else 4
         # several buffer sets cycled call by call, so that a layer whose operands fit the 256 MiB Infinity
         # Cache is not timed on cache-resident data (bench.py streams 10 GB per step; this mimics it)
         foot = b * m * k * s * 1.6 + b * m * n * s
@@ -97,7 +98,7 @@ def main():
         def f_spmma():
             S = nxt(); sm.spmma(S["blob"], Bm, S["C"], m, n, k, b, 0)
 
-        fused_ok = k % 64 == 0 and n % 8 == 0 and args.dtype == "f16"
+        fused_ok = k % 64 == 0 and n % 8 == 0 and h16
 
         def f_fused():  # the whole path in one launch; shapes the fused kernel refuses run the staged pair
             S = nxt()
@@ -124,7 +125,7 @@ def main():
         stages = [
             ("gemm", f_gemm, flops, dense_bytes, peak),
             ("gemm_rm", f_gemm_rm, flops, dense_bytes, peak),
-            ("spmma", f_spmma, flops, sp_bytes, 2 * peak if args.dtype == "f16" else peak),
+            ("spmma", f_spmma, flops, sp_bytes, 2 * peak if h16 else peak),
             ("fused", f_fused, flops, dense_bytes, 2 * peak),
             ("compress", f_compress, 0, b * m * k * (s + s / 2 + 1 / 8), 0),
             ("prune_s", f_prune_s, 0, 2 * b * m * k * s, 0),
