@@ -11,6 +11,7 @@
 #include <iostream>
 
 #include <sparsifyme.h>
+#include <sparsify.me/util/trace.hxx>
 #include <sparsify.me/util/util.hxx>
 
 namespace sparsifyme {
@@ -51,6 +52,7 @@ float gemm(type_t** A_ptrs,
            operation_t transpose_b = operation_t::N,
            type_t alpha = (type_t)1.0f,
            type_t beta = (type_t)0.0f) {
+  util::range_t range("batched-GEMM");
   util::timer_t timer;
   timer.begin();
   const int rc = detail::gemm_call(A_ptrs, B_ptrs, C_ptrs, m, n, k, batch_size, (int)transpose_a, (int)transpose_b, alpha, beta);

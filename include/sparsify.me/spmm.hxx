@@ -17,6 +17,7 @@
 #include <sparsifyme.h>
 #include <sparsify.me/containers/ell.hxx>
 #include <sparsify.me/gemm.hxx>  // operation_t
+#include <sparsify.me/util/trace.hxx>
 #include <sparsify.me/util/util.hxx>
 
 namespace sparsifyme {
@@ -60,6 +61,7 @@ float spmm(ell_t<type_t, memory_space_t::device>* As,
   if (uniform) (void)sm_spmm_bell_batched_workspace_size(As[0].rows, As[0].cols, batch_size, &ws_bytes);
   device_vector<unsigned char> ws(ws_bytes);
   t.begin();
+  util::range_t range("batched-SpMM");  // the reference's NVTX range (spmm.hxx:92,121)
   if (uniform) {
     rc = sm_spmm_bell_batched_f32(vals.data(), idx.data(), As[0].rows, As[0].cols, As[0].block_size, As[0].ell_cols,
                                   reinterpret_cast<const float*>(B), reinterpret_cast<float* const*>(Cs), n, batch_size,
@@ -96,6 +98,7 @@ float strided_coo(std::size_t A_num_rows,
   static_assert(sizeof(type_t) == 4, "this build implements the fp32 COO SpMM");
   (void)B_num_rows;  // == A_num_cols
   util::timer_t t;
+  util::range_t range("strided-COO-SpMM");
   t.begin();  // the reference times its buffer allocation too (spmm.hxx:155-156,183)
   std::size_t ws_bytes = 0;
   (void)sm_spmm_coo_workspace_size(A_num_rows, &ws_bytes);

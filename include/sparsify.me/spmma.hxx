@@ -20,6 +20,7 @@
 #include <sparsifyme.h>
 #include <sparsify.me/containers/vector.hxx>
 #include <sparsify.me/gemm.hxx>  // operation_t
+#include <sparsify.me/util/trace.hxx>
 #include <sparsify.me/util/util.hxx>
 
 namespace sparsifyme {
@@ -55,6 +56,22 @@ struct spmma_fns_f16 {
     return sm_spmma_f16(blob, B, C, m, n, k, b, sB, m * n, al, be, st);
   }
 };
+struct spmma_fns_bf16 {  // bfloat16 (extension): same blob and rules, v_smfmac_f32_16x16x64_bf16
+  static int prune(void* A, std::size_t m, std::size_t k) { return sm_prune24_bf16(A, A, m, k, k, SM_PRUNE_TILE, nullptr); }
+  static int check(void* A, std::size_t m, std::size_t k, int* v) { return sm_prune24_check_bf16(A, m, k, k, v, nullptr); }
+  static int compress(void* A, std::size_t m, std::size_t k, std::size_t b, void* blob) { return sm_compress24_bf16(A, m, k, k, b, m * k, blob, nullptr); }
+  static int mul(void* blob, void* B, void* C, std::size_t m, std::size_t n, std::size_t k, std::size_t b, float al, float be) {
+    return sm_spmma_bf16(blob, B, C, m, n, k, b, k * n, m * n, al, be, nullptr);
+  }
+  static int prune_on(void* A, std::size_t m, std::size_t k, hipStream_t st) { return sm_prune24_bf16(A, A, m, k, k, SM_PRUNE_TILE, st); }
+  static int compress_on(void* A, std::size_t m, std::size_t k, std::size_t b, void* blob, hipStream_t st) { return sm_compress24_bf16(A, m, k, k, b, m * k, blob, st); }
+  static int mul_on(const void* blob, void* B, void* C, std::size_t m, std::size_t n, std::size_t k, std::size_t b, std::size_t sB, float al,
+                    float be, hipStream_t st) {
+    return sm_spmma_bf16(blob, B, C, m, n, k, b, sB, m * n, al, be, st);
+  }
+};
+template <>
+struct spmma_fns<__bf16> : spmma_fns_bf16 {};
 template <>
 struct spmma_fns<_Float16> : spmma_fns_f16 {};
 template <>
@@ -80,6 +97,7 @@ std::vector<float> spmma(type_t* dA,
   if (transpose_a != operation_t::N || transpose_b != operation_t::N)
     std::cerr << "sparsifyme::spmma: transposed operands are not implemented; computing with N, N." << std::endl;
 
+  util::range_t range("spmma");
   util::timer_t prune_timer;
   prune_timer.begin();
   device_vector<int> valid(1);

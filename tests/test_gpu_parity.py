@@ -617,7 +617,7 @@ def test_cpp_drivers_cli_contract(gpu):
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     bins = os.path.join(root, "examples", "bin")
-    if not os.path.exists(os.path.join(bins, "spmma_plan")):
+    if not os.path.exists(os.path.join(bins, "spmma_plan_bf16")):
         subprocess.run(["make", "-C", os.path.join(root, "examples"), "-j4"], check=True, capture_output=True)
 
     def run(*args):
@@ -634,9 +634,10 @@ def test_cpp_drivers_cli_contract(gpu):
     assert bad.returncode != 0 and "Usage: ./spmma m n k b" in bad.stdout
     # cached-plan form (row f-1): compress once, multiply many; the driver compares its C with spmma()'s bit for bit
     for argv in [(196, 64, 128, 4), (784, 256, 1152, 2), (130, 72, 200, 3)]:
-        out = run("spmma_plan", *argv, 3)
-        assert out.returncode == 0, out.stdout + out.stderr
-        assert "Matches spmma(): yes" in out.stdout
+        for tool in ("spmma_plan", "spmma_plan_bf16"):
+            out = run(tool, *argv, 3)
+            assert out.returncode == 0, out.stdout + out.stderr
+            assert "Matches spmma(): yes" in out.stdout
 
 
 # ---------------------------------------------------------------------------------------------
