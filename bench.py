@@ -55,6 +55,11 @@ def main():
                          "kernel keeps the 2:4 image of a row panel in LDS across its column tiles); 0 = never")
     ap.add_argument("--streams", type=int, default=4,
                     help="HIP streams the independent layers of a step are spread over (fork/join inside the step)")
+    ap.add_argument("--graphs", choices=["single", "per-stream"], default="single",
+                    help="hipGraph form of a step: one graph holding every chain (default) or one linear graph per stream")
+    ap.add_argument("--sched", choices=["rr", "split"], default="rr",
+                    help="layer -> stream assignment: round-robin, or chip-filling layers (>= 784 row tiles) on the first half "
+                         "of the streams and the under-filling ones on the second half")
     ap.add_argument("--rehearse-gloo", action="store_true",
                     help="multi-rank rehearsal on a ONE-GPU box: gloo backend, every rank on cuda:0 (control flow only; "
                          "the ranks share the device, so the numbers mean nothing)")
@@ -102,19 +107,41 @@ def main():
     # layer stay ordered on one stream.
     side = [torch.cuda.Stream() for _ in range(max(0, args.streams - 1))]
 
-    def forked(per_layer):
-        main = torch.cuda.current_stream()
-        for s_ in side:
-            s_.wait_stream(main)
-        for li, L in enumerate(layers):
-            w = li % (len(side) + 1)
-            if w == 0:
-                per_layer(L)
-            else:
-                with torch.cuda.stream(side[w - 1]):
-                    per_layer(L)
-        for s_ in side:
-            main.wait_stream(s_)
+    nstreams = len(side) + 1
+    chains = [[] for _ in range(nstreams)]  # stream w runs chains[w] in order
+    cnt = [0, 0]
+    for li, L in enumerate(layers):
+        w = li % nstreams
+        if args.sched == "split" and nstreams >= 2:
+            big = 0 if L["m"] * L["b"] >= 784 * 128 else 1
+            half = [nstreams // 2, nstreams - nstreams // 2]
+            w = (0 if big == 0 else half[0]) + cnt[big] % half[big]
+            cnt[big] += 1
+        chains[w].append(L)
+
+    class Forked:
+        """A step whose layers are spread over the streams: fork, one chain of layers per stream, join."""
+
+        def __init__(self, per_layer):
+            self.per_layer = per_layer
+
+        def fork_join(self, run_chain):
+            main = torch.cuda.current_stream()
+            for s_ in side:
+                s_.wait_stream(main)
+            run_chain(0)
+            for w, s_ in enumerate(side, start=1):
+                with torch.cuda.stream(s_):
+                    run_chain(w)
+            for s_ in side:
+                main.wait_stream(s_)
+
+        def chain(self, w):
+            for L in chains[w]:
+                self.per_layer(L)
+
+        def __call__(self):  # launched kernel by kernel
+            self.fork_join(self.chain)
 
     def layer_full(L):
         sm.compress24(L["A"], L["m"], L["k"], L["k"], L["b"], L["m"] * L["k"], L["blob"])
@@ -131,8 +158,7 @@ def main():
         else:
             layer_full(L)
 
-    def step_full():
-        forked(layer_path)
+    step_full = Forked(layer_path)
 
     def barrier():
         if world > 1:
@@ -140,12 +166,25 @@ def main():
         torch.cuda.synchronize()
 
     def make_runner(fn):
-        """fn replayed from a hipGraph (one graph = one call of fn), or fn itself with --eager."""
+        """fn replayed from a hipGraph (one graph = one call of fn), or fn itself with --eager.  --graphs per-stream
+        turns a Forked step into one linear graph per stream, replayed into its own stream between the fork and the
+        join.  Measured the same as the single graph (1.87 vs 1.88 ms): under either form the hardware runs two or
+        three of the four chains at a time (profiles/ktrace_r01l.txt, tools/ktrace_step.py), with eager launches all
+        four, and the step takes the same time in all three cases -- it is bound by the HBM rate of the kernel mix,
+        not by how the chains interleave."""
         fn()  # first call outside capture: lazy module loads, function attributes
         torch.cuda.synchronize()
         if args.eager:
             return fn
         try:
+            if isinstance(fn, Forked) and args.graphs == "per-stream":
+                graphs = []
+                for w in range(nstreams):
+                    gw = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(gw, stream=torch.cuda.Stream()):
+                        fn.chain(w)
+                    graphs.append(gw)
+                return lambda: fn.fork_join(lambda w: graphs[w].replay())
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=torch.cuda.Stream()):
                 fn()
@@ -188,7 +227,8 @@ def main():
                                            sum(not use_fused(L) for L in layers))
                                         if args.path == "auto" else ": sm_compress24_f16 + sm_spmma_f16 on every layer"),
                    "layers": len(layers), "batch": layers[0]["b"], "dense_equiv_gflop_per_step": flops / 1e9,
-                   "launch": "eager" if args.eager else "hipGraph replay of one step", "streams": args.streams,
+                   "launch": "eager" if args.eager else ("hipGraph replay, one linear graph per stream" if args.graphs == "per-stream" else "hipGraph replay of one step"),
+                   "streams": args.streams, "sched": args.sched,
                    "parallelism": f"replicated table x{world}, per-rank batch, no data-path collective"},
     }
 
@@ -198,14 +238,9 @@ def main():
         def sec_per_call(fn):
             return timed(make_runner(fn), R, 2, collective=False) / R
 
-        def spmma_only():
-            forked(lambda L: sm.spmma(L["blob"], L["B"], L["C"], L["m"], L["n"], L["k"], L["b"], 0))
-
-        def compress_only():
-            forked(lambda L: sm.compress24(L["A"], L["m"], L["k"], L["k"], L["b"], L["m"] * L["k"], L["blob"]))
-
-        def dense_rowmajor():
-            forked(lambda L: sm.gemm_rowmajor(L["A"], L["B"], L["C"], L["m"], L["n"], L["k"], batch=L["b"]))
+        spmma_only = Forked(lambda L: sm.spmma(L["blob"], L["B"], L["C"], L["m"], L["n"], L["k"], L["b"], 0))
+        compress_only = Forked(lambda L: sm.compress24(L["A"], L["m"], L["k"], L["k"], L["b"], L["m"] * L["k"], L["blob"]))
+        dense_rowmajor = Forked(lambda L: sm.gemm_rowmajor(L["A"], L["B"], L["C"], L["m"], L["n"], L["k"], batch=L["b"]))
 
         # the reference's dense path: column-major pointer-array batched GEMM, B shared (examples/gemm.cu:60,86)
         for L in layers:
@@ -214,15 +249,13 @@ def main():
             L["Bp"] = torch.tensor([L["B"].data_ptr()] * b, dtype=torch.int64, device=dev)
             L["Cp"] = torch.tensor([L["C"].data_ptr() + 2 * i * m * n for i in range(b)], dtype=torch.int64, device=dev)
 
-        def dense_batched():
-            forked(lambda L: sm.gemm_batched(L["Ap"], L["Bp"], L["Cp"], L["m"], L["n"], L["k"], L["b"], "f16"))
+        dense_batched = Forked(lambda L: sm.gemm_batched(L["Ap"], L["Bp"], L["Cp"], L["m"], L["n"], L["k"], L["b"], "f16"))
 
         t_mul, t_cmp = sec_per_call(spmma_only), sec_per_call(compress_only)
         t_drm, t_dcm = sec_per_call(dense_rowmajor), sec_per_call(dense_batched)
         t_full = wall / args.steps
 
-        def step_staged():
-            forked(layer_full)
+        step_staged = Forked(layer_full)
 
         t_staged = t_full if args.path == "staged" else sec_per_call(step_staged)
         gfs = lambda t: flops / t / 1e9

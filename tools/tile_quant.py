@@ -26,4 +26,4 @@ for n, k, ms_list in cases:
         t = sm.graph_time_ms(f, iters=12, replays=3) * 1e3
         tiles = (m * b + 127) // 128
         by = b * m * (k + n) * 2 + k * n * 2
-        print(f"n={n:4d} k={k:5d} m={m:6d} tiles={tiles:5d} ({tiles / 256:6.2f} per CU)  {t:8.1f} us  {by / t / 1e6:7.0f} GB/s  {t / tiles * 1e3:7.1f} ns/tile", flush=True)
+        print(f"n={n:4d} k={k:5d} m={m:6d} tiles={tiles:5d} ({tiles / 256:6.2f} per CU)  {t:8.1f} us  {by / t / 1e3:7.0f} GB/s  {t / tiles * 1e3:7.1f} ns/tile", flush=True)
