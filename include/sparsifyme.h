@@ -204,6 +204,24 @@ int sm_gemm_rowmajor_bf16(const void* A, const void* B, void* C, size_t m, size_
                           sm_stream_t stream);
 int sm_fill_uniform_bf16(void* out, size_t count, uint64_t seed, float lo, float hi, sm_stream_t stream);
 
+/* ---- im2col front end (extension).  X: N x C x H x W activations (NCHW, contiguous).
+ *      A: per image the row-major L x K operand of the layer's matmul, L = out_h * out_w rows (row oh * out_w + ow),
+ *      K = C * kh * kw columns (column c * kh * kw + r * kw + u), images back to back -- the transpose of torch's
+ *      unfold, i.e. the (m, k) = (L, C * kh * kw) operand of the reference's shape tables
+ *      (datasets/get_shapes.py:30-40, 66-73).  out = floor((in + 2 pad - dilation (k - 1) - 1) / stride) + 1
+ *      (get_shapes.py:19-20).  sm_im2col_compress24_* writes sm_compress24_*'s blob of that A (m = L, k = K,
+ *      batch = N; size from sm_compress24_size) without ever materialising the dense A; same bytes as
+ *      sm_im2col_* followed by sm_compress24_*. */
+int sm_conv_out_size(size_t in, size_t kernel, size_t stride, size_t pad, size_t dilation, size_t* out /*host*/);
+int sm_im2col_f16(const void* X, size_t N, size_t C, size_t H, size_t W, size_t kh, size_t kw, size_t stride, size_t pad,
+                  size_t dilation, void* A, sm_stream_t stream);
+int sm_im2col_bf16(const void* X, size_t N, size_t C, size_t H, size_t W, size_t kh, size_t kw, size_t stride, size_t pad,
+                   size_t dilation, void* A, sm_stream_t stream);
+int sm_im2col_compress24_f16(const void* X, size_t N, size_t C, size_t H, size_t W, size_t kh, size_t kw, size_t stride,
+                             size_t pad, size_t dilation, void* blob, sm_stream_t stream);
+int sm_im2col_compress24_bf16(const void* X, size_t N, size_t C, size_t H, size_t W, size_t kh, size_t kw, size_t stride,
+                              size_t pad, size_t dilation, void* blob, sm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

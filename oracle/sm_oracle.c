@@ -721,6 +721,43 @@ void sm_widen_f16(const uint16_t* in, float* out, size_t count) {
 #pragma omp parallel for schedule(static)
   for (long long i = 0; i < (long long)count; ++i) out[i] = h2f(in[i]);
 }
+/* ------------------------------------------------------------------------------------------ */
+/* im2col (extension of the build; follows the unfold + transpose of datasets/get_shapes.py:30-40: */
+/* row l = oh * OW + ow of image n, column c * kh * kw + r * kw + u holds                          */
+/* X[n][c][oh * stride - pad + r * dil][ow * stride - pad + u * dil], zero outside the image).      */
+/* Elements are moved as opaque elt-byte values.                                                    */
+/* ------------------------------------------------------------------------------------------ */
+int sm_conv_out_size_ref(size_t in, size_t k, size_t stride, size_t pad, size_t dil, size_t* out) {
+  if (!out || k == 0 || stride == 0 || dil == 0) return SM_ERR_ARG;
+  const size_t span = dil * (k - 1) + 1;
+  if (in + 2 * pad < span) return SM_ERR_ARG;
+  *out = (in + 2 * pad - span) / stride + 1; /* get_shapes.py:19-20 */
+  return SM_OK;
+}
+int sm_im2col_ref(const void* X, size_t N, size_t C, size_t H, size_t W, size_t kh, size_t kw, size_t stride,
+                  size_t pad, size_t dil, size_t elt, void* A) {
+  size_t OH, OW;
+  if (!X || !A || sm_conv_out_size_ref(H, kh, stride, pad, dil, &OH) || sm_conv_out_size_ref(W, kw, stride, pad, dil, &OW))
+    return SM_ERR_ARG;
+  const size_t K = C * kh * kw, L = OH * OW;
+  const unsigned char* x = (const unsigned char*)X;
+  unsigned char* a = (unsigned char*)A;
+  for (size_t n = 0; n < N; ++n)
+    for (size_t oh = 0; oh < OH; ++oh)
+      for (size_t ow = 0; ow < OW; ++ow)
+        for (size_t c = 0; c < C; ++c)
+          for (size_t r = 0; r < kh; ++r)
+            for (size_t u = 0; u < kw; ++u) {
+              const long ih = (long)(oh * stride + r * dil) - (long)pad, iw = (long)(ow * stride + u * dil) - (long)pad;
+              unsigned char* dst = a + ((n * L + oh * OW + ow) * K + (c * kh + r) * kw + u) * elt;
+              if (ih >= 0 && ih < (long)H && iw >= 0 && iw < (long)W)
+                memcpy(dst, x + (((n * C + c) * H + (size_t)ih) * W + (size_t)iw) * elt, elt);
+              else
+                memset(dst, 0, elt);
+            }
+  return SM_OK;
+}
+
 void sm_widen_bf16(const uint16_t* in, float* out, size_t count) {
   for (size_t i = 0; i < count; ++i) out[i] = bf2f(in[i]);
 }

@@ -114,6 +114,21 @@ def spmma(blob, B, C, m, n, k, batch=1, strideB=0, strideC=None, alpha=1.0, beta
     return C
 
 
+def conv_out_size(size, kernel, stride=1, pad=0, dilation=1):
+    out = ctypes.c_size_t(0)
+    _ok(lib().sm_conv_out_size_ref(_sz(size), _sz(kernel), _sz(stride), _sz(pad), _sz(dilation), ctypes.byref(out)), "conv_out_size")
+    return out.value
+
+
+def im2col(X, N, C, H, W, kh, kw, stride=1, pad=0, dilation=1):
+    """X: flat NCHW array (any dtype; elements move as opaque values) -> flat [N][L][C*kh*kw]."""
+    OH, OW = conv_out_size(H, kh, stride, pad, dilation), conv_out_size(W, kw, stride, pad, dilation)
+    A = np.zeros(N * OH * OW * C * kh * kw, dtype=X.dtype)
+    _ok(lib().sm_im2col_ref(_p(X), _sz(N), _sz(C), _sz(H), _sz(W), _sz(kh), _sz(kw), _sz(stride), _sz(pad), _sz(dilation),
+                            _sz(X.dtype.itemsize), _p(A)), "im2col")
+    return A
+
+
 def gemm_batched(As, Bs, Cs, m, n, k, alpha=1.0, beta=0.0, ta=0, tb=0):
     """Column-major pointer-array GEMM (gemm.hxx:80-81); As/Bs/Cs are lists of flat arrays; Cs in place."""
     batch = len(Cs)

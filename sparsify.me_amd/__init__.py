@@ -70,9 +70,12 @@ _SIGS = {
     "sm_fill_uniform_f16": [_c_ptr, _c_size, ctypes.c_uint64, _c_f, _c_f, _c_ptr],
     "sm_fill_uniform_f32": [_c_ptr, _c_size, ctypes.c_uint64, _c_f, _c_f, _c_ptr],
 }
+_SIGS["sm_conv_out_size"] = [_c_size, _c_size, _c_size, _c_size, _c_size, ctypes.POINTER(_c_size)]
+_SIGS["sm_im2col_f16"] = [_c_ptr] + [_c_size] * 9 + [_c_ptr, _c_ptr]
+_SIGS["sm_im2col_compress24_f16"] = [_c_ptr] + [_c_size] * 9 + [_c_ptr, _c_ptr]
 # bfloat16 forms: same signatures as their _f16 counterparts
 for _name in ("sm_prune24", "sm_prune24_check", "sm_compress24", "sm_decompress24", "sm_spmma", "sm_spmma_fused",
-              "sm_gemm_rowmajor", "sm_fill_uniform"):
+              "sm_gemm_rowmajor", "sm_fill_uniform", "sm_im2col", "sm_im2col_compress24"):
     _SIGS[_name + "_bf16"] = _SIGS[_name + "_f16"]
 _RET = {"sm_version": ctypes.c_char_p, "sm_last_error": ctypes.c_char_p}
 
@@ -231,6 +234,18 @@ def spmma_fused(A, B, C, m, n, k, lda=None, batch=1, strideA=None, strideB=0, st
     fn = getattr(lib(), "sm_spmma_fused_" + _sfx(A))
     _check(fn(_dev(A), _dev(B), _dev(C), m, n, k, lda, batch, strideA, strideB, strideC, float(alpha), float(beta), _stream()),
            "sm_spmma_fused")
+
+
+def conv_out_size(size, kernel, stride=1, pad=0, dilation=1):
+    out = ctypes.c_size_t(0)
+    _check(lib().sm_conv_out_size(size, kernel, stride, pad, dilation, ctypes.byref(out)), "sm_conv_out_size")
+    return out.value
+
+
+def im2col(X, N, C, H, W, kh, kw, stride, pad, dilation, out, compress=False):
+    """NCHW activations -> the matmul operand A [N][L][C*kh*kw] (compress=False) or its 2:4 blob (compress=True)."""
+    fn = getattr(lib(), ("sm_im2col_compress24_" if compress else "sm_im2col_") + _sfx(X))
+    _check(fn(_dev(X), N, C, H, W, kh, kw, stride, pad, dilation, _dev(out), _stream()), "sm_im2col")
 
 
 def gemm_batched(A_ptrs, B_ptrs, C_ptrs, m, n, k, batch, dtype_suffix, alpha=1.0, beta=0.0, ta=0, tb=0):

@@ -782,6 +782,77 @@ def test_fill_uniform_bf16(gpu):
     assert torch.equal(x, y.to(torch.bfloat16))     # same counter-based stream, rounded once to nearest even
 
 
+# ---------------------------------------------------------------------------------------------
+# (f-3) im2col front end
+# ---------------------------------------------------------------------------------------------
+IM2COL_CFGS = [(2, 3, 9, 11, 3, 3, 1, 1, 1), (1, 4, 12, 12, 7, 7, 2, 3, 1), (2, 5, 8, 8, 1, 1, 1, 0, 1), (1, 2, 10, 9, 3, 2, 2, 0, 2),
+               (1, 3, 224, 224, 7, 7, 2, 3, 1),      # the stem: K = 147 (ragged rows, K tail in the blob)
+               (2, 64, 56, 56, 3, 3, 1, 1, 1),       # K = 576
+               (1, 256, 14, 14, 3, 3, 2, 1, 1),      # K = 2304, several channel chunks, 7 x 7 outputs
+               (1, 520, 7, 7, 1, 1, 1, 0, 1),        # 1 x 1, C not a multiple of the chunk
+               (3, 16, 33, 70, 3, 3, 1, 1, 1)]       # three column blocks, ragged last one
+
+
+@pytest.mark.parametrize("cfg", IM2COL_CFGS)
+@pytest.mark.parametrize("tdt", ["f16", "bf16"])
+def test_im2col_and_fused_compress_vs_oracle(gpu, orc, cfg, tdt):
+    import torch
+    N, C, H, W, kh, kw, s, p, d = cfg
+    rng = np.random.default_rng(sum(cfg))
+    X = rng.integers(0, 1 << 16, N * C * H * W).astype(np.uint16) if tdt == "bf16" else bits(rand(rng, N * C * H * W, np.float16))
+    X[(X & 0x7fff) > 0x7c00] = 0x3c00                  # no NaN payload games in the equality checks
+    dX = bf16_dev(X) if tdt == "bf16" else to_dev(X.view(np.float16))
+    OH, OW = gpu.conv_out_size(H, kh, s, p, d), gpu.conv_out_size(W, kw, s, p, d)
+    assert (OH, OW) == (orc.conv_out_size(H, kh, s, p, d), orc.conv_out_size(W, kw, s, p, d))
+    L, K = OH * OW, C * kh * kw
+    want = orc.im2col(X, N, C, H, W, kh, kw, s, p, d)
+    dA = torch.full((N * L * K,), 7.0, dtype=dX.dtype, device="cuda")
+    gpu.im2col(dX, N, C, H, W, kh, kw, s, p, d, dA)
+    got = bf16_host(dA) if tdt == "bf16" else bits(host(dA))
+    assert np.array_equal(got, want), f"im2col {cfg}"
+    # fused form: the blob of that A, never materialising it
+    blob = torch.full((gpu.compress24_size(L, K, 2, N),), 0xAB, dtype=torch.uint8, device="cuda")
+    gpu.im2col(dX, N, C, H, W, kh, kw, s, p, d, blob, compress=True)
+    assert np.array_equal(host(blob), orc.compress24(want, L, K, K, N)), f"im2col_compress24 {cfg}"
+    blob2 = torch.empty_like(blob)
+    gpu.compress24(dA, L, K, K, N, L * K, blob2)
+    assert torch.equal(blob, blob2)
+
+
+def test_conv_as_im2col_2to4_matmul(gpu):
+    """End to end: activations -> (im2col + 2:4 compress in one kernel) -> sm_spmma against the filters == conv2d of
+    the activations with, per output pixel, the same two-of-four receptive-field elements dropped."""
+    import torch
+    N, C, H, W, Co, kh, s, p = 2, 32, 20, 20, 64, 3, 1, 1
+    g = torch.Generator().manual_seed(3)
+    X = torch.randn(N, C, H, W, generator=g).half()
+    Wt = torch.randn(Co, C, kh, kh, generator=g).half()
+    OH = gpu.conv_out_size(H, kh, s, p, 1)
+    L, K = OH * OH, C * kh * kh
+    dX, dB = X.cuda().reshape(-1), Wt.reshape(Co, K).t().contiguous().cuda().reshape(-1)     # B = filters^T: K x Co
+    blob = torch.empty(gpu.compress24_size(L, K, 2, N), dtype=torch.uint8, device="cuda")
+    gpu.im2col(dX, N, C, H, W, kh, kh, s, p, 1, blob, compress=True)
+    dC = torch.empty(N * L * Co, dtype=torch.float16, device="cuda")
+    gpu.spmma(blob, dB, dC, L, Co, K, N, 0)
+    # reference: unfold on the CPU, prune each row 2:4 (top-2 magnitudes per strip, ties to the lower index), matmul
+    A = torch.nn.functional.unfold(X.float(), kh, padding=p, stride=s).transpose(1, 2).reshape(N * L, K // 4, 4)
+    order = torch.argsort(-A.abs(), dim=-1, stable=True)
+    keep = torch.zeros_like(A, dtype=torch.bool).scatter_(-1, order[..., :2], True)
+    ref = (A * keep).reshape(N * L, K).double() @ Wt.reshape(Co, K).t().double()
+    got = dC.cpu().double().reshape(N * L, Co)
+    scale = (A.abs().reshape(N * L, K).double() @ Wt.reshape(Co, K).t().abs().double())
+    assert ((got - ref).abs() <= FP16_TOL * scale.clamp_min(1e-30)).all()
+
+
+def test_im2col_rejects_bad_windows(gpu):
+    import torch
+    x = torch.zeros(64, dtype=torch.float16, device="cuda")
+    L_ = gpu.lib()
+    assert L_.sm_im2col_f16(x.data_ptr(), 1, 1, 4, 4, 5, 5, 1, 0, 1, x.data_ptr(), None) == 1      # window larger than the image
+    assert L_.sm_im2col_f16(x.data_ptr(), 1, 1, 4, 4, 3, 3, 0, 0, 1, x.data_ptr(), None) == 1      # zero stride
+    assert L_.sm_im2col_f16(None, 1, 1, 4, 4, 3, 3, 1, 0, 1, x.data_ptr(), None) == 1
+
+
 def test_fused_rejects_what_it_cannot_take(gpu):
     import torch
     A = torch.zeros(16 * 147, dtype=torch.float16, device="cuda")

@@ -372,6 +372,28 @@ def test_bf16_conversions_and_rules(orc):
     assert np.array_equal(C1, C2)
 
 
+@pytest.mark.parametrize("cfg", [(2, 3, 9, 11, 3, 3, 1, 1, 1), (1, 4, 12, 12, 7, 7, 2, 3, 1), (2, 5, 8, 8, 1, 1, 1, 0, 1),
+                                 (1, 2, 10, 9, 3, 2, 2, 0, 2), (1, 3, 224, 224, 7, 7, 2, 3, 1)])
+def test_im2col_restatement_is_unfold_transposed(orc, cfg):
+    """The oracle's im2col against torch's CPU unfold (what datasets/get_shapes.py:30-35 calls), transposed to rows =
+    output pixels; and the (m, k) it yields are the shape tables' (get_shapes.py:66-73)."""
+    import torch
+    N, C, H, W, kh, kw, s, p, d = cfg
+    rng = np.random.default_rng(sum(cfg))
+    X = rng.uniform(-1, 1, (N, C, H, W)).astype(np.float32)
+    want = torch.nn.functional.unfold(torch.from_numpy(X), (kh, kw), dilation=d, padding=p, stride=s)   # N x K x L
+    want = want.transpose(1, 2).contiguous().numpy()                                                       # N x L x K
+    got = orc.im2col(X.reshape(-1), N, C, H, W, kh, kw, s, p, d).reshape(want.shape)
+    assert np.array_equal(got, want)
+    assert want.shape[1] == orc.conv_out_size(H, kh, s, p, d) * orc.conv_out_size(W, kw, s, p, d)
+    if cfg == (1, 3, 224, 224, 7, 7, 2, 3, 1):
+        assert want.shape[1:] == (12544, 147)     # first row of datasets/resnet*.csv
+    # 16-bit elements move as opaque values too
+    Xh = X.astype(np.float16)
+    got16 = orc.im2col(Xh.reshape(-1).view(np.uint16), N, C, H, W, kh, kw, s, p, d)
+    assert np.array_equal(got16.view(np.float16).astype(np.float32).reshape(want.shape), want.astype(np.float16).astype(np.float32))
+
+
 def test_bell_and_coo_restatements(orc):
     rng = np.random.default_rng(2)
     rows, cols, bs, n = 8, 12, 2, 5
