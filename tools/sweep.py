@@ -134,11 +134,11 @@ def main():
             ("prune", f_prune, 0, m * k * (s + s + 8), 0),
         ]
         rec = {"m": m, "n": n, "k": k, "b": b}
-        for name, fn, fl, by, peak in stages:
+        for name, fn, fl, by, pk in stages:
             if only and name not in only:
                 continue
             ms = timeit(fn)
-            roof = max(by / HBM, fl / peak if peak else 0.0)
+            roof = max(by / HBM, fl / pk if pk else 0.0)
             print("%6d %5d %5d %3d %3d %-10s %9.4f %9.1f %8.0f %8.1f %6.3f" %
                   (m, n, k, b, cnt, name, ms, fl / ms / 1e9, by / ms / 1e6, roof * 1e6, roof * 1e3 / ms))
             rec[name] = ms
