@@ -46,6 +46,17 @@ def test_compress_size_host_entry_matches_oracle(pkg, orc):
     assert b"invalid" in pkg.lib().sm_last_error()
 
 
+def test_conv_out_size_host_entry(pkg, orc):
+    """sm_conv_out_size is host arithmetic (datasets/get_shapes.py:19-20): same answers as the oracle and as the formula."""
+    import math
+    for (size, k, s, p, d) in [(224, 7, 2, 3, 1), (112, 3, 2, 1, 1), (56, 1, 1, 0, 1), (10, 3, 2, 0, 2), (5, 5, 1, 0, 1), (7, 3, 1, 1, 1)]:
+        want = math.floor((size + 2 * p - d * (k - 1) - 1) / s + 1)
+        assert pkg.conv_out_size(size, k, s, p, d) == orc.conv_out_size(size, k, s, p, d) == want
+    out = ctypes.c_size_t(0)
+    assert pkg.lib().sm_conv_out_size(4, 5, 1, 0, 1, ctypes.byref(out)) != 0      # window larger than the padded input
+    assert pkg.lib().sm_conv_out_size(4, 3, 0, 0, 1, ctypes.byref(out)) != 0      # zero stride
+
+
 def test_product_package_never_imports_the_oracle():
     """The oracle is test infrastructure: nothing under the product package or include/ may name it."""
     bad = []
