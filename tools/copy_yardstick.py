@@ -16,6 +16,8 @@ for mb in (256, 1024, 4096):
     print(f"copy   {mb:5d} MiB: {t * 1e3:8.1f} us  {2 * n * 2 / t / 1e9:7.2f} TB/s (read + write)")
     t = sm.graph_time_ms(lambda: torch.sum(x, dtype=torch.float32), iters=5, replays=3)
     print(f"reduce {mb:5d} MiB: {t * 1e3:8.1f} us  {n * 2 / t / 1e9:7.2f} TB/s (read)")
+    t = sm.graph_time_ms(lambda: y.fill_(1.5), iters=5, replays=3)
+    print(f"fill   {mb:5d} MiB: {t * 1e3:8.1f} us  {n * 2 / t / 1e9:7.2f} TB/s (write)")
     m, k = n // 4096, 4096
     t = sm.graph_time_ms(lambda: sm.prune24(x, y, m, k, k, sm.PRUNE_STRIP), iters=5, replays=3)
     print(f"sm_prune24 STRIP (out of place) {mb:5d} MiB: {t * 1e3:8.1f} us  {2 * n * 2 / t / 1e9:7.2f} TB/s")
