@@ -224,6 +224,179 @@ static int launch32(const Gemm32Args& a0, hipStream_t st) {
   return check_launch("gemm_f32_kernel");
 }
 
+// ---------------------------------------------------------------------------------------------
+// LDS-DMA pipeline for the dense fp32 product (K % 32 == 0, 16-byte aligned rows, N % 4 == 0): the structure of the
+// fp16 kernels (gemm_f16.hip) in fp32 bytes.  Stage = 32 k: A [BM][128 B] (16-byte chunk c of row r at chunk
+// c ^ (r & 7), a_off) and B in panels of 32 columns [32 k][128 B] (chunk c of k-row kr at c ^ 4 * ((kr >> 3) & 1)),
+// all by global_load_lds into a ring of NS stage buffers, counted vmcnt + one barrier per stage.  The four k-slots of
+// v_mfma_f32_16x16x4_f32 are fed k = 8 g + s at step s (g = lane / 16) instead of 4 s + g: a lane then owns 8
+// CONSECUTIVE k of its A row per stage (two ds_read_b128 instead of eight ds_read_b32); B is read one float per step
+// (the two lane groups of a 32-lane half, k-rows 8 apart, sit in different halves of the 128-byte row).  Summation
+// order within a stage differs from the register-staged kernel's (still one fp32 fma chain per output).
+// BKM: B given k-major ([n][k], the Blocked-ELL path): its image is an A-style image and its reads are b128 too.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned b32_off(unsigned kr, unsigned col) {  // byte offset in the [panel][32][128 B] image
+  return (col >> 5) * 4096u + kr * 128u + 16u * (((col & 31u) >> 2) ^ (4u * ((kr >> 3) & 1u))) + 4u * (col & 3u);
+}
+
+template <int BM, int BN, int WM, int WN, int NS, bool BKM>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_f32_dma_kernel(const Gemm32Args p) {
+  constexpr int NW = WM * WN, TM = BM / WM, TN = BN / WN, FM = TM / 16, FN = TN / 16;
+  constexpr int SA = BM * 128, SB = BN * 128, STAGE = SA + SB;
+  constexpr int A_N = BM / 8, B_N = BN / 8, W = A_N + B_N;  // 1 KiB DMA wave-instructions per stage
+  static_assert(W % NW == 0, "equal DMA share per wave");
+  constexpr int SL = W / NW;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const unsigned tid = threadIdx.x, lane = tid & 63u;
+  const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const unsigned wm = wave / WN, wn = wave % WN;
+  const unsigned tiles = (unsigned)p.tiles_m * (unsigned)p.tiles_n;
+  const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
+  const unsigned b = lid / tiles, trem = lid - b * tiles;
+  const unsigned tile_m = trem / (unsigned)p.tiles_n, tile_n = trem - tile_m * (unsigned)p.tiles_n;
+  const int m0 = (int)tile_m * BM, n0 = (int)tile_n * BN;
+  const float* A = p.Ap ? p.Ap[b] : p.A + (size_t)b * p.sA;
+  const float* B = p.Bp ? p.Bp[b] : p.B + (size_t)b * p.sB;
+  float* C = p.Cp ? p.Cp[b] : p.C + (size_t)b * p.sC;
+  const int mlast = p.M - 1, nlast = p.N - 1;
+
+  const char* src[SL];
+  size_t step[SL];
+  unsigned loff[SL];
+#pragma unroll
+  for (int i = 0; i < SL; ++i) {
+    const unsigned t = wave + (unsigned)NW * i;
+    if (t < (unsigned)A_N) {  // 8 rows x 128 B
+      const unsigned row = 8u * t + (lane >> 3), cs = (lane & 7u) ^ (row & 7u);
+      int gr = m0 + (int)row;
+      gr = gr < mlast ? gr : mlast;
+      src[i] = reinterpret_cast<const char*>(A + (size_t)gr * p.lda + 4u * cs);
+      step[i] = 128;
+      loff[i] = t * 1024u;
+    } else if constexpr (BKM) {  // B rows are output columns, k-contiguous: the same image as A
+      const unsigned j = t - A_N, row = 8u * j + (lane >> 3), cs = (lane & 7u) ^ (row & 7u);
+      int gn = n0 + (int)row;
+      gn = gn < nlast ? gn : nlast;
+      src[i] = reinterpret_cast<const char*>(B + (size_t)gn * p.ldb + 4u * cs);
+      step[i] = 128;
+      loff[i] = SA + j * 1024u;
+    } else {  // 8 k-rows of one 32-column panel
+      const unsigned j = t - A_N, panel = j >> 2, kr = 8u * (j & 3u) + (lane >> 3);
+      const unsigned cs = (lane & 7u) ^ (4u * ((kr >> 3) & 1u));
+      int gc = n0 + (int)(32u * panel + 4u * cs);
+      gc = gc <= p.N - 4 ? gc : p.N - 4;
+      src[i] = reinterpret_cast<const char*>(B + (size_t)kr * p.ldb + gc);
+      step[i] = (size_t)32 * p.ldb * 4;
+      loff[i] = SA + panel * 4096u + (j & 3u) * 1024u;
+    }
+  }
+  auto stage = [&](int kt, int buf) {
+    char* base = smem + buf * STAGE;
+#pragma unroll
+    for (int i = 0; i < SL; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t*)(src[i] + (size_t)kt * step[i]), (lptr_t*)(base + loff[i]), 16, 0, 0);
+  };
+
+  f4 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+
+  const int nkt = p.K / 32;
+#pragma unroll
+  for (int s = 0; s < NS - 1; ++s)
+    if (s < nkt) stage(s, s);
+  const unsigned g = lane >> 4, r = lane & 15u;
+  int cur = 0, fill = NS - 1;
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int ahead = (nkt - 1 - kt) < (NS - 2) ? (nkt - 1 - kt) : (NS - 2);
+    if (NS >= 3 && ahead == 1) wait_dma_and_barrier<SL>();
+    else wait_dma_and_barrier<0>();
+    if (kt + NS - 1 < nkt) stage(kt + NS - 1, fill);
+    const char* As = smem + cur * STAGE;
+    const char* Bs = As + SA;
+    f4 alo[FM], ahi[FM];
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      const unsigned row = wm * TM + i * 16 + r;
+      alo[i] = *reinterpret_cast<const f4*>(As + a_off(row, 2u * g));
+      ahi[i] = *reinterpret_cast<const f4*>(As + a_off(row, 2u * g + 1u));
+    }
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      float bv[8];
+      const unsigned col = wn * TN + j * 16 + r;
+      if constexpr (BKM) {
+        const f4 lo = *reinterpret_cast<const f4*>(Bs + a_off(col, 2u * g));
+        const f4 hi = *reinterpret_cast<const f4*>(Bs + a_off(col, 2u * g + 1u));
+#pragma unroll
+        for (int s = 0; s < 4; ++s) { bv[s] = lo[s]; bv[4 + s] = hi[s]; }
+      } else {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) bv[s] = *reinterpret_cast<const float*>(Bs + b32_off(8u * g + s, col));
+      }
+#pragma unroll
+      for (int s = 0; s < 8; ++s)
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+          // swapped operands: lane holds C[row lane&15][cols 4*(lane>>4) .. +3]; k-slot g carries k = 8 g + s
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[s], s < 4 ? alo[i][s] : ahi[i][s - 4], acc[i][j], 0, 0, 0);
+    }
+    cur = cur + 1 == NS ? 0 : cur + 1;
+    fill = fill + 1 == NS ? 0 : fill + 1;
+  }
+
+  const bool c_vec = (p.ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(C) & 15u) == 0);
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      const int gr = m0 + (int)(wm * TM + i * 16 + r);
+      const int gc = n0 + (int)(wn * TN + j * 16 + 4u * g);
+      if (gr >= p.M || gc >= p.N) continue;
+      float* dst = C + (size_t)gr * p.ldc + gc;
+      f4 v;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] = p.alpha * acc[i][j][q];
+      if (c_vec && gc + 4 <= p.N) {
+        if (p.beta != 0.0f) {
+          const f4 old = *reinterpret_cast<const f4*>(dst);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] += p.beta * old[q];
+        }
+        __builtin_nontemporal_store(v, reinterpret_cast<f4*>(dst));
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (gc + q < p.N) dst[q] = p.beta != 0.0f ? v[q] + p.beta * dst[q] : v[q];
+      }
+    }
+}
+
+template <int BM, int BN, int WM, int WN, int NS, bool BKM>
+static int launch32_dma(const Gemm32Args& a0, hipStream_t st) {
+  Gemm32Args a = a0;
+  a.tiles_m = (a.M + BM - 1) / BM;
+  a.tiles_n = (a.N + BN - 1) / BN;
+  const size_t nwg = (size_t)a.tiles_m * a.tiles_n * a.batch;
+  if (nwg == 0) return SM_STATUS_SUCCESS;
+  if (nwg > 0x7fffffffu) {
+    set_error("gemm_f32: grid too large");
+    return SM_STATUS_NOT_SUPPORTED;
+  }
+  constexpr size_t lds = (size_t)NS * (BM + BN) * 128;
+  static bool attr_set = false;
+  if (lds > 64 * 1024 && !attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_dma_kernel<BM, BN, WM, WN, NS, BKM>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  gemm_f32_dma_kernel<BM, BN, WM, WN, NS, BKM><<<dim3((unsigned)nwg), dim3(64 * WM * WN), lds, st>>>(a);
+  return check_launch("gemm_f32_dma_kernel");
+}
+
 static int device_cu_count() {
   static int cus = 0;
   if (!cus) {
@@ -249,6 +422,31 @@ static int dispatch32(const Gemm32Args& a, hipStream_t st) {
   const double small_tiles = (double)((a.M + 63) / 64) * (double)((a.N + 63) / 64) * a.batch;
   int best = small_tiles / cus >= 32.0 ? 1 : 3;
   if (force >= 0 && force < 4) best = force;
+  if constexpr (MODE == 0 || MODE == 2) {
+    // LDS-DMA pipeline when whole 16-byte chunks can be moved: K % 32 == 0, aligned rows (pointer-array batches: the
+    // caller's bases, hipMalloc gives 256 B); SM_GEMM32_DMA=0 (tuning aid) keeps the register-staged kernel
+    static const int dma_env = getenv("SM_GEMM32_DMA") ? atoi(getenv("SM_GEMM32_DMA")) : 1;
+    const bool a_ok = (a.lda % 4 == 0) && (a.sA % 4 == 0) && (a.Ap || (reinterpret_cast<uintptr_t>(a.A) & 15u) == 0);
+    const bool b_ok = (a.ldb % 4 == 0) && (a.sB % 4 == 0) && (a.Bp || (reinterpret_cast<uintptr_t>(a.B) & 15u) == 0);
+    if (dma_env && a.K % 32 == 0 && a.K >= 32 && a_ok && b_ok && (MODE == 2 || (a.N % 4 == 0 && a.N >= 4))) {
+      constexpr bool BKM = MODE == 2;
+      const int cfg = dma_env;  // 1: default choice; 2..: forced shapes for tuning
+      if (cfg == 2) return launch32_dma<64, 64, 2, 2, 2, BKM>(a, st);
+      if (cfg == 3) return launch32_dma<64, 64, 2, 2, 3, BKM>(a, st);
+      if (cfg == 4) return launch32_dma<128, 64, 4, 1, 2, BKM>(a, st);
+      if (cfg == 5) return launch32_dma<128, 128, 2, 2, 2, BKM>(a, st);
+      if (cfg == 6) return launch32_dma<128, 128, 2, 4, 2, BKM>(a, st);
+      if (cfg == 7) return launch32_dma<128, 64, 4, 1, 3, BKM>(a, st);
+      if (cfg == 8) return launch32_dma<128, 128, 2, 4, 3, BKM>(a, st);
+      if (cfg == 9) return launch32_dma<128, 128, 4, 4, 2, BKM>(a, st);
+      // short operands get tiles as short as they are; narrow outputs 128 x 64 tiles (more of them); otherwise
+      // 128 x 128 over 16 waves (measured on the ResNet
+      // shapes and on 4096^3 / 8192^2 x 2048: tools/f32_probe.py under SM_GEMM32_DMA=2..9)
+      if (cfg == 10) return launch32_dma<64, 128, 1, 4, 2, BKM>(a, st);
+      if (a.M <= 64) return a.N <= 64 ? launch32_dma<64, 64, 2, 2, 2, BKM>(a, st) : launch32_dma<64, 128, 1, 4, 2, BKM>(a, st);
+      return a.N <= 128 ? launch32_dma<128, 64, 4, 1, 2, BKM>(a, st) : launch32_dma<128, 128, 4, 4, 2, BKM>(a, st);
+    }
+  }
   static const bool verbose = getenv("SM_GEMM32_VERBOSE") != nullptr;  // tuning aid
   if (verbose) fprintf(stderr, "gemm_f32 %d x %d x %d b=%d on %d CUs -> tile %d x %d\n", a.M, a.N, a.K, a.batch, (int)cus, cands[best].bm, cands[best].bn);
   switch (best) {
