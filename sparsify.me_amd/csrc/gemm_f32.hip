@@ -397,6 +397,169 @@ static int launch32_dma(const Gemm32Args& a0, hipStream_t st) {
   return check_launch("gemm_f32_dma_kernel");
 }
 
+// ---------------------------------------------------------------------------------------------
+// 2:4 fp32 product on the same pipeline (K % 64 == 0, even row counts, N % 4 == 0).  Stage = one 64-k plane of the
+// blob: the plane's values are 128 B per row -- exactly the dense kernel's A image -- plus 8 B of metadata per row
+// (one 1 KiB LDS-DMA instruction for the tile's 128 rows) and B for 64 k (two 32-k images).  There is no fp32 sparse
+// matrix instruction, so a lane expands its strips in registers on the way to the MFMA: for half h of the stage it
+// owns dense k 32 h + 8 g .. + 7 = two strips = ONE 16-byte chunk of kept values (chunk 4 h + g) and ONE metadata
+// byte (4 h + g); A's HBM bytes are 9/16 of the dense kernel's, the matrix work is the same.
+// ---------------------------------------------------------------------------------------------
+template <int BN, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN) void spmma_f32_dma_kernel(const Gemm32Args p) {
+  constexpr int BM = 128, NW = WM * WN, TM = BM / WM, TN = BN / WN, FM = TM / 16, FN = TN / 16;  // ring of 2
+  constexpr int SA = BM * 128, SM_ = BM * 8, SBH = BN * 128, STAGE = SA + SM_ + 2 * SBH;
+  constexpr int A_N = BM / 8, M_N = 1, B_N = 2 * (BN / 8), W = A_N + M_N + B_N;
+  constexpr int SL = (W + NW - 1) / NW;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const unsigned tid = threadIdx.x, lane = tid & 63u;
+  const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const unsigned wm = wave / WN, wn = wave % WN;
+  const unsigned tiles = (unsigned)p.tiles_m * (unsigned)p.tiles_n;
+  const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
+  const unsigned b = lid / tiles, trem = lid - b * tiles;
+  const unsigned tile_m = trem / (unsigned)p.tiles_n, tile_n = trem - tile_m * (unsigned)p.tiles_n;
+  const int m0 = (int)tile_m * BM, n0 = (int)tile_n * BN;
+  const size_t row_base = (size_t)b * p.sA;  // first blob row of this grid batch (sA counts rows here)
+  const float* B = p.Bp ? p.Bp[b] : p.B + (size_t)b * p.sB;
+  float* C = p.Cp ? p.Cp[b] : p.C + (size_t)b * p.sC;
+  const int mlast = p.M - 1;
+
+  const char* src[SL];
+  size_t step[SL];
+  unsigned loff[SL];
+#pragma unroll
+  for (int i = 0; i < SL; ++i) {
+    const unsigned t = wave + (unsigned)NW * i;
+    src[i] = nullptr; step[i] = 0; loff[i] = 0;
+    if (t < (unsigned)A_N) {  // 8 blob rows x 128 B of kept values
+      const unsigned row = 8u * t + (lane >> 3), cs = (lane & 7u) ^ (row & 7u);
+      int gr = m0 + (int)row;
+      gr = gr < mlast ? gr : mlast;
+      src[i] = p.vals + (row_base + (size_t)gr) * 128 + 16u * cs;
+      step[i] = p.Mtot * 128;
+      loff[i] = t * 1024u;
+    } else if (t == (unsigned)A_N) {  // metadata of the 128 rows: lane -> rows 2 lane, 2 lane + 1 (M even: whole pairs)
+      int gr = m0 + 2 * (int)lane;
+      gr = gr < mlast ? gr : (mlast & ~1);
+      src[i] = p.meta + (row_base + (size_t)gr) * 8;
+      step[i] = p.Mtot * 8;
+      loff[i] = SA;
+    } else if (t < (unsigned)W) {  // B: half h, 8 k-rows of one 32-column panel
+      const unsigned j = t - A_N - M_N, h = j / (BN / 8), jj = j - h * (BN / 8), panel = jj >> 2;
+      const unsigned kr = 8u * (jj & 3u) + (lane >> 3), cs = (lane & 7u) ^ (4u * ((kr >> 3) & 1u));
+      int gc = n0 + (int)(32u * panel + 4u * cs);
+      gc = gc <= p.N - 4 ? gc : p.N - 4;
+      src[i] = reinterpret_cast<const char*>(B + (size_t)(32u * h + kr) * p.ldb + gc);
+      step[i] = (size_t)64 * p.ldb * 4;
+      loff[i] = SA + SM_ + h * SBH + panel * 4096u + (jj & 3u) * 1024u;
+    }
+  }
+  auto stage = [&](int kt, int buf) {
+    char* base = smem + buf * STAGE;
+#pragma unroll
+    for (int i = 0; i < SL; ++i) {
+      const unsigned t = wave + (unsigned)NW * i;  // wave-uniform
+      if (t >= (unsigned)W) continue;
+      __builtin_amdgcn_global_load_lds((gptr_t*)(src[i] + (size_t)kt * step[i]), (lptr_t*)(base + loff[i]), 16, 0, 0);
+    }
+  };
+
+  f4 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+
+  const int nkt = p.kc / 64;
+  if (nkt > 0) stage(0, 0);
+  const unsigned g = lane >> 4, r = lane & 15u;
+  for (int kt = 0; kt < nkt; ++kt) {
+    wait_dma_and_barrier<0>();  // ring of 2: nothing newer than this stage is in flight
+    if (kt + 1 < nkt) stage(kt + 1, (kt + 1) & 1);
+    const char* As = smem + (kt & 1) * STAGE;
+    const char* Ms = As + SA;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const char* Bs = Ms + SM_ + h * SBH;
+      float ad[FM][8];
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        const unsigned row = wm * TM + i * 16 + r;
+        const f4 kv = *reinterpret_cast<const f4*>(As + a_off(row, 4u * h + g));
+        const unsigned mb = *reinterpret_cast<const unsigned char*>(Ms + row * 8u + 4u * h + g);
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+          const unsigned nib = (mb >> (4 * st)) & 0xfu, p0 = nib & 3u, p1 = nib >> 2;
+#pragma unroll
+          for (unsigned t = 0; t < 4; ++t) ad[i][4 * st + t] = t == p0 ? kv[2 * st] : (t == p1 ? kv[2 * st + 1] : 0.0f);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        float bv[8];
+        const unsigned col = wn * TN + j * 16 + r;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) bv[s] = *reinterpret_cast<const float*>(Bs + b32_off(8u * g + s, col));
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+#pragma unroll
+          for (int i = 0; i < FM; ++i)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[s], ad[i][s], acc[i][j], 0, 0, 0);
+      }
+    }
+  }
+
+  const bool c_vec = (p.ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(C) & 15u) == 0);
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      const int gr = m0 + (int)(wm * TM + i * 16 + r);
+      const int gc = n0 + (int)(wn * TN + j * 16 + 4u * g);
+      if (gr >= p.M || gc >= p.N) continue;
+      float* dst = C + (size_t)gr * p.ldc + gc;
+      f4 v;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] = p.alpha * acc[i][j][q];
+      if (c_vec && gc + 4 <= p.N) {
+        if (p.beta != 0.0f) {
+          const f4 old = *reinterpret_cast<const f4*>(dst);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] += p.beta * old[q];
+        }
+        __builtin_nontemporal_store(v, reinterpret_cast<f4*>(dst));
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (gc + q < p.N) dst[q] = p.beta != 0.0f ? v[q] + p.beta * dst[q] : v[q];
+      }
+    }
+}
+
+template <int BN, int WM, int WN>
+static int launch_spmma32_dma(const Gemm32Args& a0, hipStream_t st) {
+  Gemm32Args a = a0;
+  a.tiles_m = (a.M + 127) / 128;
+  a.tiles_n = (a.N + BN - 1) / BN;
+  const size_t nwg = (size_t)a.tiles_m * a.tiles_n * a.batch;
+  if (nwg == 0) return SM_STATUS_SUCCESS;
+  if (nwg > 0x7fffffffu) {
+    set_error("spmma_f32: grid too large");
+    return SM_STATUS_NOT_SUPPORTED;
+  }
+  constexpr size_t lds = 2 * ((size_t)128 * 128 + 128 * 8 + 2 * (size_t)BN * 128);
+  static bool attr_set = false;
+  if (lds > 64 * 1024 && !attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spmma_f32_dma_kernel<BN, WM, WN>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  spmma_f32_dma_kernel<BN, WM, WN><<<dim3((unsigned)nwg), dim3(64 * WM * WN), lds, st>>>(a);
+  return check_launch("spmma_f32_dma_kernel");
+}
+
 static int device_cu_count() {
   static int cus = 0;
   if (!cus) {
@@ -612,6 +775,16 @@ int sm_spmma_f32(const void* blob, const float* B, float* C, size_t m, size_t n,
   if (batch > 1 && strideB == 0 && strideC == m * n) {
     a.M = (int)(m * batch);
     a.batch = 1;
+  }
+  // LDS-DMA pipeline: whole 64-k planes, row pairs (metadata moves as 16-byte pairs), whole 16-byte B chunks
+  static const int dma_env = getenv("SM_SPMMA32_DMA") ? atoi(getenv("SM_SPMMA32_DMA")) : 1;  // tuning aid: 0 = register-staged kernel
+  const bool pairs = (a.batch == 1 ? (a.M % 2 == 0) : (m % 2 == 0));
+  if (dma_env && k % 64 == 0 && k >= 64 && pairs && n % 4 == 0 && n >= 4 && strideB % 4 == 0 &&
+      (reinterpret_cast<uintptr_t>(B) & 15u) == 0) {
+    if (dma_env == 3) return launch_spmma32_dma<128, 2, 4>(a, (hipStream_t)stream);
+    if (dma_env == 5) return launch_spmma32_dma<64, 4, 2>(a, (hipStream_t)stream);
+    // 128 x 64 tiles on every shape (two workgroups per CU; the 128 x 128 forms hold one and measured 25-40 % slower)
+    return launch_spmma32_dma<64, 4, 1>(a, (hipStream_t)stream);
   }
   return dispatch32<1>(a, (hipStream_t)stream);
 }
