@@ -204,6 +204,25 @@ int sm_gemm_rowmajor_bf16(const void* A, const void* B, void* C, size_t m, size_
                           sm_stream_t stream);
 int sm_fill_uniform_bf16(void* out, size_t count, uint64_t seed, float lo, float hi, sm_stream_t stream);
 
+/* ---- int8 forms (extension; SURVEY.md 8(f) rank 2, cusparseLt.h:164-169).  Elements are signed bytes; the rules
+ *      act on |x| (|-128| = 128); same blob geometry with 1-byte elements (sm_compress24_size(m, k, 1, batch, ...)).
+ *      Only the STRIP prune rule is built.  sm_spmma_i8: C (int32, row-major m x n) = A_2:4 . B (+ C when
+ *      accumulate != 0), exact integer arithmetic on v_smfmac_i32_16x16x128_i8; B is [n][k] -- K-CONTIGUOUS per output
+ *      column ("TN", the layout int8 matrix cores are fed in), B_b = B + b * strideB (0 = shared).  Needs k % 64 == 0,
+ *      an even m, a 16-byte aligned B; SM_STATUS_NOT_SUPPORTED otherwise. */
+int sm_prune24_i8(const void* A_in, void* A_out, size_t m, size_t k, size_t ld, int alg, sm_stream_t stream);
+int sm_prune24_check_i8(const void* A, size_t m, size_t k, size_t ld, int* d_valid, sm_stream_t stream);
+int sm_compress24_i8(const void* A, size_t m, size_t k, size_t ld, size_t batch, size_t strideA, void* blob,
+                     sm_stream_t stream);
+int sm_decompress24_i8(const void* blob, size_t m, size_t k, size_t ld, size_t batch, size_t strideA, void* A,
+                       sm_stream_t stream);
+int sm_spmma_i8(const void* blob, const void* B, int32_t* C, size_t m, size_t n, size_t k, size_t batch,
+                size_t strideB, size_t strideC, int accumulate, sm_stream_t stream);
+/* the same product requantised on the way out: C (int8) = saturate(round_to_nearest_even(scale * acc)), one fp32
+ * multiply of the int32 accumulator converted to fp32 */
+int sm_spmma_i8_q(const void* blob, const void* B, void* C, size_t m, size_t n, size_t k, size_t batch, size_t strideB,
+                  size_t strideC, float scale, sm_stream_t stream);
+
 /* ---- im2col front end (extension).  X: N x C x H x W activations (NCHW, contiguous).
  *      A: per image the row-major L x K operand of the layer's matmul, L = out_h * out_w rows (row oh * out_w + ow),
  *      K = C * kh * kw columns (column c * kh * kw + r * kw + u), images back to back -- the transpose of torch's

@@ -178,6 +178,8 @@ int sm_sparsify_positional_ref(void* weights, uint64_t* mask, size_t m, size_t n
  */
 static inline uint32_t key16(uint16_t v) { return v & 0x7fffu; }
 static inline uint32_t key32(uint32_t v) { return v & 0x7fffffffu; }
+/* int8 (extension): |x| of a signed byte, 0 .. 128 */
+static inline uint32_t key8(uint8_t v) { const int x = (int)(int8_t)v; return (uint32_t)(x < 0 ? -x : x); }
 
 /* STRIP rule on 4 keys: returns nibble p0 | p1 << 2 with p0 < p1 the kept positions. */
 static inline unsigned strip_select(const uint32_t key[4]) {
@@ -297,6 +299,8 @@ DEFINE_PRUNE(sm_prune24_f32_bits_ref, uint32_t, key32, mag32)
 /* bfloat16 (extension of the build): magnitudes order by bit pattern exactly as fp16's do, so
  * the STRIP rule is the same function of the bits; the TILE rule sums bfloat16 magnitudes */
 DEFINE_PRUNE(sm_prune24_bf16_ref, uint16_t, key16, magbf)
+static inline float mag8(uint8_t v) { return (float)key8(v); }
+DEFINE_PRUNE(sm_prune24_i8_ref, uint8_t, key8, mag8)
 
 int sm_prune24_f32_ref(const float* A_in, float* A_out, size_t m, size_t k, size_t ld, int alg) {
   return sm_prune24_f32_bits_ref((const uint32_t*)A_in, (uint32_t*)A_out, m, k, ld, alg);
@@ -325,6 +329,8 @@ int sm_prune24_f32_ref(const float* A_in, float* A_out, size_t m, size_t k, size
 #define ISNZ32(v) (((v) & 0x7fffffffu) != 0)
 DEFINE_CHECK(sm_prune24_check_f16_ref, uint16_t, ISNZ16)
 DEFINE_CHECK(sm_prune24_check_f32_bits_ref, uint32_t, ISNZ32)
+#define ISNZ8(v) ((v) != 0)
+DEFINE_CHECK(sm_prune24_check_i8_ref, uint8_t, ISNZ8)
 int sm_prune24_check_f32_ref(const float* A, size_t m, size_t k, size_t ld, int* valid) {
   return sm_prune24_check_f32_bits_ref((const uint32_t*)A, m, k, ld, valid);
 }
@@ -367,7 +373,7 @@ static size_t val_index(size_t M, size_t R, size_t q) { return ((q / 16) * M + R
 
 int sm_compress24_layout(size_t m, size_t k, size_t elt_bytes, size_t batch, size_t* kc_out,
                          size_t* meta_off_out, size_t* total_out) {
-  if (elt_bytes != 2 && elt_bytes != 4) return SM_ERR_ARG;
+  if (elt_bytes != 1 && elt_bytes != 2 && elt_bytes != 4) return SM_ERR_ARG;
   const size_t kc = round_up(k, 64), M = m * batch;
   const size_t meta_off = round_up(M * (kc / 2) * elt_bytes, 256);
   if (kc_out) *kc_out = kc;
@@ -414,6 +420,7 @@ int sm_compress24_size_ref(size_t m, size_t k, size_t elt_bytes, size_t batch, s
   }
 DEFINE_COMPRESS(sm_compress24_f16_ref, uint16_t, key16)
 DEFINE_COMPRESS(sm_compress24_f32_bits_ref, uint32_t, key32)
+DEFINE_COMPRESS(sm_compress24_i8_ref, uint8_t, key8)
 int sm_compress24_f32_ref(const float* A, size_t m, size_t k, size_t ld, size_t batch,
                           size_t strideA, void* blob) {
   return sm_compress24_f32_bits_ref((const uint32_t*)A, m, k, ld, batch, strideA, blob);
@@ -443,6 +450,7 @@ int sm_compress24_f32_ref(const float* A, size_t m, size_t k, size_t ld, size_t 
   }
 DEFINE_DECOMPRESS(sm_decompress24_f16_ref, uint16_t)
 DEFINE_DECOMPRESS(sm_decompress24_f32_ref, float)
+DEFINE_DECOMPRESS(sm_decompress24_i8_ref, uint8_t)
 
 /* ------------------------------------------------------------------------------------------ */
 /* (a4) 2:4 sparse x dense matmul -- the step spmma.hxx:112-113 delegates to cusparseLtMatmul   */
@@ -504,6 +512,45 @@ static void stbf(void* p, size_t i, double v) { ((uint16_t*)p)[i] = f2bf((float)
 int sm_spmma_bf16_ref(const void* blob, const uint16_t* B, uint16_t* C, size_t m, size_t n, size_t k,
                       size_t batch, size_t strideB, size_t strideC, float alpha, float beta) {
   return spmma_ref_impl(blob, B, C, m, n, k, batch, strideB, strideC, alpha, beta, 2, ldbf, stbf);
+}
+/* int8 (extension): C_b (m x n int32, row-major) = A_b . B_b (+ C_b), exact; B_b is [n][k], K-CONTIGUOUS per output
+ * column (the layout the int8 matrix instruction is fed in), B_b = B + b * strideB. */
+int sm_spmma_i8_ref(const void* blob, const int8_t* B, int32_t* C, size_t m, size_t n, size_t k, size_t batch,
+                    size_t strideB, size_t strideC, int accumulate) {
+  if (!blob || !B || !C) return SM_ERR_ARG;
+  size_t kc, meta_off, total;
+  sm_compress24_layout(m, k, 1, batch, &kc, &meta_off, &total);
+  const int8_t* vals = (const int8_t*)blob;
+  const unsigned char* meta = (const unsigned char*)blob + meta_off;
+  for (size_t b = 0; b < batch; ++b)
+    for (size_t i = 0; i < m; ++i) {
+      const size_t R = b * m + i;
+      for (size_t j = 0; j < n; ++j) {
+        int64_t acc = 0;
+        const int8_t* bc = B + b * strideB + j * k;
+        for (size_t q = 0; 4 * q < k; ++q) {
+          const unsigned nib = (meta[meta_index(m * batch, R, q)] >> (4 * (q & 1))) & 0xfu;
+          const unsigned pos[2] = {nib & 3u, nib >> 2};
+          for (int t = 0; t < 2; ++t) {
+            const size_t kk = 4 * q + pos[t];
+            if (kk < k) acc += (int64_t)vals[val_index(m * batch, R, q) + (size_t)t] * (int64_t)bc[kk];
+          }
+        }
+        const size_t ci = b * strideC + i * n + j;
+        C[ci] = (int32_t)((accumulate ? (int64_t)C[ci] : 0) + acc);
+      }
+    }
+  return SM_OK;
+}
+/* requantisation of the int32 product: saturate(round-to-nearest-even((float)acc * scale)) to a signed byte */
+int sm_requant_i8_ref(const int32_t* acc, int8_t* out, size_t count, float scale) {
+  if (!acc || !out) return SM_ERR_ARG;
+  for (size_t i = 0; i < count; ++i) {
+    float f = rintf(scale * (float)acc[i]);
+    f = f < -128.0f ? -128.0f : (f > 127.0f ? 127.0f : f);
+    out[i] = (int8_t)(int)f;
+  }
+  return SM_OK;
 }
 int sm_spmma_f32_ref(const void* blob, const float* B, float* C, size_t m, size_t n, size_t k,
                      size_t batch, size_t strideB, size_t strideC, float alpha, float beta) {

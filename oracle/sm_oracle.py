@@ -50,7 +50,7 @@ def _ok(rc, what):
 
 
 def _sfx(a):
-    return {2: "f16", 4: "f32", 8: "f64"}[a.dtype.itemsize]
+    return {1: "i8", 2: "f16", 4: "f32", 8: "f64"}[a.dtype.itemsize]
 
 
 def sparsify_positional(weights, mask, m, n, sparsity_factor=0.5, blk_m=2, blk_n=2):
@@ -139,6 +139,21 @@ def gemm_batched(As, Bs, Cs, m, n, k, alpha=1.0, beta=0.0, ta=0, tb=0):
     _ok(fn(arr(As), arr(Bs), arr(Cs), _sz(m), _sz(n), _sz(k), _sz(batch), ctypes.c_int(ta), ctypes.c_int(tb),
            sc(alpha), sc(beta)), "gemm_batched")
     return Cs
+
+
+def spmma_i8(blob, B, C, m, n, k, batch=1, strideB=0, strideC=None, accumulate=False):
+    """int8 2:4 product: B is [n][k] (k-contiguous per output column) int8, C int32 in place; exact."""
+    strideC = m * n if strideC is None else strideC
+    assert B.dtype == np.int8 and C.dtype == np.int32
+    _ok(lib().sm_spmma_i8_ref(_p(blob), _p(B), _p(C), _sz(m), _sz(n), _sz(k), _sz(batch), _sz(strideB), _sz(strideC),
+                              ctypes.c_int(1 if accumulate else 0)), "spmma_i8")
+    return C
+
+
+def requant_i8(acc, scale):
+    out = np.zeros(acc.size, dtype=np.int8)
+    _ok(lib().sm_requant_i8_ref(_p(acc), _p(out), _sz(acc.size), ctypes.c_float(scale)), "requant_i8")
+    return out
 
 
 def gemm_rowmajor(A, B, C, m, n, k, lda=None, batch=1, strideA=None, strideB=0, strideC=None, alpha=1.0, beta=0.0, bf16=False):

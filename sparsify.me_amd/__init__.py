@@ -73,6 +73,10 @@ _SIGS = {
 _SIGS["sm_conv_out_size"] = [_c_size, _c_size, _c_size, _c_size, _c_size, ctypes.POINTER(_c_size)]
 _SIGS["sm_im2col_f16"] = [_c_ptr] + [_c_size] * 9 + [_c_ptr, _c_ptr]
 _SIGS["sm_im2col_compress24_f16"] = [_c_ptr] + [_c_size] * 9 + [_c_ptr, _c_ptr]
+for _name in ("sm_prune24", "sm_prune24_check", "sm_compress24", "sm_decompress24"):
+    _SIGS[_name + "_i8"] = _SIGS[_name + "_f16"]
+_SIGS["sm_spmma_i8"] = [_c_ptr, _c_ptr, _c_ptr, _c_size, _c_size, _c_size, _c_size, _c_size, _c_size, _c_i, _c_ptr]
+_SIGS["sm_spmma_i8_q"] = [_c_ptr, _c_ptr, _c_ptr, _c_size, _c_size, _c_size, _c_size, _c_size, _c_size, _c_f, _c_ptr]
 # bfloat16 forms: same signatures as their _f16 counterparts
 for _name in ("sm_prune24", "sm_prune24_check", "sm_compress24", "sm_decompress24", "sm_spmma", "sm_spmma_fused",
               "sm_gemm_rowmajor", "sm_fill_uniform", "sm_im2col", "sm_im2col_compress24"):
@@ -131,7 +135,7 @@ def _t():
     if _torch is None:
         import torch
         _torch = torch
-        _SFX = {torch.float16: "f16", torch.bfloat16: "bf16", torch.float32: "f32", torch.float64: "f64"}
+        _SFX = {torch.float16: "f16", torch.bfloat16: "bf16", torch.float32: "f32", torch.float64: "f64", torch.int8: "i8"}
     return _torch
 
 
@@ -224,6 +228,22 @@ def spmma(blob, B, C, m, n, k, batch=1, strideB=0, strideC=None, alpha=1.0, beta
     fn = getattr(lib(), "sm_spmma_" + _sfx(B))
     _check(fn(_dev(blob), _dev(B), _dev(C), m, n, k, batch, strideB, strideC, float(alpha), float(beta), _stream()),
            "sm_spmma")
+
+
+def spmma_i8(blob, B, C, m, n, k, batch=1, strideB=0, strideC=None, accumulate=False):
+    """int8 2:4 product: B [n][k] int8 (k-contiguous per output column), C int32."""
+    strideC = m * n if strideC is None else strideC
+    if C.dtype == _t().int8:
+        raise SparsifymeError("spmma_i8 writes int32; use spmma_i8_q for a requantised int8 result")
+    _check(lib().sm_spmma_i8(_dev(blob), _dev(B), _dev(C), m, n, k, batch, strideB, strideC, 1 if accumulate else 0, _stream()),
+           "sm_spmma_i8")
+
+
+def spmma_i8_q(blob, B, C, m, n, k, scale, batch=1, strideB=0, strideC=None):
+    """int8 2:4 product requantised to int8: C = saturate(rne(scale * acc))."""
+    strideC = m * n if strideC is None else strideC
+    _check(lib().sm_spmma_i8_q(_dev(blob), _dev(B), _dev(C), m, n, k, batch, strideB, strideC, float(scale), _stream()),
+           "sm_spmma_i8_q")
 
 
 def spmma_fused(A, B, C, m, n, k, lda=None, batch=1, strideA=None, strideB=0, strideC=None, alpha=1.0, beta=0.0):

@@ -764,7 +764,7 @@ int sm_prune24_check_f32(const float* A, size_t m, size_t k, size_t ld, int* d_v
 }
 
 int sm_compress24_size(size_t m, size_t k, size_t elt_bytes, size_t batch, size_t* bytes) {
-  if (!bytes || (elt_bytes != 2 && elt_bytes != 4)) {
+  if (!bytes || (elt_bytes != 1 && elt_bytes != 2 && elt_bytes != 4)) {
     set_error("sm_compress24_size: invalid argument");
     return SM_STATUS_INVALID_VALUE;
   }

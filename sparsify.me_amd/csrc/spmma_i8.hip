@@ -1,0 +1,502 @@
+// spmma_i8.hip -- int8 forms of the 2:4 path (extension; SURVEY.md 8(f) rank 2: the vendor call behind
+// include/sparsify.me/spmma.hxx:40-113 lists int8 among its 2:4 types, examples/libcusparse_lt/include/cusparseLt.h:164-169).
+//   sm_prune24_i8 (STRIP) / sm_prune24_check_i8 / sm_compress24_i8 / sm_decompress24_i8: the fp16 rules on |x| of a
+//     signed byte (|-128| = 128 > 127; ties keep the lower k index); same blob geometry with 1-byte elements: values
+//     [kc/64][M][32 B], metadata [kc/64][M][8 B] (include/sparsifyme.h).
+//   sm_spmma_i8: C (int32) = A_2:4 . B (+ C), exact integer arithmetic on v_smfmac_i32_16x16x128_i8.  B is given
+//     K-CONTIGUOUS per output column ([n][k], "TN", the layout int8 matrix cores are fed in): a column's 128-k stage
+//     piece is one 128-byte row of the LDS image and a lane's operand is two 16-byte chunks of it.
+// Operand maps of the instruction, determined on hardware (tools/probe_i8.hip -> profiles/probe_i8_r01.txt):
+//   A lane l: row l & 15, g = l >> 4: 16 kept bytes = strips 8 g .. 8 g + 7 of the 128-k stage (dense k 32 g .. + 31),
+//     2-bit position code of kept byte e in bits [2 e, 2 e + 1] of the index operand -- i.e. the blob's nibbles of
+//     those 8 strips, 4 consecutive metadata bytes, as they are;
+//   B lane l: column l & 15, G = l >> 4: bytes 0-15 = dense k 16 G .. 16 G + 15, bytes 16-31 = dense k 64 + 16 G .. + 15;
+//   D lane l, register q: row 4 (l >> 4) + q, column l & 15 (the fp16 SMFMAC's map).
+// Stage = 128 k = two 64-k planes of the blob: A values image [BM][64 B] (plane 0 | plane 1 per row: lane g's chunk is
+// chunk g), metadata [2][BM][8 B], B image [BN][128 B]; all by global_load_lds, ring of 2, one barrier per stage.
+#include "select24.h"
+#include "mma_tile.h"
+
+namespace sm {
+
+__device__ __attribute__((aligned(256))) const unsigned char sm_zero_page_i8[256] = {0};
+
+__device__ __forceinline__ uint32_t key_i8(uint8_t v) {
+  const int x = (int)(int8_t)v;
+  return (uint32_t)(x < 0 ? -x : x);  // 0 .. 128
+}
+
+// item = 16 dense k of one row (4 strips): one 16-byte load (when aligned) -> 8 kept bytes + 2 metadata bytes
+struct I8Item {
+  uint8_t e[16];
+};
+__device__ __forceinline__ void load_item_i8(I8Item& v, const uint8_t* p, size_t nvalid, bool vec) {
+  if (vec && nvalid >= 16) {
+    *reinterpret_cast<u4*>(v.e) = *reinterpret_cast<const u4*>(p);
+  } else {
+#pragma unroll
+    for (unsigned t = 0; t < 16; ++t) v.e[t] = t < nvalid ? p[t] : (uint8_t)0;
+  }
+}
+
+__global__ __launch_bounds__(256) void prune_strip_i8_kernel(const uint8_t* A_in, uint8_t* A_out, size_t m, size_t k, size_t ld,
+                                                            bool vec) {
+  const size_t ipr = (k + 15) / 16, total = m * ipr;
+  for (size_t it = blockIdx.x * (size_t)256 + threadIdx.x; it < total; it += (size_t)gridDim.x * 256) {
+    const size_t row = it / ipr, c = (it - row * ipr) * 16;
+    const size_t nvalid = k - c < 16 ? k - c : 16;
+    __attribute__((aligned(16))) I8Item v;
+    load_item_i8(v, A_in + row * ld + c, nvalid, vec);
+#pragma unroll
+    for (unsigned s = 0; s < 4; ++s) {
+      const unsigned keep = strip_keepmask(key_i8(v.e[4 * s]), key_i8(v.e[4 * s + 1]), key_i8(v.e[4 * s + 2]), key_i8(v.e[4 * s + 3]));
+#pragma unroll
+      for (unsigned t = 0; t < 4; ++t)
+        if (!((keep >> t) & 1u)) v.e[4 * s + t] = 0;
+    }
+    uint8_t* dst = A_out + row * ld + c;
+    if (vec && nvalid >= 16) {
+      *reinterpret_cast<u4*>(dst) = *reinterpret_cast<const u4*>(v.e);
+    } else {
+#pragma unroll
+      for (unsigned t = 0; t < 16; ++t)
+        if (t < nvalid) dst[t] = v.e[t];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void prune_check_i8_kernel(const uint8_t* A, size_t m, size_t k, size_t ld, bool vec, int* d_valid) {
+  const size_t ipr = (k + 15) / 16, total = m * ipr;
+  bool bad = false;
+  for (size_t it = blockIdx.x * (size_t)256 + threadIdx.x; it < total; it += (size_t)gridDim.x * 256) {
+    const size_t row = it / ipr, c = (it - row * ipr) * 16;
+    __attribute__((aligned(16))) I8Item v;
+    load_item_i8(v, A + row * ld + c, k - c < 16 ? k - c : 16, vec);
+#pragma unroll
+    for (unsigned s = 0; s < 4; ++s) {
+      unsigned nnz = 0;
+#pragma unroll
+      for (unsigned t = 0; t < 4; ++t) nnz += v.e[4 * s + t] != 0;
+      bad |= nnz > 2;
+    }
+  }
+  if (__any(bad)) {
+    if ((threadIdx.x & 63) == 0) atomicOr(d_valid, 1);
+  }
+}
+
+// items are walked in OUTPUT order: item index = ((plane * M + R) * 4 + j4), j4 = which 16-k quarter of the plane
+__global__ __launch_bounds__(256) void compress_i8_kernel(const uint8_t* A, size_t m, size_t k, size_t ld, size_t strideA, size_t kc,
+                                                         size_t M, uint8_t* vals, unsigned char* meta, bool vec) {
+  const size_t total = M * (kc / 16);
+  for (size_t it = blockIdx.x * (size_t)256 + threadIdx.x; it < total; it += (size_t)gridDim.x * 256) {
+    const size_t t4 = it >> 2, s = t4 / M, R = t4 - s * M, c = s * 64 + (it & 3) * 16;
+    __attribute__((aligned(8))) uint8_t out[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned mb = 0x4444u;  // padding strips: positions (0, 1)
+    if (c < k) {
+      const size_t b = R / m, i = R - b * m;
+      __attribute__((aligned(16))) I8Item v;
+      load_item_i8(v, A + b * strideA + i * ld + c, k - c < 16 ? k - c : 16, vec);
+      mb = 0;
+#pragma unroll
+      for (unsigned st = 0; st < 4; ++st) {
+        const unsigned keep = c + 4 * st < k ? strip_keepmask(key_i8(v.e[4 * st]), key_i8(v.e[4 * st + 1]), key_i8(v.e[4 * st + 2]),
+                                                              key_i8(v.e[4 * st + 3]))
+                                             : 3u;
+        const unsigned nib = nibble_of(keep), p0 = nib & 3u, p1 = nib >> 2;
+        uint8_t a0 = v.e[4 * st], a1 = v.e[4 * st + 1];
+        a0 = p0 == 1 ? v.e[4 * st + 1] : a0;
+        a0 = p0 == 2 ? v.e[4 * st + 2] : a0;
+        a1 = p1 == 2 ? v.e[4 * st + 2] : a1;
+        a1 = p1 == 3 ? v.e[4 * st + 3] : a1;
+        out[2 * st] = a0;
+        out[2 * st + 1] = a1;
+        mb |= nib << (4 * st);
+      }
+    }
+    *reinterpret_cast<u2*>(vals + it * 8) = *reinterpret_cast<const u2*>(out);
+    *reinterpret_cast<unsigned short*>(meta + it * 2) = (unsigned short)mb;
+  }
+}
+
+__global__ __launch_bounds__(256) void decompress_i8_kernel(const uint8_t* vals, const unsigned char* meta, size_t m, size_t k, size_t ld,
+                                                           size_t strideA, size_t kc, size_t M, uint8_t* A) {
+  const size_t total = M * (kc / 16);
+  for (size_t it = blockIdx.x * (size_t)256 + threadIdx.x; it < total; it += (size_t)gridDim.x * 256) {
+    const size_t t4 = it >> 2, s = t4 / M, R = t4 - s * M, c = s * 64 + (it & 3) * 16;
+    if (c >= k) continue;
+    const size_t b = R / m, i = R - b * m;
+    const unsigned mb = *reinterpret_cast<const unsigned short*>(meta + it * 2);
+    uint8_t* dst = A + b * strideA + i * ld + c;
+#pragma unroll
+    for (unsigned st = 0; st < 4; ++st) {
+      const unsigned nib = (mb >> (4 * st)) & 0xfu, p0 = nib & 3u, p1 = nib >> 2;
+#pragma unroll
+      for (unsigned t = 0; t < 4; ++t)
+        if (c + 4 * st + t < k) dst[4 * st + t] = t == p0 ? vals[it * 8 + 2 * st] : (t == p1 ? vals[it * 8 + 2 * st + 1] : (uint8_t)0);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// matmul
+// ---------------------------------------------------------------------------------------------
+struct SpmmaI8Args {
+  const char* vals;
+  const char* meta;
+  size_t Mtot;
+  const int8_t* B;  // [n][k] per batch, ldb = k
+  int* C;           // int32 output, or
+  int8_t* C8;       // requantised output: sat_int8(rne(scale * acc))
+  float scale;
+  size_t sB, sC;    // batch strides (elements)
+  int m, Mrows, N, K, batch, tiles_m, tiles_n, nplanes;
+  int accumulate;
+};
+
+typedef int i4v __attribute__((ext_vector_type(4)));
+typedef int i8v __attribute__((ext_vector_type(8)));
+
+template <int BN, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN) void spmma_i8_kernel(const SpmmaI8Args p) {
+  constexpr int BM = 128, NW = WM * WN, TM = BM / WM, TN = BN / WN, FM = TM / 16, FN = TN / 16;
+  constexpr int SA = BM * 64, SM_ = 2 * BM * 8, SB = BN * 128, STAGE = SA + SM_ + SB;
+  constexpr int A_N = BM / 16, M_N = 2, B_N = BN / 8, W = A_N + M_N + B_N;  // 1 KiB DMA wave-instructions per stage
+  constexpr int SL = (W + NW - 1) / NW;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const unsigned tid = threadIdx.x, lane = tid & 63u;
+  const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const unsigned wm = wave / WN, wn = wave % WN;
+  const unsigned tiles = (unsigned)p.tiles_m * (unsigned)p.tiles_n;
+  const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
+  const unsigned b = lid / tiles, trem = lid - b * tiles;
+  const unsigned tile_m = trem / (unsigned)p.tiles_n, tile_n = trem - tile_m * (unsigned)p.tiles_n;
+  const int m0 = (int)tile_m * BM, n0 = (int)tile_n * BN;
+  const size_t row_base = (size_t)b * p.m;
+  const int8_t* B = p.B + (size_t)b * p.sB;
+  int* C = p.C ? p.C + (size_t)b * p.sC : nullptr;
+  int8_t* C8 = p.C8 ? p.C8 + (size_t)b * p.sC : nullptr;
+  const int mlast = p.Mrows - 1, nlast = p.N - 1;
+  const int nkt = (p.nplanes + 1) / 2;
+  const bool odd = (p.nplanes & 1) != 0;  // the last stage then has one plane: its second half meets zeros
+
+  // per slot: source of stage 0, per-stage step, LDS offset, and whether it belongs to the stage's second plane / half
+  const char* src[SL];
+  size_t step[SL];
+  unsigned loff[SL];
+  bool second[SL];
+#pragma unroll
+  for (int i = 0; i < SL; ++i) {
+    const unsigned t = wave + (unsigned)NW * i;
+    src[i] = nullptr; step[i] = 0; loff[i] = 0; second[i] = false;
+    if (t < (unsigned)A_N) {  // 16 rows x 64 B of kept values: lane -> row 16 t + lane / 4, LDS chunk lane % 4
+      const unsigned row = 16u * t + (lane >> 2), cs = (lane & 3u) ^ a64_swz(row);  // source chunk: plane cs >> 1, half cs & 1
+      int gr = m0 + (int)row;
+      gr = gr < mlast ? gr : mlast;
+      src[i] = p.vals + ((size_t)(cs >> 1) * p.Mtot + row_base + (size_t)gr) * 32 + 16u * (cs & 1u);
+      step[i] = 2 * p.Mtot * 32;
+      loff[i] = t * 1024u;
+      second[i] = (cs >> 1) != 0;  // per lane
+    } else if (t < (unsigned)(A_N + M_N)) {  // metadata of plane pl: lane -> rows 2 lane, 2 lane + 1
+      const unsigned pl = t - A_N;
+      int gr = m0 + 2 * (int)lane;
+      gr = gr < mlast ? gr : (mlast & ~1);
+      src[i] = p.meta + ((size_t)pl * p.Mtot + row_base + (size_t)gr) * 8;
+      step[i] = 2 * p.Mtot * 8;
+      loff[i] = SA + pl * (BM * 8);
+      second[i] = pl != 0;
+    } else if (t < (unsigned)W) {  // B: 8 columns x 128 B (k-contiguous)
+      const unsigned j = t - A_N - M_N, col = 8u * j + (lane >> 3), cs = (lane & 7u) ^ (col & 7u);
+      int gn = n0 + (int)col;
+      gn = gn < nlast ? gn : nlast;
+      src[i] = reinterpret_cast<const char*>(B + (size_t)gn * p.K) + 16u * cs;
+      step[i] = 128;
+      loff[i] = SA + SM_ + j * 1024u;
+      second[i] = cs >= 4u;
+    }
+  }
+  auto stage = [&](int kt, int buf) {
+    char* base = smem + buf * STAGE;
+    const bool tail = odd && kt == nkt - 1;
+#pragma unroll
+    for (int i = 0; i < SL; ++i) {
+      const unsigned t = wave + (unsigned)NW * i;  // wave-uniform
+      if (t >= (unsigned)W) continue;
+      const char* g = src[i] + (size_t)kt * step[i];
+      // one-plane tail: the absent plane's values and metadata come from a zero page, and B's k 64 .. 127 (past the end
+      // of the column) from the same page -- 0 x anything = 0 in integers
+      if (tail && second[i]) g = reinterpret_cast<const char*>(sm_zero_page_i8) + 16u * (lane & 7u);
+      __builtin_amdgcn_global_load_lds((gptr_t*)g, (lptr_t*)(base + loff[i]), 16, 0, 0);
+    }
+  };
+
+  i4v acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = i4v{0, 0, 0, 0};
+
+  if (nkt > 0) stage(0, 0);
+  const unsigned g = lane >> 4, r = lane & 15u;
+  for (int kt = 0; kt < nkt; ++kt) {
+    wait_dma_and_barrier<0>();  // ring of 2: nothing newer than this stage is in flight
+    if (kt + 1 < nkt) stage(kt + 1, (kt + 1) & 1);
+    const char* As = smem + (kt & 1) * STAGE;
+    const char* Ms = As + SA;
+    const char* Bs = Ms + SM_;
+    i4v af[FM];
+    int idx[FM];
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      const unsigned row = wm * TM + i * 16 + r;
+      af[i] = *reinterpret_cast<const i4v*>(As + row * 64u + 16u * (g ^ a64_swz(row)));
+      idx[i] = *reinterpret_cast<const int*>(Ms + (g >> 1) * (BM * 8) + row * 8u + 4u * (g & 1u));
+    }
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      const unsigned col = wn * TN + j * 16 + r;
+      const u4 lo = *reinterpret_cast<const u4*>(Bs + a_off(col, g));
+      const u4 hi = *reinterpret_cast<const u4*>(Bs + a_off(col, 4u + g));
+      const i8v bf = {(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+#pragma unroll
+      for (int i = 0; i < FM; ++i) acc[i][j] = __builtin_amdgcn_smfmac_i32_16x16x128_i8(af[i], bf, acc[i][j], idx[i], 0, 0);
+    }
+  }
+  __syncthreads();
+
+  // ---- epilogue: a lane holds 4 consecutive ROWS of one column; transpose through LDS, store 16-byte row pieces
+  constexpr int CP = BN * 4 + 16;  // bytes per row of the image
+  auto quant = [&](int a) -> int {   // sat_int8(rne(scale * acc)): one fp32 multiply, round to nearest even, clamp
+    float f = __builtin_rintf(p.scale * (float)a);
+    f = f < -128.0f ? -128.0f : (f > 127.0f ? 127.0f : f);
+    return (int)f;
+  };
+  if (C8) {
+    const bool q_vec = (p.N % 16 == 0) && ((reinterpret_cast<uintptr_t>(C8) & 15u) == 0);
+    if (q_vec) {
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+          const unsigned row = wm * TM + i * 16 + 4u * g, col = wn * TN + j * 16 + r;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) *reinterpret_cast<int*>(smem + (row + q) * CP + col * 4) = acc[i][j][q];
+        }
+      __syncthreads();
+      constexpr int NCH = BM * (BN / 16);
+      for (unsigned q = tid; q < (unsigned)NCH; q += 64u * NW) {
+        const unsigned row = q / (BN / 16), cn = q % (BN / 16);
+        const int gr = m0 + (int)row, gc = n0 + 16 * (int)cn;
+        if (gr >= p.Mrows || gc >= p.N) continue;  // N % 16 == 0: a chunk is all in or all out
+        u4 o;
+#pragma unroll
+        for (int w4 = 0; w4 < 4; ++w4) {
+          const i4v v = *reinterpret_cast<const i4v*>(smem + row * CP + cn * 64 + w4 * 16);
+          o[w4] = (unsigned)(quant(v[0]) & 0xff) | ((unsigned)(quant(v[1]) & 0xff) << 8) | ((unsigned)(quant(v[2]) & 0xff) << 16) |
+                  ((unsigned)(quant(v[3]) & 0xff) << 24);
+        }
+        __builtin_nontemporal_store(o, reinterpret_cast<u4*>(C8 + (size_t)gr * p.N + gc));
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+          const int gc = n0 + (int)(wn * TN + j * 16 + r);
+          if (gc >= p.N) continue;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int gr = m0 + (int)(wm * TM + i * 16 + 4u * g) + q;
+            if (gr < p.Mrows) C8[(size_t)gr * p.N + gc] = (int8_t)quant(acc[i][j][q]);
+          }
+        }
+    }
+    return;
+  }
+  const bool c_vec = (p.N % 4 == 0) && ((reinterpret_cast<uintptr_t>(C) & 15u) == 0);
+  if (c_vec) {
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const unsigned row = wm * TM + i * 16 + 4u * g, col = wn * TN + j * 16 + r;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<int*>(smem + (row + q) * CP + col * 4) = acc[i][j][q];
+      }
+    __syncthreads();
+    constexpr int NCH = BM * (BN / 4);
+    for (unsigned q = tid; q < (unsigned)NCH; q += 64u * NW) {
+      const unsigned row = q / (BN / 4), cn = q % (BN / 4);
+      const int gr = m0 + (int)row, gc = n0 + 4 * (int)cn;
+      if (gr >= p.Mrows || gc >= p.N) continue;
+      i4v v = *reinterpret_cast<const i4v*>(smem + row * CP + cn * 16);
+      int* dst = C + (size_t)gr * p.N + gc;
+      if (p.accumulate) {
+        const i4v old = *reinterpret_cast<const i4v*>(dst);
+        v += old;
+      }
+      __builtin_nontemporal_store(v, reinterpret_cast<i4v*>(dst));
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const int gc = n0 + (int)(wn * TN + j * 16 + r);
+        if (gc >= p.N) continue;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int gr = m0 + (int)(wm * TM + i * 16 + 4u * g) + q;
+          if (gr >= p.Mrows) continue;
+          int* dst = C + (size_t)gr * p.N + gc;
+          *dst = p.accumulate ? *dst + acc[i][j][q] : acc[i][j][q];
+        }
+      }
+  }
+}
+
+template <int BN, int WM, int WN>
+static int launch_spmma_i8(const SpmmaI8Args& a0, hipStream_t st) {
+  SpmmaI8Args a = a0;
+  a.tiles_m = (a.Mrows + 127) / 128;
+  a.tiles_n = (a.N + BN - 1) / BN;
+  const size_t nwg = (size_t)a.tiles_m * a.tiles_n * a.batch;
+  if (nwg == 0) return SM_STATUS_SUCCESS;
+  if (nwg > 0x7fffffffu) {
+    set_error("sm_spmma_i8: grid too large");
+    return SM_STATUS_NOT_SUPPORTED;
+  }
+  constexpr size_t lds_main = 2 * ((size_t)128 * 64 + 2 * 128 * 8 + (size_t)BN * 128);
+  constexpr size_t lds_epi = (size_t)128 * (BN * 4 + 16);
+  constexpr size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
+  static bool attr_set = false;
+  if (lds > 64 * 1024 && !attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spmma_i8_kernel<BN, WM, WN>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
+    attr_set = true;
+  }
+  spmma_i8_kernel<BN, WM, WN><<<dim3((unsigned)nwg), dim3(64 * WM * WN), lds, st>>>(a);
+  return check_launch("spmma_i8_kernel");
+}
+
+}  // namespace sm
+
+using namespace sm;
+
+extern "C" {
+
+int sm_prune24_i8(const void* A_in, void* A_out, size_t m, size_t k, size_t ld, int alg, sm_stream_t s) {
+  if (!A_in || !A_out || ld < k) {
+    set_error("sm_prune24_i8: invalid argument");
+    return SM_STATUS_INVALID_VALUE;
+  }
+  if (alg != SM_PRUNE_STRIP) {
+    set_error("sm_prune24_i8: only SM_PRUNE_STRIP is built for int8");
+    return SM_STATUS_NOT_SUPPORTED;
+  }
+  if (m == 0 || k == 0) return SM_STATUS_SUCCESS;
+  const bool vec = aligned16(A_in) && aligned16(A_out) && ld % 16 == 0;
+  prune_strip_i8_kernel<<<stream_grid(m * ceil_div(k, (size_t)16), 256), 256, 0, (hipStream_t)s>>>((const uint8_t*)A_in, (uint8_t*)A_out, m, k,
+                                                                                                     ld, vec);
+  return check_launch("prune_strip_i8_kernel");
+}
+
+int sm_prune24_check_i8(const void* A, size_t m, size_t k, size_t ld, int* d_valid, sm_stream_t s) {
+  if (!A || !d_valid || ld < k) {
+    set_error("sm_prune24_check_i8: invalid argument");
+    return SM_STATUS_INVALID_VALUE;
+  }
+  if (hipMemsetAsync(d_valid, 0, sizeof(int), (hipStream_t)s) != hipSuccess) return check_launch("hipMemsetAsync");
+  if (m == 0 || k == 0) return SM_STATUS_SUCCESS;
+  prune_check_i8_kernel<<<stream_grid(m * ceil_div(k, (size_t)16), 256), 256, 0, (hipStream_t)s>>>((const uint8_t*)A, m, k, ld,
+                                                                                                     aligned16(A) && ld % 16 == 0, d_valid);
+  return check_launch("prune_check_i8_kernel");
+}
+
+int sm_compress24_i8(const void* A, size_t m, size_t k, size_t ld, size_t batch, size_t strideA, void* blob, sm_stream_t s) {
+  if (!A || !blob || ld < k || !aligned16(blob)) {
+    set_error("sm_compress24_i8: invalid argument (blob must be 16-byte aligned)");
+    return SM_STATUS_INVALID_VALUE;
+  }
+  const BlobLayout L = blob_layout(m, k, 1, batch);
+  if (L.M == 0 || k == 0) return SM_STATUS_SUCCESS;
+  hipStream_t st = (hipStream_t)s;
+  const size_t vbytes = L.M * (L.kc / 2), mbytes = L.M * (L.kc / 8);
+  if (L.meta_off > vbytes && hipMemsetAsync((char*)blob + vbytes, 0, L.meta_off - vbytes, st) != hipSuccess) return check_launch("hipMemsetAsync");
+  if (L.total > L.meta_off + mbytes && hipMemsetAsync((char*)blob + L.meta_off + mbytes, 0, L.total - L.meta_off - mbytes, st) != hipSuccess)
+    return check_launch("hipMemsetAsync");
+  const bool vec = aligned16(A) && ld % 16 == 0 && strideA % 16 == 0;
+  compress_i8_kernel<<<stream_grid(L.M * (L.kc / 16), 256), 256, 0, st>>>((const uint8_t*)A, m, k, ld, strideA, L.kc, L.M, (uint8_t*)blob,
+                                                                          (unsigned char*)blob + L.meta_off, vec);
+  return check_launch("compress_i8_kernel");
+}
+
+int sm_decompress24_i8(const void* blob, size_t m, size_t k, size_t ld, size_t batch, size_t strideA, void* A, sm_stream_t s) {
+  if (!A || !blob || ld < k) {
+    set_error("sm_decompress24_i8: invalid argument");
+    return SM_STATUS_INVALID_VALUE;
+  }
+  const BlobLayout L = blob_layout(m, k, 1, batch);
+  if (L.M == 0 || k == 0) return SM_STATUS_SUCCESS;
+  decompress_i8_kernel<<<stream_grid(L.M * (L.kc / 16), 256), 256, 0, (hipStream_t)s>>>(
+      (const uint8_t*)blob, (const unsigned char*)blob + L.meta_off, m, k, ld, strideA, L.kc, L.M, (uint8_t*)A);
+  return check_launch("decompress_i8_kernel");
+}
+
+}  // extern "C"
+
+static int spmma_i8_entry(const void* blob, const void* B, int32_t* C, int8_t* C8, float scale, size_t m, size_t n, size_t k, size_t batch,
+                          size_t strideB, size_t strideC, int accumulate, sm_stream_t stream) {
+  if (!blob || !B || (!C && !C8) || !aligned16(blob)) {
+    set_error("sm_spmma_i8: invalid argument (blob must be 16-byte aligned)");
+    return SM_STATUS_INVALID_VALUE;
+  }
+  if (m == 0 || n == 0 || batch == 0) return SM_STATUS_SUCCESS;
+  if (m * batch > 0x7fffffffull || n > 0x7fffffffull || k > 0x7fffffffull) {
+    set_error("sm_spmma_i8: dimension exceeds 2^31-1");
+    return SM_STATUS_NOT_SUPPORTED;
+  }
+  // whole 64-k planes of 16-byte chunks; metadata moves as 16-byte row pairs: even row counts
+  if (k % 64 != 0 || m % 2 != 0 || !aligned16(B) || strideB % 16 != 0) {
+    set_error("sm_spmma_i8: needs k %% 64 == 0, an even m and a 16-byte aligned B ([n][k], k-contiguous)");
+    return SM_STATUS_NOT_SUPPORTED;
+  }
+  const BlobLayout L = blob_layout(m, k, 1, batch);
+  SpmmaI8Args a = {};
+  a.vals = (const char*)blob;
+  a.meta = (const char*)blob + L.meta_off;
+  a.Mtot = L.M;
+  a.B = (const int8_t*)B;
+  a.C = C;
+  a.C8 = C8;
+  a.scale = scale;
+  a.sB = strideB; a.sC = strideC;
+  a.m = (int)m; a.Mrows = (int)m; a.N = (int)n; a.K = (int)k; a.nplanes = (int)(L.kc / 64);
+  a.batch = (int)batch; a.accumulate = accumulate != 0;
+  if (batch > 1 && strideB == 0 && strideC == m * n) {  // shared B + contiguous C: one tall matrix
+    a.Mrows = (int)(m * batch);
+    a.batch = 1;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  static const int cfg = getenv("SM_SPMMA_I8_CFG") ? atoi(getenv("SM_SPMMA_I8_CFG")) : 0;  // tuning aid
+  if (cfg == 1) return launch_spmma_i8<64, 4, 1>(a, st);
+  if (cfg == 2) return launch_spmma_i8<128, 2, 2>(a, st);
+  if (cfg == 3) return launch_spmma_i8<128, 2, 4>(a, st);
+  if (cfg == 4) return launch_spmma_i8<128, 4, 4>(a, st);
+  // narrow outputs: 128 x 64 tiles over 4 waves (more tiles); otherwise 128 x 128 over 8 (tools/i8_probe.py)
+  return n <= 128 ? launch_spmma_i8<64, 4, 1>(a, st) : launch_spmma_i8<128, 2, 4>(a, st);
+}
+
+extern "C" {
+
+int sm_spmma_i8(const void* blob, const void* B, int32_t* C, size_t m, size_t n, size_t k, size_t batch, size_t strideB, size_t strideC,
+                int accumulate, sm_stream_t stream) {
+  return spmma_i8_entry(blob, B, C, nullptr, 1.0f, m, n, k, batch, strideB, strideC, accumulate, stream);
+}
+int sm_spmma_i8_q(const void* blob, const void* B, void* C, size_t m, size_t n, size_t k, size_t batch, size_t strideB, size_t strideC,
+                  float scale, sm_stream_t stream) {
+  return spmma_i8_entry(blob, B, nullptr, (int8_t*)C, scale, m, n, k, batch, strideB, strideC, 0, stream);
+}
+
+}  // extern "C"

@@ -783,6 +783,79 @@ def test_fill_uniform_bf16(gpu):
 
 
 # ---------------------------------------------------------------------------------------------
+# (f-2) int8 forms of the 2:4 path (bit-exact: integer arithmetic)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(4, 4), (7, 10), (196, 512), (130, 147), (784, 64), (33, 17)])
+def test_prune24_i8_vs_oracle(gpu, orc, shape):
+    import torch
+    m, k = shape
+    rng = np.random.default_rng(m * 7 + k)
+    for kind in ("full", "ties"):
+        A = (rng.integers(-128, 128, m * k) if kind == "full" else rng.integers(-2, 3, m * k)).astype(np.int8)
+        dA = to_dev(A)
+        out = torch.empty_like(dA)
+        gpu.prune24(dA, out, m, k, k, gpu.PRUNE_STRIP)
+        want = orc.prune24(A.view(np.uint8), m, k, k, orc.STRIP).view(np.int8)
+        assert np.array_equal(host(out), want), f"prune24 i8 {shape} {kind}"
+        valid = torch.full((1,), 7, dtype=torch.int32, device="cuda")
+        gpu.prune24_check(out, m, k, k, valid)
+        assert int(host(valid)[0]) == 0
+        gpu.prune24_check(dA, m, k, k, valid)
+        assert int(host(valid)[0]) == orc.prune24_check(A.view(np.uint8), m, k, k)
+    with pytest.raises(gpu.SparsifymeError):
+        gpu.prune24(dA, out, m, k, k, gpu.PRUNE_TILE)          # only STRIP is built for int8
+
+
+@pytest.mark.parametrize("shape", [(128, 64, 64, 1), (196, 512, 256, 2), (784, 256, 1024, 2), (130, 72, 192, 3), (12544, 64, 576, 1),
+                                   (3136, 128, 1152, 1), (300, 520, 128, 2), (2, 8, 64, 1), (258, 35, 320, 2)])
+@pytest.mark.parametrize("shared_b", [True, False])
+def test_spmma_i8_vs_oracle(gpu, orc, shape, shared_b):
+    """compress (bit-exact) + v_smfmac_i32_16x16x128_i8 matmul: the int32 result equals the oracle's exactly, on one- and
+    two-plane tails (k = 64, 192, 320, 576), row / column tails, shared and per-batch B, with and without accumulation."""
+    import torch
+    m, n, k, batch = shape
+    rng = np.random.default_rng(m + 3 * n + 5 * k)
+    A = rng.integers(-128, 128, batch * m * k).astype(np.int8)
+    A[rng.uniform(0, 1, A.size) < 0.2] = 0
+    nb = 1 if shared_b else batch
+    B = rng.integers(-128, 128, nb * n * k).astype(np.int8)           # [n][k] per batch
+    sB = 0 if shared_b else n * k
+    dA, dB = to_dev(A), to_dev(B)
+    blob = torch.full((gpu.compress24_size(m, k, 1, batch),), 0xAB, dtype=torch.uint8, device="cuda")
+    gpu.compress24(dA, m, k, k, batch, m * k, blob)
+    ob = orc.compress24(A.view(np.uint8), m, k, k, batch)
+    assert np.array_equal(host(blob), ob)
+    back = torch.empty_like(dA)
+    gpu.decompress24(blob, m, k, k, batch, m * k, back)
+    assert np.array_equal(host(back).view(np.uint8), orc.prune24(A.view(np.uint8), batch * m, k, k, orc.STRIP))
+    C0 = rng.integers(-1000, 1000, batch * m * n).astype(np.int32)
+    for acc in (False, True):
+        dC = to_dev(C0.copy())
+        gpu.spmma_i8(blob, dB, dC, m, n, k, batch, sB, accumulate=acc)
+        Cref = C0.copy()
+        orc.spmma_i8(ob, B, Cref, m, n, k, batch, sB, accumulate=acc)
+        assert np.array_equal(host(dC), Cref), f"spmma_i8 {shape} shared={shared_b} accumulate={acc}"
+    # requantised int8 output: saturate(rne(scale * acc)), bit-exact against the oracle's fp32 arithmetic
+    Cacc = np.zeros(batch * m * n, dtype=np.int32)
+    orc.spmma_i8(ob, B, Cacc, m, n, k, batch, sB)
+    for scale in (2.0 ** -8, 0.0123):
+        dQ = torch.full((batch * m * n,), 77, dtype=torch.int8, device="cuda")
+        gpu.spmma_i8_q(blob, dB, dQ, m, n, k, scale, batch, sB)
+        assert np.array_equal(host(dQ), orc.requant_i8(Cacc, scale)), f"spmma_i8_q {shape} scale {scale}"
+
+
+def test_spmma_i8_rejects_what_it_cannot_take(gpu):
+    import torch
+    blob = torch.zeros(1 << 16, dtype=torch.uint8, device="cuda")
+    B = torch.zeros(1 << 16, dtype=torch.int8, device="cuda")
+    C = torch.zeros(1 << 16, dtype=torch.int32, device="cuda")
+    with pytest.raises(gpu.SparsifymeError):
+        gpu.spmma_i8(blob, B, C, 16, 16, 100)       # k % 64 != 0
+    with pytest.raises(gpu.SparsifymeError):
+        gpu.spmma_i8(blob, B, C, 15, 16, 64)        # odd m
+
+
+# ---------------------------------------------------------------------------------------------
 # (f-3) im2col front end
 # ---------------------------------------------------------------------------------------------
 IM2COL_CFGS = [(2, 3, 9, 11, 3, 3, 1, 1, 1), (1, 4, 12, 12, 7, 7, 2, 3, 1), (2, 5, 8, 8, 1, 1, 1, 0, 1), (1, 2, 10, 9, 3, 2, 2, 0, 2),

@@ -394,6 +394,31 @@ def test_im2col_restatement_is_unfold_transposed(orc, cfg):
     assert np.array_equal(got16.view(np.float16).astype(np.float32).reshape(want.shape), want.astype(np.float16).astype(np.float32))
 
 
+def test_int8_restatements(orc):
+    """int8 forms in the oracle: STRIP on |x| of signed bytes (|-128| = 128 beats 127, ties keep the lower index),
+    compress/decompress round trip, and the exact int32 product against numpy on the pruned operand ([n][k] B)."""
+    A = np.array([[-128, 127, 3, -3], [5, -5, 5, 5], [0, 0, 0, 0], [1, -2, 2, -1]], dtype=np.int8).reshape(-1)
+    P = orc.prune24(A.view(np.uint8), 4, 4, 4, orc.STRIP).view(np.int8).reshape(4, 4)
+    assert P.tolist() == [[-128, 127, 0, 0], [5, -5, 0, 0], [0, 0, 0, 0], [0, -2, 2, 0]]
+    assert orc.prune24_check(P.reshape(-1).view(np.uint8), 4, 4, 4) == 0
+    assert orc.prune24_check(A.view(np.uint8), 4, 4, 4) == 1
+    rng = np.random.default_rng(21)
+    m, n, k, batch = 10, 7, 128, 2
+    A = rng.integers(-128, 128, batch * m * k).astype(np.int8)
+    B = rng.integers(-128, 128, n * k).astype(np.int8)                      # [n][k]
+    blob = orc.compress24(A.view(np.uint8), m, k, k, batch)
+    assert blob.size == orc.compress24_size(m, k, 1, batch)
+    P = orc.prune24(A.view(np.uint8), batch * m, k, k, orc.STRIP)
+    assert np.array_equal(orc.decompress24(blob, m, k, k, np.uint8, batch), P)
+    assert np.array_equal(orc.compress24(P, m, k, k, batch), blob)
+    C = np.full(batch * m * n, 5, dtype=np.int32)
+    orc.spmma_i8(blob, B, C, m, n, k, batch, 0)
+    want = P.view(np.int8).reshape(batch * m, k).astype(np.int64) @ B.reshape(n, k).astype(np.int64).T
+    assert np.array_equal(C.reshape(batch * m, n), want)
+    orc.spmma_i8(blob, B, C, m, n, k, batch, 0, accumulate=True)
+    assert np.array_equal(C.reshape(batch * m, n), 2 * want)
+
+
 def test_bell_and_coo_restatements(orc):
     rng = np.random.default_rng(2)
     rows, cols, bs, n = 8, 12, 2, 5
