@@ -26,6 +26,31 @@ __device__ __forceinline__ uint32_t key_i8(uint8_t v) {
   return (uint32_t)(x < 0 ? -x : x);  // 0 .. 128
 }
 
+// One strip (four signed bytes in a dword) in the composite-key form of select24.h: key_i = |x_i| << 2 | (3 - i) --
+// distinct, larger = kept earlier, equal magnitudes ordered by the lower index -- the two largest by a max / min / med
+// chain, their low two bits name the kept positions, one v_perm_b32 pulls the two kept bytes out in position order.
+//   d = {x3:x2:x1:x0}  ->  kept = {x[p1]:x[p0]} in the low 16 bits,  nib = p0 | p1 << 2  (p0 < p1)
+__device__ __forceinline__ void strip_select_i8(uint32_t d, uint32_t& kept, uint32_t& nib) {
+  uint32_t K[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int x = (int)(d << (24 - 8 * i)) >> 24;  // sign-extended byte i
+    const int a = x < 0 ? -x : x;                  // 0 .. 128
+    K[i] = ((uint32_t)a << 2) | (uint32_t)(3 - i);
+  }
+  const uint32_t m01 = K[0] > K[1] ? K[0] : K[1], n01 = K[0] > K[1] ? K[1] : K[0];
+  const uint32_t m = m01 > K[2] ? m01 : K[2];
+  const uint32_t c01 = m01 < K[2] ? m01 : K[2];
+  const uint32_t med = n01 > c01 ? n01 : c01;
+  const uint32_t first = m > K[3] ? m : K[3], lo = m > K[3] ? K[3] : m;
+  const uint32_t second = lo > med ? lo : med;
+  const uint32_t a = first & 3u, b = second & 3u;
+  const uint32_t A = a > b ? a : b, B = a > b ? b : a;  // p0 = 3 - A < p1 = 3 - B
+  const uint32_t sel = 0x0c0c0000u | ((3u - B) << 8) | (3u - A);
+  kept = __builtin_amdgcn_perm(0u, d, sel);
+  nib = 15u - (A | (B << 2));
+}
+
 // item = 16 dense k of one row (4 strips): one 16-byte load (when aligned) -> 8 kept bytes + 2 metadata bytes
 struct I8Item {
   uint8_t e[16];
@@ -85,37 +110,43 @@ __global__ __launch_bounds__(256) void prune_check_i8_kernel(const uint8_t* A, s
   }
 }
 
-// items are walked in OUTPUT order: item index = ((plane * M + R) * 4 + j4), j4 = which 16-k quarter of the plane
+// Items (16 dense k of one row -> 8 kept bytes + 2 metadata bytes) are walked so that a row's 128 input bytes of a PAIR
+// of planes are read by 8 consecutive lanes (whole cache lines; walking plane by plane reads every line twice, half
+// each time: 2.3-2.9 TB/s) -- item it = ((pair * M + R) * 8 + j8): plane 2 pair + j8 / 4, quarter j8 % 4.  The writes
+// are then runs of 32 B of values and 8 B of metadata per row and plane, consecutive rows adjacent.
 __global__ __launch_bounds__(256) void compress_i8_kernel(const uint8_t* A, size_t m, size_t k, size_t ld, size_t strideA, size_t kc,
                                                          size_t M, uint8_t* vals, unsigned char* meta, bool vec) {
-  const size_t total = M * (kc / 16);
+  // blockIdx.y = plane pair, so that no item needs a 64-bit division; contiguous batches (strideA == m * ld) are one
+  // tall matrix and need none for the row either
+  const size_t nplanes = kc / 64, total = M * 8, sp = blockIdx.y;
+  const bool tall = strideA == m * ld;
   for (size_t it = blockIdx.x * (size_t)256 + threadIdx.x; it < total; it += (size_t)gridDim.x * 256) {
-    const size_t t4 = it >> 2, s = t4 / M, R = t4 - s * M, c = s * 64 + (it & 3) * 16;
+    const size_t R = it >> 3, j8 = it & 7, s = 2 * sp + (j8 >> 2), c = s * 64 + (j8 & 3) * 16;
+    if (s >= nplanes) continue;  // odd plane count: the last pair has one plane
+    const size_t o = (s * M + R) * 4 + (j8 & 3);  // output item: 8 value bytes at 8 o, 2 metadata bytes at 2 o
     __attribute__((aligned(8))) uint8_t out[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned mb = 0x4444u;  // padding strips: positions (0, 1)
     if (c < k) {
-      const size_t b = R / m, i = R - b * m;
+      const uint8_t* src = A + R * ld + c;
+      if (!tall) {
+        const size_t b = R / m, i = R - b * m;
+        src = A + b * strideA + i * ld + c;
+      }
       __attribute__((aligned(16))) I8Item v;
-      load_item_i8(v, A + b * strideA + i * ld + c, k - c < 16 ? k - c : 16, vec);
+      load_item_i8(v, src, k - c < 16 ? k - c : 16, vec);
       mb = 0;
+      const u4 d4 = *reinterpret_cast<const u4*>(v.e);
+      uint32_t kp[4];
 #pragma unroll
       for (unsigned st = 0; st < 4; ++st) {
-        const unsigned keep = c + 4 * st < k ? strip_keepmask(key_i8(v.e[4 * st]), key_i8(v.e[4 * st + 1]), key_i8(v.e[4 * st + 2]),
-                                                              key_i8(v.e[4 * st + 3]))
-                                             : 3u;
-        const unsigned nib = nibble_of(keep), p0 = nib & 3u, p1 = nib >> 2;
-        uint8_t a0 = v.e[4 * st], a1 = v.e[4 * st + 1];
-        a0 = p0 == 1 ? v.e[4 * st + 1] : a0;
-        a0 = p0 == 2 ? v.e[4 * st + 2] : a0;
-        a1 = p1 == 2 ? v.e[4 * st + 2] : a1;
-        a1 = p1 == 3 ? v.e[4 * st + 3] : a1;
-        out[2 * st] = a0;
-        out[2 * st + 1] = a1;
+        uint32_t nib;
+        strip_select_i8(d4[st], kp[st], nib);  // a strip at or beyond k is all zeros here: keeps (0, 1), nibble 0x4
         mb |= nib << (4 * st);
       }
+      *reinterpret_cast<u2*>(out) = u2{kp[0] | (kp[1] << 16), kp[2] | (kp[3] << 16)};
     }
-    *reinterpret_cast<u2*>(vals + it * 8) = *reinterpret_cast<const u2*>(out);
-    *reinterpret_cast<unsigned short*>(meta + it * 2) = (unsigned short)mb;
+    *reinterpret_cast<u2*>(vals + o * 8) = *reinterpret_cast<const u2*>(out);
+    *reinterpret_cast<unsigned short*>(meta + o * 2) = (unsigned short)mb;
   }
 }
 
@@ -421,13 +452,17 @@ int sm_compress24_i8(const void* A, size_t m, size_t k, size_t ld, size_t batch,
   }
   const BlobLayout L = blob_layout(m, k, 1, batch);
   if (L.M == 0 || k == 0) return SM_STATUS_SUCCESS;
+  if ((L.kc / 64 + 1) / 2 > 65535) {
+    set_error("sm_compress24_i8: k too large");
+    return SM_STATUS_NOT_SUPPORTED;
+  }
   hipStream_t st = (hipStream_t)s;
   const size_t vbytes = L.M * (L.kc / 2), mbytes = L.M * (L.kc / 8);
   if (L.meta_off > vbytes && hipMemsetAsync((char*)blob + vbytes, 0, L.meta_off - vbytes, st) != hipSuccess) return check_launch("hipMemsetAsync");
   if (L.total > L.meta_off + mbytes && hipMemsetAsync((char*)blob + L.meta_off + mbytes, 0, L.total - L.meta_off - mbytes, st) != hipSuccess)
     return check_launch("hipMemsetAsync");
   const bool vec = aligned16(A) && ld % 16 == 0 && strideA % 16 == 0;
-  compress_i8_kernel<<<stream_grid(L.M * (L.kc / 16), 256), 256, 0, st>>>((const uint8_t*)A, m, k, ld, strideA, L.kc, L.M, (uint8_t*)blob,
+  compress_i8_kernel<<<dim3(stream_grid(L.M * 8, 256), (unsigned)((L.kc / 64 + 1) / 2)), 256, 0, st>>>((const uint8_t*)A, m, k, ld, strideA, L.kc, L.M, (uint8_t*)blob,
                                                                           (unsigned char*)blob + L.meta_off, vec);
   return check_launch("compress_i8_kernel");
 }
