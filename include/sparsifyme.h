@@ -210,6 +210,9 @@ int sm_fill_uniform_bf16(void* out, size_t count, uint64_t seed, float lo, float
  *      accumulate != 0), exact integer arithmetic on v_smfmac_i32_16x16x128_i8; B is [n][k] -- K-CONTIGUOUS per output
  *      column ("TN", the layout int8 matrix cores are fed in), B_b = B + b * strideB (0 = shared).  Needs k % 64 == 0,
  *      an even m, a 16-byte aligned B; SM_STATUS_NOT_SUPPORTED otherwise. */
+/* out[c][r] = in[r][c] for a row-major rows x cols byte matrix (out of place): turns the reference's row-major k x n B
+ * (spmma.hxx:40-64) into the [n][k] operand of sm_spmma_i8; a one-off for the small, reused weight operand */
+int sm_transpose_i8(const void* in, void* out, size_t rows, size_t cols, sm_stream_t stream);
 int sm_prune24_i8(const void* A_in, void* A_out, size_t m, size_t k, size_t ld, int alg, sm_stream_t stream);
 int sm_prune24_check_i8(const void* A, size_t m, size_t k, size_t ld, int* d_valid, sm_stream_t stream);
 int sm_compress24_i8(const void* A, size_t m, size_t k, size_t ld, size_t batch, size_t strideA, void* blob,

@@ -75,6 +75,7 @@ _SIGS["sm_im2col_f16"] = [_c_ptr] + [_c_size] * 9 + [_c_ptr, _c_ptr]
 _SIGS["sm_im2col_compress24_f16"] = [_c_ptr] + [_c_size] * 9 + [_c_ptr, _c_ptr]
 for _name in ("sm_prune24", "sm_prune24_check", "sm_compress24", "sm_decompress24"):
     _SIGS[_name + "_i8"] = _SIGS[_name + "_f16"]
+_SIGS["sm_transpose_i8"] = [_c_ptr, _c_ptr, _c_size, _c_size, _c_ptr]
 _SIGS["sm_spmma_i8"] = [_c_ptr, _c_ptr, _c_ptr, _c_size, _c_size, _c_size, _c_size, _c_size, _c_size, _c_i, _c_ptr]
 _SIGS["sm_spmma_i8_q"] = [_c_ptr, _c_ptr, _c_ptr, _c_size, _c_size, _c_size, _c_size, _c_size, _c_size, _c_f, _c_ptr]
 # bfloat16 forms: same signatures as their _f16 counterparts
@@ -228,6 +229,10 @@ def spmma(blob, B, C, m, n, k, batch=1, strideB=0, strideC=None, alpha=1.0, beta
     fn = getattr(lib(), "sm_spmma_" + _sfx(B))
     _check(fn(_dev(blob), _dev(B), _dev(C), m, n, k, batch, strideB, strideC, float(alpha), float(beta), _stream()),
            "sm_spmma")
+
+
+def transpose_i8(src, dst, rows, cols):
+    _check(lib().sm_transpose_i8(_dev(src), _dev(dst), rows, cols, _stream()), "sm_transpose_i8")
 
 
 def spmma_i8(blob, B, C, m, n, k, batch=1, strideB=0, strideC=None, accumulate=False):

@@ -169,6 +169,22 @@ __global__ __launch_bounds__(256) void decompress_i8_kernel(const uint8_t* vals,
   }
 }
 
+// B of the reference's spmma is row-major k x n (spmma.hxx:40-64); sm_spmma_i8 wants it [n][k].  One-off helper for
+// the (small, reused) weight operand: 64 x 64 byte tiles through LDS.
+__global__ __launch_bounds__(256) void transpose_i8_kernel(const uint8_t* in, uint8_t* out, size_t rows, size_t cols) {
+  __shared__ uint8_t tile[64][65];
+  const size_t r0 = (size_t)blockIdx.y * 64, c0 = (size_t)blockIdx.x * 64;
+  for (unsigned i = threadIdx.x; i < 64 * 64; i += 256) {
+    const unsigned r = i >> 6, c = i & 63u;
+    tile[r][c] = (r0 + r < rows && c0 + c < cols) ? in[(r0 + r) * cols + c0 + c] : (uint8_t)0;
+  }
+  __syncthreads();
+  for (unsigned i = threadIdx.x; i < 64 * 64; i += 256) {
+    const unsigned c = i >> 6, r = i & 63u;
+    if (r0 + r < rows && c0 + c < cols) out[(c0 + c) * rows + r0 + r] = tile[r][c];
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // matmul
 // ---------------------------------------------------------------------------------------------
@@ -416,6 +432,21 @@ static int launch_spmma_i8(const SpmmaI8Args& a0, hipStream_t st) {
 using namespace sm;
 
 extern "C" {
+
+int sm_transpose_i8(const void* in, void* out, size_t rows, size_t cols, sm_stream_t s) {
+  if (!in || !out || in == out) {
+    set_error("sm_transpose_i8: invalid argument (out of place only)");
+    return SM_STATUS_INVALID_VALUE;
+  }
+  if (rows == 0 || cols == 0) return SM_STATUS_SUCCESS;
+  if (ceil_div(rows, (size_t)64) > 65535 || ceil_div(cols, (size_t)64) > 0x7fffffffull) {
+    set_error("sm_transpose_i8: matrix too large");
+    return SM_STATUS_NOT_SUPPORTED;
+  }
+  transpose_i8_kernel<<<dim3((unsigned)ceil_div(cols, (size_t)64), (unsigned)ceil_div(rows, (size_t)64)), 256, 0, (hipStream_t)s>>>(
+      (const uint8_t*)in, (uint8_t*)out, rows, cols);
+  return check_launch("transpose_i8_kernel");
+}
 
 int sm_prune24_i8(const void* A_in, void* A_out, size_t m, size_t k, size_t ld, int alg, sm_stream_t s) {
   if (!A_in || !A_out || ld < k) {

@@ -844,6 +844,28 @@ def test_spmma_i8_vs_oracle(gpu, orc, shape, shared_b):
         assert np.array_equal(host(dQ), orc.requant_i8(Cacc, scale)), f"spmma_i8_q {shape} scale {scale}"
 
 
+def test_transpose_i8_then_spmma_matches_row_major_b(gpu, orc):
+    """The reference's B is row-major k x n; sm_transpose_i8 makes the [n][k] operand sm_spmma_i8 takes."""
+    import torch
+    rng = np.random.default_rng(5)
+    for (k, n) in [(64, 64), (200, 72), (1, 5), (130, 257)]:
+        Bkn = rng.integers(-128, 128, (k, n)).astype(np.int8)
+        dT = torch.zeros(n * k, dtype=torch.int8, device="cuda")
+        gpu.transpose_i8(to_dev(Bkn.reshape(-1)), dT, k, n)
+        assert np.array_equal(host(dT).reshape(n, k), Bkn.T)
+    m, n, k = 130, 72, 192
+    A = rng.integers(-128, 128, m * k).astype(np.int8)
+    Bkn = rng.integers(-128, 128, (k, n)).astype(np.int8)
+    blob = torch.empty(gpu.compress24_size(m, k, 1, 1), dtype=torch.uint8, device="cuda")
+    gpu.compress24(to_dev(A), m, k, k, 1, m * k, blob)
+    dT = torch.empty(n * k, dtype=torch.int8, device="cuda")
+    gpu.transpose_i8(to_dev(Bkn.reshape(-1)), dT, k, n)
+    dC = torch.zeros(m * n, dtype=torch.int32, device="cuda")
+    gpu.spmma_i8(blob, dT, dC, m, n, k)
+    P = orc.prune24(A.view(np.uint8), m, k, k, orc.STRIP).view(np.int8).reshape(m, k).astype(np.int64)
+    assert np.array_equal(host(dC).reshape(m, n), P @ Bkn.astype(np.int64))
+
+
 def test_spmma_i8_rejects_what_it_cannot_take(gpu):
     import torch
     blob = torch.zeros(1 << 16, dtype=torch.uint8, device="cuda")
