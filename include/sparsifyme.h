@@ -225,6 +225,13 @@ int sm_spmma_i8(const void* blob, const void* B, int32_t* C, size_t m, size_t n,
  * multiply of the int32 accumulator converted to fp32 */
 int sm_spmma_i8_q(const void* blob, const void* B, void* C, size_t m, size_t n, size_t k, size_t batch, size_t strideB,
                   size_t strideC, float scale, sm_stream_t stream);
+/* prune (STRIP) + compress + matmul in one kernel straight from the dense int8 A (row-major, lda): bit-identical to
+ * sm_compress24_i8 + sm_spmma_i8[_q], no blob.  Needs k % 64 == 0 and 16-byte aligned rows; SM_STATUS_NOT_SUPPORTED
+ * otherwise (use the pair). */
+int sm_spmma_fused_i8(const void* A, const void* B, int32_t* C, size_t m, size_t n, size_t k, size_t lda, size_t batch,
+                      size_t strideA, size_t strideB, size_t strideC, int accumulate, sm_stream_t stream);
+int sm_spmma_fused_i8_q(const void* A, const void* B, void* C, size_t m, size_t n, size_t k, size_t lda, size_t batch,
+                        size_t strideA, size_t strideB, size_t strideC, float scale, sm_stream_t stream);
 
 /* ---- im2col front end (extension).  X: N x C x H x W activations (NCHW, contiguous).
  *      A: per image the row-major L x K operand of the layer's matmul, L = out_h * out_w rows (row oh * out_w + ow),

@@ -75,6 +75,8 @@ _SIGS["sm_im2col_f16"] = [_c_ptr] + [_c_size] * 9 + [_c_ptr, _c_ptr]
 _SIGS["sm_im2col_compress24_f16"] = [_c_ptr] + [_c_size] * 9 + [_c_ptr, _c_ptr]
 for _name in ("sm_prune24", "sm_prune24_check", "sm_compress24", "sm_decompress24"):
     _SIGS[_name + "_i8"] = _SIGS[_name + "_f16"]
+_SIGS["sm_spmma_fused_i8"] = [_c_ptr, _c_ptr, _c_ptr] + [_c_size] * 8 + [_c_i, _c_ptr]
+_SIGS["sm_spmma_fused_i8_q"] = [_c_ptr, _c_ptr, _c_ptr] + [_c_size] * 8 + [_c_f, _c_ptr]
 _SIGS["sm_transpose_i8"] = [_c_ptr, _c_ptr, _c_size, _c_size, _c_ptr]
 _SIGS["sm_spmma_i8"] = [_c_ptr, _c_ptr, _c_ptr, _c_size, _c_size, _c_size, _c_size, _c_size, _c_size, _c_i, _c_ptr]
 _SIGS["sm_spmma_i8_q"] = [_c_ptr, _c_ptr, _c_ptr, _c_size, _c_size, _c_size, _c_size, _c_size, _c_size, _c_f, _c_ptr]
@@ -229,6 +231,19 @@ def spmma(blob, B, C, m, n, k, batch=1, strideB=0, strideC=None, alpha=1.0, beta
     fn = getattr(lib(), "sm_spmma_" + _sfx(B))
     _check(fn(_dev(blob), _dev(B), _dev(C), m, n, k, batch, strideB, strideC, float(alpha), float(beta), _stream()),
            "sm_spmma")
+
+
+def spmma_fused_i8(A, B, C, m, n, k, lda=None, batch=1, strideA=None, strideB=0, strideC=None, accumulate=False, scale=None):
+    """int8 prune + compress + matmul in one kernel; C int32 (scale None) or int8 requantised with `scale`."""
+    lda = k if lda is None else lda
+    strideA = m * lda if strideA is None else strideA
+    strideC = m * n if strideC is None else strideC
+    if scale is None:
+        _check(lib().sm_spmma_fused_i8(_dev(A), _dev(B), _dev(C), m, n, k, lda, batch, strideA, strideB, strideC,
+                                       1 if accumulate else 0, _stream()), "sm_spmma_fused_i8")
+    else:
+        _check(lib().sm_spmma_fused_i8_q(_dev(A), _dev(B), _dev(C), m, n, k, lda, batch, strideA, strideB, strideC, float(scale),
+                                         _stream()), "sm_spmma_fused_i8_q")
 
 
 def transpose_i8(src, dst, rows, cols):

@@ -192,6 +192,9 @@ struct SpmmaI8Args {
   const char* vals;
   const char* meta;
   size_t Mtot;
+  const int8_t* Ad;  // fused form: the DENSE A (row-major, lda), selected in the consumer's registers
+  size_t sA;         //   its batch stride (elements)
+  int lda;
   const int8_t* B;  // [n][k] per batch, ldb = k
   int* C;           // int32 output, or
   int8_t* C8;       // requantised output: sat_int8(rne(scale * acc))
@@ -204,11 +207,15 @@ struct SpmmaI8Args {
 typedef int i4v __attribute__((ext_vector_type(4)));
 typedef int i8v __attribute__((ext_vector_type(8)));
 
-template <int BN, int WM, int WN>
+// FUSED: prune + compress + matmul in one kernel, the int8 counterpart of spmma_f16_fused_direct_kernel: the stage's A
+// image is the DENSE tile [BM][128 B] (128 k), no metadata, and the lane that feeds the matrix instruction selects its
+// 8 strips (dense k 32 g .. 32 g + 31 = chunks 2 g, 2 g + 1 of its row) in registers: the same kept bytes and codes as
+// sm_compress24_i8 would have stored, so the result is bit-identical to compress + spmma; no blob exists.
+template <int BN, int WM, int WN, bool FUSED = false>
 __global__ __launch_bounds__(64 * WM * WN) void spmma_i8_kernel(const SpmmaI8Args p) {
   constexpr int BM = 128, NW = WM * WN, TM = BM / WM, TN = BN / WN, FM = TM / 16, FN = TN / 16;
-  constexpr int SA = BM * 64, SM_ = 2 * BM * 8, SB = BN * 128, STAGE = SA + SM_ + SB;
-  constexpr int A_N = BM / 16, M_N = 2, B_N = BN / 8, W = A_N + M_N + B_N;  // 1 KiB DMA wave-instructions per stage
+  constexpr int SA = FUSED ? BM * 128 : BM * 64, SM_ = FUSED ? 0 : 2 * BM * 8, SB = BN * 128, STAGE = SA + SM_ + SB;
+  constexpr int A_N = FUSED ? BM / 8 : BM / 16, M_N = FUSED ? 0 : 2, B_N = BN / 8, W = A_N + M_N + B_N;  // 1 KiB DMA wave-instructions per stage
   constexpr int SL = (W + NW - 1) / NW;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -237,7 +244,15 @@ __global__ __launch_bounds__(64 * WM * WN) void spmma_i8_kernel(const SpmmaI8Arg
   for (int i = 0; i < SL; ++i) {
     const unsigned t = wave + (unsigned)NW * i;
     src[i] = nullptr; step[i] = 0; loff[i] = 0; second[i] = false;
-    if (t < (unsigned)A_N) {  // 16 rows x 64 B of kept values: lane -> row 16 t + lane / 4, LDS chunk lane % 4
+    if (FUSED && t < (unsigned)A_N) {  // 8 rows x 128 B of the dense A
+      const unsigned row = 8u * t + (lane >> 3), cs = (lane & 7u) ^ (row & 7u);
+      int gr = m0 + (int)row;
+      gr = gr < mlast ? gr : mlast;
+      src[i] = reinterpret_cast<const char*>(p.Ad + (size_t)b * p.sA + (size_t)gr * p.lda) + 16u * cs;
+      step[i] = 128;
+      loff[i] = t * 1024u;
+      second[i] = cs >= 4u;  // k 64 .. 127 of the stage
+    } else if (t < (unsigned)A_N) {  // 16 rows x 64 B of kept values: lane -> row 16 t + lane / 4, LDS chunk lane % 4
       const unsigned row = 16u * t + (lane >> 2), cs = (lane & 3u) ^ a64_swz(row);  // source chunk: plane cs >> 1, half cs & 1
       int gr = m0 + (int)row;
       gr = gr < mlast ? gr : mlast;
@@ -297,6 +312,19 @@ __global__ __launch_bounds__(64 * WM * WN) void spmma_i8_kernel(const SpmmaI8Arg
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
       const unsigned row = wm * TM + i * 16 + r;
+      if constexpr (FUSED) {
+        const u4 lo = *reinterpret_cast<const u4*>(As + a_off(row, 2u * g));
+        const u4 hi = *reinterpret_cast<const u4*>(As + a_off(row, 2u * g + 1u));
+        uint32_t kp[8], nb[8];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          strip_select_i8(lo[t], kp[t], nb[t]);
+          strip_select_i8(hi[t], kp[4 + t], nb[4 + t]);
+        }
+        af[i] = i4v{(int)(kp[0] | (kp[1] << 16)), (int)(kp[2] | (kp[3] << 16)), (int)(kp[4] | (kp[5] << 16)), (int)(kp[6] | (kp[7] << 16))};
+        idx[i] = (int)(nb[0] | (nb[1] << 4) | (nb[2] << 8) | (nb[3] << 12) | (nb[4] << 16) | (nb[5] << 20) | (nb[6] << 24) | (nb[7] << 28));
+        continue;
+      }
       af[i] = *reinterpret_cast<const i4v*>(As + row * 64u + 16u * (g ^ a64_swz(row)));
       idx[i] = *reinterpret_cast<const int*>(Ms + (g >> 1) * (BM * 8) + row * 8u + 4u * (g & 1u));
     }
@@ -403,7 +431,7 @@ __global__ __launch_bounds__(64 * WM * WN) void spmma_i8_kernel(const SpmmaI8Arg
   }
 }
 
-template <int BN, int WM, int WN>
+template <int BN, int WM, int WN, bool FUSED = false>
 static int launch_spmma_i8(const SpmmaI8Args& a0, hipStream_t st) {
   SpmmaI8Args a = a0;
   a.tiles_m = (a.Mrows + 127) / 128;
@@ -414,16 +442,16 @@ static int launch_spmma_i8(const SpmmaI8Args& a0, hipStream_t st) {
     set_error("sm_spmma_i8: grid too large");
     return SM_STATUS_NOT_SUPPORTED;
   }
-  constexpr size_t lds_main = 2 * ((size_t)128 * 64 + 2 * 128 * 8 + (size_t)BN * 128);
+  constexpr size_t lds_main = 2 * ((FUSED ? (size_t)128 * 128 : (size_t)128 * 64 + 2 * 128 * 8) + (size_t)BN * 128);
   constexpr size_t lds_epi = (size_t)128 * (BN * 4 + 16);
   constexpr size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
   static bool attr_set = false;
   if (lds > 64 * 1024 && !attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spmma_i8_kernel<BN, WM, WN>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spmma_i8_kernel<BN, WM, WN, FUSED>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds);
     attr_set = true;
   }
-  spmma_i8_kernel<BN, WM, WN><<<dim3((unsigned)nwg), dim3(64 * WM * WN), lds, st>>>(a);
+  spmma_i8_kernel<BN, WM, WN, FUSED><<<dim3((unsigned)nwg), dim3(64 * WM * WN), lds, st>>>(a);
   return check_launch("spmma_i8_kernel");
 }
 
@@ -554,7 +582,50 @@ static int spmma_i8_entry(const void* blob, const void* B, int32_t* C, int8_t* C
   return n <= 128 ? launch_spmma_i8<64, 4, 1>(a, st) : launch_spmma_i8<128, 2, 4>(a, st);
 }
 
+static int spmma_fused_i8_entry(const void* A, const void* B, int32_t* C, int8_t* C8, float scale, size_t m, size_t n, size_t k, size_t lda,
+                                size_t batch, size_t strideA, size_t strideB, size_t strideC, int accumulate, sm_stream_t stream) {
+  if (!A || !B || (!C && !C8) || lda < k) {
+    set_error("sm_spmma_fused_i8: invalid argument");
+    return SM_STATUS_INVALID_VALUE;
+  }
+  if (m == 0 || n == 0 || batch == 0) return SM_STATUS_SUCCESS;
+  if (m * batch > 0x7fffffffull || n > 0x7fffffffull || k > 0x7fffffffull || lda > 0x7fffffffull) {
+    set_error("sm_spmma_fused_i8: dimension exceeds 2^31-1");
+    return SM_STATUS_NOT_SUPPORTED;
+  }
+  if (k % 64 != 0 || lda % 16 != 0 || strideA % 16 != 0 || strideB % 16 != 0 || !aligned16(A) || !aligned16(B)) {
+    set_error("sm_spmma_fused_i8: needs k %% 64 == 0 and 16-byte aligned rows of A and B (use sm_compress24_i8 + sm_spmma_i8)");
+    return SM_STATUS_NOT_SUPPORTED;
+  }
+  SpmmaI8Args a = {};
+  a.Ad = (const int8_t*)A; a.sA = strideA; a.lda = (int)lda;
+  a.B = (const int8_t*)B;
+  a.C = C; a.C8 = C8; a.scale = scale;
+  a.sB = strideB; a.sC = strideC;
+  a.m = (int)m; a.Mrows = (int)m; a.N = (int)n; a.K = (int)k; a.nplanes = (int)(k / 64);
+  a.batch = (int)batch; a.accumulate = accumulate != 0;
+  if (batch > 1 && strideB == 0 && strideA == m * lda && strideC == m * n) {
+    a.Mrows = (int)(m * batch);
+    a.batch = 1;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  static const int cfg = getenv("SM_SPMMA_I8_FUSED_CFG") ? atoi(getenv("SM_SPMMA_I8_FUSED_CFG")) : 0;  // tuning aid
+  if (cfg == 1) return launch_spmma_i8<64, 4, 1, true>(a, st);
+  if (cfg == 2) return launch_spmma_i8<128, 2, 4, true>(a, st);
+  if (cfg == 3) return launch_spmma_i8<128, 4, 2, true>(a, st);
+  return n <= 64 ? launch_spmma_i8<64, 4, 1, true>(a, st) : launch_spmma_i8<128, 4, 2, true>(a, st);
+}
+
 extern "C" {
+
+int sm_spmma_fused_i8(const void* A, const void* B, int32_t* C, size_t m, size_t n, size_t k, size_t lda, size_t batch, size_t strideA,
+                      size_t strideB, size_t strideC, int accumulate, sm_stream_t stream) {
+  return spmma_fused_i8_entry(A, B, C, nullptr, 1.0f, m, n, k, lda, batch, strideA, strideB, strideC, accumulate, stream);
+}
+int sm_spmma_fused_i8_q(const void* A, const void* B, void* C, size_t m, size_t n, size_t k, size_t lda, size_t batch, size_t strideA,
+                        size_t strideB, size_t strideC, float scale, sm_stream_t stream) {
+  return spmma_fused_i8_entry(A, B, nullptr, (int8_t*)C, scale, m, n, k, lda, batch, strideA, strideB, strideC, 0, stream);
+}
 
 int sm_spmma_i8(const void* blob, const void* B, int32_t* C, size_t m, size_t n, size_t k, size_t batch, size_t strideB, size_t strideC,
                 int accumulate, sm_stream_t stream) {

@@ -835,6 +835,10 @@ def test_spmma_i8_vs_oracle(gpu, orc, shape, shared_b):
         Cref = C0.copy()
         orc.spmma_i8(ob, B, Cref, m, n, k, batch, sB, accumulate=acc)
         assert np.array_equal(host(dC), Cref), f"spmma_i8 {shape} shared={shared_b} accumulate={acc}"
+    # fused form (dense A in, no blob): the same int32 result bit for bit
+    dF = to_dev(C0.copy())
+    gpu.spmma_fused_i8(dA, dB, dF, m, n, k, batch=batch, strideB=sB, accumulate=True)
+    assert np.array_equal(host(dF), Cref), f"spmma_fused_i8 {shape} shared={shared_b}"
     # requantised int8 output: saturate(rne(scale * acc)), bit-exact against the oracle's fp32 arithmetic
     Cacc = np.zeros(batch * m * n, dtype=np.int32)
     orc.spmma_i8(ob, B, Cacc, m, n, k, batch, sB)
@@ -842,6 +846,9 @@ def test_spmma_i8_vs_oracle(gpu, orc, shape, shared_b):
         dQ = torch.full((batch * m * n,), 77, dtype=torch.int8, device="cuda")
         gpu.spmma_i8_q(blob, dB, dQ, m, n, k, scale, batch, sB)
         assert np.array_equal(host(dQ), orc.requant_i8(Cacc, scale)), f"spmma_i8_q {shape} scale {scale}"
+        dQ2 = torch.full((batch * m * n,), 77, dtype=torch.int8, device="cuda")
+        gpu.spmma_fused_i8(dA, dB, dQ2, m, n, k, batch=batch, strideB=sB, scale=scale)
+        assert torch.equal(dQ, dQ2), f"spmma_fused_i8_q {shape} scale {scale}"
 
 
 def test_transpose_i8_then_spmma_matches_row_major_b(gpu, orc):
