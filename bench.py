@@ -53,6 +53,10 @@ def main():
     ap.add_argument("--fused-max-k-wide", type=int, default=512,
                     help="auto path: wider layers (n > --fused-max-n) are still fused when k <= this (the A-stationary "
                          "kernel keeps the 2:4 image of a row panel in LDS across its column tiles); 0 = never")
+    ap.add_argument("--dtype", choices=["f16", "bf16"], default="f16",
+                    help="element type of the 16-bit path (BASELINE's metric is quoted on f16; bf16 runs the same kernels "
+                         "with the bfloat16 matrix instructions; the reference's column-major dense GEMM has no bf16 form "
+                         "and is skipped)")
     ap.add_argument("--streams", type=int, default=4,
                     help="HIP streams the independent layers of a step are spread over (fork/join inside the step)")
     ap.add_argument("--graphs", choices=["single", "per-stream"], default="single",
@@ -90,14 +94,15 @@ def main():
     sm.device_check()  # raises when the HIP library or a gfx950 device is missing: no fallback
 
     shapes = read_shapes(args.table)
+    tdt = torch.float16 if args.dtype == "f16" else torch.bfloat16
     layers = []
     for li, (m, n, k, b) in enumerate(shapes):
-        A = torch.empty(b * m * k, dtype=torch.float16, device=dev)
-        B = torch.empty(k * n, dtype=torch.float16, device=dev)
+        A = torch.empty(b * m * k, dtype=tdt, device=dev)
+        B = torch.empty(k * n, dtype=tdt, device=dev)
         sm.fill_uniform(A, 0x5EED0000 + 1000 * rank + li, 0.0, 1.0)
         sm.fill_uniform(B, 0xB0000000 + li, 0.0, 1.0)
         blob = torch.empty(sm.compress24_size(m, k, 2, b), dtype=torch.uint8, device=dev)
-        C = torch.empty(b * m * n, dtype=torch.float16, device=dev)
+        C = torch.empty(b * m * n, dtype=tdt, device=dev)
         layers.append(dict(m=m, n=n, k=k, b=b, A=A, B=B, blob=blob, C=C))
     flops = sum(2.0 * L["m"] * L["n"] * L["k"] * L["b"] for L in layers)
 
@@ -218,10 +223,10 @@ def main():
         "metric": "effective GF/s (2:4 spmma vs dense gemm) on ResNet-50 layer shapes",
         "value": value, "unit": "GF/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f16", "data": "synthetic",
-        "config": {"workload": "datasets/%s: %d conv layers as im2col GEMMs (m,n,k) at b=%d, fp16; "
+        "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": "datasets/%s: %d conv layers as im2col GEMMs (m,n,k) at b=%d, %s; "
                                "step = per layer 2:4 prune+compress+matmul (path: %s)"
-                               % (os.path.basename(args.table), len(layers), layers[0]["b"], args.path),
+                               % (os.path.basename(args.table), len(layers), layers[0]["b"], "fp16" if args.dtype == "f16" else "bfloat16", args.path),
                    "path": args.path + (": sm_spmma_fused_f16 on %d layers (n <= %d or k <= %d), sm_compress24_f16 + sm_spmma_f16 on %d"
                                         % (sum(use_fused(L) for L in layers), args.fused_max_n, args.fused_max_k_wide,
                                            sum(not use_fused(L) for L in layers))
@@ -252,7 +257,8 @@ def main():
         dense_batched = Forked(lambda L: sm.gemm_batched(L["Ap"], L["Bp"], L["Cp"], L["m"], L["n"], L["k"], L["b"], "f16"))
 
         t_mul, t_cmp = sec_per_call(spmma_only), sec_per_call(compress_only)
-        t_drm, t_dcm = sec_per_call(dense_rowmajor), sec_per_call(dense_batched)
+        t_drm = sec_per_call(dense_rowmajor)
+        t_dcm = sec_per_call(dense_batched) if args.dtype == "f16" else None  # cublasHgemmBatched's role: fp16 only
         t_full = wall / args.steps
 
         step_staged = Forked(layer_full)
@@ -262,9 +268,9 @@ def main():
         out["stages"] = {
             "spmma_mul_gfs": gfs(t_mul), "spmma_mul_ms": t_mul * 1e3, "compress_ms": t_cmp * 1e3,
             "dense_gemm_rowmajor_gfs": gfs(t_drm), "dense_gemm_rowmajor_ms": t_drm * 1e3,
-            "dense_gemm_batched_colmajor_gfs": gfs(t_dcm), "dense_gemm_batched_colmajor_ms": t_dcm * 1e3,
-            "speedup_mul_vs_dense_rowmajor": t_drm / t_mul, "speedup_mul_vs_dense_batched": t_dcm / t_mul,
-            "speedup_full_vs_dense_rowmajor": t_drm / t_full, "speedup_full_vs_dense_batched": t_dcm / t_full,
+            "dense_gemm_batched_colmajor_gfs": gfs(t_dcm) if t_dcm else None, "dense_gemm_batched_colmajor_ms": t_dcm * 1e3 if t_dcm else None,
+            "speedup_mul_vs_dense_rowmajor": t_drm / t_mul, "speedup_mul_vs_dense_batched": t_dcm / t_mul if t_dcm else None,
+            "speedup_full_vs_dense_rowmajor": t_drm / t_full, "speedup_full_vs_dense_batched": t_dcm / t_full if t_dcm else None,
             "full_path_staged_gfs": gfs(t_staged), "full_path_staged_ms": t_staged * 1e3,
             "timed_path": args.path, "timed_path_ms": t_full * 1e3,
             # what 2:4 can buy on these shapes when both products are HBM-bound (they are: DESIGN.md 4.2): the ratio of
