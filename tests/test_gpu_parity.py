@@ -617,7 +617,7 @@ def test_cpp_drivers_cli_contract(gpu):
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     bins = os.path.join(root, "examples", "bin")
-    if not os.path.exists(os.path.join(bins, "spmma_plan_bf16")):
+    if not os.path.exists(os.path.join(bins, "spmma_i8")):
         subprocess.run(["make", "-C", os.path.join(root, "examples"), "-j4"], check=True, capture_output=True)
 
     def run(*args):
@@ -632,6 +632,11 @@ def test_cpp_drivers_cli_contract(gpu):
     assert "Incorrect pruning" not in out.stderr
     bad = run("spmma", 1, 2)
     assert bad.returncode != 0 and "Usage: ./spmma m n k b" in bad.stdout
+    # int8 driver: stage labels of the fp16 one; its fused kernel must return the staged pair's bytes
+    for argv in [(196, 64, 128, 4), (784, 256, 1152, 2), (130, 72, 192, 3)]:
+        out = run("spmma_i8", *argv)
+        assert out.returncode == 0, out.stdout + out.stderr
+        assert "SpMMA Time (ms)" in out.stdout and "Fused matches: yes" in out.stdout
     # cached-plan form (row f-1): compress once, multiply many; the driver compares its C with spmma()'s bit for bit
     for argv in [(196, 64, 128, 4), (784, 256, 1152, 2), (130, 72, 200, 3)]:
         for tool in ("spmma_plan", "spmma_plan_bf16"):
