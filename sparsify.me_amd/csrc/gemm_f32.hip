@@ -689,6 +689,130 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(const Gemm64Args p) {
     }
 }
 
+// ---- fp64 on the matrix cores: v_mfma_f64_16x16x4_f64 on the fp32 kernel's LDS-DMA pipeline (K % 16 == 0, even N).
+// Stage = 16 k = 128 B per A row; B in panels of 16 columns [16 k][128 B] (chunk c of k-row kr at c ^ 4 * ((kr >> 2) & 1));
+// the instruction's four k-slots carry k = 4 g + s at step s, so a lane owns 4 consecutive k of its A row per stage (two
+// ds_read_b128).  Operands swapped as in the fp32 kernels; the f64 result map then leaves lane l, register q with
+// C[row l & 15][column (l >> 4) + 4 q] (cdna_hip_programming.md, "v_mfma_f64_16x16x4_f64").
+typedef double d4v __attribute__((ext_vector_type(4)));
+typedef double d2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned b64_off(unsigned kr, unsigned col) {  // byte offset in the [panel][16][128 B] image
+  return (col >> 4) * 2048u + kr * 128u + 16u * (((col & 15u) >> 1) ^ (4u * ((kr >> 2) & 1u))) + 8u * (col & 1u);
+}
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_f64_dma_kernel(const Gemm64Args p) {
+  constexpr int NW = WM * WN, TM = BM / WM, TN = BN / WN, FM = TM / 16, FN = TN / 16;
+  constexpr int SA = BM * 128, SB = BN * 128, STAGE = SA + SB;
+  constexpr int A_N = BM / 8, B_N = BN / 8, W = A_N + B_N;  // 1 KiB DMA wave-instructions per stage
+  static_assert(W % NW == 0, "equal DMA share per wave");
+  constexpr int SL = W / NW;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const unsigned tid = threadIdx.x, lane = tid & 63u;
+  const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const unsigned wm = wave / WN, wn = wave % WN;
+  const int m0 = (int)blockIdx.y * BM, n0 = (int)blockIdx.x * BN;
+  const double* A = p.Ap[blockIdx.z];
+  const double* B = p.Bp[blockIdx.z];
+  double* C = p.Cp[blockIdx.z];
+  const int mlast = p.M - 1;
+
+  const char* src[SL];
+  size_t step[SL];
+  unsigned loff[SL];
+#pragma unroll
+  for (int i = 0; i < SL; ++i) {
+    const unsigned t = wave + (unsigned)NW * i;
+    if (t < (unsigned)A_N) {  // 8 rows x 128 B
+      const unsigned row = 8u * t + (lane >> 3), cs = (lane & 7u) ^ (row & 7u);
+      int gr = m0 + (int)row;
+      gr = gr < mlast ? gr : mlast;
+      src[i] = reinterpret_cast<const char*>(A + (size_t)gr * p.lda + 2u * cs);
+      step[i] = 128;
+      loff[i] = t * 1024u;
+    } else {  // 8 k-rows of one 16-column panel
+      const unsigned j = t - A_N, panel = j >> 1, kr = 8u * (j & 1u) + (lane >> 3);
+      const unsigned cs = (lane & 7u) ^ (4u * ((kr >> 2) & 1u));
+      int gc = n0 + (int)(16u * panel + 2u * cs);
+      gc = gc <= p.N - 2 ? gc : p.N - 2;
+      src[i] = reinterpret_cast<const char*>(B + (size_t)kr * p.ldb + gc);
+      step[i] = (size_t)16 * p.ldb * 8;
+      loff[i] = SA + panel * 2048u + (j & 1u) * 1024u;
+    }
+  }
+  auto stage = [&](int kt, int buf) {
+    char* base = smem + buf * STAGE;
+#pragma unroll
+    for (int i = 0; i < SL; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t*)(src[i] + (size_t)kt * step[i]), (lptr_t*)(base + loff[i]), 16, 0, 0);
+  };
+
+  d4v acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = d4v{0.0, 0.0, 0.0, 0.0};
+
+  const int nkt = p.K / 16;
+  if (nkt > 0) stage(0, 0);
+  const unsigned g = lane >> 4, r = lane & 15u;
+  for (int kt = 0; kt < nkt; ++kt) {
+    wait_dma_and_barrier<0>();  // ring of 2
+    if (kt + 1 < nkt) stage(kt + 1, (kt + 1) & 1);
+    const char* As = smem + (kt & 1) * STAGE;
+    const char* Bs = As + SA;
+    d2v alo[FM], ahi[FM];
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      const unsigned row = wm * TM + i * 16 + r;
+      alo[i] = *reinterpret_cast<const d2v*>(As + a_off(row, 2u * g));
+      ahi[i] = *reinterpret_cast<const d2v*>(As + a_off(row, 2u * g + 1u));
+    }
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      double bv[4];
+      const unsigned col = wn * TN + j * 16 + r;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) bv[s] = *reinterpret_cast<const double*>(Bs + b64_off(4u * g + s, col));
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[s], s < 2 ? alo[i][s] : ahi[i][s - 2], acc[i][j], 0, 0, 0);
+    }
+  }
+
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      const int gr = m0 + (int)(wm * TM + i * 16 + r);
+      if (gr >= p.M) continue;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int gc = n0 + (int)(wn * TN + j * 16 + 4u * q + g);
+        if (gc >= p.N) continue;
+        double* d = C + (size_t)gr * p.ldc + gc;
+        *d = p.beta != 0.0 ? p.alpha * acc[i][j][q] + p.beta * *d : p.alpha * acc[i][j][q];
+      }
+    }
+}
+
+template <int BM, int BN, int WM, int WN>
+static int launch64_dma(const Gemm64Args& a, size_t batch, hipStream_t st) {
+  constexpr size_t lds = 2 * (size_t)(BM + BN) * 128;
+  static bool attr_set = false;
+  if (lds > 64 * 1024 && !attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f64_dma_kernel<BM, BN, WM, WN>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  dim3 grid((unsigned)ceil_div(a.N, BN), (unsigned)ceil_div(a.M, BM), (unsigned)batch);
+  gemm_f64_dma_kernel<BM, BN, WM, WN><<<grid, dim3(64 * WM * WN), lds, st>>>(a);
+  return check_launch("gemm_f64_dma_kernel");
+}
+
 }  // namespace sm
 
 using namespace sm;
@@ -814,6 +938,20 @@ int sm_gemm_batched_f64(const double* const* A_ptrs, const double* const* B_ptrs
   a.lda = (int)k; a.ldb = (int)m; a.ldc = (int)m;
   a.ta = tb == SM_OP_T; a.tb = ta == SM_OP_T;  // roles swap with the operands
   a.alpha = alpha; a.beta = beta;
+  // matrix-core path: whole 16-k stages of 16-byte chunks (even leading dimensions; the pointer arrays live on the
+  // device, their bases are the caller's -- a 16-byte global access needs dword alignment only); SM_GEMM64_DMA=0
+  // (tuning aid) keeps the FMA kernel
+  static const int dma_env = getenv("SM_GEMM64_DMA") ? atoi(getenv("SM_GEMM64_DMA")) : 1;
+  if (dma_env && !a.ta && !a.tb && a.K % 16 == 0 && a.K >= 16 && a.N % 2 == 0 && a.N >= 2 && a.lda % 2 == 0 && a.ldb % 2 == 0 &&
+      ceil_div((size_t)a.M, (size_t)64) <= 65535) {
+    if (dma_env == 2) return launch64_dma<64, 64, 2, 2>(a, batch, (hipStream_t)stream);
+    if (dma_env == 5) return launch64_dma<128, 128, 4, 4>(a, batch, (hipStream_t)stream);
+    // 128 x 128 tiles over 16 waves once they fill 3/4 of the CUs, 64 x 64 otherwise (tools/f64_probe.py under SM_GEMM64_DMA=2..5)
+    const size_t big_tiles = ceil_div((size_t)a.M, (size_t)128) * ceil_div((size_t)a.N, (size_t)128) * batch;
+    if (a.M > 64 && a.N > 64 && 4 * big_tiles >= 3 * (size_t)device_cu_count())
+      return launch64_dma<128, 128, 4, 4>(a, batch, (hipStream_t)stream);
+    return launch64_dma<64, 64, 2, 2>(a, batch, (hipStream_t)stream);
+  }
   dim3 grid((unsigned)ceil_div(a.N, 64), (unsigned)ceil_div(a.M, 64), (unsigned)batch);
   gemm_f64_kernel<<<grid, dim3(256), 0, (hipStream_t)stream>>>(a);
   return check_launch("gemm_f64_kernel");
