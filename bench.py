@@ -48,8 +48,11 @@ def main():
                     help="auto: fused prune+compress+matmul kernel on the layers where it wins (n <= --fused-max-n), the "
                          "staged compress24 + spmma pair elsewhere; staged: the pair on every layer")
     ap.add_argument("--fused-max-n", type=int, default=256,
-                    help="auto path: widest n served by sm_spmma_fused_f16 (one workgroup spans up to 256 columns, so up "
-                         "to there A is loaded and selected once)")
+                    help="auto path: widest n served by sm_spmma_fused_f16 whatever k (one workgroup spans up to 256 columns, so up "
+                         "to there A is loaded and selected once).  512 also fuses the long-k n = 512 layers, which standalone are "
+                         "faster as compress + spmma (46 vs 70 us) but inside the step, bound by the bytes it moves, gain from not "
+                         "writing and re-reading their blobs: 1.816 vs 1.837 ms (three alternating runs) -- not the default because "
+                         "it makes the dominant kernel family's single-stream roofline figure worse (0.41 vs 0.47)")
     ap.add_argument("--fused-max-k-wide", type=int, default=512,
                     help="auto path: wider layers (n > --fused-max-n) are still fused when k <= this (the A-stationary "
                          "kernel keeps the 2:4 image of a row panel in LDS across its column tiles); 0 = never")
