@@ -206,7 +206,7 @@ int sm_fill_uniform_bf16(void* out, size_t count, uint64_t seed, float lo, float
 
 /* ---- int8 forms (extension; SURVEY.md 8(f) rank 2, cusparseLt.h:164-169).  Elements are signed bytes; the rules
  *      act on |x| (|-128| = 128); same blob geometry with 1-byte elements (sm_compress24_size(m, k, 1, batch, ...)).
- *      Only the STRIP prune rule is built.  sm_spmma_i8: C (int32, row-major m x n) = A_2:4 . B (+ C when
+ *      sm_spmma_i8: C (int32, row-major m x n) = A_2:4 . B (+ C when
  *      accumulate != 0), exact integer arithmetic on v_smfmac_i32_16x16x128_i8; B is [n][k] -- K-CONTIGUOUS per output
  *      column ("TN", the layout int8 matrix cores are fed in), B_b = B + b * strideB (0 = shared).  Needs k % 64 == 0,
  *      an even m, a 16-byte aligned B; SM_STATUS_NOT_SUPPORTED otherwise. */

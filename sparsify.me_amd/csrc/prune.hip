@@ -36,33 +36,6 @@ __device__ __forceinline__ float mag_sel(T v) {
   else return mag_of(v);
 }
 
-// TILE rule: 16-bit keep mask (bit 4*r + c) of the best of the 90 candidates.
-__device__ __forceinline__ unsigned tile_keepmask(const float (&mag)[4][4]) {
-  float s0[6], s1[6], s2[6], s3[6];
-#define SM_PAIRS(S, R)            \
-  S[0] = mag[R][0] + mag[R][1];   \
-  S[1] = mag[R][0] + mag[R][2];   \
-  S[2] = mag[R][0] + mag[R][3];   \
-  S[3] = mag[R][1] + mag[R][2];   \
-  S[4] = mag[R][1] + mag[R][3];   \
-  S[5] = mag[R][2] + mag[R][3];
-  SM_PAIRS(s0, 0) SM_PAIRS(s1, 1) SM_PAIRS(s2, 2) SM_PAIRS(s3, 3)
-#undef SM_PAIRS
-  float best = -1.0f;
-  unsigned bm = 0;
-#define TILE_CAND(I, P0, P1, P2, P3, MK)                        \
-  {                                                             \
-    const float sc = (s0[P0] + s1[P1]) + (s2[P2] + s3[P3]);     \
-    if (sc > best) {                                            \
-      best = sc;                                                \
-      bm = MK;                                                  \
-    }                                                           \
-  }
-#include "tile_patterns.inc"
-#undef TILE_CAND
-  return bm;
-}
-
 // Two tiles at once: every add of the rule (24 pair sums, 36 + 36 partial sums, 90 totals per tile) is a packed
 // v_pk_add_f32 on {tile 0, tile 1}; only the compare / select tail stays per tile.  Same candidate order, same
 // fp32 association as tile_keepmask, so the two agree bit for bit.

@@ -54,4 +54,32 @@ __device__ __forceinline__ void strip_select_f16(uint32_t d0, uint32_t d1, uint3
   nib = 15u - (A | (B << 2));
 }
 
+// TILE rule: 16-bit keep mask (bit 4*r + c) of the best of the 90 candidates.
+__device__ __forceinline__ unsigned tile_keepmask(const float (&mag)[4][4]) {
+  float s0[6], s1[6], s2[6], s3[6];
+#define SM_PAIRS(S, R)            \
+  S[0] = mag[R][0] + mag[R][1];   \
+  S[1] = mag[R][0] + mag[R][2];   \
+  S[2] = mag[R][0] + mag[R][3];   \
+  S[3] = mag[R][1] + mag[R][2];   \
+  S[4] = mag[R][1] + mag[R][3];   \
+  S[5] = mag[R][2] + mag[R][3];
+  SM_PAIRS(s0, 0) SM_PAIRS(s1, 1) SM_PAIRS(s2, 2) SM_PAIRS(s3, 3)
+#undef SM_PAIRS
+  float best = -1.0f;
+  unsigned bm = 0;
+#define TILE_CAND(I, P0, P1, P2, P3, MK)                        \
+  {                                                             \
+    const float sc = (s0[P0] + s1[P1]) + (s2[P2] + s3[P3]);     \
+    if (sc > best) {                                            \
+      best = sc;                                                \
+      bm = MK;                                                  \
+    }                                                           \
+  }
+#include "tile_patterns.inc"
+#undef TILE_CAND
+  return bm;
+}
+
+
 }  // namespace sm

@@ -1,6 +1,6 @@
 // spmma_i8.hip -- int8 forms of the 2:4 path (extension; SURVEY.md 8(f) rank 2: the vendor call behind
 // include/sparsify.me/spmma.hxx:40-113 lists int8 among its 2:4 types, examples/libcusparse_lt/include/cusparseLt.h:164-169).
-//   sm_prune24_i8 (STRIP) / sm_prune24_check_i8 / sm_compress24_i8 / sm_decompress24_i8: the fp16 rules on |x| of a
+//   sm_prune24_i8 (STRIP and TILE) / sm_prune24_check_i8 / sm_compress24_i8 / sm_decompress24_i8: the fp16 rules on |x| of a
 //     signed byte (|-128| = 128 > 127; ties keep the lower k index); same blob geometry with 1-byte elements: values
 //     [kc/64][M][32 B], metadata [kc/64][M][8 B] (include/sparsifyme.h).
 //   sm_spmma_i8: C (int32) = A_2:4 . B (+ C), exact integer arithmetic on v_smfmac_i32_16x16x128_i8.  B is given
@@ -86,6 +86,42 @@ __global__ __launch_bounds__(256) void prune_strip_i8_kernel(const uint8_t* A_in
 #pragma unroll
       for (unsigned t = 0; t < 16; ++t)
         if (t < nvalid) dst[t] = v.e[t];
+    }
+  }
+}
+
+// TILE rule (the variant the reference's spmma asks for, spmma.hxx:86): one 4 x 4 tile per thread, magnitudes as fp32
+// (exact), the frozen candidate order of select24.h: tile_keepmask.
+__global__ __launch_bounds__(256) void prune_tile_i8_kernel(const uint8_t* A_in, uint8_t* A_out, size_t m, size_t k, size_t ld, bool vec) {
+  const size_t tpr = (k + 3) / 4, trows = (m + 3) / 4, total = tpr * trows;
+  for (size_t it = blockIdx.x * (size_t)256 + threadIdx.x; it < total; it += (size_t)gridDim.x * 256) {
+    const size_t tr = it / tpr, tc = it - tr * tpr, r0 = tr * 4, c0 = tc * 4;
+    const unsigned ncol = k - c0 < 4 ? (unsigned)(k - c0) : 4u;
+    uint8_t v[4][4];
+    float mag[4][4];
+#pragma unroll
+    for (unsigned r = 0; r < 4; ++r) {
+      const bool rv = r0 + r < m;
+      const uint8_t* p = A_in + (r0 + r) * ld + c0;
+      if (rv && vec && ncol == 4) {
+        const uint32_t d = *reinterpret_cast<const uint32_t*>(p);
+#pragma unroll
+        for (unsigned t = 0; t < 4; ++t) v[r][t] = (uint8_t)(d >> (8 * t));
+      } else {
+#pragma unroll
+        for (unsigned t = 0; t < 4; ++t) v[r][t] = (rv && t < ncol) ? p[t] : (uint8_t)0;
+      }
+#pragma unroll
+      for (unsigned t = 0; t < 4; ++t) mag[r][t] = (float)key_i8(v[r][t]);
+    }
+    const unsigned keep = tile_keepmask(mag);
+#pragma unroll
+    for (unsigned r = 0; r < 4; ++r) {
+      if (r0 + r >= m) continue;
+      uint8_t* p = A_out + (r0 + r) * ld + c0;
+#pragma unroll
+      for (unsigned t = 0; t < 4; ++t)
+        if (t < ncol) p[t] = ((keep >> (4 * r + t)) & 1u) ? v[r][t] : (uint8_t)0;
     }
   }
 }
@@ -481,11 +517,17 @@ int sm_prune24_i8(const void* A_in, void* A_out, size_t m, size_t k, size_t ld, 
     set_error("sm_prune24_i8: invalid argument");
     return SM_STATUS_INVALID_VALUE;
   }
-  if (alg != SM_PRUNE_STRIP) {
-    set_error("sm_prune24_i8: only SM_PRUNE_STRIP is built for int8");
-    return SM_STATUS_NOT_SUPPORTED;
+  if (alg != SM_PRUNE_STRIP && alg != SM_PRUNE_TILE) {
+    set_error("sm_prune24_i8: invalid rule");
+    return SM_STATUS_INVALID_VALUE;
   }
   if (m == 0 || k == 0) return SM_STATUS_SUCCESS;
+  if (alg == SM_PRUNE_TILE) {
+    const bool vec4 = (reinterpret_cast<uintptr_t>(A_in) & 3u) == 0 && (reinterpret_cast<uintptr_t>(A_out) & 3u) == 0 && ld % 4 == 0;
+    prune_tile_i8_kernel<<<stream_grid(ceil_div(m, (size_t)4) * ceil_div(k, (size_t)4), 256), 256, 0, (hipStream_t)s>>>(
+        (const uint8_t*)A_in, (uint8_t*)A_out, m, k, ld, vec4);
+    return check_launch("prune_tile_i8_kernel");
+  }
   const bool vec = aligned16(A_in) && aligned16(A_out) && ld % 16 == 0;
   prune_strip_i8_kernel<<<stream_grid(m * ceil_div(k, (size_t)16), 256), 256, 0, (hipStream_t)s>>>((const uint8_t*)A_in, (uint8_t*)A_out, m, k,
                                                                                                      ld, vec);

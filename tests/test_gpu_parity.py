@@ -799,6 +799,9 @@ def test_prune24_i8_vs_oracle(gpu, orc, shape):
         A = (rng.integers(-128, 128, m * k) if kind == "full" else rng.integers(-2, 3, m * k)).astype(np.int8)
         dA = to_dev(A)
         out = torch.empty_like(dA)
+        gpu.prune24(dA, out, m, k, k, gpu.PRUNE_TILE)
+        want_t = orc.prune24(A.view(np.uint8), m, k, k, orc.TILE).view(np.int8)
+        assert np.array_equal(host(out), want_t), f"prune24 i8 TILE {shape} {kind}"
         gpu.prune24(dA, out, m, k, k, gpu.PRUNE_STRIP)
         want = orc.prune24(A.view(np.uint8), m, k, k, orc.STRIP).view(np.int8)
         assert np.array_equal(host(out), want), f"prune24 i8 {shape} {kind}"
@@ -807,8 +810,6 @@ def test_prune24_i8_vs_oracle(gpu, orc, shape):
         assert int(host(valid)[0]) == 0
         gpu.prune24_check(dA, m, k, k, valid)
         assert int(host(valid)[0]) == orc.prune24_check(A.view(np.uint8), m, k, k)
-    with pytest.raises(gpu.SparsifymeError):
-        gpu.prune24(dA, out, m, k, k, gpu.PRUNE_TILE)          # only STRIP is built for int8
 
 
 @pytest.mark.parametrize("shape", [(128, 64, 64, 1), (196, 512, 256, 2), (784, 256, 1024, 2), (130, 72, 192, 3), (12544, 64, 576, 1),
