@@ -961,6 +961,58 @@ def test_im2col_rejects_bad_windows(gpu):
     assert L_.sm_im2col_f16(None, 1, 1, 4, 4, 3, 3, 1, 0, 1, x.data_ptr(), None) == 1
 
 
+def test_entry_points_are_graph_capturable(gpu):
+    """C-ABI calls only enqueue on the given stream (no allocation, no synchronisation), so a
+    whole pipeline can be captured into a hipGraph and replayed; the replay must reproduce the eager results."""
+    import torch
+    m, n, k, b = 196, 64, 128, 2
+    g = torch.Generator(device="cuda").manual_seed(1)
+    A0 = torch.rand(b * m * k, generator=g, device="cuda").half()
+    B = torch.rand(k * n, generator=g, device="cuda").half()
+    A8 = torch.randint(-128, 128, (b * m * k,), generator=g, device="cuda", dtype=torch.int8)
+    B8 = torch.randint(-128, 128, (n * k,), generator=g, device="cuda", dtype=torch.int8)
+    X = torch.rand(2 * 8 * 12 * 12, generator=g, device="cuda").half()
+    bufs = dict(A=A0.clone(), P=torch.empty_like(A0), valid=torch.zeros(1, dtype=torch.int32, device="cuda"),
+                blob=torch.empty(gpu.compress24_size(m, k, 2, b), dtype=torch.uint8, device="cuda"),
+                back=torch.empty_like(A0), C=torch.empty(b * m * n, dtype=torch.float16, device="cuda"),
+                Cf=torch.empty(b * m * n, dtype=torch.float16, device="cuda"), Cd=torch.empty(b * m * n, dtype=torch.float16, device="cuda"),
+                blob8=torch.empty(gpu.compress24_size(m, k, 1, b), dtype=torch.uint8, device="cuda"),
+                C8=torch.empty(b * m * n, dtype=torch.int32, device="cuda"), Q8=torch.empty(b * m * n, dtype=torch.int8, device="cuda"),
+                im=torch.empty(2 * 144 * 72, dtype=torch.float16, device="cuda"),
+                mask=torch.empty(m * k, dtype=torch.int64, device="cuda"), W=A0[: m * k].clone())
+
+    def pipeline(o):
+        gpu.prune24(o["A"], o["P"], b * m, k, k, gpu.PRUNE_TILE)
+        gpu.prune24_check(o["P"], b * m, k, k, o["valid"])
+        gpu.compress24(o["P"], m, k, k, b, m * k, o["blob"])
+        gpu.decompress24(o["blob"], m, k, k, b, m * k, o["back"])
+        gpu.spmma(o["blob"], B, o["C"], m, n, k, b, 0)
+        gpu.spmma_fused(o["P"], B, o["Cf"], m, n, k, batch=b)
+        gpu.gemm_rowmajor(o["P"], B, o["Cd"], m, n, k, batch=b)
+        gpu.compress24(A8, m, k, k, b, m * k, o["blob8"])
+        gpu.spmma_i8(o["blob8"], B8, o["C8"], m, n, k, b, 0)
+        gpu.spmma_fused_i8(A8, B8, o["Q8"], m, n, k, batch=b, scale=2.0 ** -9)
+        gpu.im2col(X, 2, 8, 12, 12, 3, 3, 1, 1, 1, o["im"])
+        gpu.sparsify(o["W"], o["mask"], m, k, 0.5)
+
+    eager = {kk: v.clone() for kk, v in bufs.items()}
+    pipeline(eager)
+    torch.cuda.synchronize()
+    graphed = {kk: v.clone() for kk, v in bufs.items()}
+    pipeline(graphed)          # first call outside capture (lazy function attributes)
+    torch.cuda.synchronize()
+    for kk in ("P", "valid", "blob", "back", "C", "Cf", "Cd", "blob8", "C8", "Q8", "im", "mask"):
+        graphed[kk].fill_(0) if graphed[kk].dtype != torch.float16 else graphed[kk].zero_()
+    graphed["W"].copy_(bufs["W"])
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr, stream=torch.cuda.Stream()):
+        pipeline(graphed)
+    gr.replay()
+    torch.cuda.synchronize()
+    for kk in eager:
+        assert torch.equal(eager[kk].view(torch.uint8), graphed[kk].view(torch.uint8)), f"graph replay differs from eager in {kk}"
+
+
 def test_fused_rejects_what_it_cannot_take(gpu):
     import torch
     A = torch.zeros(16 * 147, dtype=torch.float16, device="cuda")
