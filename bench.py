@@ -2,12 +2,13 @@
 """bench.py -- the hot path on BASELINE.json's headline workload.
 
 Metric: effective GF/s (2:4 spmma vs dense gemm) on the ResNet-50 layer shapes, fp16, b = 32.
-A "step" is one pass of the hot path over the whole table: for each of the 49 layers, compress
-(the fused 2:4 prune + compress of the per-batch activation operand A) and then the 2:4
-sparse x dense matmul.  value = dense-equivalent flops (2*m*n*k*b summed over the table, summed
-over ranks) / time.  Inputs are generated on the device and are resident in HBM before the timed
-region starts.  The step's 98 launches are captured once into a hipGraph and replayed (the launches
-are 7-80 us each; without the graph the Python/ctypes call cost would be on the clock).
+A "step" is one pass of the hot path over the whole table: for each of the 49 layers the 2:4 prune + compress of the
+per-batch activation operand A and the sparse x dense matmul -- as ONE fused kernel (sm_spmma_fused_f16) on the layers
+where that wins (--path auto: n <= 256 or k <= 512, 42 layers) and as sm_compress24_f16 + sm_spmma_f16 on the rest; both
+give the same C bit for bit.  value = dense-equivalent flops (2*m*n*k*b summed over the table, summed over ranks) / time.
+Inputs are generated on the device and are resident in HBM before the timed region starts.  The step's 56 launches,
+spread over 4 HIP streams, are captured once into a hipGraph and replayed (the launches are 7-100 us each; without the
+graph the Python/ctypes call cost would be on the clock).
 
 Multi-GPU: one process per GPU; every rank runs the same table on its own seeded batch (weak
 scaling, no data-path collective); one tiny all-reduce (RCCL) gives sum(flops) and max(time).
