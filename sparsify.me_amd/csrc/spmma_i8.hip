@@ -31,13 +31,13 @@ __device__ __forceinline__ uint32_t key_i8(uint8_t v) {
 // chain, their low two bits name the kept positions, one v_perm_b32 pulls the two kept bytes out in position order.
 //   d = {x3:x2:x1:x0}  ->  kept = {x[p1]:x[p0]} in the low 16 bits,  nib = p0 | p1 << 2  (p0 < p1)
 __device__ __forceinline__ void strip_select_i8(uint32_t d, uint32_t& kept, uint32_t& nib) {
+  // |x| of the four bytes at once: flip the negative ones and add their sign bit (0x80 -> 0x7f + 1 = 0x80: no carry
+  // ever leaves a byte)
+  const uint32_t sgn = (d >> 7) & 0x01010101u;
+  const uint32_t ab = (d ^ (sgn * 0xffu)) + sgn;
   uint32_t K[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int x = (int)(d << (24 - 8 * i)) >> 24;  // sign-extended byte i
-    const int a = x < 0 ? -x : x;                  // 0 .. 128
-    K[i] = ((uint32_t)a << 2) | (uint32_t)(3 - i);
-  }
+  for (int i = 0; i < 4; ++i) K[i] = (((ab >> (8 * i)) & 0xffu) << 2) | (uint32_t)(3 - i);
   const uint32_t m01 = K[0] > K[1] ? K[0] : K[1], n01 = K[0] > K[1] ? K[1] : K[0];
   const uint32_t m = m01 > K[2] ? m01 : K[2];
   const uint32_t c01 = m01 < K[2] ? m01 : K[2];
