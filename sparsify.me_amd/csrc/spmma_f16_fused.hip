@@ -147,9 +147,11 @@ static int launch_fused_direct(const FusedArgs& a0, hipStream_t st) {
     set_error("sm_spmma_fused_f16: grid too large");
     return SM_STATUS_NOT_SUPPORTED;
   }
-  constexpr size_t lds_main = (size_t)NS * (128 * 128 + 64 * BN * 2);
+  // a single-stage problem (k = 64) never touches the ring's other buffers: without them more workgroups share a CU
+  constexpr size_t stage_bytes = 128 * 128 + 64 * BN * 2;
+  const size_t lds_main = (a.K <= 64 ? 1 : (size_t)NS) * stage_bytes;
   constexpr size_t lds_epi = (size_t)128 * (BN * 2 + 16);
-  constexpr size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
+  const size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
   static bool attr_set = false;
   if (lds > 64 * 1024 && !attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spmma_f16_fused_direct_kernel<BN, NS, BF>),
