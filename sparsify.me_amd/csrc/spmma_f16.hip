@@ -527,7 +527,10 @@ static int launch_pc(const SpmmaArgs& a0, hipStream_t st) {
   }
   constexpr size_t lds_main = NS * ((size_t)BM * 72 + (size_t)64 * BN * 2);
   constexpr size_t lds_epi = (size_t)BM * (BN * 2 + 16);
-  constexpr size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
+  constexpr size_t lds = lds_main > lds_epi ? lds_main : lds_epi;  // the most this configuration ever asks for
+  // a K of fewer stages than the ring never touches the ring's other buffers: without them more workgroups share a CU
+  const size_t used = ((size_t)(a.kc / 64) < (size_t)NS ? (size_t)(a.kc / 64) : (size_t)NS) * ((size_t)BM * 72 + (size_t)64 * BN * 2);
+  const size_t lds_launch = used > lds_epi ? used : lds_epi;
   static bool attr_set = false;
   if (lds > 64 * 1024 && !attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spmma_f16_pc_kernel<BM, BN, WM, WN, NL, NS, BF>),
@@ -542,7 +545,7 @@ static int launch_pc(const SpmmaArgs& a0, hipStream_t st) {
     static size_t cap = 0;
     if (cnt > cap) { if (dbg) (void)hipFree(dbg); (void)hipMalloc((void**)&dbg, cnt * 8); cap = cnt; }
     a.dbg = dbg;
-    spmma_f16_pc_kernel<BM, BN, WM, WN, NL, NS, BF><<<dim3((unsigned)nwg), dim3(64 * NWV), lds, st>>>(a);
+    spmma_f16_pc_kernel<BM, BN, WM, WN, NL, NS, BF><<<dim3((unsigned)nwg), dim3(64 * NWV), lds_launch, st>>>(a);
     (void)hipDeviceSynchronize();
     std::vector<unsigned long long> h(cnt);
     (void)hipMemcpy(h.data(), dbg, cnt * 8, hipMemcpyDeviceToHost);
@@ -558,7 +561,7 @@ static int launch_pc(const SpmmaArgs& a0, hipStream_t st) {
     return check_launch("spmma_f16_pc_kernel");
   }
 #endif
-  spmma_f16_pc_kernel<BM, BN, WM, WN, NL, NS, BF><<<dim3((unsigned)nwg), dim3(64 * (WM * WN + NL)), lds, st>>>(a);
+  spmma_f16_pc_kernel<BM, BN, WM, WN, NL, NS, BF><<<dim3((unsigned)nwg), dim3(64 * (WM * WN + NL)), lds_launch, st>>>(a);
   return check_launch("spmma_f16_pc_kernel");
 }
 
@@ -575,7 +578,10 @@ static int launch_dma(const SpmmaArgs& a0, hipStream_t st) {
   }
   constexpr size_t lds_main = NS * ((size_t)BM * 72 + (size_t)64 * BN * 2);
   constexpr size_t lds_epi = (size_t)BM * (BN * 2 + 16);
-  constexpr size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
+  constexpr size_t lds = lds_main > lds_epi ? lds_main : lds_epi;  // the most this configuration ever asks for
+  // a K of fewer stages than the ring never touches the ring's other buffers: without them more workgroups share a CU
+  const size_t used = ((size_t)(a.kc / 64) < (size_t)NS ? (size_t)(a.kc / 64) : (size_t)NS) * ((size_t)BM * 72 + (size_t)64 * BN * 2);
+  const size_t lds_launch = used > lds_epi ? used : lds_epi;
   static bool attr_set = false;
   if (lds > 64 * 1024 && !attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spmma_f16_dma_kernel<BM, BN, WM, WN, NS, BF>),
@@ -589,7 +595,7 @@ static int launch_dma(const SpmmaArgs& a0, hipStream_t st) {
     static size_t cap = 0;
     if (cnt > cap) { if (dbg) (void)hipFree(dbg); (void)hipMalloc((void**)&dbg, cnt * 8); cap = cnt; }
     a.dbg = dbg;
-    spmma_f16_dma_kernel<BM, BN, WM, WN, NS, BF><<<dim3((unsigned)nwg), dim3(64 * WM * WN), lds, st>>>(a);
+    spmma_f16_dma_kernel<BM, BN, WM, WN, NS, BF><<<dim3((unsigned)nwg), dim3(64 * WM * WN), lds_launch, st>>>(a);
     (void)hipDeviceSynchronize();
     std::vector<unsigned long long> h(cnt);
     (void)hipMemcpy(h.data(), dbg, cnt * 8, hipMemcpyDeviceToHost);
@@ -607,7 +613,7 @@ static int launch_dma(const SpmmaArgs& a0, hipStream_t st) {
     return check_launch("spmma_f16_dma_kernel");
   }
 #endif
-  spmma_f16_dma_kernel<BM, BN, WM, WN, NS, BF><<<dim3((unsigned)nwg), dim3(64 * WM * WN), lds, st>>>(a);
+  spmma_f16_dma_kernel<BM, BN, WM, WN, NS, BF><<<dim3((unsigned)nwg), dim3(64 * WM * WN), lds_launch, st>>>(a);
   return check_launch("spmma_f16_dma_kernel");
 }
 

@@ -149,7 +149,7 @@ static int launch_fused_direct(const FusedArgs& a0, hipStream_t st) {
   }
   // a single-stage problem (k = 64) never touches the ring's other buffers: without them more workgroups share a CU
   constexpr size_t stage_bytes = 128 * 128 + 64 * BN * 2;
-  const size_t lds_main = (a.K <= 64 ? 1 : (size_t)NS) * stage_bytes;
+  const size_t lds_main = ((size_t)(a.K / 64) < (size_t)NS ? (size_t)(a.K / 64) : (size_t)NS) * stage_bytes;
   constexpr size_t lds_epi = (size_t)128 * (BN * 2 + 16);
   const size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
   static bool attr_set = false;
