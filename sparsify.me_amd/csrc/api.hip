@@ -17,6 +17,43 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+int ensure_dyn_lds(LdsOptIn& s, const void* fn, size_t bytes, const char* what) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 256) {
+    (void)hipGetLastError();
+    set_error("%s: cannot identify the current device", what);
+    return SM_STATUS_LAUNCH_FAILED;
+  }
+  const unsigned long long bit = 1ull << (dev & 63);
+  std::atomic<unsigned long long>& w = s.done[dev >> 6];
+  if (w.load(std::memory_order_acquire) & bit) return SM_STATUS_SUCCESS;
+  const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    set_error("%s: device %d refused %zu bytes of dynamic LDS: %s", what, dev, bytes, hipGetErrorString(e));
+    return SM_STATUS_LAUNCH_FAILED;
+  }
+  w.fetch_or(bit, std::memory_order_release);
+  return SM_STATUS_SUCCESS;
+}
+
+int device_cu_count() {
+  static std::atomic<int> cus[256];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 256) {
+    (void)hipGetLastError();
+    return 256;
+  }
+  int c = cus[dev].load(std::memory_order_relaxed);
+  if (c > 0) return c;
+  if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c <= 0) {
+    (void)hipGetLastError();
+    return 256;
+  }
+  cus[dev].store(c, std::memory_order_relaxed);
+  return c;
+}
+
 // splitmix64 of (seed, i): element i depends on nothing else, so a fill is reproducible for any
 // grid shape and can be regenerated per GPU from (seed, layer, batch) without host traffic.
 __device__ __forceinline__ float uniform01(uint64_t seed, uint64_t i) {

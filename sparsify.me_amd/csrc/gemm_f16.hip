@@ -437,11 +437,9 @@ static int launch_dma(const GemmArgs& a0, hipStream_t st) {
   // fewer K stages than ring buffers: the unused buffers are not allocated (more workgroups per CU)
   const size_t used = ((size_t)(a.K / 64) < (size_t)NS ? (size_t)(a.K / 64) : (size_t)NS) * ((size_t)BM * 128 + (size_t)64 * BN * 2);
   const size_t lds_launch = used > lds_epi ? used : lds_epi;
-  static bool attr_set = false;
-  if (lds > 64 * 1024 && !attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16_dma_kernel<BM, BN, WM, WN, NS, BF>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
+  static LdsOptIn lds_optin;
+  if (lds > 64 * 1024) {
+    if (const int rc = ensure_dyn_lds(lds_optin, reinterpret_cast<const void*>(&gemm_f16_dma_kernel<BM, BN, WM, WN, NS, BF>), lds, "gemm_f16_dma_kernel")) return rc;
   }
   gemm_f16_dma_kernel<BM, BN, WM, WN, NS, BF><<<dim3((unsigned)nwg), dim3(64 * WM * WN), lds_launch, st>>>(a);
   return check_launch("gemm_f16_dma_kernel");

@@ -387,11 +387,9 @@ static int launch32_dma(const Gemm32Args& a0, hipStream_t st) {
     return SM_STATUS_NOT_SUPPORTED;
   }
   constexpr size_t lds = (size_t)NS * (BM + BN) * 128;
-  static bool attr_set = false;
-  if (lds > 64 * 1024 && !attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_dma_kernel<BM, BN, WM, WN, NS, BKM>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
+  static LdsOptIn lds_optin;
+  if (lds > 64 * 1024) {
+    if (const int rc = ensure_dyn_lds(lds_optin, reinterpret_cast<const void*>(&gemm_f32_dma_kernel<BM, BN, WM, WN, NS, BKM>), lds, "gemm_f32_dma_kernel")) return rc;
   }
   gemm_f32_dma_kernel<BM, BN, WM, WN, NS, BKM><<<dim3((unsigned)nwg), dim3(64 * WM * WN), lds, st>>>(a);
   return check_launch("gemm_f32_dma_kernel");
@@ -550,26 +548,14 @@ static int launch_spmma32_dma(const Gemm32Args& a0, hipStream_t st) {
     return SM_STATUS_NOT_SUPPORTED;
   }
   constexpr size_t lds = 2 * ((size_t)128 * 128 + 128 * 8 + 2 * (size_t)BN * 128);
-  static bool attr_set = false;
-  if (lds > 64 * 1024 && !attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spmma_f32_dma_kernel<BN, WM, WN>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
+  static LdsOptIn lds_optin;
+  if (lds > 64 * 1024) {
+    if (const int rc = ensure_dyn_lds(lds_optin, reinterpret_cast<const void*>(&spmma_f32_dma_kernel<BN, WM, WN>), lds, "spmma_f32_dma_kernel")) return rc;
   }
   spmma_f32_dma_kernel<BN, WM, WN><<<dim3((unsigned)nwg), dim3(64 * WM * WN), lds, st>>>(a);
   return check_launch("spmma_f32_dma_kernel");
 }
 
-static int device_cu_count() {
-  static int cus = 0;
-  if (!cus) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-    if (cus <= 0) cus = 256;
-  }
-  return cus;
-}
 
 // Tile shape: the kernel is bound by the fp32 matrix pipe, not by operand traffic, so small tiles cost nothing per
 // flop (4096^3: 104.7 / 111.1 / 101.7 / 105.3 TF/s for 128x128 / 128x64 / 64x128 / 64x64) and win whenever the
@@ -580,7 +566,7 @@ template <int MODE>
 static int dispatch32(const Gemm32Args& a, hipStream_t st) {
   struct Cand { int bm, bn; };
   static const Cand cands[4] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
-  static const int force = getenv("SM_GEMM32_CFG") ? atoi(getenv("SM_GEMM32_CFG")) : -1;  // tuning aid: candidate index
+  static const int force = tuning_int("SM_GEMM32_CFG", -1);  // tuning aid: candidate index
   const double cus = (double)device_cu_count();
   const double small_tiles = (double)((a.M + 63) / 64) * (double)((a.N + 63) / 64) * a.batch;
   int best = small_tiles / cus >= 32.0 ? 1 : 3;
@@ -588,7 +574,7 @@ static int dispatch32(const Gemm32Args& a, hipStream_t st) {
   if constexpr (MODE == 0 || MODE == 2) {
     // LDS-DMA pipeline when whole 16-byte chunks can be moved: K % 32 == 0, aligned rows (pointer-array batches: the
     // caller's bases, hipMalloc gives 256 B); SM_GEMM32_DMA=0 (tuning aid) keeps the register-staged kernel
-    static const int dma_env = getenv("SM_GEMM32_DMA") ? atoi(getenv("SM_GEMM32_DMA")) : 1;
+    static const int dma_env = tuning_int("SM_GEMM32_DMA", 1);
     const bool a_ok = (a.lda % 4 == 0) && (a.sA % 4 == 0) && (a.Ap || (reinterpret_cast<uintptr_t>(a.A) & 15u) == 0);
     const bool b_ok = (a.ldb % 4 == 0) && (a.sB % 4 == 0) && (a.Bp || (reinterpret_cast<uintptr_t>(a.B) & 15u) == 0);
     if (dma_env && a.K % 32 == 0 && a.K >= 32 && a_ok && b_ok && (MODE == 2 || (a.N % 4 == 0 && a.N >= 4))) {
@@ -610,7 +596,7 @@ static int dispatch32(const Gemm32Args& a, hipStream_t st) {
       return a.N <= 128 ? launch32_dma<128, 64, 4, 1, 2, BKM>(a, st) : launch32_dma<128, 128, 4, 4, 2, BKM>(a, st);
     }
   }
-  static const bool verbose = getenv("SM_GEMM32_VERBOSE") != nullptr;  // tuning aid
+  static const bool verbose = tuning_env("SM_GEMM32_VERBOSE") != nullptr;  // tuning aid
   if (verbose) fprintf(stderr, "gemm_f32 %d x %d x %d b=%d on %d CUs -> tile %d x %d\n", a.M, a.N, a.K, a.batch, (int)cus, cands[best].bm, cands[best].bn);
   switch (best) {
     case 1: return launch32<128, 64, 4, 1, MODE>(a, st);
@@ -802,11 +788,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f64_dma_kernel(const Gemm64
 template <int BM, int BN, int WM, int WN>
 static int launch64_dma(const Gemm64Args& a, size_t batch, hipStream_t st) {
   constexpr size_t lds = 2 * (size_t)(BM + BN) * 128;
-  static bool attr_set = false;
-  if (lds > 64 * 1024 && !attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f64_dma_kernel<BM, BN, WM, WN>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
+  static LdsOptIn lds_optin;
+  if (lds > 64 * 1024) {
+    if (const int rc = ensure_dyn_lds(lds_optin, reinterpret_cast<const void*>(&gemm_f64_dma_kernel<BM, BN, WM, WN>), lds, "gemm_f64_dma_kernel")) return rc;
   }
   dim3 grid((unsigned)ceil_div(a.N, BN), (unsigned)ceil_div(a.M, BM), (unsigned)batch);
   gemm_f64_dma_kernel<BM, BN, WM, WN><<<grid, dim3(64 * WM * WN), lds, st>>>(a);
@@ -901,7 +885,7 @@ int sm_spmma_f32(const void* blob, const float* B, float* C, size_t m, size_t n,
     a.batch = 1;
   }
   // LDS-DMA pipeline: whole 64-k planes, row pairs (metadata moves as 16-byte pairs), whole 16-byte B chunks
-  static const int dma_env = getenv("SM_SPMMA32_DMA") ? atoi(getenv("SM_SPMMA32_DMA")) : 1;  // tuning aid: 0 = register-staged kernel
+  static const int dma_env = tuning_int("SM_SPMMA32_DMA", 1);  // tuning aid: 0 = register-staged kernel
   const bool pairs = (a.batch == 1 ? (a.M % 2 == 0) : (m % 2 == 0));
   if (dma_env && k % 64 == 0 && k >= 64 && pairs && n % 4 == 0 && n >= 4 && strideB % 4 == 0 &&
       (reinterpret_cast<uintptr_t>(B) & 15u) == 0) {
@@ -941,7 +925,7 @@ int sm_gemm_batched_f64(const double* const* A_ptrs, const double* const* B_ptrs
   // matrix-core path: whole 16-k stages of 16-byte chunks (even leading dimensions; the pointer arrays live on the
   // device, their bases are the caller's -- a 16-byte global access needs dword alignment only); SM_GEMM64_DMA=0
   // (tuning aid) keeps the FMA kernel
-  static const int dma_env = getenv("SM_GEMM64_DMA") ? atoi(getenv("SM_GEMM64_DMA")) : 1;
+  static const int dma_env = tuning_int("SM_GEMM64_DMA", 1);
   if (dma_env && !a.ta && !a.tb && a.K % 16 == 0 && a.K >= 16 && a.N % 2 == 0 && a.N >= 2 && a.lda % 2 == 0 && a.ldb % 2 == 0 &&
       ceil_div((size_t)a.M, (size_t)64) <= 65535) {
     if (dma_env == 2) return launch64_dma<64, 64, 2, 2>(a, batch, (hipStream_t)stream);

@@ -636,7 +636,7 @@ static int launch_compress(const void* A, size_t m, size_t k, size_t ld, size_t 
   const size_t items = L.M * (L.kc / 8);
   const size_t nunits = ceil_div(L.M, (size_t)8) * (L.kc / 64);
   if (vec_ok && L.kc == k && ld == k && (batch == 1 || strideA == m * ld) && nunits < 0xfffffff0ull) {
-    static const bool nt = !(getenv("SM_COMPRESS_NT") && atoi(getenv("SM_COMPRESS_NT")) == 0);
+    static const bool nt = tuning_int("SM_COMPRESS_NT", 1) != 0;
     // two loads per lane (8 units per block) measured best on the ResNet-50 table (1.72 ms against 1.85 with 4,
     // 2.00 with 8, 1.84 with 1: profiles/sweep_r01_i_compress.txt)
     constexpr int NLD = 2;

@@ -4,6 +4,9 @@
 #include <stddef.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
+
+#include <atomic>
 
 #include "../../include/sparsifyme.h"
 
@@ -29,6 +32,28 @@ inline int check_launch(const char* what) {
     return SM_STATUS_LAUNCH_FAILED;
   }
   return SM_STATUS_SUCCESS;
+}
+
+// One-shot opt-in of a kernel to more than 64 KiB of dynamic LDS, done once PER DEVICE (the attribute belongs to the
+// function object of the current device; one bit per device ordinal, set after the call succeeded, so two threads
+// racing on the first launch at worst both set it).  A refused opt-in is reported here, not as a later launch error.
+struct LdsOptIn {
+  std::atomic<unsigned long long> done[4];  // 256 device ordinals
+};
+int ensure_dyn_lds(LdsOptIn& s, const void* fn, size_t bytes, const char* what);
+// Compute units of the current device, queried once per device ordinal (hipGetDeviceProperties costs tens of
+// microseconds; launchers that size a grid by the CU count call this on every launch).
+int device_cu_count();
+// Tuning hooks of tools/ (SM_* environment variables) exist only in -DSM_TUNING builds; the product library
+// never reads the environment.
+#ifdef SM_TUNING
+inline const char* tuning_env(const char* name) { return getenv(name); }
+#else
+inline const char* tuning_env(const char*) { return nullptr; }
+#endif
+inline int tuning_int(const char* name, int dflt) {
+  const char* v = tuning_env(name);
+  return v ? atoi(v) : dflt;
 }
 
 inline size_t round_up(size_t x, size_t a) { return (x + a - 1) / a * a; }

@@ -164,7 +164,13 @@ __global__ __launch_bounds__(256) void coo_rowptr_kernel(const int* __restrict__
     row_ptr[i] = (int)lo;
   }
   bool bad = false;
-  for (size_t e = i; e + 1 < nnz; e += (size_t)gridDim.x * 256) bad |= rows[e] > rows[e + 1];
+  // a row index outside [0, A_rows) breaks the monotonic sequence the search above relies on: such input goes to
+  // the atomic kernel, which skips the bad entries one by one
+  for (size_t e = i; e < nnz; e += (size_t)gridDim.x * 256) {
+    const int r0 = rows[e];
+    bad |= r0 < 0 || (size_t)r0 >= A_rows;
+    if (e + 1 < nnz) bad |= r0 > rows[e + 1];
+  }
   if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(ws, 1);
 }
 
@@ -294,19 +300,16 @@ __global__ __launch_bounds__(64 * LDS_WAVES) void spmm_csr_lds_kernel(size_t A_r
 }
 
 template <int J>
-static void launch_csr_lds(size_t A_rows, size_t A_cols, size_t nv, const int* ws, const int* cols, const float* vals,
+static int launch_csr_lds(size_t A_rows, size_t A_cols, size_t nv, const int* ws, const int* cols, const float* vals,
                            const float* B, float* C, float alpha, float beta, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_csr_lds_kernel<J>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)(144 * 1024));
-    attr_set = true;
-  }
+  static LdsOptIn lds_optin;
+  if (const int rc = ensure_dyn_lds(lds_optin, reinterpret_cast<const void*>(&spmm_csr_lds_kernel<J>), (144 * 1024), "spmm_csr_lds_kernel")) return rc;
   // enough workgroups for the chip: split the rows when there are few vector groups (>= 256 rows per split)
   const size_t groups = ceil_div(nv, (size_t)J);
   size_t rsplit = 1;
   while (groups * rsplit < 1024 && A_rows / (rsplit * 2) >= 256) rsplit *= 2;
   spmm_csr_lds_kernel<J><<<dim3((unsigned)groups, (unsigned)rsplit), 64 * LDS_WAVES, A_cols * J * sizeof(float), st>>>(A_rows, A_cols, nv, ws, cols, vals, B, C, alpha, beta);
+  return SM_STATUS_SUCCESS;
 }
 
 // atomic fallback gated on the flag (runs only when the rows were NOT sorted)
@@ -477,14 +480,16 @@ int sm_spmm_coo_f32_ws(size_t A_num_rows, size_t A_num_cols, size_t A_nnz, size_
   if (hipMemsetAsync(ws, 0, sizeof(int), st) != hipSuccess) return check_launch("hipMemsetAsync");
   coo_rowptr_kernel<<<(unsigned)ceil_div(A_num_rows + 1, 256), 256, 0, st>>>(rows, A_nnz, A_num_rows, ws);
   const size_t nv = B_num_cols * num_batches, col_bytes = A_num_cols * sizeof(float);
-  static const int lds_env = getenv("SM_SPMM_LDS") ? atoi(getenv("SM_SPMM_LDS")) : -1;  // tuning aid: 0 = off, 8/16/32 = J
+  static const int lds_env = tuning_int("SM_SPMM_LDS", -1);  // tuning aid: 0 = off, 8/16/32 = J
   // as many vectors per workgroup as keep two workgroups on a CU (72 KB each): more FMAs per loaded non-zero
   int J = col_bytes * 32 <= 72 * 1024 ? 32 : (col_bytes * 16 <= 144 * 1024 ? 16 : 8);
   if (lds_env == 8 || lds_env == 16 || lds_env == 32) J = lds_env;
   if (lds_env != 0 && col_bytes * J <= 144 * 1024 && ceil_div(nv, (size_t)J) <= 0x7fffffffull) {
-    if (J == 32) launch_csr_lds<32>(A_num_rows, A_num_cols, nv, ws, cols, vals, B, C, alpha, beta, st);
-    else if (J == 16) launch_csr_lds<16>(A_num_rows, A_num_cols, nv, ws, cols, vals, B, C, alpha, beta, st);
-    else launch_csr_lds<8>(A_num_rows, A_num_cols, nv, ws, cols, vals, B, C, alpha, beta, st);
+    int rc;
+    if (J == 32) rc = launch_csr_lds<32>(A_num_rows, A_num_cols, nv, ws, cols, vals, B, C, alpha, beta, st);
+    else if (J == 16) rc = launch_csr_lds<16>(A_num_rows, A_num_cols, nv, ws, cols, vals, B, C, alpha, beta, st);
+    else rc = launch_csr_lds<8>(A_num_rows, A_num_cols, nv, ws, cols, vals, B, C, alpha, beta, st);
+    if (rc != SM_STATUS_SUCCESS) return rc;
   } else {
     dim3 grid((unsigned)ceil_div(A_num_rows, 256), (unsigned)ceil_div(B_num_cols, CSR_J), (unsigned)num_batches);
     spmm_csr_kernel<<<grid, dim3(256), 0, st>>>(A_num_rows, A_num_cols, B_num_cols, ws, cols, vals, B, C, alpha, beta);

@@ -531,11 +531,9 @@ static int launch_pc(const SpmmaArgs& a0, hipStream_t st) {
   // a K of fewer stages than the ring never touches the ring's other buffers: without them more workgroups share a CU
   const size_t used = ((size_t)(a.kc / 64) < (size_t)NS ? (size_t)(a.kc / 64) : (size_t)NS) * ((size_t)BM * 72 + (size_t)64 * BN * 2);
   const size_t lds_launch = used > lds_epi ? used : lds_epi;
-  static bool attr_set = false;
-  if (lds > 64 * 1024 && !attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spmma_f16_pc_kernel<BM, BN, WM, WN, NL, NS, BF>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
+  static LdsOptIn lds_optin;
+  if (lds > 64 * 1024) {
+    if (const int rc = ensure_dyn_lds(lds_optin, reinterpret_cast<const void*>(&spmma_f16_pc_kernel<BM, BN, WM, WN, NL, NS, BF>), lds, "spmma_f16_pc_kernel")) return rc;
   }
 #ifdef SM_STAMP
   {
@@ -582,11 +580,9 @@ static int launch_dma(const SpmmaArgs& a0, hipStream_t st) {
   // a K of fewer stages than the ring never touches the ring's other buffers: without them more workgroups share a CU
   const size_t used = ((size_t)(a.kc / 64) < (size_t)NS ? (size_t)(a.kc / 64) : (size_t)NS) * ((size_t)BM * 72 + (size_t)64 * BN * 2);
   const size_t lds_launch = used > lds_epi ? used : lds_epi;
-  static bool attr_set = false;
-  if (lds > 64 * 1024 && !attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spmma_f16_dma_kernel<BM, BN, WM, WN, NS, BF>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
+  static LdsOptIn lds_optin;
+  if (lds > 64 * 1024) {
+    if (const int rc = ensure_dyn_lds(lds_optin, reinterpret_cast<const void*>(&spmma_f16_dma_kernel<BM, BN, WM, WN, NS, BF>), lds, "spmma_f16_dma_kernel")) return rc;
   }
 #ifdef SM_STAMP
   {
@@ -677,10 +673,10 @@ static int spmma16(const void* blob, const void* B, void* C, size_t m, size_t n,
     // "<waves>x<ring>" forces a configuration.
     // 256 x 128 tiles (B lines amortised over twice the rows) pay with a long K and enough rows for >= 64 such
     // tiles per n-tile (profiles/sweep_r01_*.txt: 784x256x{1024,2304}, 3136x128x1152 at b=32)
-    if (!getenv("SM_SPMMA_PC") && !getenv("SM_SPMMA_CFG") && n >= 128 && n <= 256 && k >= 1024 &&
+    if (!tuning_env("SM_SPMMA_PC") && !tuning_env("SM_SPMMA_CFG") && n >= 128 && n <= 256 && k >= 1024 &&
         (size_t)a.Mrows >= 16384)
       return launch_pc<256, 128, 4, 2, 4, 3, BF>(a, st);
-    static const char* pc_env = getenv("SM_SPMMA_PC");  // tuning aid: "<loaders>x<ring>", "0" = previous kernel
+    static const char* pc_env = tuning_env("SM_SPMMA_PC");  // tuning aid: "<loaders>x<ring>", "0" = previous kernel
     // default: long K -> producer/consumer kernel (4 loader waves, ring of 3); short K -> the kernel
     // above with more tiles per CU (measured per shape on the ResNet tables, profiles/sweep_r01_*.txt)
     // (n <= 64 is HBM-bound at every K: the plain DMA kernel with more tiles per CU wins there)
@@ -697,7 +693,7 @@ static int spmma16(const void* blob, const void* B, void* C, size_t m, size_t n,
       if (nl == 2) return pns >= 3 ? launch_pc<128, 128, 2, 2, 2, 3, BF>(a, st) : launch_pc<128, 128, 2, 2, 2, 2, BF>(a, st);
       return pns >= 4 ? launch_pc<128, 128, 2, 2, 4, 4, BF>(a, st) : (pns == 3 ? launch_pc<128, 128, 2, 2, 4, 3, BF>(a, st) : launch_pc<128, 128, 2, 2, 4, 2, BF>(a, st));
     }
-    static const char* cfg_env = getenv("SM_SPMMA_CFG");
+    static const char* cfg_env = tuning_env("SM_SPMMA_CFG");
     const size_t Mr = (size_t)a.Mrows;
     int nw, ns;
     if (n <= 64) {

@@ -152,11 +152,11 @@ static int launch_fused_direct(const FusedArgs& a0, hipStream_t st) {
   const size_t lds_main = ((size_t)(a.K / 64) < (size_t)NS ? (size_t)(a.K / 64) : (size_t)NS) * stage_bytes;
   constexpr size_t lds_epi = (size_t)128 * (BN * 2 + 16);
   const size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
-  static bool attr_set = false;
-  if (lds > 64 * 1024 && !attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spmma_f16_fused_direct_kernel<BN, NS, BF>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
+  // the opt-in records the most this instantiation can ever ask for, the launch below only what this K touches
+  constexpr size_t lds_max = NS * stage_bytes > lds_epi ? NS * stage_bytes : lds_epi;
+  static LdsOptIn lds_optin;
+  if (lds_max > 64 * 1024) {
+    if (const int rc = ensure_dyn_lds(lds_optin, reinterpret_cast<const void*>(&spmma_f16_fused_direct_kernel<BN, NS, BF>), lds_max, "spmma_f16_fused_direct_kernel")) return rc;
   }
 #ifdef SM_STAMP
   {
@@ -418,11 +418,9 @@ static int launch_fused_wide(const FusedArgs& a0, hipStream_t st) {
   constexpr size_t lds_main = 2 * (size_t)128 * 72 + (size_t)NSB * 64 * BN * 2;
   constexpr size_t lds_epi = (size_t)128 * (BN * 2 + 16);
   constexpr size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
-  static bool attr_set = false;
-  if (lds > 64 * 1024 && !attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spmma_f16_fused_wide_kernel<BN, WM, WN, NLB, PF, NSB, BF>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
+  static LdsOptIn lds_optin;
+  if (lds > 64 * 1024) {
+    if (const int rc = ensure_dyn_lds(lds_optin, reinterpret_cast<const void*>(&spmma_f16_fused_wide_kernel<BN, WM, WN, NLB, PF, NSB, BF>), lds, "spmma_f16_fused_wide_kernel")) return rc;
   }
 #ifdef SM_STAMP
   {
@@ -652,12 +650,9 @@ static int launch_fused_astat(const FusedArgs& a0, hipStream_t st) {
   // split the column range of a row panel over several workgroups until 3/4 of the CUs have one (a split re-selects
   // its A panel, so no more than needed: 784 x 1024 x 256, b = 32: 29 / 33 / 41 us with 1 / 2 / 4 splits); >= 2 tiles
   // per split
-  int dev = 0, cus = 256;
-  hipDeviceProp_t prop;
-  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-    cus = prop.multiProcessorCount;
+  const int cus = device_cu_count();
   const size_t panels = (size_t)a.tiles_m * a.batch;
-  static const int nsplit_env = getenv("SM_FUSED_NSPLIT") ? atoi(getenv("SM_FUSED_NSPLIT")) : 0;  // tuning aid
+  static const int nsplit_env = tuning_int("SM_FUSED_NSPLIT", 0);  // tuning aid
   int nsplit = 1;
   while (!nsplit_env && panels * nsplit * 4 < (size_t)3 * cus && (a.tiles_n + 2 * nsplit - 1) / (2 * nsplit) >= 2) nsplit *= 2;
   if (nsplit_env > 0) nsplit = nsplit_env < a.tiles_n ? nsplit_env : a.tiles_n;
@@ -671,12 +666,8 @@ static int launch_fused_astat(const FusedArgs& a0, hipStream_t st) {
   }
   constexpr int NSB = 3;  // (a ring of 4 measured the same)
   const size_t lds = astat_lds_bytes(a.K / 64, NSB);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spmma_f16_fused_astat_kernel<NSB, BF>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
-    attr_set = true;
-  }
+  static LdsOptIn lds_optin;
+  if (const int rc = ensure_dyn_lds(lds_optin, reinterpret_cast<const void*>(&spmma_f16_fused_astat_kernel<NSB, BF>), (160 * 1024), "spmma_f16_fused_astat_kernel")) return rc;
   spmma_f16_fused_astat_kernel<NSB, BF><<<dim3((unsigned)nwg), dim3(64 * 16), lds, st>>>(a, nsplit, tps);
   return check_launch("spmma_f16_fused_astat_kernel");
 }
@@ -715,14 +706,14 @@ static int spmma_fused16(const void* A, const void* B, void* C, size_t m, size_t
   hipStream_t st = (hipStream_t)stream;
   // n <= 128 (and n <= 256 with a single stage): the direct kernel -- dense A by LDS-DMA, selection in the consumer's
   // registers, ring of 2 so that three workgroups share a CU.  SM_FUSED_DIRECT=3 (tuning aid): ring of 3.
-  static const int direct_env = getenv("SM_FUSED_DIRECT") ? atoi(getenv("SM_FUSED_DIRECT")) : 2;
-  static const int wide_env = getenv("SM_FUSED_WIDE") ? atoi(getenv("SM_FUSED_WIDE")) : 0;  // tuning aid: force the wide kernel
+  static const int direct_env = tuning_int("SM_FUSED_DIRECT", 2);
+  static const int wide_env = tuning_int("SM_FUSED_WIDE", 0);  // tuning aid: force the wide kernel
   if (!wide_env && (n <= 128 || (n <= 256 && k <= 64))) {
     if (n <= 64) return direct_env >= 3 ? launch_fused_direct<64, 3, BF>(a, st) : launch_fused_direct<64, 2, BF>(a, st);
     return direct_env >= 3 ? launch_fused_direct<128, 3, BF>(a, st) : launch_fused_direct<128, 2, BF>(a, st);
   }
   // n > 256, short K, plain store: A-stationary (the 2:4 image of a row panel stays in LDS across column tiles)
-  static const int astat_env = getenv("SM_FUSED_ASTAT") ? atoi(getenv("SM_FUSED_ASTAT")) : 1;  // tuning aid: 0 = off
+  static const int astat_env = tuning_int("SM_FUSED_ASTAT", 1);  // tuning aid: 0 = off
   if (astat_env && n > 256 && k <= 512 && beta == 0.0f && aligned16(C) && (strideC % 8 == 0) &&
       astat_lds_bytes((int)(k / 64), 3) <= 160 * 1024)
     return launch_fused_astat<BF>(a, st);

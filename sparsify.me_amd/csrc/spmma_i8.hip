@@ -481,11 +481,9 @@ static int launch_spmma_i8(const SpmmaI8Args& a0, hipStream_t st) {
   constexpr size_t lds_main = 2 * ((FUSED ? (size_t)128 * 128 : (size_t)128 * 64 + 2 * 128 * 8) + (size_t)BN * 128);
   constexpr size_t lds_epi = (size_t)128 * (BN * 4 + 16);
   constexpr size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
-  static bool attr_set = false;
-  if (lds > 64 * 1024 && !attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spmma_i8_kernel<BN, WM, WN, FUSED>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)lds);
-    attr_set = true;
+  static LdsOptIn lds_optin;
+  if (lds > 64 * 1024) {
+    if (const int rc = ensure_dyn_lds(lds_optin, reinterpret_cast<const void*>(&spmma_i8_kernel<BN, WM, WN, FUSED>), lds, "spmma_i8_kernel")) return rc;
   }
   spmma_i8_kernel<BN, WM, WN, FUSED><<<dim3((unsigned)nwg), dim3(64 * WM * WN), lds, st>>>(a);
   return check_launch("spmma_i8_kernel");
@@ -615,7 +613,7 @@ static int spmma_i8_entry(const void* blob, const void* B, int32_t* C, int8_t* C
     a.batch = 1;
   }
   hipStream_t st = (hipStream_t)stream;
-  static const int cfg = getenv("SM_SPMMA_I8_CFG") ? atoi(getenv("SM_SPMMA_I8_CFG")) : 0;  // tuning aid
+  static const int cfg = tuning_int("SM_SPMMA_I8_CFG", 0);  // tuning aid
   if (cfg == 1) return launch_spmma_i8<64, 4, 1>(a, st);
   if (cfg == 2) return launch_spmma_i8<128, 2, 2>(a, st);
   if (cfg == 3) return launch_spmma_i8<128, 2, 4>(a, st);
@@ -651,7 +649,7 @@ static int spmma_fused_i8_entry(const void* A, const void* B, int32_t* C, int8_t
     a.batch = 1;
   }
   hipStream_t st = (hipStream_t)stream;
-  static const int cfg = getenv("SM_SPMMA_I8_FUSED_CFG") ? atoi(getenv("SM_SPMMA_I8_FUSED_CFG")) : 0;  // tuning aid
+  static const int cfg = tuning_int("SM_SPMMA_I8_FUSED_CFG", 0);  // tuning aid
   if (cfg == 1) return launch_spmma_i8<64, 4, 1, true>(a, st);
   if (cfg == 2) return launch_spmma_i8<128, 2, 4, true>(a, st);
   if (cfg == 3) return launch_spmma_i8<128, 4, 2, true>(a, st);
