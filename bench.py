@@ -2,23 +2,29 @@
 """bench.py -- the hot path on BASELINE.json's headline workload.
 
 Metric: effective GF/s (2:4 spmma vs dense gemm) on the ResNet-50 layer shapes, fp16, b = 32.
-A "step" is one pass of the hot path over the whole table: for each of the 49 layers the 2:4 prune + compress of the
-per-batch activation operand A and the sparse x dense matmul -- as ONE fused kernel (sm_spmma_fused_f16) on the layers
-where that wins (--path auto: n <= 256 or k <= 512, 42 layers) and as sm_compress24_f16 + sm_spmma_f16 on the rest; both
-give the same C bit for bit.  value = dense-equivalent flops (2*m*n*k*b summed over the table, summed over ranks) / time.
-Inputs are generated on the device and are resident in HBM before the timed region starts.  The step's 56 launches,
-spread over 4 HIP streams, are captured once into a hipGraph and replayed (the launches are 7-100 us each; without the
-graph the Python/ctypes call cost would be on the clock).
+A "step" is one pass of the hot path over this rank's units of the table(s): for each layer the 2:4 prune + compress
+of the per-batch activation operand A and the sparse x dense matmul -- as ONE fused kernel (sm_spmma_fused_f16) on the
+layers where that wins (--path auto) and as sm_compress24_f16 + sm_spmma_f16 on the rest; both give the same C bit for
+bit.  (This is compress(STRIP)+spmma on the UNPRUNED A, bit-identical to the reference's spmma() call sequence only for
+an A that is already 2:4; the API-faithful sequence -- TILE prune in place, check, compress, multiply, spmma.hxx:82-113
+-- is timed beside it as stages.api_spmma_ms.)  value = dense-equivalent flops (2*m*n*k per batch index, summed over
+the units of every rank) / time.  Inputs are generated on the device, per (layer, global batch index), and are
+resident in HBM before the timed region starts.  A step's launches, spread over 4 HIP streams, are captured once into a
+hipGraph and replayed (the launches are 7-100 us each; without the graph the Python/ctypes call cost would be on the
+clock).
 
-Multi-GPU: one process per GPU; every rank runs the same table on its own seeded batch (weak
-scaling, no data-path collective); one tiny all-reduce (RCCL) gives sum(flops) and max(time).
+Multi-GPU (--scaling): one process per GPU, no data-path collective, one tiny all-reduce (RCCL) of sum(flops) and
+max(time).  weak (default): every rank runs every layer on its own b batch indices (rank r = global indices
+[r*b, (r+1)*b)).  strong: every layer's batch is split [g*b/G, (g+1)*b/G), B replicated.  lpt: whole
+layers, longest-processing-time assignment -- the config-4 sweep: --tables resnet50,resnet101,resnet152 --scaling lpt.
 
-Besides the contract line's fields the JSON carries `stages` (matmul only, compress only, and the
-dense GEMMs that are the metric's denominator), `roofline` for the dominant kernel of the timed step
-and `cpu_baseline` (the oracle's arithmetic timed on the host cores; rank 0, N = 1 only).
+Besides the contract line's fields the JSON carries `stages` (matmul only, compress only, the API-faithful sequence and
+the dense GEMMs that are the metric's denominator), `roofline` for the dominant kernel of the timed step and
+`cpu_baseline` (the oracle's arithmetic timed on the host cores; rank 0, N = 1 only).
 """
 import argparse
 import csv
+import hashlib
 import json
 import os
 import sys
@@ -27,7 +33,8 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+F32_MATRIX_PEAK_TFS = 157.3  # same guide: v_mfma_f32_16x16x4_f32, 64 FLOP/clk/SIMD
 
 
 def read_shapes(path):
@@ -36,12 +43,46 @@ def read_shapes(path):
     return [tuple(int(x) for x in r[:4]) for r in rows if r]
 
 
+def table_path(name):
+    if os.path.exists(name):
+        return name
+    p = os.path.join(ROOT, "datasets", name if name.endswith(".csv") else name + ".csv")
+    if not os.path.exists(p):
+        raise SystemExit(f"bench: no shape table {name!r}")
+    return p
+
+
+def file_tag(path):
+    """provenance of a replayed (not measured-in-this-run) profile file: relative path + content hash"""
+    with open(path, "rb") as fh:
+        return {"file": os.path.relpath(path, ROOT), "sha256_12": hashlib.sha256(fh.read()).hexdigest()[:12],
+                "measured_in_this_run": False,
+                "how": "rocprofv3 --pmc passes of an earlier run of the same step (tools/pmc_traffic.py, tools/pmc_mfma.py); "
+                       "the committed file is replayed here, the counters are not collected by bench.py itself"}
+
+
+def fused_variant(n, k):
+    """Which kernel sm_spmma_fused_f16 dispatches a (n, k) layer to (csrc/spmma_f16_fused.hip: spmma_fused16)."""
+    if n <= 128 or (n <= 256 and k <= 64):
+        return "direct"
+    if n > 256 and k <= 512:
+        return "astat"
+    return "wide"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--table", default=os.path.join(ROOT, "datasets", "resnet50.csv"))
+    ap.add_argument("--tables", default=None,
+                    help="comma-separated shape tables (names under datasets/ or paths), concatenated into one work list; "
+                         "default resnet50 (fp16 / bf16) or resnet18 (f32: BASELINE config 2); "
+                         "config 4 = resnet50,resnet101,resnet152")
+    ap.add_argument("--table", default=None, help="one shape table (alias of --tables)")
+    ap.add_argument("--scaling", choices=["weak", "strong", "lpt"], default="weak",
+                    help="multi-GPU partitioning of the (layer, batch) units: weak = every rank the whole table on its own "
+                         "batch; strong = batch split b/G per layer; lpt = whole layers by longest-processing-time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the per-stage / denominator passes")
     ap.add_argument("--eager", action="store_true", help="launch from Python instead of replaying a hipGraph")
@@ -50,17 +91,14 @@ def main():
                          "staged compress24 + spmma pair elsewhere; staged: the pair on every layer")
     ap.add_argument("--fused-max-n", type=int, default=256,
                     help="auto path: widest n served by sm_spmma_fused_f16 whatever k (one workgroup spans up to 256 columns, so up "
-                         "to there A is loaded and selected once).  512 also fuses the long-k n = 512 layers, which standalone are "
-                         "faster as compress + spmma (46 vs 70 us) but inside the step, bound by the bytes it moves, gain from not "
-                         "writing and re-reading their blobs: 1.816 vs 1.837 ms (three alternating runs) -- not the default because "
-                         "it makes the dominant kernel family's single-stream roofline figure worse (0.41 vs 0.47)")
+                         "to there A is loaded and selected once)")
     ap.add_argument("--fused-max-k-wide", type=int, default=512,
                     help="auto path: wider layers (n > --fused-max-n) are still fused when k <= this (the A-stationary "
                          "kernel keeps the 2:4 image of a row panel in LDS across its column tiles); 0 = never")
-    ap.add_argument("--dtype", choices=["f16", "bf16"], default="f16",
-                    help="element type of the 16-bit path (BASELINE's metric is quoted on f16; bf16 runs the same kernels "
-                         "with the bfloat16 matrix instructions; the reference's column-major dense GEMM has no bf16 form "
-                         "and is skipped)")
+    ap.add_argument("--dtype", choices=["f16", "bf16", "f32"], default="f16",
+                    help="element type (BASELINE's metric is quoted on f16; bf16 runs the same kernels with the bfloat16 matrix "
+                         "instructions; f32 is BASELINE config 2: sm_compress24_f32 + sm_spmma_f32 against the fp32 dense GEMMs, "
+                         "default table resnet18)")
     ap.add_argument("--streams", type=int, default=4,
                     help="HIP streams the independent layers of a step are spread over (fork/join inside the step)")
     ap.add_argument("--graphs", choices=["single", "per-stream"], default="single",
@@ -97,30 +135,37 @@ def main():
     mg = ge.load_package_module("multigpu")
     sm.device_check()  # raises when the HIP library or a gfx950 device is missing: no fallback
 
-    shapes = read_shapes(args.table)
-    tdt = torch.float16 if args.dtype == "f16" else torch.bfloat16
+    f32 = args.dtype == "f32"
+    tables = (args.tables or args.table or ("resnet18" if f32 else "resnet50")).split(",")
+    tables = [table_path(t) for t in tables]
+    shapes = [s_ for t in tables for s_ in read_shapes(t)]
+    units = mg.plan_units(shapes, world, rank, args.scaling)
+    tdt = {"f16": torch.float16, "bf16": torch.bfloat16, "f32": torch.float32}[args.dtype]
+    es = 4 if f32 else 2
     layers = []
-    for li, (m, n, k, b) in enumerate(shapes):
+    for (li, lo, hi) in units:
+        m, n, k, _ = shapes[li]
+        b = hi - lo
         A = torch.empty(b * m * k, dtype=tdt, device=dev)
         B = torch.empty(k * n, dtype=tdt, device=dev)
-        sm.fill_uniform(A, 0x5EED0000 + 1000 * rank + li, 0.0, 1.0)
-        sm.fill_uniform(B, 0xB0000000 + li, 0.0, 1.0)
-        blob = torch.empty(sm.compress24_size(m, k, 2, b), dtype=torch.uint8, device=dev)
+        for bi in range(lo, hi):  # operand of (layer, global batch index): the same matrix whatever the sharding
+            sm.fill_uniform(A[(bi - lo) * m * k:(bi - lo + 1) * m * k], mg.unit_seed(0x5EED0000, li, bi), 0.0, 1.0)
+        sm.fill_uniform(B, mg.unit_seed(0xB0000000, li, -1), 0.0, 1.0)
+        blob = torch.empty(sm.compress24_size(m, k, es, b), dtype=torch.uint8, device=dev)
         C = torch.empty(b * m * n, dtype=tdt, device=dev)
-        layers.append(dict(m=m, n=n, k=k, b=b, A=A, B=B, blob=blob, C=C))
-    flops = sum(2.0 * L["m"] * L["n"] * L["k"] * L["b"] for L in layers)
+        layers.append(dict(li=li, m=m, n=n, k=k, b=b, A=A, B=B, blob=blob, C=C))
+    flops = mg.unit_flops(shapes, units)
 
-    # The 49 layers of a step are independent problems (the reference's sweep runs them as separate
+    # The layers of a step are independent problems (the reference's sweep runs them as separate
     # processes, examples/profiling.py:6-17), so a step forks them over a few HIP streams and joins:
     # one layer's ramp-up and tail overlap another layer's streaming phase.  compress -> spmma of one
     # layer stay ordered on one stream.
     side = [torch.cuda.Stream() for _ in range(max(0, args.streams - 1))]
-
     nstreams = len(side) + 1
     chains = [[] for _ in range(nstreams)]  # stream w runs chains[w] in order
     cnt = [0, 0]
-    for li, L in enumerate(layers):
-        w = li % nstreams
+    for i, L in enumerate(layers):
+        w = i % nstreams
         if args.sched == "split" and nstreams >= 2:
             big = 0 if L["m"] * L["b"] >= 784 * 128 else 1
             half = [nstreams // 2, nstreams - nstreams // 2]
@@ -131,33 +176,35 @@ def main():
     class Forked:
         """A step whose layers are spread over the streams: fork, one chain of layers per stream, join."""
 
-        def __init__(self, per_layer):
+        def __init__(self, per_layer, only=None):
             self.per_layer = per_layer
+            self.only = only  # optional predicate: the layers this pass runs
 
         def fork_join(self, run_chain):
-            main = torch.cuda.current_stream()
+            main_s = torch.cuda.current_stream()
             for s_ in side:
-                s_.wait_stream(main)
+                s_.wait_stream(main_s)
             run_chain(0)
             for w, s_ in enumerate(side, start=1):
                 with torch.cuda.stream(s_):
                     run_chain(w)
             for s_ in side:
-                main.wait_stream(s_)
+                main_s.wait_stream(s_)
 
         def chain(self, w):
             for L in chains[w]:
-                self.per_layer(L)
+                if self.only is None or self.only(L):
+                    self.per_layer(L)
 
         def __call__(self):  # launched kernel by kernel
             self.fork_join(self.chain)
 
-    def layer_full(L):
+    def layer_staged(L):
         sm.compress24(L["A"], L["m"], L["k"], L["k"], L["b"], L["m"] * L["k"], L["blob"])
         sm.spmma(L["blob"], L["B"], L["C"], L["m"], L["n"], L["k"], L["b"], 0)
 
     def use_fused(L):
-        return args.path == "auto" and L["k"] % 64 == 0 and (L["n"] <= args.fused_max_n or L["k"] <= args.fused_max_k_wide)
+        return (not f32) and args.path == "auto" and L["k"] % 64 == 0 and (L["n"] <= args.fused_max_n or L["k"] <= args.fused_max_k_wide)
 
     # (f-1) the fused kernel computes the same C bit for bit straight from the dense A (the 2:4 selection
     # and compaction happen in registers / LDS; no blob goes to HBM)
@@ -165,7 +212,7 @@ def main():
         if use_fused(L):
             sm.spmma_fused(L["A"], L["B"], L["C"], L["m"], L["n"], L["k"], batch=L["b"])
         else:
-            layer_full(L)
+            layer_staged(L)
 
     step_full = Forked(layer_path)
 
@@ -177,10 +224,7 @@ def main():
     def make_runner(fn):
         """fn replayed from a hipGraph (one graph = one call of fn), or fn itself with --eager.  --graphs per-stream
         turns a Forked step into one linear graph per stream, replayed into its own stream between the fork and the
-        join.  Measured the same as the single graph (1.87 vs 1.88 ms): under either form the hardware runs two or
-        three of the four chains at a time (profiles/ktrace_r01l.txt, tools/ktrace_step.py), with eager launches all
-        four, and the step takes the same time in all three cases -- it is bound by the HBM rate of the kernel mix,
-        not by how the chains interleave."""
+        join (measured the same as the single graph, profiles/ktrace_r01l.txt)."""
         fn()  # first call outside capture: lazy module loads, function attributes
         torch.cuda.synchronize()
         if args.eager:
@@ -203,8 +247,8 @@ def main():
             return fn
 
     def timed(run, steps, warmup, collective=True):
-        """collective=False: rank-local timing (the per-stage / per-family passes only rank 0 runs: a distributed
-        barrier there would pair with the other ranks' final barrier and hang the job)."""
+        """Wall time of `steps` calls.  collective=False: rank-local timing (the per-stage / per-family passes only rank
+        0 runs: a distributed barrier there would pair with the other ranks' final barrier and hang the job)."""
         sync = barrier if collective else torch.cuda.synchronize
         for _ in range(warmup):
             run()
@@ -217,129 +261,58 @@ def main():
         sync()
         return wall
 
+    def event_seconds(run, reps, warmup=2):
+        """Device time per call by a HIP event pair on the stream the work is launched on (torch's current stream: the
+        graph replays and the eager launches both go there)."""
+        for _ in range(warmup):
+            run()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e-3 / reps
+
     run_full = make_runner(step_full)
     wall = timed(run_full, args.steps, args.warmup)
     tot_flops, wall_max = mg.rollup(flops * args.steps, wall, None if args.rehearse_gloo else dev)
     ms_per_step = wall_max / args.steps * 1e3
     value = tot_flops / wall_max / 1e9
 
+    names = ",".join(os.path.basename(t) for t in tables)
+    nfused = sum(use_fused(L) for L in layers)
+    sfx = args.dtype
+    if f32:
+        path_desc = "sm_compress24_f32 + sm_spmma_f32 on every layer"
+    elif args.path == "auto":
+        path_desc = ("auto: sm_spmma_fused_%s on %d layers (n <= %d or k <= %d), sm_compress24_%s + sm_spmma_%s on %d"
+                     % (sfx, nfused, args.fused_max_n, args.fused_max_k_wide, sfx, sfx, len(layers) - nfused))
+    else:
+        path_desc = "staged: sm_compress24_%s + sm_spmma_%s on every layer" % (sfx, sfx)
+    split = {"weak": f"every rank runs all {len(shapes)} layers on its own batch (rank r = global batch indices [r*b, (r+1)*b))",
+             "strong": f"batch split: rank g runs batch indices [g*b/{world}, (g+1)*b/{world}) of every layer, B replicated",
+             "lpt": f"whole layers by longest-processing-time over {len(shapes)} layer instances"}[args.scaling]
     out = {
         "metric": "effective GF/s (2:4 spmma vs dense gemm) on ResNet-50 layer shapes",
         "value": value, "unit": "GF/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": "datasets/%s: %d conv layers as im2col GEMMs (m,n,k) at b=%d, %s; "
-                               "step = per layer 2:4 prune+compress+matmul (path: %s)"
-                               % (os.path.basename(args.table), len(layers), layers[0]["b"], "fp16" if args.dtype == "f16" else "bfloat16", args.path),
-                   "path": args.path + (": sm_spmma_fused_f16 on %d layers (n <= %d or k <= %d), sm_compress24_f16 + sm_spmma_f16 on %d"
-                                        % (sum(use_fused(L) for L in layers), args.fused_max_n, args.fused_max_k_wide,
-                                           sum(not use_fused(L) for L in layers))
-                                        if args.path == "auto" else ": sm_compress24_f16 + sm_spmma_f16 on every layer"),
-                   "layers": len(layers), "batch": layers[0]["b"], "dense_equiv_gflop_per_step": flops / 1e9,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak" if args.scaling == "weak" else "strong",
+        "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": "datasets/%s: %d conv layers as im2col GEMMs (m,n,k) at b=%d, %s; step = per layer "
+                               "2:4 prune(STRIP)+compress+matmul of the unpruned A"
+                               % (names, len(shapes), shapes[0][3], {"f16": "fp16", "bf16": "bfloat16", "f32": "fp32"}[args.dtype]),
+                   "path": path_desc,
+                   "layers": len(shapes), "layers_this_rank": len(layers), "batch": shapes[0][3],
+                   "dense_equiv_gflop_per_step": tot_flops / args.steps / 1e9,
                    "launch": "eager" if args.eager else ("hipGraph replay, one linear graph per stream" if args.graphs == "per-stream" else "hipGraph replay of one step"),
                    "streams": args.streams, "sched": args.sched,
-                   "parallelism": f"replicated table x{world}, per-rank batch, no data-path collective"},
+                   "parallelism": f"{args.scaling} x{world}: {split}; no data-path collective, one all-reduce of "
+                                  "{sum flops, max seconds}"},
     }
 
     if rank == 0 and not args.no_extras:
-        R = max(5, args.steps)
-
-        def sec_per_call(fn):
-            return timed(make_runner(fn), R, 2, collective=False) / R
-
-        spmma_only = Forked(lambda L: sm.spmma(L["blob"], L["B"], L["C"], L["m"], L["n"], L["k"], L["b"], 0))
-        compress_only = Forked(lambda L: sm.compress24(L["A"], L["m"], L["k"], L["k"], L["b"], L["m"] * L["k"], L["blob"]))
-        dense_rowmajor = Forked(lambda L: sm.gemm_rowmajor(L["A"], L["B"], L["C"], L["m"], L["n"], L["k"], batch=L["b"]))
-
-        # the reference's dense path: column-major pointer-array batched GEMM, B shared (examples/gemm.cu:60,86)
-        for L in layers:
-            m, n, k, b = L["m"], L["n"], L["k"], L["b"]
-            L["Ap"] = torch.tensor([L["A"].data_ptr() + 2 * i * m * k for i in range(b)], dtype=torch.int64, device=dev)
-            L["Bp"] = torch.tensor([L["B"].data_ptr()] * b, dtype=torch.int64, device=dev)
-            L["Cp"] = torch.tensor([L["C"].data_ptr() + 2 * i * m * n for i in range(b)], dtype=torch.int64, device=dev)
-
-        dense_batched = Forked(lambda L: sm.gemm_batched(L["Ap"], L["Bp"], L["Cp"], L["m"], L["n"], L["k"], L["b"], "f16"))
-
-        t_mul, t_cmp = sec_per_call(spmma_only), sec_per_call(compress_only)
-        t_drm = sec_per_call(dense_rowmajor)
-        t_dcm = sec_per_call(dense_batched) if args.dtype == "f16" else None  # cublasHgemmBatched's role: fp16 only
-        t_full = wall / args.steps
-
-        step_staged = Forked(layer_full)
-
-        t_staged = t_full if args.path == "staged" else sec_per_call(step_staged)
-        gfs = lambda t: flops / t / 1e9
-        out["stages"] = {
-            "spmma_mul_gfs": gfs(t_mul), "spmma_mul_ms": t_mul * 1e3, "compress_ms": t_cmp * 1e3,
-            "dense_gemm_rowmajor_gfs": gfs(t_drm), "dense_gemm_rowmajor_ms": t_drm * 1e3,
-            "dense_gemm_batched_colmajor_gfs": gfs(t_dcm) if t_dcm else None, "dense_gemm_batched_colmajor_ms": t_dcm * 1e3 if t_dcm else None,
-            "speedup_mul_vs_dense_rowmajor": t_drm / t_mul, "speedup_mul_vs_dense_batched": t_dcm / t_mul if t_dcm else None,
-            "speedup_full_vs_dense_rowmajor": t_drm / t_full, "speedup_full_vs_dense_batched": t_dcm / t_full if t_dcm else None,
-            "full_path_staged_gfs": gfs(t_staged), "full_path_staged_ms": t_staged * 1e3,
-            "timed_path": args.path, "timed_path_ms": t_full * 1e3,
-            # what 2:4 can buy on these shapes when both products are HBM-bound (they are: DESIGN.md 4.2): the ratio of
-            # the algorithmic bytes, dense (A + B + C) over sparse (9/16 A + B + C)
-            "hbm_bound_speedup_ceiling": sum(L["b"] * 2.0 * (L["m"] * L["k"] + L["m"] * L["n"]) + 2.0 * L["k"] * L["n"] for L in layers)
-            / sum(L["b"] * (L["m"] * L["k"] * (1.0 + 1.0 / 8) + 2.0 * L["m"] * L["n"]) + 2.0 * L["k"] * L["n"] for L in layers),
-        }
-        # matrix-pipe view of the 2:4 matmul (north_star: "MFMA utilisation for the matmul against chip peak"):
-        # dense-equivalent rate of the matmul-only pass against 2 x the dense fp16 peak (v_smfmac does a 16x16x64
-        # product in the cycles of a dense 16x16x32), plus the PMC MfmaUtil per kernel when a profile is present
-        mfma = {"achieved_TFs": gfs(t_mul) / 1e3, "peak_TFs": 2.0 * 2500.0, "frac": gfs(t_mul) / 1e3 / 5000.0,
-                "peak": "2 x 2.5 PF/s dense fp16 (MI355X_MICROARCH.md); the v_smfmac issue rate measured on this chip "
-                        "is 3.4-3.8 PF/s dense-equivalent (profiles/mfma_rate_r01.txt)",
-                "pmc_mfma_util_percent": None}
-        mpath = os.path.join(ROOT, "profiles", "mfma_util_latest.json")  # tools/pmc_mfma.py, from a rocprofv3 --pmc pass
-        if os.path.exists(mpath):
-            try:
-                mfma["pmc_mfma_util_percent"] = {k: round(v["mfma_util_percent"], 2) for k, v in json.load(open(mpath)).items()}
-            except Exception:
-                pass
-        out["stages"]["matmul_mfma"] = mfma
-        # roofline of the dominant kernel family of the timed step: algorithmic bytes (SURVEY.md 8(d),
-        # DESIGN.md 4) / time of a single-stream pass that launches only that family on the layers it serves
-        s = 2
-        fam = {"spmma_f16": dict(names=["spmma_f16_dma_kernel", "spmma_f16_pc_kernel", "spmma_f16_kernel"],
-                                 layers=[L for L in layers if not use_fused(L)],
-                                 call=lambda L: sm.spmma(L["blob"], L["B"], L["C"], L["m"], L["n"], L["k"], L["b"], 0),
-                                 bytes=lambda L: L["b"] * (L["m"] * L["k"] * s / 2 + L["m"] * L["k"] / 8 + L["m"] * L["n"] * s) + s * L["k"] * L["n"]),
-               "compress": dict(names=["compress_flat_kernel", "compress_rowspan_f16_kernel", "compress_kernel"],
-                                layers=[L for L in layers if not use_fused(L)],
-                                call=lambda L: sm.compress24(L["A"], L["m"], L["k"], L["k"], L["b"], L["m"] * L["k"], L["blob"]),
-                                bytes=lambda L: L["b"] * L["m"] * L["k"] * (s + s / 2 + 1 / 8)),
-               "spmma_f16_fused": dict(names=["spmma_f16_fused_direct_kernel", "spmma_f16_fused_wide_kernel", "spmma_f16_fused_astat_kernel"],
-                                       layers=[L for L in layers if use_fused(L)],
-                                       call=lambda L: sm.spmma_fused(L["A"], L["B"], L["C"], L["m"], L["n"], L["k"], batch=L["b"]),
-                                       bytes=lambda L: L["b"] * s * (L["m"] * L["k"] + L["m"] * L["n"]) + s * L["k"] * L["n"])}
-        traffic_tab = {}
-        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")  # tools/pmc_traffic.py, from rocprofv3 --pmc passes
-        if os.path.exists(tpath):
-            try:
-                traffic_tab = json.load(open(tpath))
-            except Exception:
-                traffic_tab = {}
-        rows = {}
-        for name, f in fam.items():
-            if not f["layers"]:
-                continue
-
-            def serial(f=f):
-                for L in f["layers"]:
-                    f["call"](L)
-            t = sec_per_call(serial)
-            by = sum(f["bytes"](L) for L in f["layers"])
-            tb = [(traffic_tab[n]["hbm_bytes_per_launch"], traffic_tab[n]["launches_profiled"]) for n in f["names"] if n in traffic_tab]
-            traffic = sum(b_ * c_ for b_, c_ in tb) / sum(c_ for _, c_ in tb) if tb else None
-            rows[name] = dict(seconds=t, launches=len(f["layers"]), bytes=by, GBs=by / t / 1e9, traffic=traffic)
-        dom = max(rows, key=lambda n_: rows[n_]["seconds"])
-        d = rows[dom]
-        out["roofline"] = {"bound": "hbm", "achieved": d["GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": d["GBs"] / HBM_PEAK_GBS, "traffic": d["traffic"], "kernel": dom,
-                           "launches_per_step": d["launches"], "avg_launch_us": d["seconds"] / d["launches"] * 1e6,
-                           "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],
-                           "measured": "single stream, one kernel family at a time, hipGraph replay",
-                           "families": {n_: {"ms_per_step": r_["seconds"] * 1e3, "launches": r_["launches"], "GBs": r_["GBs"],
-                                             "hbm_traffic_per_launch": r_["traffic"]} for n_, r_ in rows.items()}}
+        extras(args, sm, torch, dev, layers, flops, wall / args.steps, Forked, make_runner, timed, event_seconds, use_fused, out)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(ge, shapes)
@@ -349,6 +322,155 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out))
+
+
+def extras(args, sm, torch, dev, layers, flops, t_full, Forked, make_runner, timed, event_seconds, use_fused, out):
+    """Rank 0 only: per-stage times, the dense denominators, the API-faithful sequence and the roofline of the
+    dominant kernel family."""
+    f32 = args.dtype == "f32"
+    s = 4 if f32 else 2
+    R = max(5, args.steps)
+
+    def sec_per_call(fn):
+        return timed(make_runner(fn), R, 2, collective=False) / R
+
+    gfs = lambda t: flops / t / 1e9
+    spmma_only = Forked(lambda L: sm.spmma(L["blob"], L["B"], L["C"], L["m"], L["n"], L["k"], L["b"], 0))
+    compress_only = Forked(lambda L: sm.compress24(L["A"], L["m"], L["k"], L["k"], L["b"], L["m"] * L["k"], L["blob"]))
+    dense_rowmajor = Forked(lambda L: sm.gemm_rowmajor(L["A"], L["B"], L["C"], L["m"], L["n"], L["k"], batch=L["b"]))
+
+    # the reference's dense path: column-major pointer-array batched GEMM, B shared (examples/gemm.cu:60,86)
+    for L in layers:
+        m, n, k, b = L["m"], L["n"], L["k"], L["b"]
+        L["Ap"] = torch.tensor([L["A"].data_ptr() + s * i * m * k for i in range(b)], dtype=torch.int64, device=dev)
+        L["Bp"] = torch.tensor([L["B"].data_ptr()] * b, dtype=torch.int64, device=dev)
+        L["Cp"] = torch.tensor([L["C"].data_ptr() + s * i * m * n for i in range(b)], dtype=torch.int64, device=dev)
+    has_batched = args.dtype in ("f16", "f32")  # cublas{H,S}gemmBatched's role; no bf16 form in the reference
+    dense_batched = Forked(lambda L: sm.gemm_batched(L["Ap"], L["Bp"], L["Cp"], L["m"], L["n"], L["k"], L["b"], args.dtype))
+
+    t_mul, t_cmp = sec_per_call(spmma_only), sec_per_call(compress_only)
+    t_drm = sec_per_call(dense_rowmajor)
+    t_dcm = sec_per_call(dense_batched) if has_batched else None
+    t_staged = t_full if (args.path == "staged" or f32) else sec_per_call(Forked(lambda L: (
+        sm.compress24(L["A"], L["m"], L["k"], L["k"], L["b"], L["m"] * L["k"], L["blob"]),
+        sm.spmma(L["blob"], L["B"], L["C"], L["m"], L["n"], L["k"], L["b"], 0))))
+    out["stages"] = {
+        "spmma_mul_gfs": gfs(t_mul), "spmma_mul_ms": t_mul * 1e3, "compress_ms": t_cmp * 1e3,
+        "dense_gemm_rowmajor_gfs": gfs(t_drm), "dense_gemm_rowmajor_ms": t_drm * 1e3,
+        "dense_gemm_batched_colmajor_gfs": gfs(t_dcm) if t_dcm else None, "dense_gemm_batched_colmajor_ms": t_dcm * 1e3 if t_dcm else None,
+        "speedup_mul_vs_dense_rowmajor": t_drm / t_mul, "speedup_mul_vs_dense_batched": t_dcm / t_mul if t_dcm else None,
+        "speedup_full_vs_dense_rowmajor": t_drm / t_full, "speedup_full_vs_dense_batched": t_dcm / t_full if t_dcm else None,
+        "full_path_staged_gfs": gfs(t_staged), "full_path_staged_ms": t_staged * 1e3,
+        "timed_path": "staged" if f32 else args.path, "timed_path_ms": t_full * 1e3,
+        # what 2:4 can buy on these shapes when both products are HBM-bound (fp16: they are, DESIGN.md 4.2): the ratio of
+        # the algorithmic bytes, dense (A + B + C) over sparse (9/16 A + B + C)
+        "hbm_bound_speedup_ceiling": sum(L["b"] * s * (L["m"] * L["k"] + L["m"] * L["n"]) + s * L["k"] * L["n"] for L in layers)
+        / sum(L["b"] * (L["m"] * L["k"] * (s / 2 + 1.0 / 8) + s * L["m"] * L["n"]) + s * L["k"] * L["n"] for L in layers),
+    }
+
+    # The API-faithful sequence of sparsifyme::spmma() (reference spmma.hxx:82-113, include/sparsify.me/spmma.hxx):
+    # TILE prune in place -> prune check -> compress -> multiply.  A is re-pruned every step (TILE of a TILE-pruned
+    # matrix is the same matrix, so the bytes moved per step do not change after the first).
+    if hasattr(sm, "api_spmma_step"):
+        valid = torch.zeros(1, dtype=torch.int32, device=dev)
+        for L in layers:
+            L["Aapi"] = L["A"].clone()
+        t_api = sec_per_call(Forked(lambda L: sm.api_spmma_step(L["Aapi"], L["B"], L["C"], L["blob"], valid, L["m"], L["n"], L["k"], L["b"])))
+        out["stages"]["api_spmma_ms"] = t_api * 1e3
+        out["stages"]["api_spmma_gfs"] = gfs(t_api)
+        out["stages"]["api_spmma_sequence"] = sm.API_SPMMA_SEQUENCE
+        for L in layers:
+            del L["Aapi"]
+
+    if not f32:
+        # matrix-pipe view of the 2:4 matmul (north_star: "MFMA utilisation for the matmul against chip peak"):
+        # dense-equivalent rate of the matmul-only pass against 2 x the dense fp16 peak (v_smfmac does a 16x16x64
+        # product in the cycles of a dense 16x16x32), plus the PMC MfmaUtil per kernel when a profile is present
+        mfma = {"achieved_TFs": gfs(t_mul) / 1e3, "peak_TFs": 2.0 * 2500.0, "frac": gfs(t_mul) / 1e3 / 5000.0,
+                "peak": "2 x 2.5 PF/s dense fp16 (MI355X_MICROARCH.md); the v_smfmac issue rate measured on this chip "
+                        "is 3.4-3.8 PF/s dense-equivalent (profiles/mfma_rate_r01.txt)",
+                "pmc_mfma_util_percent": None, "pmc_source": None}
+        mpath = os.path.join(ROOT, "profiles", "mfma_util_latest.json")  # tools/pmc_mfma.py, from a rocprofv3 --pmc pass
+        if os.path.exists(mpath):
+            try:
+                mfma["pmc_mfma_util_percent"] = {k: round(v["mfma_util_percent"], 2) for k, v in json.load(open(mpath)).items()}
+                mfma["pmc_source"] = file_tag(mpath)
+            except Exception:
+                pass
+        out["stages"]["matmul_mfma"] = mfma
+
+    # roofline of the dominant kernel family of the timed step: algorithmic bytes (SURVEY.md 8(d), DESIGN.md 4) / device
+    # time (HIP events on the launch stream) of a single-stream pass that launches only that family on its layers
+    A_sp = lambda L: L["b"] * (L["m"] * L["k"] * s / 2 + L["m"] * L["k"] / 8 + L["m"] * L["n"] * s) + s * L["k"] * L["n"]
+    A_fu = lambda L: L["b"] * s * (L["m"] * L["k"] + L["m"] * L["n"]) + s * L["k"] * L["n"]
+    fam = {}
+    if f32:
+        fam["spmma_f32"] = dict(names=["spmma_f32_dma_kernel", "spmma_f32_kernel"], layers=layers,
+                                call=lambda L: sm.spmma(L["blob"], L["B"], L["C"], L["m"], L["n"], L["k"], L["b"], 0), bytes=A_sp)
+        fam["compress"] = dict(names=["compress_kernel"], layers=layers,
+                               call=lambda L: sm.compress24(L["A"], L["m"], L["k"], L["k"], L["b"], L["m"] * L["k"], L["blob"]),
+                               bytes=lambda L: L["b"] * L["m"] * L["k"] * (s + s / 2 + 1 / 8))
+    else:
+        staged = [L for L in layers if not use_fused(L)]
+        fam["spmma_f16"] = dict(names=["spmma_f16_dma_kernel", "spmma_f16_pc_kernel", "spmma_f16_kernel", "spmma_f16_splitk_kernel"],
+                                layers=staged, call=lambda L: sm.spmma(L["blob"], L["B"], L["C"], L["m"], L["n"], L["k"], L["b"], 0), bytes=A_sp)
+        fam["compress"] = dict(names=["compress_flat_kernel", "compress_rowspan_f16_kernel", "compress_kernel"], layers=staged,
+                               call=lambda L: sm.compress24(L["A"], L["m"], L["k"], L["k"], L["b"], L["m"] * L["k"], L["blob"]),
+                               bytes=lambda L: L["b"] * L["m"] * L["k"] * (s + s / 2 + 1 / 8))
+        for var in ("direct", "wide", "astat"):
+            fam["spmma_f16_fused_" + var] = dict(names=["spmma_f16_fused_%s_kernel" % var],
+                                                 layers=[L for L in layers if use_fused(L) and fused_variant(L["n"], L["k"]) == var],
+                                                 call=lambda L: sm.spmma_fused(L["A"], L["B"], L["C"], L["m"], L["n"], L["k"], batch=L["b"]),
+                                                 bytes=A_fu)
+    traffic_tab, tsrc = {}, None
+    tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")  # tools/pmc_traffic.py, from rocprofv3 --pmc passes
+    if os.path.exists(tpath):
+        try:
+            traffic_tab = json.load(open(tpath))
+            tsrc = file_tag(tpath)
+        except Exception:
+            traffic_tab = {}
+    rows = {}
+    for name, f in fam.items():
+        if not f["layers"]:
+            continue
+
+        def serial(f=f):
+            for L in f["layers"]:
+                f["call"](L)
+        t = event_seconds(make_runner(serial), R)
+        by = sum(f["bytes"](L) for L in f["layers"])
+        fl = sum(2.0 * L["m"] * L["n"] * L["k"] * L["b"] for L in f["layers"])
+        tb = [(traffic_tab[n]["hbm_bytes_per_launch"], traffic_tab[n]["launches_profiled"]) for n in f["names"] if n in traffic_tab]
+        traffic = sum(b_ * c_ for b_, c_ in tb) / sum(c_ for _, c_ in tb) if tb else None
+        rows[name] = dict(seconds=t, launches=len(f["layers"]), bytes=by, GBs=by / t / 1e9, TFs=fl / t / 1e12, traffic=traffic)
+    # the fused variants are one family for the "dominant kernel" choice (they are one entry point), reported each
+    groups = {}
+    for n_, r_ in rows.items():
+        groups.setdefault("spmma_f16_fused" if n_.startswith("spmma_f16_fused") else n_, []).append(r_)
+    gsum = {g: dict(seconds=sum(r["seconds"] for r in rs), launches=sum(r["launches"] for r in rs), bytes=sum(r["bytes"] for r in rs),
+                    TFs=None, traffic=(sum(r["traffic"] * r["launches"] for r in rs) / sum(r["launches"] for r in rs)
+                                       if all(r["traffic"] is not None for r in rs) else None)) for g, rs in groups.items()}
+    dom = max(gsum, key=lambda g: gsum[g]["seconds"])
+    d = gsum[dom]
+    fams_out = {n_: {"ms_per_step": r_["seconds"] * 1e3, "launches": r_["launches"], "GBs": r_["GBs"], "frac_of_hbm_peak": r_["GBs"] / HBM_PEAK_GBS,
+                     "hbm_traffic_per_launch": r_["traffic"]} for n_, r_ in rows.items()}
+    if f32:
+        r_ = rows["spmma_f32"]
+        out["roofline"] = {"bound": "mfma", "achieved": r_["TFs"], "peak": F32_MATRIX_PEAK_TFS, "unit": "TFLOP/s",
+                           "frac": r_["TFs"] / F32_MATRIX_PEAK_TFS, "traffic": r_["traffic"], "traffic_source": tsrc, "kernel": "spmma_f32",
+                           "launches_per_step": r_["launches"], "avg_launch_us": r_["seconds"] / r_["launches"] * 1e6,
+                           "algorithmic_flops_per_launch": sum(2.0 * L["m"] * L["n"] * L["k"] * L["b"] for L in layers) / r_["launches"],
+                           "note": "the fp32 2:4 kernel expands to dense fp32 MFMA (no fp32 sparse matrix instruction exists): executed = dense-equivalent flops",
+                           "measured": "single stream, HIP events on the launch stream, hipGraph replay", "families": fams_out}
+    else:
+        GBs = d["bytes"] / d["seconds"] / 1e9
+        out["roofline"] = {"bound": "hbm", "achieved": GBs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": GBs / HBM_PEAK_GBS, "traffic": d["traffic"], "traffic_source": tsrc if d["traffic"] is not None else None,
+                           "kernel": dom, "launches_per_step": d["launches"], "avg_launch_us": d["seconds"] / d["launches"] * 1e6,
+                           "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],
+                           "measured": "single stream, one kernel family at a time, HIP events on the launch stream, hipGraph replay",
+                           "families": fams_out}
 
 
 def cpu_baseline(ge, shapes):
@@ -379,7 +501,7 @@ def cpu_baseline(ge, shapes):
     return {"value": fl / t_sparse / 1e9, "unit": "GF/s", "cores": orc.num_threads(), "kind": "port",
             "dense_value": fl / t_dense / 1e9,
             "sample": f"oracle sm_cpu_spmma_f32 (2:4 path) / sm_cpu_gemm_f32 (dense_value), fp32, one batch (b=1) of each of "
-                      f"the {len(uniq)} unique ResNet-50 shapes x {reps} repetitions ({fl / 1e9:.1f} dense-equivalent GFLOP, "
+                      f"the {len(uniq)} unique shapes of the table x {reps} repetitions ({fl / 1e9:.1f} dense-equivalent GFLOP, "
                       f"{t_dense + t_sparse:.1f} s of CPU work); effective GF/s = dense-equivalent flops / time"}
 
 

@@ -9,6 +9,13 @@
 // (examples/spmma.cu:48-59); the data type is the template type (the reference hard-codes fp16
 // descriptors even for float, :40-41); the blob is sized in bytes (the reference allocates that
 // many ELEMENTS, :101).
+// Transposed operands (reference :30-31 -> matmul descriptor :67-69): op(A) is m x k and op(B) is k x n, so with
+// transpose_a = T the STORED A is k x m and with transpose_b = T the stored B is n x k, row-major and contiguous
+// (ld = m resp. k; batches m*k resp. k*n apart, as the drivers allocate).  On the reference's own descriptors
+// (always rows m, cols k, ld k) a transposed product is dimensionally consistent only for square operands, where
+// this reading and the vendor's coincide.  The 2:4 structure runs along k of op(A): the operand is brought to the N
+// form (sm_transpose), pruned there with the TILE rule, and the pruned matrix is written back transposed, so dA
+// ends pruned in place as the reference leaves it.  The extra passes are timed in the stage they serve.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
@@ -43,6 +50,9 @@ struct spmma_fns<float> {
   }
 };
 struct spmma_fns_f16 {
+  static int fused(void* A, void* B, void* C, std::size_t m, std::size_t n, std::size_t k, std::size_t b, float al, float be) {
+    return sm_spmma_fused_f16(A, B, C, m, n, k, k, b, m * k, k * n, m * n, al, be, nullptr);
+  }
   static int prune(void* A, std::size_t m, std::size_t k) { return sm_prune24_f16(A, A, m, k, k, SM_PRUNE_TILE, nullptr); }
   static int check(void* A, std::size_t m, std::size_t k, int* v) { return sm_prune24_check_f16(A, m, k, k, v, nullptr); }
   static int compress(void* A, std::size_t m, std::size_t k, std::size_t b, void* blob) { return sm_compress24_f16(A, m, k, k, b, m * k, blob, nullptr); }
@@ -57,6 +67,9 @@ struct spmma_fns_f16 {
   }
 };
 struct spmma_fns_bf16 {  // bfloat16 (extension): same blob and rules, v_smfmac_f32_16x16x64_bf16
+  static int fused(void* A, void* B, void* C, std::size_t m, std::size_t n, std::size_t k, std::size_t b, float al, float be) {
+    return sm_spmma_fused_bf16(A, B, C, m, n, k, k, b, m * k, k * n, m * n, al, be, nullptr);
+  }
   static int prune(void* A, std::size_t m, std::size_t k) { return sm_prune24_bf16(A, A, m, k, k, SM_PRUNE_TILE, nullptr); }
   static int check(void* A, std::size_t m, std::size_t k, int* v) { return sm_prune24_check_bf16(A, m, k, k, v, nullptr); }
   static int compress(void* A, std::size_t m, std::size_t k, std::size_t b, void* blob) { return sm_compress24_bf16(A, m, k, k, b, m * k, blob, nullptr); }
@@ -94,15 +107,27 @@ std::vector<float> spmma(type_t* dA,
   if (batch_size == 0) batch_size = 1;
   // the reference warns (and continues) when a dimension is not a multiple of 8 (spmma.hxx:45-49);
   // this build has no such restriction -- ragged shapes take the slower, fully predicated kernels
-  if (transpose_a != operation_t::N || transpose_b != operation_t::N)
-    std::cerr << "sparsifyme::spmma: transposed operands are not implemented; computing with N, N." << std::endl;
+  const bool ta = transpose_a != operation_t::N, tb = transpose_b != operation_t::N;
+  device_vector<type_t> a_n, b_n;  // N-form copies of transposed operands (empty otherwise)
+  type_t* A_n = dA;
+  type_t* B_n = dB;
 
   util::range_t range("spmma");
   util::timer_t prune_timer;
   prune_timer.begin();
   device_vector<int> valid(1);
-  int rc = fns::prune(dA, m * batch_size, k);  // the batches are contiguous: one (batch*m) x k matrix
-  rc |= fns::check(dA, m * batch_size, k, valid.data().get());
+  int rc = SM_STATUS_SUCCESS;
+  if (ta) {  // stored k x m -> m x k
+    a_n.resize(m * k * batch_size);
+    A_n = a_n.data().get();
+    rc |= sm_transpose(dA, A_n, k, m, m, k, sizeof(type_t), batch_size, m * k, m * k, nullptr);
+  }
+  // the batches are contiguous: one (batch*m) x k matrix -- unless a 4 x 4 TILE would straddle two of them
+  if (m % 4 == 0 || batch_size == 1) rc |= fns::prune(A_n, m * batch_size, k);
+  else
+    for (std::size_t b = 0; b < batch_size; ++b) rc |= fns::prune(A_n + b * m * k, m, k);
+  rc |= fns::check(A_n, m * batch_size, k, valid.data().get());
+  if (ta) rc |= sm_transpose(A_n, dA, m, k, k, m, sizeof(type_t), batch_size, m * k, m * k, nullptr);  // pruned, in place
   int is_valid = 1;
   (void)hipMemcpyAsync(&is_valid, valid.data().get(), sizeof(is_valid), hipMemcpyDeviceToHost, nullptr);
   (void)hipStreamSynchronize(nullptr);
@@ -114,37 +139,44 @@ std::vector<float> spmma(type_t* dA,
   std::size_t compressed_size = 0;
   (void)sm_compress24_size(m, k, sizeof(type_t), batch_size, &compressed_size);
   device_vector<unsigned char> compressed(compressed_size);
-  rc = fns::compress(dA, m, k, batch_size, compressed.data().get());
+  rc = fns::compress(A_n, m, k, batch_size, compressed.data().get());
   float compress_time = compress_timer.end();
 
   util::timer_t mul_timer;
   mul_timer.begin();
-  rc |= fns::mul(compressed.data().get(), dB, dC, m, n, k, batch_size, alpha, beta);
+  if (tb) {  // stored n x k -> k x n
+    b_n.resize(k * n * batch_size);
+    B_n = b_n.data().get();
+    rc |= sm_transpose(dB, B_n, n, k, k, n, sizeof(type_t), batch_size, k * n, k * n, nullptr);
+  }
+  rc |= fns::mul(compressed.data().get(), B_n, dC, m, n, k, batch_size, alpha, beta);
   float mul_time = mul_timer.end();
   if (rc != SM_STATUS_SUCCESS) std::cerr << "sparsifyme::spmma: " << sm_last_error() << std::endl;
   return {prune_time, compress_time, mul_time};
 }
 
-// Extension of this build (no reference counterpart): the same result as spmma()
-// -- C = alpha * prune_2:4(A) * B + beta * C -- in ONE kernel straight from the dense A: nothing is pruned in
-// place, no blob is built, A is read from HBM once.  fp16 only; needs k % 64 == 0, n % 8 == 0.  Returns the
+// Extension of this build (no reference counterpart): the result
+// of compress(STRIP) + multiply on the UNPRUNED A -- C = alpha * prune_strip_2:4(A) * B + beta * C -- in ONE kernel
+// straight from the dense A: nothing is pruned in place (A is left as it is), no blob is built, A is read from HBM
+// once.  Bit-identical to spmma() only for an A that already is 2:4 (spmma() prunes with the TILE rule first: for a
+// dense A the two rules keep different elements).  fp16 and bfloat16; needs k % 64 == 0, n % 8 == 0.  Returns the
 // elapsed milliseconds.  A shape the fused kernels cannot take (SM_STATUS_NOT_SUPPORTED) runs as sm_compress24 +
 // sm_spmma with a temporary blob: the same C bit for bit, so callers need no shape logic.
 template <typename type_t>
 float spmma_fused(type_t* dA, type_t* dB, type_t* dC, std::size_t m, std::size_t n, std::size_t k, std::size_t batch_size,
                   float alpha = 1.0f, float beta = 0.0f) {
-  static_assert(sizeof(type_t) == 2, "the fused kernel is fp16");
+  static_assert(sizeof(type_t) == 2, "the fused kernels are fp16 / bfloat16");
+  using fns = detail::spmma_fns<type_t>;
   if (batch_size == 0) batch_size = 1;
   util::timer_t timer;
   timer.begin();
-  int rc = sm_spmma_fused_f16(dA, dB, dC, m, n, k, k, batch_size, m * k, k * n, m * n, alpha, beta, nullptr);
+  int rc = fns::fused(dA, dB, dC, m, n, k, batch_size, alpha, beta);
   if (rc == SM_STATUS_NOT_SUPPORTED) {
     std::size_t compressed_size = 0;
     (void)sm_compress24_size(m, k, sizeof(type_t), batch_size, &compressed_size);
     device_vector<unsigned char> compressed(compressed_size);
-    rc = sm_compress24_f16(dA, m, k, k, batch_size, m * k, compressed.data().get(), nullptr);
-    if (rc == SM_STATUS_SUCCESS)
-      rc = sm_spmma_f16(compressed.data().get(), dB, dC, m, n, k, batch_size, k * n, m * n, alpha, beta, nullptr);
+    rc = fns::compress(dA, m, k, batch_size, compressed.data().get());
+    if (rc == SM_STATUS_SUCCESS) rc = fns::mul(compressed.data().get(), dB, dC, m, n, k, batch_size, alpha, beta);
     (void)hipStreamSynchronize(nullptr);  // the blob is released when this scope ends
   }
   const float ms = timer.end();

@@ -184,6 +184,13 @@ int sm_spmm_coo_f32_ws(size_t A_num_rows, size_t A_num_cols, size_t A_nnz, size_
 int sm_fill_uniform_f16(void* out, size_t count, uint64_t seed, float lo, float hi, sm_stream_t stream);
 int sm_fill_uniform_f32(float* out, size_t count, uint64_t seed, float lo, float hi, sm_stream_t stream);
 
+/* ---- transposed operands of sparsifyme::spmma (spmma.hxx:30-31,67-69: transpose_a / transpose_b go to the vendor's matmul
+ *      descriptor).  out[b][c * ld_out + r] = in[b][r * ld_in + c] for `batch` row-major rows x cols matrices of 2-, 4- or
+ *      8-byte elements (out of place).  include/sparsify.me/spmma.hxx brings a transposed operand to the N form with
+ *      it, prunes / compresses / multiplies there, and writes the pruned A back in its stored orientation. */
+int sm_transpose(const void* in, void* out, size_t rows, size_t cols, size_t ld_in, size_t ld_out, size_t elt_bytes,
+                 size_t batch, size_t stride_in, size_t stride_out, sm_stream_t stream);
+
 /* ---- bfloat16 forms (extension; SURVEY.md 8(f) rank 2: the vendor call behind spmma.hxx:40-113 lists bf16 among its
  *      2:4 types, examples/libcusparse_lt/include/cusparseLt.h:164-169).  Same arguments, blob layout and rules as the
  *      _f16 entry points: the selection looks at magnitude bit patterns only, so prune (STRIP), check, compress and

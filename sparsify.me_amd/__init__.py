@@ -70,6 +70,7 @@ _SIGS = {
     "sm_fill_uniform_f16": [_c_ptr, _c_size, ctypes.c_uint64, _c_f, _c_f, _c_ptr],
     "sm_fill_uniform_f32": [_c_ptr, _c_size, ctypes.c_uint64, _c_f, _c_f, _c_ptr],
 }
+_SIGS["sm_transpose"] = [_c_ptr, _c_ptr] + [_c_size] * 8 + [_c_ptr]
 _SIGS["sm_conv_out_size"] = [_c_size, _c_size, _c_size, _c_size, _c_size, ctypes.POINTER(_c_size)]
 _SIGS["sm_im2col_f16"] = [_c_ptr] + [_c_size] * 9 + [_c_ptr, _c_ptr]
 _SIGS["sm_im2col_compress24_f16"] = [_c_ptr] + [_c_size] * 9 + [_c_ptr, _c_ptr]
@@ -274,6 +275,16 @@ def spmma_fused(A, B, C, m, n, k, lda=None, batch=1, strideA=None, strideB=0, st
     fn = getattr(lib(), "sm_spmma_fused_" + _sfx(A))
     _check(fn(_dev(A), _dev(B), _dev(C), m, n, k, lda, batch, strideA, strideB, strideC, float(alpha), float(beta), _stream()),
            "sm_spmma_fused")
+
+
+def transpose(src, dst, rows, cols, ld_in=None, ld_out=None, batch=1, stride_in=None, stride_out=None):
+    """dst[b][c][r] = src[b][r][c] (row-major, out of place): the transposed operands of sparsifyme::spmma."""
+    ld_in = cols if ld_in is None else ld_in
+    ld_out = rows if ld_out is None else ld_out
+    stride_in = rows * ld_in if stride_in is None else stride_in
+    stride_out = cols * ld_out if stride_out is None else stride_out
+    _check(lib().sm_transpose(_dev(src), _dev(dst), rows, cols, ld_in, ld_out, src.element_size(), batch, stride_in, stride_out,
+                              _stream()), "sm_transpose")
 
 
 def conv_out_size(size, kernel, stride=1, pad=0, dilation=1):

@@ -1,27 +1,74 @@
-"""Multi-GPU roll-up for the layer sweep (new capability: the reference is single-GPU, device 0 only --
-examples/spmma.cu:27-28).  The path shards with NO data-path collective: every (layer, batch) unit is an
-independent prune -> compress -> matmul, so each rank (one process per GPU) runs its own units and the
-only communication is one tiny all-reduce of {dense-equivalent flops done (SUM), elapsed seconds (MAX)}
-over RCCL ("nccl" backend on ROCm) -- or gloo in the CPU tests.  Aggregate GF/s = sum(flops) / max(t)."""
+"""Multi-GPU sharding plan and roll-up for the layer sweep (new capability: the reference is single-GPU, device 0
+only -- examples/spmma.cu:27-28).  The path shards with NO data-path collective: every (layer, batch index) unit is
+an independent prune -> compress -> matmul, so each rank (one process per GPU) runs its own units
+and the only communication is one tiny all-reduce of {dense-equivalent flops done (SUM), elapsed seconds (MAX)} over
+RCCL ("nccl" backend on ROCm) -- or gloo in the CPU tests.  Aggregate GF/s = sum(flops) / max(t).
+
+A plan is a list of units (layer, batch_begin, batch_end): `layer` indexes the concatenated shape tables, the batch
+range is in GLOBAL batch indices.  Operand data are generated per (layer, global batch index) -- see unit_seed() --
+so a sharded run multiplies exactly the matrices the unsharded run does, whatever the world size."""
 import os
+
+MODES = ("weak", "strong", "lpt")
 
 
 def env_world():
     return int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
 
 
-def shard_units(num_layers, batch, world, rank, mode="weak"):
-    """Units this rank runs, as (layer, batch_begin, batch_end).
-    weak  : every rank runs every layer on its own full batch (per-GPU work fixed as N grows)
-    strong: the batch dimension of every layer is split across ranks (total work fixed)"""
-    if mode == "weak":
-        return [(l, 0, batch) for l in range(num_layers)]
-    if mode != "strong":
-        raise ValueError(mode)
+def _split(batch, world, rank):
     per, extra = divmod(batch, world)
     lo = rank * per + min(rank, extra)
-    hi = lo + per + (1 if rank < extra else 0)
-    return [(l, lo, hi) for l in range(num_layers) if hi > lo]
+    return lo, lo + per + (1 if rank < extra else 0)
+
+
+def shard_units(num_layers, batch, world, rank, mode="weak"):
+    """Units this rank runs when every layer has the same batch, as (layer, batch_begin, batch_end).
+    weak  : every rank runs every layer on its own full batch (per-GPU work fixed as N grows); rank r owns global
+            batch indices [r*batch, (r+1)*batch) of a virtual batch of world*batch
+    strong: the batch dimension of every layer is split across ranks (total work fixed)"""
+    return plan_units([(0, 0, 0, batch)] * num_layers, world, rank, mode)
+
+
+def plan_units(shapes, world, rank, mode="weak"):
+    """shapes: [(m, n, k, b)] of the concatenated tables.  Returns this rank's [(layer, batch_begin, batch_end)].
+    weak  : all layers, global batch indices [rank*b, (rank+1)*b)
+    strong: all layers, [g*b/G, (g+1)*b/G) of each layer's batch (SURVEY.md 8(e) primary partitioning; B replicated)
+    lpt   : whole layers, greedy longest-processing-time assignment by 2*m*n*k*b (SURVEY.md 8(e) alternative; the
+            config-4 sweep over several tables), deterministic: ties by layer index, equal loads to the lower rank"""
+    if mode not in MODES:
+        raise ValueError(mode)
+    if world < 1 or not (0 <= rank < world):
+        raise ValueError((world, rank))
+    if mode == "weak":
+        return [(l, rank * b, (rank + 1) * b) for l, (_, _, _, b) in enumerate(shapes)]
+    if mode == "strong":
+        out = []
+        for l, (_, _, _, b) in enumerate(shapes):
+            lo, hi = _split(b, world, rank)
+            if hi > lo:
+                out.append((l, lo, hi))
+        return out
+    cost = [2.0 * m * n * k * b for (m, n, k, b) in shapes]
+    order = sorted(range(len(shapes)), key=lambda l: (-cost[l], l))
+    load = [0.0] * world
+    mine = []
+    for l in order:
+        g = min(range(world), key=lambda r: (load[r], r))
+        load[g] += cost[l]
+        if g == rank:
+            mine.append(l)
+    return [(l, 0, shapes[l][3]) for l in sorted(mine)]
+
+
+def unit_flops(shapes, units):
+    """Dense-equivalent flops (2*m*n*k per batch index) of a list of units."""
+    return sum(2.0 * shapes[l][0] * shapes[l][1] * shapes[l][2] * (hi - lo) for l, lo, hi in units)
+
+
+def unit_seed(base, layer, batch_index):
+    """Seed of the operand of (layer, global batch index): independent of world size, rank and sharding mode."""
+    return (int(base) + 0x9E3779B1 * (layer + 1) + 0x85EBCA77 * (batch_index + 1)) & 0xFFFFFFFFFFFF
 
 
 def rollup(flops_done, seconds, device=None):

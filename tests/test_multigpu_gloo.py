@@ -17,6 +17,15 @@ def _free_port():
         return s.getsockname()[1]
 
 
+def _tables(names):
+    import csv
+    shapes = []
+    for nme in names:
+        with open(os.path.join(ROOT, "datasets", nme + ".csv"), newline="") as fh:
+            shapes += [tuple(int(x) for x in r[:4]) for r in list(csv.reader(fh))[1:] if r]
+    return shapes
+
+
 def _worker(rank, world, port, out):
     sys.path.insert(0, ROOT)
     import __graft_entry__ as ge
@@ -28,7 +37,13 @@ def _worker(rank, world, port, out):
     flops = 1000.0 * (rank + 1)          # pretend work
     seconds = 2.0 if rank == 0 else 5.0  # the slow rank sets the time
     tot, tmax = mg.rollup(flops, seconds)
-    out[rank] = (len(weak), weak[0], strong[0], tot, tmax)
+    # the real tables: every rank's planned flops, summed by the same all-reduce bench.py uses
+    shapes = _tables(["resnet50", "resnet101", "resnet152"])
+    sums = {}
+    for mode in ("strong", "lpt"):
+        mine = mg.unit_flops(shapes, mg.plan_units(shapes, world, rank, mode))
+        sums[mode], _ = mg.rollup(mine, 1.0)
+    out[rank] = (len(weak), weak[0], strong[0], tot, tmax, sums, mg.unit_flops(shapes, [(l, 0, s_[3]) for l, s_ in enumerate(shapes)]))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -41,10 +56,13 @@ def test_rollup_and_sharding_world2():
         mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
         res = dict(out)
     for rank in range(world):
-        nweak, w0, s0, tot, tmax = res[rank]
-        assert nweak == 49 and w0 == (0, 0, 32)
+        nweak, w0, s0, tot, tmax, sums, table_flops = res[rank]
+        assert nweak == 49 and w0 == (0, 32 * rank, 32 * rank + 32)   # weak: rank r owns global batch indices [32r, 32r+32)
         assert s0 == (0, 16 * rank, 16 * rank + 16)
         assert tot == 3000.0 and tmax == 5.0  # every rank sees sum(flops) and max(time)
+        # sharded flops, summed over the ranks by the roll-up, are the unsharded sweep's (config 4: 5,645.7 GFLOP)
+        assert sums["strong"] == table_flops and sums["lpt"] == table_flops
+        assert abs(table_flops / 1e9 - 5645.7) < 0.1
 
 
 def test_strong_sharding_covers_the_batch_exactly_once():
@@ -60,3 +78,38 @@ def test_strong_sharding_covers_the_batch_exactly_once():
             assert sorted(seen) == list(range(batch))
     # rollup without a process group is the identity
     assert mg.rollup(7.0, 3.0) == (7.0, 3.0)
+
+
+def test_plans_cover_every_layer_batch_unit_exactly_once():
+    """strong and lpt plans over the config-4 work list (resnet50 + 101 + 152 = 300 layer instances): the ranks' units
+    are disjoint, their union is every (layer, batch index), and the flops add up to the unsharded table's."""
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as ge
+    mg = ge.load_package_module("multigpu")
+    shapes = _tables(["resnet50", "resnet101", "resnet152"])
+    assert len(shapes) == 300
+    every = sorted((l, bi) for l, s_ in enumerate(shapes) for bi in range(s_[3]))
+    total = mg.unit_flops(shapes, [(l, 0, s_[3]) for l, s_ in enumerate(shapes)])
+    for world in (1, 2, 4, 8, 3):
+        for mode in ("strong", "lpt"):
+            seen, fl, loads = [], 0.0, []
+            for rank in range(world):
+                units = mg.plan_units(shapes, world, rank, mode)
+                seen += [(l, bi) for l, lo, hi in units for bi in range(lo, hi)]
+                loads.append(mg.unit_flops(shapes, units))
+                fl += loads[-1]
+            assert sorted(seen) == every, (world, mode)
+            assert fl == total
+            # balance: strong is exact when the batch divides; LPT over 300 layers stays within 2 % of the mean
+            if mode == "strong" and 32 % world == 0:
+                assert max(loads) == min(loads)
+            if mode == "lpt":
+                assert max(loads) <= 1.02 * total / world
+    # N = 1: both plans are the whole table in order
+    assert mg.plan_units(shapes, 1, 0, "strong") == [(l, 0, s_[3]) for l, s_ in enumerate(shapes)]
+    assert mg.plan_units(shapes, 1, 0, "lpt") == [(l, 0, s_[3]) for l, s_ in enumerate(shapes)]
+    # weak: disjoint GLOBAL batch ranges per rank (rank r = batch indices [r*b, (r+1)*b) of a world*b batch)
+    w = [mg.plan_units(shapes[:3], 4, r, "weak") for r in range(4)]
+    assert [u[0][1:] for u in w] == [(0, 32), (32, 64), (64, 96), (96, 128)]
+    # seeds depend on (layer, global batch index) only
+    assert mg.unit_seed(5, 3, 7) == mg.unit_seed(5, 3, 7) != mg.unit_seed(5, 3, 8) != mg.unit_seed(5, 4, 7)
