@@ -369,13 +369,14 @@ def extras(args, sm, torch, dev, layers, flops, t_full, Forked, make_runner, tim
     }
 
     # The API-faithful sequence of sparsifyme::spmma() (reference spmma.hxx:82-113, include/sparsify.me/spmma.hxx):
-    # TILE prune in place -> prune check -> compress -> multiply.  A is re-pruned every step (TILE of a TILE-pruned
-    # matrix is the same matrix, so the bytes moved per step do not change after the first).
-    if hasattr(sm, "api_spmma_step"):
+    # TILE prune -> prune check -> compress -> multiply.  The prune reads the step's dense A and writes the pruned
+    # operand to a second buffer (the bytes of the in-place prune, without turning the bench's operand into an already
+    # pruned one for the next step).
+    if hasattr(sm, "api_spmma_step") and not f32:
         valid = torch.zeros(1, dtype=torch.int32, device=dev)
         for L in layers:
-            L["Aapi"] = L["A"].clone()
-        t_api = sec_per_call(Forked(lambda L: sm.api_spmma_step(L["Aapi"], L["B"], L["C"], L["blob"], valid, L["m"], L["n"], L["k"], L["b"])))
+            L["Aapi"] = torch.empty_like(L["A"])
+        t_api = sec_per_call(Forked(lambda L: sm.api_spmma_step(L["A"], L["Aapi"], L["B"], L["C"], L["blob"], valid, L["m"], L["n"], L["k"], L["b"])))
         out["stages"]["api_spmma_ms"] = t_api * 1e3
         out["stages"]["api_spmma_gfs"] = gfs(t_api)
         out["stages"]["api_spmma_sequence"] = sm.API_SPMMA_SEQUENCE

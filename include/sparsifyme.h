@@ -98,6 +98,18 @@ int sm_decompress24_f16(const void* blob, size_t m, size_t k, size_t ld, size_t 
 int sm_decompress24_f32(const void* blob, size_t m, size_t k, size_t ld, size_t batch,
                         size_t strideA, float* A, sm_stream_t stream);
 
+/* ---- (a2 + a3 in one pass) prune -> check -> compress as sparsifyme::spmma() runs them (spmma.hxx:82-104:
+ *      cusparseLtSpMMAPrune in place, cusparseLtSpMMAPruneCheck, cusparseLtSpMMACompress): reads A_in once and writes
+ *      the pruned operand to A_out (may alias A_in: in place; NULL: not wanted), the compressed blob (NULL: not wanted)
+ *      and *d_valid (NULL: not wanted; 0 iff every strip written holds <= 2 non-zeros).  `batch` row-major m x k
+ *      matrices strideA elements apart; a 4 x 4 TILE never straddles two of them.  alg = SM_PRUNE_TILE or
+ *      SM_PRUNE_STRIP.  Same bytes as sm_prune24_* followed by sm_prune24_check_* and sm_compress24_* (which is what
+ *      runs for shapes the one-pass kernel does not take: k % 64 != 0 or unaligned rows). */
+int sm_prune24_compress24_f16(const void* A_in, void* A_out, size_t m, size_t k, size_t ld, size_t batch, size_t strideA,
+                              void* blob, int* d_valid, int alg, sm_stream_t stream);
+int sm_prune24_compress24_bf16(const void* A_in, void* A_out, size_t m, size_t k, size_t ld, size_t batch, size_t strideA,
+                               void* blob, int* d_valid, int alg, sm_stream_t stream);
+
 /* ---- (a4) 2:4 sparse x dense matmul: replaces cusparseLtMatmul (spmma.hxx:112-113).
  *      C_b = alpha * A_b * B_b + beta * C_b, row-major, ld(B) = ld(C) = n (spmma.hxx:56-64);
  *      B_b = B + b*strideB (strideB = 0: one shared B), C_b = C + b*strideC (elements).

@@ -201,12 +201,58 @@ static const unsigned char PAIR_C1[6] = {1, 2, 3, 2, 3, 3};
 
 /*
  * TILE rule on a 4x4 tile of magnitudes (float; NaN replaced by +inf by the caller).
- * Row r keeps column pair pr[r] in 0..5.  Candidates: all (p0,p1,p2,p3) whose column counts
- * are exactly 2 each (90 of the 1296), visited in lexicographic order; score =
- * (s0[p0] + s1[p1]) + (s2[p2] + s3[p3]) in fp32 with s_r[p] = mag[r][c0] + mag[r][c1];
- * the first candidate with the strictly greatest score wins.
+ * Row r keeps column pair pr[r] in 0..5; a pattern (p0,p1,p2,p3) is valid when every column is kept exactly twice
+ * (90 of the 1296).  With s_r[p] = mag[r][c0] + mag[r][c1] (fp32), the frozen rule is stated in two levels:
+ *   for every choice (p0,p1) of rows 0-1, in lexicographic order:
+ *     completion(p0,p1) = the valid (p2,p3) with the greatest fp32 s2[p2] + s3[p3], the first in lexicographic
+ *                         order among equals;
+ *     score(p0,p1)      = (s0[p0] + s1[p1]) + (s2[p2] + s3[p3]) of that completion, in fp32;
+ *   the first (p0,p1) with the strictly greatest score wins, with its completion.
+ * fp32 addition is monotone, so the winning score is the maximum of (s0+s1)+(s2+s3) over all 90 patterns, and in
+ * exact arithmetic (integer data, int8) the winner is the lexicographically first maximal pattern -- the definition
+ * of round 1 (tile_select_exhaustive below, kept to check exactly that).  The two can differ only when fp32
+ * rounding makes patterns with different (s2+s3) collide on the same total.  Stated this way the rule needs 36 + 36
+ * pair-of-row sums, 19 completion maxima (choices that use the columns equally share their completions) and 36
+ * scores instead of 90 four-term totals: that is what the kernels compute (csrc/tile_rule.inc).
  */
+static int tile_valid(unsigned p0, unsigned p1, unsigned p2, unsigned p3) {
+  unsigned cnt[4] = {0, 0, 0, 0};
+  ++cnt[PAIR_C0[p0]]; ++cnt[PAIR_C1[p0]];
+  ++cnt[PAIR_C0[p1]]; ++cnt[PAIR_C1[p1]];
+  ++cnt[PAIR_C0[p2]]; ++cnt[PAIR_C1[p2]];
+  ++cnt[PAIR_C0[p3]]; ++cnt[PAIR_C1[p3]];
+  return cnt[0] == 2 && cnt[1] == 2 && cnt[2] == 2 && cnt[3] == 2;
+}
+
 static void tile_select(const float mag[4][4], unsigned pr[4]) {
+  float s[4][6];
+  for (int r = 0; r < 4; ++r)
+    for (int p = 0; p < 6; ++p) s[r][p] = mag[r][PAIR_C0[p]] + mag[r][PAIR_C1[p]];
+  float best = -1.0f;
+  pr[0] = pr[1] = pr[2] = pr[3] = 0;
+  for (unsigned p0 = 0; p0 < 6; ++p0)
+    for (unsigned p1 = 0; p1 < 6; ++p1) {
+      float bb = -1.0f;
+      unsigned b2 = 0, b3 = 0;
+      for (unsigned p2 = 0; p2 < 6; ++p2)
+        for (unsigned p3 = 0; p3 < 6; ++p3) {
+          if (!tile_valid(p0, p1, p2, p3)) continue;
+          const float b = s[2][p2] + s[3][p3];
+          if (b > bb) {
+            bb = b;
+            b2 = p2; b3 = p3;
+          }
+        }
+      const float sc = (s[0][p0] + s[1][p1]) + bb;
+      if (sc > best) {
+        best = sc;
+        pr[0] = p0; pr[1] = p1; pr[2] = b2; pr[3] = b3;
+      }
+    }
+}
+
+/* Round 1's statement of the rule: first strictly greatest of all 90 totals in lexicographic order.  Test aid. */
+static void tile_select_exhaustive(const float mag[4][4], unsigned pr[4]) {
   float s[4][6];
   for (int r = 0; r < 4; ++r)
     for (int p = 0; p < 6; ++p) s[r][p] = mag[r][PAIR_C0[p]] + mag[r][PAIR_C1[p]];
@@ -216,18 +262,36 @@ static void tile_select(const float mag[4][4], unsigned pr[4]) {
     for (unsigned p1 = 0; p1 < 6; ++p1)
       for (unsigned p2 = 0; p2 < 6; ++p2)
         for (unsigned p3 = 0; p3 < 6; ++p3) {
-          unsigned cnt[4] = {0, 0, 0, 0};
-          ++cnt[PAIR_C0[p0]]; ++cnt[PAIR_C1[p0]];
-          ++cnt[PAIR_C0[p1]]; ++cnt[PAIR_C1[p1]];
-          ++cnt[PAIR_C0[p2]]; ++cnt[PAIR_C1[p2]];
-          ++cnt[PAIR_C0[p3]]; ++cnt[PAIR_C1[p3]];
-          if (cnt[0] != 2 || cnt[1] != 2 || cnt[2] != 2 || cnt[3] != 2) continue;
+          if (!tile_valid(p0, p1, p2, p3)) continue;
           const float sc = (s[0][p0] + s[1][p1]) + (s[2][p2] + s[3][p3]);
           if (sc > best) {
             best = sc;
             pr[0] = p0; pr[1] = p1; pr[2] = p2; pr[3] = p3;
           }
         }
+}
+
+/* Both statements on one tile of fp32 magnitudes: keep masks (bit 4*row + col) and scores.  Test aid. */
+int sm_tile_select_both_ref(const float* mag16, unsigned* mask_two_level, unsigned* mask_exhaustive, float* score_two_level,
+                            float* score_exhaustive) {
+  float mag[4][4];
+  for (int r = 0; r < 4; ++r)
+    for (int c = 0; c < 4; ++c) mag[r][c] = mag16[4 * r + c];
+  unsigned pa[4], pb[4];
+  tile_select(mag, pa);
+  tile_select_exhaustive(mag, pb);
+  unsigned ma = 0, mb = 0;
+  float sa = 0.0f, sb = 0.0f, ra[4], rb[4];
+  for (int r = 0; r < 4; ++r) {
+    ma |= (1u << (4 * r + PAIR_C0[pa[r]])) | (1u << (4 * r + PAIR_C1[pa[r]]));
+    mb |= (1u << (4 * r + PAIR_C0[pb[r]])) | (1u << (4 * r + PAIR_C1[pb[r]]));
+    ra[r] = mag[r][PAIR_C0[pa[r]]] + mag[r][PAIR_C1[pa[r]]];
+    rb[r] = mag[r][PAIR_C0[pb[r]]] + mag[r][PAIR_C1[pb[r]]];
+  }
+  sa = (ra[0] + ra[1]) + (ra[2] + ra[3]);
+  sb = (rb[0] + rb[1]) + (rb[2] + rb[3]);
+  *mask_two_level = ma; *mask_exhaustive = mb; *score_two_level = sa; *score_exhaustive = sb;
+  return SM_OK;
 }
 
 static inline float mag16(uint16_t v) {

@@ -69,6 +69,15 @@ def prune24(A, m, k, ld, alg=STRIP, bf16=False):
     return out
 
 
+def tile_select_both(mag):
+    """(mask two-level, mask exhaustive, score two-level, score exhaustive) of one 4x4 tile of fp32 magnitudes."""
+    mag = np.ascontiguousarray(mag, dtype=np.float32).reshape(16)
+    ma, mb = ctypes.c_uint(0), ctypes.c_uint(0)
+    sa, sb = ctypes.c_float(0), ctypes.c_float(0)
+    _ok(lib().sm_tile_select_both_ref(_p(mag), ctypes.byref(ma), ctypes.byref(mb), ctypes.byref(sa), ctypes.byref(sb)), "tile_select_both")
+    return ma.value, mb.value, sa.value, sb.value
+
+
 def prune24_check(A, m, k, ld):
     v = ctypes.c_int(-1)
     fn = getattr(lib(), "sm_prune24_check_%s_ref" % _sfx(A))

@@ -70,6 +70,8 @@ _SIGS = {
     "sm_fill_uniform_f16": [_c_ptr, _c_size, ctypes.c_uint64, _c_f, _c_f, _c_ptr],
     "sm_fill_uniform_f32": [_c_ptr, _c_size, ctypes.c_uint64, _c_f, _c_f, _c_ptr],
 }
+_SIGS["sm_prune24_compress24_f16"] = [_c_ptr, _c_ptr, _c_size, _c_size, _c_size, _c_size, _c_size, _c_ptr, _c_ptr, _c_i, _c_ptr]
+_SIGS["sm_prune24_compress24_bf16"] = _SIGS["sm_prune24_compress24_f16"]
 _SIGS["sm_transpose"] = [_c_ptr, _c_ptr] + [_c_size] * 8 + [_c_ptr]
 _SIGS["sm_conv_out_size"] = [_c_size, _c_size, _c_size, _c_size, _c_size, ctypes.POINTER(_c_size)]
 _SIGS["sm_im2col_f16"] = [_c_ptr] + [_c_size] * 9 + [_c_ptr, _c_ptr]
@@ -218,6 +220,24 @@ def compress24_size(m, k, elt_bytes, batch=1):
 def compress24(A, m, k, ld, batch, strideA, blob):
     fn = getattr(lib(), "sm_compress24_" + _sfx(A))
     _check(fn(_dev(A), m, k, ld, batch, strideA, _dev(blob), _stream()), "sm_compress24")
+
+
+def prune24_compress24(A_in, A_out, m, k, ld, batch, strideA, blob, d_valid, alg=PRUNE_TILE):
+    """prune -> check -> compress in one pass (spmma.hxx:82-104); A_out / blob / d_valid may be None."""
+    fn = getattr(lib(), "sm_prune24_compress24_" + _sfx(A_in))
+    opt = lambda t: _dev(t) if t is not None else None
+    _check(fn(_dev(A_in), opt(A_out), m, k, ld, batch, strideA, opt(blob), opt(d_valid), alg, _stream()), "sm_prune24_compress24")
+
+
+API_SPMMA_SEQUENCE = ("sm_prune24_compress24 (TILE prune out of place from the dense A + check flag + blob, one pass) -> "
+                      "sm_spmma; the flag stays on the device (the reference reads it back and synchronises, spmma.hxx:89-92)")
+
+
+def api_spmma_step(A, Apruned, B, C, blob, d_valid, m, n, k, batch):
+    """One call of sparsifyme::spmma() as device work (reference spmma.hxx:82-113): TILE prune (A -> Apruned, the bytes of
+    an in-place prune without destroying the bench's operand), check, compress, multiply."""
+    prune24_compress24(A, Apruned, m, k, k, batch, m * k, blob, d_valid, PRUNE_TILE)
+    spmma(blob, B, C, m, n, k, batch, 0)
 
 
 def decompress24(blob, m, k, ld, batch, strideA, A):

@@ -36,39 +36,20 @@ __device__ __forceinline__ float mag_sel(T v) {
   else return mag_of(v);
 }
 
-// Two tiles at once: every add of the rule (24 pair sums, 36 + 36 partial sums, 90 totals per tile) is a packed
-// v_pk_add_f32 on {tile 0, tile 1}; only the compare / select tail stays per tile.  Same candidate order, same
-// fp32 association as tile_keepmask, so the two agree bit for bit.
+// Two tiles of one thread (4 rows x 8 columns, 16-byte accesses): the rule of select24.h on each.
 typedef float f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void tile_keepmask2(const f2 (&mag)[4][4], unsigned& keep0, unsigned& keep1) {
-  f2 s0[6], s1[6], s2[6], s3[6];
-#define SM_PAIRS(S, R)            \
-  S[0] = mag[R][0] + mag[R][1];   \
-  S[1] = mag[R][0] + mag[R][2];   \
-  S[2] = mag[R][0] + mag[R][3];   \
-  S[3] = mag[R][1] + mag[R][2];   \
-  S[4] = mag[R][1] + mag[R][3];   \
-  S[5] = mag[R][2] + mag[R][3];
-  SM_PAIRS(s0, 0) SM_PAIRS(s1, 1) SM_PAIRS(s2, 2) SM_PAIRS(s3, 3)
-#undef SM_PAIRS
-  float best0 = -1.0f, best1 = -1.0f;
-  unsigned bm0 = 0, bm1 = 0;
-#define TILE_CAND(I, P0, P1, P2, P3, MK)                        \
-  {                                                             \
-    const f2 sc = (s0[P0] + s1[P1]) + (s2[P2] + s3[P3]);        \
-    if (sc[0] > best0) {                                        \
-      best0 = sc[0];                                            \
-      bm0 = MK;                                                 \
-    }                                                           \
-    if (sc[1] > best1) {                                        \
-      best1 = sc[1];                                            \
-      bm1 = MK;                                                 \
-    }                                                           \
-  }
-#include "tile_patterns.inc"
-#undef TILE_CAND
-  keep0 = bm0;
-  keep1 = bm1;
+  float m0[4][4], m1[4][4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      m0[r][c] = mag[r][c][0];
+      m1[r][c] = mag[r][c][1];
+    }
+  keep0 = tile_keepmask(m0);
+  __builtin_amdgcn_sched_barrier(0);  // one tile after the other: interleaved, the two rules' live values double the registers
+  keep1 = tile_keepmask(m1);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -613,6 +594,14 @@ static int launch_check(const void* A, size_t m, size_t k, size_t ld, int* d_val
   if (m == 0 || k == 0) return SM_STATUS_SUCCESS;
   const bool vec_ok = vec_ok_2d<T>(A, A, ld, 0);
   prune_check_kernel<T><<<stream_grid(m * ceil_div(k, 8), 256), 256, 0, st>>>((const T*)A, m, k, ld, vec_ok, d_valid);
+  return check_launch("prune_check_kernel");
+}
+
+// the check kernel without the reset of the flag (prune_fused.hip: one flag over several batch matrices)
+int prune_check_accumulate_u16(const void* A, size_t m, size_t k, size_t ld, int* d_valid, hipStream_t st) {
+  if (m == 0 || k == 0) return SM_STATUS_SUCCESS;
+  const bool vec_ok = vec_ok_2d<uint16_t>(A, A, ld, 0);
+  prune_check_kernel<uint16_t><<<stream_grid(m * ceil_div(k, 8), 256), 256, 0, st>>>((const uint16_t*)A, m, k, ld, vec_ok, d_valid);
   return check_launch("prune_check_kernel");
 }
 

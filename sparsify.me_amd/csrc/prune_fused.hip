@@ -1,0 +1,298 @@
+// prune_fused.hip -- the prune / check / compress steps of sparsifyme::spmma() (reference
+// include/sparsify.me/spmma.hxx:82-104: cusparseLtSpMMAPrune TILE in place, cusparseLtSpMMAPruneCheck + readback,
+// cusparseLtSpMMACompress) as ONE pass over A: read the dense operand once, write the pruned operand, the compressed
+// blob and the validity flag.  Bytes per element of A (s = 2): read s, write s + s/2 + 1/8 -- 2.56 s instead of the
+// 2 s + s + 1.56 s of the three separate launches.  HBM-bound; the TILE rule is ~260 VALU per 4x4 tile (select24.h).
+//
+// Work item = 4 rows x 8 columns (two TILE tiles, or eight strips) of one batch matrix: a lane moves 16 bytes per row
+// per access, lanes run along k, so a wave-instruction covers up to 1 KiB of one row; the four 8-byte value pieces of
+// an item go to four consecutive blob rows of one stage plane, the item's four metadata bytes are gathered across
+// the lane quad with DPP so that one lane stores a dword per row.
+#include "sm_common.h"
+#include "select24.h"
+
+namespace sm {
+
+// magnitudes of the two 16-bit elements of a dword as fp32 for the TILE sums; NaN -> +inf: the magnitude bits are
+// clamped to the infinity pattern (integer min) before the conversion.  (Written on scalar halves: extracting element 1
+// of a packed 16-bit min result is miscompiled by this toolchain -- the high half's conversion disappears.)
+template <bool BF>
+__device__ __forceinline__ void mag2(uint32_t d, float& lo, float& hi) {
+  constexpr uint32_t LIM = BF ? 0x7f80u : 0x7c00u;
+  const uint32_t a = d & 0x7fff7fffu;
+  uint32_t l = a & 0xffffu, h = a >> 16;
+  l = l < LIM ? l : LIM;
+  h = h < LIM ? h : LIM;
+  if constexpr (BF) {
+    lo = __builtin_bit_cast(float, l << 16);
+    hi = __builtin_bit_cast(float, h << 16);
+  } else {
+    lo = (float)__builtin_bit_cast(_Float16, (uint16_t)l);
+    hi = (float)__builtin_bit_cast(_Float16, (uint16_t)h);
+  }
+}
+
+// AND-mask a strip {d0 = x1:x0, d1 = x3:x2} with its 4-bit keep-mask (pruned positions become +0)
+__device__ __forceinline__ void strip_mask(uint32_t d0, uint32_t d1, uint32_t rm, uint32_t& o0, uint32_t& o1) {
+  const uint32_t m0 = (uint32_t)__builtin_amdgcn_sbfe((int)rm, 0, 1), m1 = (uint32_t)__builtin_amdgcn_sbfe((int)rm, 1, 1);
+  const uint32_t m2 = (uint32_t)__builtin_amdgcn_sbfe((int)rm, 2, 1), m3 = (uint32_t)__builtin_amdgcn_sbfe((int)rm, 3, 1);
+  o0 = d0 & __builtin_amdgcn_perm(m1, m0, 0x07060100u);
+  o1 = d1 & __builtin_amdgcn_perm(m3, m2, 0x07060100u);
+}
+
+struct PruneFusedArgs {
+  const uint16_t* A_in;
+  uint16_t* A_out;      // may be null (no pruned copy wanted) or alias A_in
+  uint16_t* vals;       // blob values, stage-major [kc/64][M][32]; null = no blob
+  unsigned char* meta;  // blob metadata [kc/64][M][8]
+  int* d_valid;         // null = no flag
+  size_t m, ld, strideA, M;
+  unsigned rows;        // FLAT: rows of the one tall matrix (m * batch); else unused
+  unsigned trows;       // tile rows per batch matrix (non-FLAT)
+  unsigned gtr_total;   // tile rows in all
+  unsigned ppr;         // 8-column items per row (k / 8)
+  unsigned lpr_log2;    // lanes along k per tile row: the largest power of two <= 64 that divides ppr
+};
+
+// Mapping (no integer division on the FLAT path): a wave covers 64 >> lpr_log2 consecutive tile rows x LPR consecutive
+// 8-column items per pass -- each row of a pass is read in whole 128-byte lines or more -- and walks the row's
+// k / (8 LPR) passes before it moves to its next group of tile rows (grid-stride over waves).  The next pass's four
+// 16-byte loads are issued before the current pass's selection starts.
+// FLAT: the batch is one tall matrix (contiguous batches and m % 4 == 0, or batch == 1).
+template <bool BF, bool TILE, bool FLAT>
+__global__ __launch_bounds__(256) void prune_compress_kernel(const PruneFusedArgs p) {
+  bool bad = false;
+  const unsigned lane = threadIdx.x & 63u;
+  const unsigned wave_g = blockIdx.x * 4u + (threadIdx.x >> 6), nwaves = gridDim.x * 4u;
+  const unsigned lg = p.lpr_log2, rw = lane >> lg, pcl = lane & ((1u << lg) - 1u), rpw = 64u >> lg;
+  const unsigned nj = p.ppr >> lg;
+  const unsigned ngroups = (p.gtr_total + rpw - 1u) / rpw;  // wave-uniform
+
+  struct Pos {
+    size_t aoff;      // element offset of the item's first row in A
+    size_t R0;        // blob row of the item's first row
+    unsigned nrows;   // valid rows of the item (0..4)
+    unsigned pc;
+  };
+  auto locate = [&](unsigned g, unsigned j) {
+    Pos q;
+    const unsigned gtr = g * rpw + rw;
+    q.pc = (j << lg) + pcl;
+    if constexpr (FLAT) {
+      const unsigned r0 = gtr * 4u;
+      q.nrows = gtr < p.gtr_total ? (p.rows - r0 < 4u ? p.rows - r0 : 4u) : 0u;
+      q.aoff = (size_t)r0 * p.ld + (size_t)q.pc * 8u;
+      q.R0 = r0;
+    } else {
+      const unsigned b = gtr / p.trows, tr = gtr - b * p.trows, r0 = tr * 4u;
+      const unsigned left = (unsigned)p.m - r0;
+      q.nrows = gtr < p.gtr_total ? (left < 4u ? left : 4u) : 0u;
+      q.aoff = (size_t)b * p.strideA + (size_t)r0 * p.ld + (size_t)q.pc * 8u;
+      q.R0 = (size_t)b * p.m + r0;
+    }
+    return q;
+  };
+  auto load = [&](const Pos& q, u4 (&v)[4]) {
+    const uint16_t* src = p.A_in + q.aoff;
+#pragma unroll
+    for (unsigned r = 0; r < 4; ++r) {
+      v[r] = r < q.nrows ? __builtin_nontemporal_load(reinterpret_cast<const u4*>(src)) : u4{0u, 0u, 0u, 0u};
+      src += p.ld;
+    }
+  };
+
+  // wave-level work units u = g * nj + j, grid-stride over waves; (g, j) advance without a division per pass
+  const unsigned long long units = (unsigned long long)ngroups * nj;
+  if (wave_g >= units) return;
+  unsigned g = wave_g / nj, j = wave_g - g * nj;
+  const unsigned dg = nwaves / nj, dj = nwaves - dg * nj;
+  unsigned long long u = wave_g;
+  Pos cur = locate(g, j);
+  u4 v[4];
+  load(cur, v);
+  for (;;) {
+    // next pass of this wave (wave-uniform counters)
+    unsigned gn = g + dg, jn = j + dj;
+    if (jn >= nj) {
+      jn -= nj;
+      ++gn;
+    }
+    const bool more = u + nwaves < units;
+    Pos nxt = cur;
+    u4 vn[4];
+    if (more) {
+      nxt = locate(gn, jn);
+      load(nxt, vn);
+    }
+
+    // pruned dwords o, and what sm_compress24 stores for the pruned strip: the STRIP selection of ITS values (kept
+    // pair in position order + nibble).  For the STRIP rule that is the selection itself; for the TILE rule it differs
+    // from the TILE positions exactly when TILE kept a zero (the blob then names the lowest-index zeros), and a blob
+    // must be the bytes of compress(prune(A)).
+    uint32_t o[4][4], kp[4][2], nb[4][2];
+    bool ok2 = true;
+    if constexpr (TILE) {
+#pragma unroll
+      for (unsigned t = 0; t < 2; ++t) {
+        float mag[4][4];
+#pragma unroll
+        for (unsigned r = 0; r < 4; ++r) {
+          mag2<BF>(v[r][2 * t], mag[r][0], mag[r][1]);
+          mag2<BF>(v[r][2 * t + 1], mag[r][2], mag[r][3]);
+        }
+        unsigned top, bot;
+        tile_select_pairs(mag, top, bot);
+        const unsigned pr[4] = {top >> 3, top & 7u, bot >> 3, bot & 7u};
+#pragma unroll
+        for (unsigned r = 0; r < 4; ++r) {
+          const uint32_t rm = pair_rowmask(pr[r]);
+          ok2 &= __builtin_popcount(rm) <= 2;  // what is about to be written
+          strip_mask(v[r][2 * t], v[r][2 * t + 1], rm, o[r][2 * t], o[r][2 * t + 1]);
+          strip_select_f16(o[r][2 * t], o[r][2 * t + 1], kp[r][t], nb[r][t]);
+        }
+      }
+    } else {
+#pragma unroll
+      for (unsigned r = 0; r < 4; ++r)
+#pragma unroll
+        for (unsigned t = 0; t < 2; ++t) {
+          strip_select_f16(v[r][2 * t], v[r][2 * t + 1], kp[r][t], nb[r][t]);
+          const uint32_t rm = (1u << (nb[r][t] & 3u)) | (1u << (nb[r][t] >> 2));
+          ok2 &= __builtin_popcount(rm) <= 2;
+          strip_mask(v[r][2 * t], v[r][2 * t + 1], rm, o[r][2 * t], o[r][2 * t + 1]);
+        }
+    }
+    bad |= !ok2;
+    const size_t stage = cur.pc >> 3;
+    const unsigned q2 = cur.pc & 7u;  // byte of the row's 8 metadata bytes / 8-byte piece of its 64 value bytes
+    uint16_t* dst = p.A_out ? p.A_out + cur.aoff : nullptr;
+    uint16_t* vdst = p.vals ? p.vals + (stage * p.M + cur.R0) * 32 + q2 * 4 : nullptr;
+    unsigned char* mdst = p.vals ? p.meta + (stage * p.M + cur.R0) * 8 + q2 : nullptr;
+#pragma unroll
+    for (unsigned r = 0; r < 4; ++r) {
+      const int mb = (int)(nb[r][0] | (nb[r][1] << 4));
+      // the four metadata bytes of a lane quad (same rows, same stage, consecutive q2) -> one dword
+      const unsigned b0 = (unsigned)__builtin_amdgcn_update_dpp(0, mb, 0x00, 0xf, 0xf, true);
+      const unsigned b1 = (unsigned)__builtin_amdgcn_update_dpp(0, mb, 0x55, 0xf, 0xf, true);
+      const unsigned b2 = (unsigned)__builtin_amdgcn_update_dpp(0, mb, 0xaa, 0xf, 0xf, true);
+      const unsigned b3 = (unsigned)__builtin_amdgcn_update_dpp(0, mb, 0xff, 0xf, 0xf, true);
+      if (r < cur.nrows) {
+        if (dst) *reinterpret_cast<u4*>(dst) = u4{o[r][0], o[r][1], o[r][2], o[r][3]};
+        if (vdst) {
+          __builtin_nontemporal_store(u2{kp[r][0], kp[r][1]}, reinterpret_cast<u2*>(vdst + r * 32));
+          if ((lane & 3u) == 0) *reinterpret_cast<unsigned*>(mdst + r * 8) = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+        }
+      }
+      if (dst) dst += p.ld;
+    }
+    if (!more) break;
+    u += nwaves;
+    g = gn;
+    j = jn;
+    cur = nxt;
+#pragma unroll
+    for (unsigned r = 0; r < 4; ++r) v[r] = vn[r];
+  }
+  if (p.d_valid && __any(bad)) {
+    if (lane == 0) atomicOr(p.d_valid, 1);
+  }
+}
+
+}  // namespace sm
+
+using namespace sm;
+
+// prune.hip
+extern "C" int sm_prune24_f16(const void*, void*, size_t, size_t, size_t, int, sm_stream_t);
+extern "C" int sm_prune24_bf16(const void*, void*, size_t, size_t, size_t, int, sm_stream_t);
+namespace sm {
+int prune_check_accumulate_u16(const void* A, size_t m, size_t k, size_t ld, int* d_valid, hipStream_t st);  // ORs into *d_valid
+}
+extern "C" int sm_compress24_f16(const void*, size_t, size_t, size_t, size_t, size_t, void*, sm_stream_t);
+
+template <bool BF>
+static int prune_compress16(const void* A_in, void* A_out, size_t m, size_t k, size_t ld, size_t batch, size_t strideA,
+                            void* blob, int* d_valid, int alg, sm_stream_t stream) {
+  const char* name = BF ? "sm_prune24_compress24_bf16" : "sm_prune24_compress24_f16";
+  if (!A_in || ld < k || (alg != SM_PRUNE_STRIP && alg != SM_PRUNE_TILE) || (blob && !aligned16(blob))) {
+    set_error("%s: invalid argument", name);
+    return SM_STATUS_INVALID_VALUE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (d_valid && hipMemsetAsync(d_valid, 0, sizeof(int), st) != hipSuccess) return check_launch("hipMemsetAsync(d_valid)");
+  if (m == 0 || k == 0 || batch == 0) return SM_STATUS_SUCCESS;
+  const bool fast = k % 64 == 0 && ld % 8 == 0 && strideA % 8 == 0 && aligned16(A_in) && (!A_out || aligned16(A_out)) &&
+                    batch * ceil_div(m, (size_t)4) < 0x3fffffffull && k / 8 < 0xffffffffull && m * batch < 0xfffffff0ull;
+  if (!fast) {
+    // shapes the one-pass kernel does not take (k % 64 != 0: the 7x7x3 stem layer; unaligned rows): the same three
+    // steps as separate launches, per batch matrix (a TILE never straddles two matrices)
+    int rc = SM_STATUS_SUCCESS;
+    const void* src = A_in;
+    // the batch as one tall matrix when its matrices are back to back and no TILE can straddle two of them
+    const bool tall = batch == 1 || (strideA == m * ld && (alg == SM_PRUNE_STRIP || m % 4 == 0));
+    const size_t nbm = tall ? 1 : batch, rows = tall ? m * batch : m;
+    if (A_out) {
+      for (size_t b = 0; b < nbm && rc == SM_STATUS_SUCCESS; ++b) {
+        const uint16_t* ai = (const uint16_t*)A_in + b * strideA;
+        uint16_t* ao = (uint16_t*)A_out + b * strideA;
+        rc = BF ? sm_prune24_bf16(ai, ao, rows, k, ld, alg, stream) : sm_prune24_f16(ai, ao, rows, k, ld, alg, stream);
+      }
+      src = A_out;
+    } else if (alg == SM_PRUNE_TILE && blob) {
+      set_error("%s: TILE + blob without A_out needs k %% 64 == 0 and 16-byte aligned rows", name);
+      return SM_STATUS_NOT_SUPPORTED;
+    }
+    if (rc == SM_STATUS_SUCCESS && d_valid && A_out) {
+      // the flag of every batch matrix is OR-ed into *d_valid (zeroed above)
+      for (size_t b = 0; b < nbm && rc == SM_STATUS_SUCCESS; ++b)
+        rc = prune_check_accumulate_u16((const uint16_t*)A_out + b * strideA, rows, k, ld, d_valid, st);
+    }
+    if (rc == SM_STATUS_SUCCESS && blob) rc = sm_compress24_f16(src, m, k, ld, batch, strideA, blob, stream);
+    return rc;
+  }
+  const BlobLayout L = blob_layout(m, k, 2, batch);
+  if (blob) {  // zero the alignment gaps so a blob is a pure function of its input (as sm_compress24_*)
+    const size_t vbytes = L.M * (L.kc / 2) * 2, mbytes = L.M * (L.kc / 8);
+    if (L.meta_off > vbytes && hipMemsetAsync((char*)blob + vbytes, 0, L.meta_off - vbytes, st) != hipSuccess)
+      return check_launch("hipMemsetAsync");
+    if (L.total > L.meta_off + mbytes &&
+        hipMemsetAsync((char*)blob + L.meta_off + mbytes, 0, L.total - L.meta_off - mbytes, st) != hipSuccess)
+      return check_launch("hipMemsetAsync");
+  }
+  PruneFusedArgs a = {};
+  a.A_in = (const uint16_t*)A_in;
+  a.A_out = (uint16_t*)A_out;
+  a.vals = (uint16_t*)blob;
+  a.meta = blob ? (unsigned char*)blob + L.meta_off : nullptr;
+  a.d_valid = d_valid;
+  a.m = m; a.ld = ld; a.strideA = strideA; a.M = L.M;
+  const bool flat = batch == 1 || (strideA == m * ld && m % 4 == 0);
+  a.rows = (unsigned)(flat ? m * batch : 0);
+  a.trows = (unsigned)ceil_div(m, (size_t)4);
+  a.gtr_total = (unsigned)(flat ? ceil_div(m * batch, (size_t)4) : batch * a.trows);
+  a.ppr = (unsigned)(k / 8);
+  a.lpr_log2 = 3;  // k % 64 == 0: ppr is a multiple of 8
+  while (a.lpr_log2 < 6 && a.ppr % (2u << a.lpr_log2) == 0) ++a.lpr_log2;
+  const size_t wave_units = ceil_div((size_t)a.gtr_total, (size_t)(64u >> a.lpr_log2));
+  size_t blocks = ceil_div(wave_units, (size_t)4);
+  const size_t cap = (size_t)device_cu_count() * 8;  // 2 blocks per SIMD: the kernel holds ~3 waves per SIMD
+  if (blocks > cap) blocks = cap;
+  const unsigned grid = (unsigned)(blocks ? blocks : 1);
+  if (alg == SM_PRUNE_TILE) {
+    if (flat) prune_compress_kernel<BF, true, true><<<grid, 256, 0, st>>>(a);
+    else prune_compress_kernel<BF, true, false><<<grid, 256, 0, st>>>(a);
+  } else {
+    if (flat) prune_compress_kernel<BF, false, true><<<grid, 256, 0, st>>>(a);
+    else prune_compress_kernel<BF, false, false><<<grid, 256, 0, st>>>(a);
+  }
+  return check_launch("prune_compress_kernel");
+}
+
+extern "C" int sm_prune24_compress24_f16(const void* A_in, void* A_out, size_t m, size_t k, size_t ld, size_t batch, size_t strideA,
+                                         void* blob, int* d_valid, int alg, sm_stream_t stream) {
+  return prune_compress16<false>(A_in, A_out, m, k, ld, batch, strideA, blob, d_valid, alg, stream);
+}
+extern "C" int sm_prune24_compress24_bf16(const void* A_in, void* A_out, size_t m, size_t k, size_t ld, size_t batch,
+                                          size_t strideA, void* blob, int* d_valid, int alg, sm_stream_t stream) {
+  return prune_compress16<true>(A_in, A_out, m, k, ld, batch, strideA, blob, d_valid, alg, stream);
+}

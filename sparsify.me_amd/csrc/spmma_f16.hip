@@ -379,7 +379,7 @@ __global__ __launch_bounds__(64 * WM * WN) void spmma_f16_dma_kernel(const Spmma
 template <int BM, int BN, int WM, int WN, int NL, int NS, bool BF = false>
 __global__ __launch_bounds__(64 * (WM * WN + NL)) void spmma_f16_pc_kernel(const SpmmaArgs p) {
   constexpr int NC = WM * WN, NW = NC + NL;
-  static_assert(NS >= 2 && NS <= 4, "ring depth");
+  static_assert(NS >= 2 && NS <= 6, "ring depth");
   constexpr int TM = BM / WM, TN = BN / WN, FM = TM / 16, FN = TN / 16;
   static_assert(FM >= 1 && FN >= 1, "wave tile");
   constexpr int SA = BM * 64, SM_ = BM * 8, SB = 64 * BN * 2, STAGE = SA + SM_ + SB;
@@ -389,6 +389,7 @@ __global__ __launch_bounds__(64 * (WM * WN + NL)) void spmma_f16_pc_kernel(const
   constexpr int LPS = W / NL;            // least any loader wave issues per stage: the vmcnt unit (a wave
                                          // with one more then waits slightly longer than it must -- safe)
   static_assert(LPS >= 1, "loader waves");
+  static_assert((NS - 2) * ((W + NL - 1) / NL) <= 63, "the counted vmcnt must fit its 6-bit field");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const unsigned tid = threadIdx.x, lane = tid & 63u;
@@ -483,7 +484,9 @@ __global__ __launch_bounds__(64 * (WM * WN + NL)) void spmma_f16_pc_kernel(const
       asm volatile("s_barrier" ::: "memory");
       unsigned long long s2 = sm_stamp(); tb += s2 - s1;
 #else
-      if (NS >= 4 && ahead == 2) wait_dma_and_barrier<2 * LPS>();
+      if (NS >= 6 && ahead == 4) wait_dma_and_barrier<4 * LPS>();
+      else if (NS >= 5 && ahead == 3) wait_dma_and_barrier<3 * LPS>();
+      else if (NS >= 4 && ahead == 2) wait_dma_and_barrier<2 * LPS>();
       else if (NS >= 3 && ahead == 1) wait_dma_and_barrier<LPS>();
       else wait_dma_and_barrier<0>();
 #endif
@@ -683,8 +686,20 @@ static int spmma16(const void* blob, const void* B, void* C, size_t m, size_t n,
     int nl = (k >= 512 && n > 64) ? 4 : 0, pns = 3;
     if (pc_env) sscanf(pc_env, "%dx%d", &nl, &pns);
     if (nl == 256 && n > 64) {  // tuning aid: 256 x 128 tiles, 8 consumer waves (64 x 64) + 4 loaders, 64-deep stages
-      return pns >= 3 ? launch_pc<256, 128, 4, 2, 4, 3, BF>(a, st) : launch_pc<256, 128, 4, 2, 4, 2, BF>(a, st);
+      return pns >= 4 ? launch_pc<256, 128, 4, 2, 4, 4, BF>(a, st) : (pns == 3 ? launch_pc<256, 128, 4, 2, 4, 3, BF>(a, st) : launch_pc<256, 128, 4, 2, 4, 2, BF>(a, st));
     }
+#ifdef SM_TUNING
+    if (pc_env && n > 64) {  // deep rings / more loaders / 8 consumer waves on 128 x 128 tiles: "<nl>x<ns>x<c>", c = 4 or 8 consumers
+      int cw = 4;
+      sscanf(pc_env, "%*dx%*dx%d", &cw);
+      if (cw == 8) {
+        if (nl == 8) return pns >= 5 ? launch_pc<128, 128, 2, 4, 8, 5, BF>(a, st) : (pns == 4 ? launch_pc<128, 128, 2, 4, 8, 4, BF>(a, st) : launch_pc<128, 128, 2, 4, 8, 3, BF>(a, st));
+        return pns >= 5 ? launch_pc<128, 128, 2, 4, 4, 5, BF>(a, st) : (pns == 4 ? launch_pc<128, 128, 2, 4, 4, 4, BF>(a, st) : launch_pc<128, 128, 2, 4, 4, 3, BF>(a, st));
+      }
+      if (nl == 8) return pns >= 6 ? launch_pc<128, 128, 2, 2, 8, 6, BF>(a, st) : (pns == 5 ? launch_pc<128, 128, 2, 2, 8, 5, BF>(a, st) : (pns == 4 ? launch_pc<128, 128, 2, 2, 8, 4, BF>(a, st) : launch_pc<128, 128, 2, 2, 8, 3, BF>(a, st)));
+      if (nl == 4 && pns >= 5) return pns >= 6 ? launch_pc<128, 128, 2, 2, 4, 6, BF>(a, st) : launch_pc<128, 128, 2, 2, 4, 5, BF>(a, st);
+    }
+#endif
     if (nl > 0) {
       if (n <= 64) {
         if (nl == 2) return pns >= 3 ? launch_pc<128, 64, 4, 1, 2, 3, BF>(a, st) : launch_pc<128, 64, 4, 1, 2, 2, BF>(a, st);

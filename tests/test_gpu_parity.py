@@ -168,6 +168,86 @@ def test_compress24_bit_exact(gpu, orc, dtype, shape, pruned_first):
 
 
 # ---------------------------------------------------------------------------------------------
+# (a2 + a3) prune -> check -> compress in one pass, as sparsifyme::spmma() runs them (spmma.hxx:82-104)
+# ---------------------------------------------------------------------------------------------
+PC_SHAPES = [(4, 64, 64, 1, 0), (196, 512, 512, 2, 0), (130, 128, 128, 3, 0), (130, 128, 136, 3, 24), (7, 64, 64, 5, 0),
+             (784, 1152, 1152, 1, 0), (33, 576, 576, 2, 0), (257, 64, 72, 1, 0),
+             # shapes the one-pass kernel does not take (k % 64 != 0, odd leading dimension): the three-launch sequence
+             (12, 147, 147, 2, 0), (20, 72, 72, 2, 0), (9, 8, 8, 3, 0)]
+
+
+@pytest.mark.parametrize("alg", [0, 1], ids=["tile", "strip"])
+@pytest.mark.parametrize("shape", PC_SHAPES)
+@pytest.mark.parametrize("bf", [False, True], ids=["f16", "bf16"])
+def test_prune_compress_one_pass_bit_exact(gpu, orc, alg, shape, bf):
+    """sm_prune24_compress24_*: pruned A, blob and flag must be the bytes of prune (per batch matrix) + check +
+    compress of the oracle; in place and out of place; A_out / blob / flag individually optional."""
+    import torch
+    m, k, ld, batch, pad = shape
+    stride = m * ld + pad
+    rng = np.random.default_rng(m * 31 + k * 7 + alg + batch)
+    if bf:
+        A = bf16_bits(rng, batch * stride, "ties" if m % 2 else "uniform")
+    else:
+        A = bits(rand(rng, batch * stride, np.float16, "ties" if m % 2 else "uniform"))
+    if m == 196:   # specials: NaN, inf, signed zeros, subnormals
+        A[:16] = np.array([1.0, np.nan, np.inf, 2.0, -0.0, 0.0, -0.0, 0.0, np.nan, np.nan, np.nan, 1.0, 6e-8, -6e-8, 6e-8, 0.0],
+                          dtype=np.float16).view(np.uint16) if not bf else np.array([0x3f80, 0x7fc0, 0x7f80, 0x4000, 0x8000, 0, 0x8000, 0,
+                                                                                      0x7fc1, 0xffc0, 0x7fff, 0x3f80, 1, 0x8001, 1, 0], dtype=np.uint16)
+    want = A.copy()
+    for b in range(batch):
+        seg = want[b * stride:b * stride + m * ld]
+        seg[:] = orc.prune24(seg.copy(), m, k, ld, alg, bf16=bf)
+    want_blob = orc.compress24(want, m, k, ld, batch, stride)
+    todev = (lambda x: bf16_dev(x)) if bf else (lambda x: torch.from_numpy(x.view(np.int16)).cuda().view(torch.float16))
+    tohost = (lambda t: bf16_host(t)) if bf else (lambda t: bits(host(t)))
+    nbytes = gpu.compress24_size(m, k, 2, batch)
+    for in_place in (False, True):
+        dA = todev(A)
+        dOut = dA if in_place else todev(A)
+        blob = torch.full((nbytes,), 0xAB, dtype=torch.uint8, device="cuda")
+        valid = torch.full((1,), -5, dtype=torch.int32, device="cuda")
+        gpu.prune24_compress24(dA, dOut, m, k, ld, batch, stride, blob, valid, alg)
+        assert np.array_equal(tohost(dOut), want), f"pruned A differs (in_place={in_place})"
+        if not in_place:
+            assert np.array_equal(tohost(dA), A), "out-of-place call touched its input"
+        assert np.array_equal(host(blob), want_blob), "blob differs from compress(prune(A))"
+        assert int(host(valid)[0]) == 0
+    # optional outputs
+    blob2 = torch.full((nbytes,), 0xCD, dtype=torch.uint8, device="cuda")
+    dA = todev(A)
+    if alg == 1 or (k % 64 == 0 and ld % 8 == 0 and stride % 8 == 0):   # TILE without A_out needs the one-pass kernel
+        gpu.prune24_compress24(dA, None, m, k, ld, batch, stride, blob2, None, alg)
+        assert np.array_equal(host(blob2), want_blob) and np.array_equal(tohost(dA), A)
+    dOut = todev(A)
+    gpu.prune24_compress24(dA, dOut, m, k, ld, batch, stride, None, None, alg)
+    assert np.array_equal(tohost(dOut), want)
+
+
+def test_prune_compress_full_size_resnet50_layer(gpu, orc):
+    """One ResNet-50 layer at b = 32 (784 x 2304): the one-pass TILE kernel equals the three separate launches bit for
+    bit, and sampled tile rows equal the oracle."""
+    import torch
+    m, k, batch = 784, 2304, 32
+    dA = torch.empty(batch * m * k, dtype=torch.float16, device="cuda")
+    gpu.fill_uniform(dA, 0xA91, -1.0, 1.0)
+    P1 = dA.clone()
+    gpu.prune24(P1, P1, batch * m, k, k, gpu.PRUNE_TILE)
+    blob1 = torch.empty(gpu.compress24_size(m, k, 2, batch), dtype=torch.uint8, device="cuda")
+    gpu.compress24(P1, m, k, k, batch, m * k, blob1)
+    P2 = torch.empty_like(dA)
+    blob2 = torch.empty_like(blob1)
+    valid = torch.ones(1, dtype=torch.int32, device="cuda")
+    gpu.prune24_compress24(dA, P2, m, k, k, batch, m * k, blob2, valid, gpu.PRUNE_TILE)
+    assert torch.equal(P1.view(torch.int16), P2.view(torch.int16)) and torch.equal(blob1, blob2) and int(valid.item()) == 0
+    rows = 16
+    for b in (0, batch - 1):
+        seg = bits(host(dA[b * m * k: b * m * k + rows * k]))
+        want = orc.prune24(seg, rows, k, k, orc.TILE)
+        assert np.array_equal(bits(host(P2[b * m * k: b * m * k + rows * k])), want)
+
+
+# ---------------------------------------------------------------------------------------------
 # (a4) spmma and (a5) dense gemm
 # ---------------------------------------------------------------------------------------------
 # What the arithmetic allows, not just what north_star asks: the kernels accumulate in fp32 (k products, any order)

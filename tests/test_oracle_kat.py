@@ -448,3 +448,35 @@ def test_bell_and_coo_restatements(orc):
     orc.spmm_coo(rows, cols, 5, n, 2, r, c, v, Bcm, C2)
     for b in range(2):
         assert np.array_equal(C2[b * rows * n:(b + 1) * rows * n].reshape(n, rows).T, d2 @ B2[b])
+
+
+def test_tile_rule_two_level_statement_vs_exhaustive(orc):
+    """The TILE rule is frozen in its two-level statement (oracle/sm_oracle.c: tile_select; what the kernels compute
+    from csrc/tile_rule.inc).  It always reaches the same maximal fp32 score as round 1's exhaustive statement (first
+    strictly greatest of the 90 totals), picks the same pattern whenever the sums are exact (integers; fp16 data of
+    ordinary dynamic range), and can differ from it only through fp32 rounding collisions on data spanning many
+    binades -- one such tile is pinned here."""
+    rng = np.random.default_rng(2)
+    differing = 0
+    for trial in range(6000):
+        kind = trial % 3
+        if kind == 0:
+            mag = rng.integers(0, 4, 16).astype(np.float32)                      # heavy ties, exact sums
+        elif kind == 1:
+            mag = np.abs(rng.uniform(-1, 1, 16)).astype(np.float16).astype(np.float32)
+        else:
+            mag = (2.0 ** rng.integers(-20, 20, 16) * rng.uniform(1, 2, 16)).astype(np.float32)
+        ma, mb, sa, sb = orc.tile_select_both(mag)
+        assert sa == sb, "the two statements must reach the same maximal score"
+        for m_ in (ma, mb):   # two per row, two per column
+            bitsm = [(m_ >> i) & 1 for i in range(16)]
+            assert all(sum(bitsm[4 * r:4 * r + 4]) == 2 for r in range(4)) and all(sum(bitsm[c::4]) == 2 for c in range(4))
+        if kind < 2:
+            assert ma == mb, (mag, hex(ma), hex(mb))
+        differing += ma != mb
+    # a rounding collision (found by search): both patterns total 19200.771484375 in fp32
+    mag = np.array([0.5947265625, 61.4375, 3690.0, 0.111328125, 15016.0, 0.00022077560424804688, 0.0033855438232421875, 6.7578125,
+                    0.007778167724609375, 0.019287109375, 0.0550537109375, 4.5234375, 0.00018393993377685547, 0.01409912109375,
+                    0.04827880859375, 426.5], dtype=np.float32)
+    ma, mb, sa, sb = orc.tile_select_both(mag)
+    assert (ma, mb) == (0xa596, 0xc396) and sa == sb == np.float32(19200.771484375)

@@ -120,6 +120,12 @@ def main():
         def f_check():
             S = nxt(); sm.prune24_check(S["A2"], b * m, k, k, valid)
 
+        def f_api_pc():  # the prune + check + compress of sparsifyme::spmma() in one pass (TILE, out of place from the dense A)
+            S = nxt(); sm.prune24_compress24(S["A"], S["A2"], m, k, k, b, m * k, S["blob"], valid, sm.PRUNE_TILE)
+
+        def f_pc_strip():
+            S = nxt(); sm.prune24_compress24(S["A"], S["A2"], m, k, k, b, m * k, S["blob"], valid, sm.PRUNE_STRIP)
+
         def f_prune():
             S = nxt(); sm.sparsify(S["A2"][: m * k], mask, m, k, 0.5)
         stages = [
@@ -131,11 +137,15 @@ def main():
             ("prune_s", f_prune_s, 0, 2 * b * m * k * s, 0),
             ("prune_t", f_prune_t, 0, 2 * b * m * k * s, 0),
             ("check", f_check, 0, b * m * k * s, 0),
+            ("api_pc", f_api_pc, 0, b * m * k * (s + s + s / 2 + 1 / 8), 0),
+            ("pc_strip", f_pc_strip, 0, b * m * k * (s + s + s / 2 + 1 / 8), 0),
             ("prune", f_prune, 0, m * k * (s + s + 8), 0),
         ]
         rec = {"m": m, "n": n, "k": k, "b": b}
         for name, fn, fl, by, pk in stages:
             if only and name not in only:
+                continue
+            if name in ("api_pc", "pc_strip") and not h16:
                 continue
             ms = timeit(fn)
             roof = max(by / HBM, fl / pk if pk else 0.0)
