@@ -270,6 +270,18 @@ int sm_im2col_compress24_f16(const void* X, size_t N, size_t C, size_t H, size_t
 int sm_im2col_compress24_bf16(const void* X, size_t N, size_t C, size_t H, size_t W, size_t kh, size_t kw, size_t stride,
                               size_t pad, size_t dilation, void* blob, sm_stream_t stream);
 
+/* ---- implicit-GEMM form for convolution layers (extension; SURVEY.md 8(f) rank 3, datasets/get_shapes.py:30-40,66-73):
+ *      C[i][l][:] = alpha * prune24_strip(A_i)[l][:] * B + beta * C[i][l][:] with A_i = the im2col operand of image i
+ *      (sm_im2col_*'s layout: L = out_h * out_w rows, K = Cin * kh * kw columns), computed straight from the NCHW
+ *      activations X: neither the dense A nor its blob is ever written to or read from HBM.  B: K x n_out row-major
+ *      (shared by the images), C: N * L rows x n_out row-major.  Bit-identical to sm_im2col_compress24_* followed by
+ *      sm_spmma_* (m = L, k = K, batch = N, strideB = 0).  Needs K % 64 == 0, n_out % 8 == 0, an even W of at most ~120
+ *      columns and kh * kw <= 64; SM_STATUS_NOT_SUPPORTED otherwise (use the pair). */
+int sm_conv_spmma_fused_f16(const void* X, const void* B, void* C, size_t N, size_t Cin, size_t H, size_t W, size_t kh, size_t kw,
+                            size_t stride, size_t pad, size_t dilation, size_t n_out, float alpha, float beta, sm_stream_t stream);
+int sm_conv_spmma_fused_bf16(const void* X, const void* B, void* C, size_t N, size_t Cin, size_t H, size_t W, size_t kh, size_t kw,
+                             size_t stride, size_t pad, size_t dilation, size_t n_out, float alpha, float beta, sm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

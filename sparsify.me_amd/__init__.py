@@ -72,6 +72,8 @@ _SIGS = {
 }
 _SIGS["sm_prune24_compress24_f16"] = [_c_ptr, _c_ptr, _c_size, _c_size, _c_size, _c_size, _c_size, _c_ptr, _c_ptr, _c_i, _c_ptr]
 _SIGS["sm_prune24_compress24_bf16"] = _SIGS["sm_prune24_compress24_f16"]
+_SIGS["sm_conv_spmma_fused_f16"] = [_c_ptr, _c_ptr, _c_ptr] + [_c_size] * 10 + [_c_f, _c_f, _c_ptr]
+_SIGS["sm_conv_spmma_fused_bf16"] = _SIGS["sm_conv_spmma_fused_f16"]
 _SIGS["sm_transpose"] = [_c_ptr, _c_ptr] + [_c_size] * 8 + [_c_ptr]
 _SIGS["sm_conv_out_size"] = [_c_size, _c_size, _c_size, _c_size, _c_size, ctypes.POINTER(_c_size)]
 _SIGS["sm_im2col_f16"] = [_c_ptr] + [_c_size] * 9 + [_c_ptr, _c_ptr]
@@ -317,6 +319,13 @@ def im2col(X, N, C, H, W, kh, kw, stride, pad, dilation, out, compress=False):
     """NCHW activations -> the matmul operand A [N][L][C*kh*kw] (compress=False) or its 2:4 blob (compress=True)."""
     fn = getattr(lib(), ("sm_im2col_compress24_" if compress else "sm_im2col_") + _sfx(X))
     _check(fn(_dev(X), N, C, H, W, kh, kw, stride, pad, dilation, _dev(out), _stream()), "sm_im2col")
+
+
+def conv_spmma_fused(X, B, C, N, Cin, H, W, kh, kw, stride, pad, dilation, n_out, alpha=1.0, beta=0.0):
+    """Implicit-GEMM 2:4 convolution matmul straight from NCHW activations (no dense A, no blob)."""
+    fn = getattr(lib(), "sm_conv_spmma_fused_" + _sfx(X))
+    _check(fn(_dev(X), _dev(B), _dev(C), N, Cin, H, W, kh, kw, stride, pad, dilation, n_out, float(alpha), float(beta), _stream()),
+           "sm_conv_spmma_fused")
 
 
 def gemm_batched(A_ptrs, B_ptrs, C_ptrs, m, n, k, batch, dtype_suffix, alpha=1.0, beta=0.0, ta=0, tb=0):

@@ -1,0 +1,306 @@
+// conv_spmma.hip -- implicit-GEMM form of the hot path for convolution layers ("fuse im2col into
+// the A-tile loader so A is never materialised"; reference datasets/get_shapes.py:30-40,66-73 defines the operand:
+// A = unfold(X) transposed, m = L = out_h * out_w rows per image, k = C * kh * kw columns, column c * kh * kw + r * kw + u).
+//   C[n][l][:] = alpha * prune24_strip(A_n)[l][:] * B + beta * C[n][l][:]
+// straight from the NCHW activations X: neither the kh*kw-times larger dense A nor its 2:4 blob ever exists in HBM.
+// Bit-identical to sm_im2col_compress24_* followed by sm_spmma_* (same STRIP selection on the same values, the same
+// v_smfmac sequence per output element).
+//
+// Structure = the direct fused kernel (spmma_f16_fused.hip) with the dense-A stage replaced by an activation PATCH:
+//   workgroup = 128 consecutive output pixels of one image x BN output channels, 4 waves, wave w owns pixels 32w..32w+31
+//   and all BN columns; K advances in stages of 64 (c, r, u) columns = `nch` whole or partial input channels;
+//   per stage the workgroup brings, by LDS-DMA (4 bytes per lane, several patch rows per wave instruction), the input
+//   rows its pixels' windows touch for those channels into LDS -- [channel][input row][padl + W] halves, zero borders
+//   kept in place so the gather needs no bounds checks -- and the B tile [64][BN] as the other matmul kernels do;
+//   the lane that feeds row l, k-group g to the SMFMAC gathers its 16 values (2-byte LDS reads at
+//   patch + pixel_offset(l) + k_offset(k); the k offsets come from a table with one 64-entry row per phase of
+//   (64 * stage) mod (kh * kw), built once per workgroup), applies the 2:4 STRIP selection in registers and issues the
+//   SMFMACs.  Double-buffered stages, one barrier per stage.
+// HBM bytes: X once per column tile (+ halo re-reads served by L2) + B + C, instead of kh*kw times X.
+#include "mma_tile.h"
+
+namespace sm {
+
+struct ConvArgs {
+  const half_t* X;
+  const half_t* B;
+  half_t* C;
+  int N, Cin, H, W, kh, kw, stride, pad, dil, OH, OW, L, Nout, K, khkw;
+  int tiles_m, tiles_n;
+  int RI;      // patch rows per channel: (max output-row span of a tile) * stride + (kh - 1) * dil + 1
+  int pitch;   // patch row pitch in halves = padl + W (even); a row's right border is the next row's left border
+  int padl;    // zero halves in front of each row (even, >= pad and >= what (kw - 1) * dil - pad overshoots)
+  int rpi;     // patch rows per DMA wave-instruction = 64 / (pitch / 2)
+  int nch;     // input channels a 64-k stage can touch
+  int a_n;     // patch DMA instructions per stage
+  int patch_bytes;  // per stage buffer, 16-byte multiple (incl. the zero tail after the last row)
+  float alpha, beta;
+  int ablate;  // diagnostic timing builds (-DSM_TUNING, SM_CONV_ABLATE): 1 no patch DMA, 2 no gather, 4 no B DMA, 8 no SMFMAC; 0 in the product
+};
+
+__device__ __attribute__((aligned(256))) const unsigned char sm_conv_zero_page[256] = {0};
+
+template <int BN, bool BF>
+__global__ __launch_bounds__(256) void conv_spmma_fused_kernel(const ConvArgs p) {
+  constexpr int BM = 128, NW = 4, TM = 32, FM = 2, FN = BN / 16;
+  constexpr int SB = 64 * BN * 2, B_N = BN / 8;
+  constexpr int MAXA = 12;  // patch DMA slots per wave (a_n <= 48)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int STAGE = p.patch_bytes + SB;
+  // layout: [stage 0: patch | B][stage 1: patch | B][k-offset table: khkw rows of 64 u16]
+  char* tab = smem + 2 * STAGE;
+
+  const unsigned tid = threadIdx.x, lane = tid & 63u;
+  const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const unsigned tiles = (unsigned)p.tiles_m * (unsigned)p.tiles_n;
+  const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
+  const unsigned img = lid / tiles, trem = lid - img * tiles;
+  const unsigned tile_m = trem / (unsigned)p.tiles_n, tile_n = trem - tile_m * (unsigned)p.tiles_n;
+  const int m0 = (int)tile_m * BM, n0 = (int)tile_n * BN;
+  const int nkt = p.K / 64;
+  const int plast = (m0 + BM - 1 < p.L ? m0 + BM - 1 : p.L - 1);
+  const int oh_first = m0 / p.OW;
+  const int ih_lo = oh_first * p.stride - p.pad;  // input row of patch row 0
+  (void)plast;
+
+  // ---- once: zero both patch buffers (borders stay zero for the whole kernel: the DMA only writes the W data
+  //      columns of a row), build the k-offset table
+  for (unsigned o = tid * 16u; o < (unsigned)p.patch_bytes; o += 256u * 16u) {
+    *reinterpret_cast<u4*>(smem + o) = u4{0u, 0u, 0u, 0u};
+    *reinterpret_cast<u4*>(smem + STAGE + o) = u4{0u, 0u, 0u, 0u};
+  }
+  for (int e = (int)tid; e < p.khkw * 64; e += 256) {
+    const int phase = e >> 6, kk = e & 63;
+    const int q = phase + kk;                 // column index relative to the stage's first channel
+    const int c = q / p.khkw, rem = q - c * p.khkw, r3 = rem / p.kw, u = rem - r3 * p.kw;
+    reinterpret_cast<unsigned short*>(tab)[e] = (unsigned short)(((c * p.RI + r3 * p.dil) * p.pitch + u * p.dil) * 2);
+  }
+
+  // ---- per-lane DMA plan (fixed over the stages except for the channel base)
+  const int pdw = p.pitch >> 1;
+  const size_t chan_bytes = (size_t)p.H * p.W * 2;
+  const char* Ximg = reinterpret_cast<const char*>(p.X) + (size_t)img * p.Cin * chan_bytes;
+  long long a_src[MAXA];   // byte offset from Ximg + cbase * chan_bytes; < 0: this lane reads zeros
+  int a_ch[MAXA];          // channel (relative) of the lane's row, for the Cin bound
+  bool a_on[MAXA];         // lane takes part in slot i
+#pragma unroll
+  for (int i = 0; i < MAXA; ++i) {
+    const int t = (int)wave + NW * i;
+    const int prow = t * p.rpi + (int)lane / pdw, d = (int)lane % pdw;
+    const int ch = prow / p.RI, rr = prow - ch * p.RI, ih = ih_lo + rr;
+    a_on[i] = t < p.a_n && (int)lane < p.rpi * pdw && prow < p.nch * p.RI && d >= (p.padl >> 1) && d < (p.padl >> 1) + (p.W >> 1);
+    a_ch[i] = ch;
+    a_src[i] = (ih >= 0 && ih < p.H) ? (long long)(((size_t)ch * p.H + ih) * p.W * 2 + (size_t)(d - (p.padl >> 1)) * 4) : -1;
+  }
+  // B slots: B_N instructions of 8 k-rows x 128 B, instruction j -> wave j % 4
+  constexpr int SLB = (B_N + NW - 1) / NW;
+  const char* b_src[SLB];
+  unsigned b_lds[SLB];
+#pragma unroll
+  for (int i = 0; i < SLB; ++i) {
+    const unsigned j = wave + (unsigned)NW * i, panel = j >> 3, kr = 8u * (j & 7u) + (lane >> 3);
+    const unsigned cs = (lane & 7u) ^ b_swz(kr);
+    int gc = n0 + (int)(64u * panel + 8u * cs);
+    gc = gc <= p.Nout - 8 ? gc : p.Nout - 8;
+    b_src[i] = reinterpret_cast<const char*>(p.B + (size_t)kr * p.Nout + gc);
+    b_lds[i] = panel * 8192u + (j & 7u) * 1024u;
+  }
+  auto stage = [&](int kt, int buf) {
+    char* base = smem + buf * STAGE;
+    const int cbase = (64 * kt) / p.khkw;
+    const char* Xc = Ximg + (size_t)cbase * chan_bytes;
+#pragma unroll
+    for (int i = 0; i < MAXA; ++i) {
+      const int t = (int)wave + NW * i;  // wave-uniform
+      if (t >= p.a_n) break;
+      if (a_on[i] && !(p.ablate & 1)) {
+        const bool live = a_src[i] >= 0 && cbase + a_ch[i] < p.Cin;
+        gptr_t* g = live ? (gptr_t*)(Xc + a_src[i]) : (gptr_t*)(sm_conv_zero_page + 4u * lane);
+        __builtin_amdgcn_global_load_lds(g, (lptr_t*)(base + (size_t)t * p.rpi * pdw * 4), 4, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < SLB; ++i) {
+      const unsigned j = wave + (unsigned)NW * i;
+      if (j >= (unsigned)B_N) break;
+      if (p.ablate & 4) continue;
+      __builtin_amdgcn_global_load_lds((gptr_t*)(b_src[i] + (size_t)kt * 64 * p.Nout * 2), (lptr_t*)(base + p.patch_bytes + b_lds[i]), 16, 0, 0);
+    }
+  };
+
+  // ---- per-lane pixel offsets of the two 16-row fragments
+  const unsigned g = lane >> 4, r16 = lane & 15u;
+  unsigned poff[FM];
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+    int px = m0 + (int)(wave * TM + i * 16 + r16);
+    px = px < p.L ? px : p.L - 1;  // rows past the image: any valid pixel (their products are never stored)
+    const int oh = px / p.OW, ow = px - oh * p.OW;
+    poff[i] = (unsigned)((((oh - oh_first) * p.stride) * p.pitch + ow * p.stride + p.padl - p.pad) * 2);
+  }
+
+  f4 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+
+  __syncthreads();  // zeroed patches and the table are in place before any DMA lands / any gather reads
+  stage(0, 0);
+  for (int kt = 0; kt < nkt; ++kt) {
+    wait_dma_and_barrier<0>();  // stage kt landed for every wave; every wave finished reading the other buffer
+    if (kt + 1 < nkt) stage(kt + 1, (kt + 1) & 1);
+    const char* Ps = smem + (kt & 1) * STAGE;
+    const char* Bs = Ps + p.patch_bytes;
+    const int phase = (64 * kt) % p.khkw;
+    const u4 t0 = *reinterpret_cast<const u4*>(tab + phase * 128 + 32 * g);
+    const u4 t1 = *reinterpret_cast<const u4*>(tab + phase * 128 + 32 * g + 16);
+    const uint32_t tw[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
+    h8 af[FM];
+    int idx[FM];
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      const char* base = Ps + poff[i];
+      uint32_t d[8];
+      if (p.ablate & 2) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) d[e] = tw[e] + poff[i];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const uint32_t lo = *reinterpret_cast<const unsigned short*>(base + (tw[e] & 0xffffu));
+          const uint32_t hi = *reinterpret_cast<const unsigned short*>(base + (tw[e] >> 16));
+          d[e] = lo | (hi << 16);
+        }
+      }
+      uint32_t k0, k1, k2, k3, q0, q1, q2, q3;
+      strip_select_f16(d[0], d[1], k0, q0);
+      strip_select_f16(d[2], d[3], k1, q1);
+      strip_select_f16(d[4], d[5], k2, q2);
+      strip_select_f16(d[6], d[7], k3, q3);
+      af[i] = __builtin_bit_cast(h8, u4{k0, k1, k2, k3});
+      idx[i] = (int)(q0 | (q1 << 4) | (q2 << 8) | (q3 << 12));
+    }
+    // B fragments by the transposing read, fragment j+1's reads in flight under fragment j's SMFMACs (mma_tile.h)
+    const unsigned bs_addr = (unsigned)(uintptr_t)(lds_char*)Bs;
+    s4 x0[2], x1[2], x2[2], x3[2];
+    auto issue = [&](int j, s4& v0, s4& v1, s4& v2, s4& v3) {
+      const unsigned c0 = j * 16, q = r16 >> 2, pp = r16 & 3u;
+      const unsigned a = bs_addr + b_off<64>(8u * g + q, c0 + 4u * pp);
+      asm volatile("ds_read_b64_tr_b16 %0, %4\n\tds_read_b64_tr_b16 %1, %4 offset:512\n\t"
+                   "ds_read_b64_tr_b16 %2, %4 offset:4096\n\tds_read_b64_tr_b16 %3, %4 offset:4608"
+                   : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3) : "v"(a) : "memory");
+    };
+    issue(0, x0[0], x1[0], x2[0], x3[0]);
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      const int c = j & 1, nx = c ^ 1;
+      if (j + 1 < FN) {
+        issue(j + 1, x0[nx], x1[nx], x2[nx], x3[nx]);
+        asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(x0[c]), "+v"(x1[c]), "+v"(x2[c]), "+v"(x3[c]) :: "memory");
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x0[c]), "+v"(x1[c]), "+v"(x2[c]), "+v"(x3[c]) :: "memory");
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      typedef short s16 __attribute__((ext_vector_type(16)));
+      const s16 all = {x0[c][0], x0[c][1], x0[c][2], x0[c][3], x1[c][0], x1[c][1], x1[c][2], x1[c][3],
+                       x2[c][0], x2[c][1], x2[c][2], x2[c][3], x3[c][0], x3[c][1], x3[c][2], x3[c][3]};
+      const h16 bf = __builtin_bit_cast(h16, all);
+      if (!(p.ablate & 8))
+#pragma unroll
+        for (int i = 0; i < FM; ++i) acc[i][j] = smfmac16<BF>(af[i], bf, acc[i][j], idx[i]);
+    }
+  }
+  __syncthreads();  // nothing is in flight: the last iteration issued no DMA
+  half_t* C = p.C + (size_t)img * p.L * p.Nout;
+  store_c_tile<BM, BN, FM, FN, 64 * NW, BF>(smem, C, acc, true, wave * TM, 0, m0, n0, p.L, p.Nout, p.alpha, p.beta, tid);
+}
+
+template <int BN, bool BF>
+static int launch_conv(const ConvArgs& a0, hipStream_t st) {
+  ConvArgs a = a0;
+  a.tiles_m = (a.L + 127) / 128;
+  a.tiles_n = (a.Nout + BN - 1) / BN;
+  const size_t nwg = (size_t)a.tiles_m * a.tiles_n * a.N;
+  if (nwg == 0) return SM_STATUS_SUCCESS;
+  if (nwg > 0x7fffffffu) {
+    set_error("sm_conv_spmma_fused: grid too large");
+    return SM_STATUS_NOT_SUPPORTED;
+  }
+  const size_t lds_main = 2 * ((size_t)a.patch_bytes + 64 * BN * 2) + (size_t)a.khkw * 128;
+  const size_t lds_epi = (size_t)128 * (BN * 2 + 16);
+  const size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
+  if (lds > 160 * 1024) {
+    set_error("sm_conv_spmma_fused: the activation patch of a stage (%d bytes) does not fit LDS", a.patch_bytes);
+    return SM_STATUS_NOT_SUPPORTED;
+  }
+  static LdsOptIn lds_optin;
+  if (const int rc = ensure_dyn_lds(lds_optin, reinterpret_cast<const void*>(&conv_spmma_fused_kernel<BN, BF>), 160 * 1024, "conv_spmma_fused_kernel")) return rc;
+  conv_spmma_fused_kernel<BN, BF><<<dim3((unsigned)nwg), dim3(256), lds, st>>>(a);
+  return check_launch("conv_spmma_fused_kernel");
+}
+
+template <bool BF>
+static int conv_spmma16(const void* X, const void* B, void* C, size_t N, size_t Cin, size_t H, size_t W, size_t kh, size_t kw,
+                        size_t stride, size_t pad, size_t dil, size_t n_out, float alpha, float beta, sm_stream_t stream) {
+  const char* name = BF ? "sm_conv_spmma_fused_bf16" : "sm_conv_spmma_fused_f16";
+  if (!X || !B || !C || kh == 0 || kw == 0 || stride == 0 || dil == 0) {
+    set_error("%s: invalid argument", name);
+    return SM_STATUS_INVALID_VALUE;
+  }
+  const size_t sh = dil * (kh - 1) + 1, sw = dil * (kw - 1) + 1;
+  if (H + 2 * pad < sh || W + 2 * pad < sw) {
+    set_error("%s: window larger than the padded input", name);
+    return SM_STATUS_INVALID_VALUE;
+  }
+  if (N == 0 || Cin == 0 || n_out == 0) return SM_STATUS_SUCCESS;
+  const size_t OH = (H + 2 * pad - sh) / stride + 1, OW = (W + 2 * pad - sw) / stride + 1, L = OH * OW, K = Cin * kh * kw;
+  // what the kernel takes: whole 64-deep stages, 16-byte aligned B rows, 4-byte aligned input rows that fit one DMA
+  // instruction with their border; anything else: sm_im2col_compress24_* + sm_spmma_* (the same result)
+  size_t padl = pad > (sw - 1 > pad ? sw - 1 - pad : 0) ? pad : (sw - 1 > pad ? sw - 1 - pad : 0);
+  padl = (padl + 1) / 2 * 2;
+  if (padl == 0) padl = 2;  // a row's right border is the next row's left border: at least one dword
+  const size_t pitch = padl + W;
+  if (K % 64 != 0 || n_out % 8 != 0 || W % 2 != 0 || pitch / 2 > 64 || !aligned16(B) || (reinterpret_cast<uintptr_t>(X) & 3u) != 0 ||
+      kh * kw > 64 || H > 0x7fff || N * L > 0x7fffffffull || K > 0x7fffffffull || n_out > 0x7fffffffull) {
+    set_error("%s: needs C*kh*kw %% 64 == 0, n %% 8 == 0, an even W <= %zu and kh*kw <= 64 (use sm_im2col_compress24 + sm_spmma)", name,
+              (size_t)(128 - padl));
+    return SM_STATUS_NOT_SUPPORTED;
+  }
+  ConvArgs a = {};
+  a.X = (const half_t*)X; a.B = (const half_t*)B; a.C = (half_t*)C;
+  a.N = (int)N; a.Cin = (int)Cin; a.H = (int)H; a.W = (int)W; a.kh = (int)kh; a.kw = (int)kw;
+  a.stride = (int)stride; a.pad = (int)pad; a.dil = (int)dil; a.OH = (int)OH; a.OW = (int)OW; a.L = (int)L;
+  a.Nout = (int)n_out; a.K = (int)K; a.khkw = (int)(kh * kw);
+  const size_t span = L < 128 ? (L - 1) / OW : (127 + OW - 1) / OW;  // most output rows a 128-pixel tile straddles, minus one
+  a.RI = (int)(span * stride + sh);
+  a.pitch = (int)pitch; a.padl = (int)padl;
+  a.rpi = (int)(64 / (pitch / 2));
+  a.nch = (int)((kh * kw - 1 + 63) / (kh * kw) + 1);
+  a.a_n = (int)ceil_div((size_t)a.nch * a.RI, (size_t)a.rpi);
+  a.patch_bytes = (int)round_up(((size_t)a.nch * a.RI * pitch + padl + 2 * (sw + pad)) * 2 + 256, 16);
+  a.alpha = alpha; a.beta = beta;
+  a.ablate = tuning_int("SM_CONV_ABLATE", 0);
+  if (a.a_n > 48) {
+    set_error("%s: a stage's activation patch needs %d DMA instructions (limit 48)", name, a.a_n);
+    return SM_STATUS_NOT_SUPPORTED;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (n_out <= 64) return launch_conv<64, BF>(a, st);
+  return launch_conv<128, BF>(a, st);
+}
+
+}  // namespace sm
+
+using namespace sm;
+
+extern "C" int sm_conv_spmma_fused_f16(const void* X, const void* B, void* C, size_t N, size_t Cin, size_t H, size_t W, size_t kh,
+                                       size_t kw, size_t stride, size_t pad, size_t dilation, size_t n_out, float alpha, float beta,
+                                       sm_stream_t stream) {
+  return conv_spmma16<false>(X, B, C, N, Cin, H, W, kh, kw, stride, pad, dilation, n_out, alpha, beta, stream);
+}
+extern "C" int sm_conv_spmma_fused_bf16(const void* X, const void* B, void* C, size_t N, size_t Cin, size_t H, size_t W, size_t kh,
+                                        size_t kw, size_t stride, size_t pad, size_t dilation, size_t n_out, float alpha, float beta,
+                                        sm_stream_t stream) {
+  return conv_spmma16<true>(X, B, C, N, Cin, H, W, kh, kw, stride, pad, dilation, n_out, alpha, beta, stream);
+}

@@ -258,41 +258,61 @@ __global__ __launch_bounds__(64 * LDS_WAVES) void spmm_csr_lds_kernel(size_t A_r
   // blockIdx.y splits the rows (each split stages the same vectors again: B comes from L2 then)
   const size_t rows_per = (A_rows + gridDim.y - 1) / gridDim.y, r_begin = blockIdx.y * rows_per;
   const size_t r_end = r_begin + rows_per < A_rows ? r_begin + rows_per : A_rows;
-  for (size_t r = r_begin + wave; r < r_end; r += LDS_WAVES) {
-    const int e0 = row_ptr[r], e1 = row_ptr[r + 1];  // wave-uniform: scalar loads
-    f4 acc = {0.f, 0.f, 0.f, 0.f};
-    // four steps of EL non-zeros per round: all eight global loads of a round are issued before the first use
-    // (prefetching the next round -- or the next row's first -- during the current one measured 10 % slower)
-    for (int base = e0; base < e1; base += 4 * EL) {
-      int ci[4];
-      float av[4];
+  // A wave walks its rows G at a time: the column-index / value loads of one round of all G rows (8 G global loads) are
+  // issued before the first of them is used.  With one row at a time a round's latency (L2, ~1-2 us under load) was
+  // exposed once per 64 non-zeros and the kernel ran at 3 % of the HBM roofline: it is bound by that latency, not by
+  // the LDS gather or the FMAs.
+  constexpr int G = 4;
+  for (size_t r0 = r_begin + (size_t)wave * G; r0 < r_end; r0 += (size_t)LDS_WAVES * G) {
+    int e0[G], e1[G];
+    int longest = 0;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int i = base + EL * u + (int)e;
-        const bool ok = i < e1;
-        ci[u] = ok ? colsidx[i] : 0;
-        av[u] = ok ? vals[i] : 0.0f;
-      }
+    for (int gi = 0; gi < G; ++gi) {
+      const size_t r = r0 + gi < r_end ? r0 + gi : r_end - 1;  // wave-uniform: scalar loads
+      e0[gi] = row_ptr[r];
+      e1[gi] = r0 + gi < r_end ? row_ptr[r + 1] : e0[gi];
+      longest = e1[gi] - e0[gi] > longest ? e1[gi] - e0[gi] : longest;
+    }
+    f4 acc[G];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const size_t c = (size_t)ci[u] < A_cols ? (size_t)ci[u] : 0;
-        const float a = (size_t)ci[u] < A_cols ? av[u] : 0.0f;
-        const f4 x = *reinterpret_cast<const f4*>(Xs + c * J + 4u * q);
+    for (int gi = 0; gi < G; ++gi) acc[gi] = f4{0.f, 0.f, 0.f, 0.f};
+    for (int base = 0; base < longest; base += 4 * EL) {
+      int ci[G][4];
+      float av[G][4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) acc[t] = fmaf(a, x[t], acc[t]);
-      }
+      for (int gi = 0; gi < G; ++gi)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int i = e0[gi] + base + EL * u + (int)e;
+          const bool ok = i < e1[gi];
+          ci[gi][u] = ok ? colsidx[i] : 0;
+          av[gi][u] = ok ? vals[i] : 0.0f;
+        }
+#pragma unroll
+      for (int gi = 0; gi < G; ++gi)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const size_t c = (size_t)ci[gi][u] < A_cols ? (size_t)ci[gi][u] : 0;
+          const float a = (size_t)ci[gi][u] < A_cols ? av[gi][u] : 0.0f;
+          const f4 x = *reinterpret_cast<const f4*>(Xs + c * J + 4u * q);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) acc[gi][t] = fmaf(a, x[t], acc[gi][t]);
+        }
     }
 #pragma unroll
-    for (int off = QL; off < 64; off <<= 1)
+    for (int gi = 0; gi < G; ++gi) {
 #pragma unroll
-      for (int t = 0; t < 4; ++t) acc[t] += __shfl_xor(acc[t], off, 64);
-    if (e == 0) {
+      for (int off = QL; off < 64; off <<= 1)
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const size_t v = v0 + 4u * q + t;
-        if (v < NV) {
-          float* d = C + v * A_rows + r;
-          *d = beta != 0.0f ? alpha * acc[t] + beta * *d : alpha * acc[t];
+        for (int t = 0; t < 4; ++t) acc[gi][t] += __shfl_xor(acc[gi][t], off, 64);
+      if (e == 0 && r0 + gi < r_end) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const size_t v = v0 + 4u * q + t;
+          if (v < NV) {
+            float* d = C + v * A_rows + r0 + gi;
+            *d = beta != 0.0f ? alpha * acc[gi][t] + beta * *d : alpha * acc[gi][t];
+          }
         }
       }
     }

@@ -1327,6 +1327,86 @@ def test_conv_as_im2col_2to4_matmul(gpu):
     assert ((got - ref).abs() <= FP16_TOL * scale.clamp_min(1e-30)).all()
 
 
+CONV_CASES = [  # N, Cin, H, W, kh, kw, stride, pad, dil, n_out
+    (2, 64, 14, 14, 3, 3, 1, 1, 1, 64),      # 196 pixels: one full and one partial tile per image, 13 patch rows
+    (2, 64, 28, 28, 3, 3, 1, 1, 1, 128),
+    (1, 128, 56, 56, 3, 3, 1, 1, 1, 128),    # ResNet-50 conv3_x geometry
+    (1, 64, 112, 112, 3, 3, 1, 1, 1, 64),    # one patch row per DMA instruction
+    (2, 64, 28, 28, 3, 3, 2, 1, 1, 64),      # stride 2
+    (2, 64, 14, 14, 1, 1, 1, 0, 1, 72),      # 1 x 1, n % 64 != 0
+    (1, 64, 20, 20, 3, 3, 1, 2, 2, 64),      # dilation 2
+    (1, 256, 14, 14, 3, 3, 1, 1, 1, 256),    # two column tiles
+    (1, 64, 18, 18, 5, 5, 1, 2, 1, 64),      # 25 phases
+    (1, 64, 30, 30, 7, 7, 2, 3, 1, 64),      # 49 phases, stride 2
+    (3, 64, 6, 6, 3, 3, 1, 1, 1, 64),        # L = 36 < 128
+    (1, 64, 10, 12, 3, 3, 1, 0, 1, 64),      # no padding, H != W
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "x".join(map(str, c)))
+@pytest.mark.parametrize("bf", [False, True], ids=["f16", "bf16"])
+def test_conv_spmma_fused_equals_im2col_compress_spmma(gpu, orc, case, bf):
+    """sm_conv_spmma_fused_* (implicit GEMM: the A operand is gathered from an activation patch in LDS) must be
+    BIT-identical to sm_im2col_compress24_* + sm_spmma_* -- same kept values, same codes, same SMFMAC sequence -- and,
+    through that pair, match the oracle (im2col restatement -> compress -> spmma, fp64 accumulation)."""
+    import torch
+    N, Cin, H, W, kh, kw, s_, p_, d_, n_out = case
+    rng = np.random.default_rng(Cin + H * 3 + kh * 7 + s_)
+    OH, OW = gpu.conv_out_size(H, kh, s_, p_, d_), gpu.conv_out_size(W, kw, s_, p_, d_)
+    L, K = OH * OW, Cin * kh * kw
+    if bf:
+        X, Bw = bf16_bits(rng, N * Cin * H * W, "ties" if H == 14 else "uniform"), bf16_bits(rng, K * n_out)
+        dX, dB = bf16_dev(X), bf16_dev(Bw)
+        tdt = torch.bfloat16
+    else:
+        X = bits(rand(rng, N * Cin * H * W, np.float16, "ties" if H == 14 else "uniform"))
+        Bw = bits(rand(rng, K * n_out, np.float16))
+        dX = torch.from_numpy(X.view(np.int16)).cuda().view(torch.float16)
+        dB = torch.from_numpy(Bw.view(np.int16)).cuda().view(torch.float16)
+        tdt = torch.float16
+    blob = torch.empty(gpu.compress24_size(L, K, 2, N), dtype=torch.uint8, device="cuda")
+    gpu.im2col(dX, N, Cin, H, W, kh, kw, s_, p_, d_, blob, compress=True)
+    C1 = torch.zeros(N * L * n_out, dtype=tdt, device="cuda")
+    gpu.spmma(blob, dB, C1, L, n_out, K, N, 0)
+    C2 = torch.full((N * L * n_out,), 7.0, dtype=tdt, device="cuda")
+    if kh * kw == 1:
+        # a 1 x 1 window makes A a plain transpose of X (64 channels per stage: nothing to gather, nothing saved); the
+        # kernel declines it and the documented pair above is the path
+        with pytest.raises(gpu.SparsifymeError, match="status 2"):
+            gpu.conv_spmma_fused(dX, dB, C2, N, Cin, H, W, kh, kw, s_, p_, d_, n_out)
+        return
+    gpu.conv_spmma_fused(dX, dB, C2, N, Cin, H, W, kh, kw, s_, p_, d_, n_out)
+    torch.cuda.synchronize()
+    assert torch.equal(C1.view(torch.int16), C2.view(torch.int16)), "implicit-GEMM result differs from im2col_compress24 + spmma"
+    # alpha / beta through the same epilogue
+    C0 = bf16_bits(rng, N * L * n_out) if bf else bits(rand(rng, N * L * n_out, np.float16))
+    mk = (lambda x: bf16_dev(x)) if bf else (lambda x: torch.from_numpy(x.view(np.int16)).cuda().view(torch.float16))
+    C3, C4 = mk(C0.copy()), mk(C0.copy())
+    gpu.spmma(blob, dB, C3, L, n_out, K, N, 0, alpha=0.5, beta=-1.5)
+    gpu.conv_spmma_fused(dX, dB, C4, N, Cin, H, W, kh, kw, s_, p_, d_, n_out, alpha=0.5, beta=-1.5)
+    assert torch.equal(C3.view(torch.int16), C4.view(torch.int16))
+    # the oracle, on the first image
+    if not bf:
+        A = orc.im2col(X[:Cin * H * W], 1, Cin, H, W, kh, kw, s_, p_, d_)
+        ob = orc.compress24(A, L, K, K)
+        Cref = np.zeros(L * n_out, dtype=np.uint16)
+        orc.spmma(ob, Bw, Cref, L, n_out, K)
+        P = np.abs(orc.decompress24(ob, L, K, K, np.uint16).view(np.float16).astype(np.float64)).reshape(L, K)
+        scale = (P @ np.abs(Bw.view(np.float16).astype(np.float64)).reshape(K, n_out)).reshape(-1)
+        check_close(host(C2[:L * n_out]), Cref.view(np.float16), scale, FP16_TOL, f"conv implicit {case}", K)
+
+
+def test_conv_spmma_fused_rejects_what_it_cannot_take(gpu):
+    import torch
+    x = torch.zeros(4096, dtype=torch.float16, device="cuda")
+    L_ = gpu.lib()
+    args = lambda N, C, H, W, kh, kw, s_, p_, d_, n: (x.data_ptr(), x.data_ptr(), x.data_ptr(), N, C, H, W, kh, kw, s_, p_, d_, n, 1.0, 0.0, None)
+    assert L_.sm_conv_spmma_fused_f16(*args(1, 3, 8, 8, 7, 7, 2, 3, 1, 64)) == 2      # K = 147: not whole stages (NOT_SUPPORTED)
+    assert L_.sm_conv_spmma_fused_f16(*args(1, 64, 8, 9, 3, 3, 1, 1, 1, 64)) == 2      # odd W
+    assert L_.sm_conv_spmma_fused_f16(*args(1, 64, 4, 4, 5, 5, 1, 0, 1, 64)) == 1      # window larger than the input (INVALID_VALUE)
+    assert L_.sm_conv_spmma_fused_f16(*args(1, 64, 8, 8, 3, 3, 0, 1, 1, 64)) == 1      # zero stride
+
+
 def test_im2col_rejects_bad_windows(gpu):
     import torch
     x = torch.zeros(64, dtype=torch.float16, device="cuda")
@@ -1334,6 +1414,53 @@ def test_im2col_rejects_bad_windows(gpu):
     assert L_.sm_im2col_f16(x.data_ptr(), 1, 1, 4, 4, 5, 5, 1, 0, 1, x.data_ptr(), None) == 1      # window larger than the image
     assert L_.sm_im2col_f16(x.data_ptr(), 1, 1, 4, 4, 3, 3, 0, 0, 1, x.data_ptr(), None) == 1      # zero stride
     assert L_.sm_im2col_f16(None, 1, 1, 4, 4, 3, 3, 1, 0, 1, x.data_ptr(), None) == 1
+
+
+def test_two_host_threads_two_streams(gpu):
+    """Concurrent callers: two host threads, each on its own HIP stream, run the fused and the staged 2:4 matmuls (kernels
+    that opt in to > 64 KiB of LDS on first use -- the opt-in is per device and must tolerate a race on the first call)
+    on different problems at the same time; every result must equal the single-threaded one bit for bit."""
+    import threading
+    import torch
+    shapes = [(196, 512, 1024, 4), (784, 1024, 256, 2), (300, 520, 576, 2), (3136, 128, 1152, 1)]
+    probs = []
+    g = torch.Generator(device="cuda").manual_seed(11)
+    for (m, n, k, b) in shapes:
+        A = (torch.rand(b * m * k, generator=g, device="cuda") - 0.5).half()
+        B = (torch.rand(k * n, generator=g, device="cuda") - 0.5).half()
+        blob = torch.empty(gpu.compress24_size(m, k, 2, b), dtype=torch.uint8, device="cuda")
+        gpu.compress24(A, m, k, k, b, m * k, blob)
+        ref = torch.empty(b * m * n, dtype=torch.float16, device="cuda")
+        gpu.spmma(blob, B, ref, m, n, k, b, 0)
+        probs.append((m, n, k, b, A, B, blob, ref))
+    torch.cuda.synchronize()
+    errors = []
+
+    def worker(idx):
+        try:
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                for rep in range(6):
+                    for j, (m, n, k, b, A, B, blob, ref) in enumerate(probs):
+                        if (j + idx) % 2:
+                            continue
+                        out = torch.full_like(ref, 3.0)
+                        if rep % 2:
+                            gpu.spmma(blob, B, out, m, n, k, b, 0)
+                        else:
+                            gpu.spmma_fused(A, B, out, m, n, k, batch=b)
+                        st.synchronize()
+                        if not torch.equal(out.view(torch.int16), ref.view(torch.int16)):
+                            errors.append((idx, rep, j))
+        except Exception as e:  # noqa: BLE001 -- reported by the assert below
+            errors.append((idx, repr(e)))
+
+    ts = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
 
 
 def test_entry_points_are_graph_capturable(gpu):
