@@ -517,219 +517,11 @@ __global__ __launch_bounds__(64 * (WM * WN + NL)) void spmma_f16_pc_kernel(const
   store_c_tile<BM, BN, FM, FN, 64 * NW, BF>(smem, C, acc, wave < (unsigned)NC, wm * TM, wn * TN, m0, n0, p.Mrows, p.N, p.alpha, p.beta, tid);
 }
 
-// ---------------------------------------------------------------------------------------------
-// Producer / consumer kernel with the consumers' operand reads pipelined ACROSS stages.  In the kernel above a consumer
-// wave starts every stage with nothing in registers: after the barrier it reads its A fragments, then B fragment 0,
-// and only then issues the first SMFMAC -- two LDS round trips (~300-450 cycles) exposed per stage on top of the
-// 16 x 16 = 256 cycles of matrix work (profiles/stamp_r01b.txt: compute 609-701, barrier 250-490 per stage).  Here the
-// loaders run one stage further ahead (ring of 4: barrier kt guarantees stages <= kt + 1 have landed), so while a
-// consumer issues the last fragment's SMFMACs of stage kt it already has the reads of stage kt + 1's A fragments and
-// B fragment 0 in flight; the next stage starts with its operands in registers.  All LDS reads are issued by hand
-// (inline asm) with counted lgkmcnt, A fragments included: LDS returns in order, and the count must be exact.
-// ---------------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, int NL, bool BF = false>
-__global__ __launch_bounds__(64 * (WM * WN + NL)) void spmma_f16_pc2_kernel(const SpmmaArgs p) {
-  constexpr int NS = 4;
-  constexpr int NC = WM * WN, NW = NC + NL;
-  constexpr int TM = BM / WM, TN = BN / WN, FM = TM / 16, FN = TN / 16;
-  static_assert(FM >= 1 && FN >= 2, "wave tile");
-  static_assert(2 * FM + 4 <= 15, "lgkmcnt is a 4-bit counter");
-  constexpr int SA = BM * 64, SM_ = BM * 8, SB = 64 * BN * 2, STAGE = SA + SM_ + SB;
-  static_assert(BM % 128 == 0, "metadata DMA moves 128 rows per instruction");
-  constexpr int A_N = BM / 16, M_N = BM / 128, B_N = BN / 8, W = A_N + M_N + B_N;
-  constexpr int SL = (W + NL - 1) / NL;
-  constexpr int LPS = W / NL;
-  static_assert(LPS >= 1 && SL <= 63, "loader waves");
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-
-  const unsigned tid = threadIdx.x, lane = tid & 63u;
-  const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const unsigned tiles = (unsigned)p.tiles_m * (unsigned)p.tiles_n;
-  const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
-  const unsigned b = lid / tiles, trem = lid - b * tiles;
-  const unsigned tile_m = trem / (unsigned)p.tiles_n, tile_n = trem - tile_m * (unsigned)p.tiles_n;
-  const int m0 = (int)tile_m * BM, n0 = (int)tile_n * BN;
-  const int nkt = p.kc / 64;
-  half_t* C = p.C + (size_t)b * p.sC;
-
-  f4 acc[FM][FN];
-#pragma unroll
-  for (int i = 0; i < FM; ++i)
-#pragma unroll
-    for (int j = 0; j < FN; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
-  const unsigned wm = wave / WN, wn = wave % WN;  // meaningful for consumer waves only
-
-  if (wave >= (unsigned)NC) {
-    // ------------------------------------------------------------------ loader wave (as spmma_f16_pc_kernel)
-    const unsigned lw = wave - NC;
-    const size_t row_base = (size_t)b * p.m;
-    const char* vals = p.vals + row_base * 64;
-    const char* meta = p.meta + row_base * 8;
-    const half_t* B = p.B + (size_t)b * p.sB;
-    const int mlast = p.Mrows - 1;
-    const char* src[SL];
-    size_t step[SL];
-    unsigned loff[SL];
-#pragma unroll
-    for (int i = 0; i < SL; ++i) {
-      const unsigned t = lw + (unsigned)NL * i;
-      if (t < (unsigned)A_N) {
-        const unsigned row = 16u * t + (lane >> 2), cs = (lane & 3u) ^ a64_swz(row);
-        int gr = m0 + (int)row;
-        gr = gr < mlast ? gr : mlast;
-        src[i] = vals + (size_t)gr * 64 + 16u * cs;
-        step[i] = p.Mtot * 64;
-        loff[i] = t * 1024u;
-      } else if (t < (unsigned)(A_N + M_N)) {
-        const unsigned u = t - A_N;
-        size_t off = ((size_t)m0 + 128u * u + 2u * lane) * 8;
-        const size_t last = (size_t)p.Mrows * 8 - 16;
-        off = off < last ? off : last;
-        src[i] = meta + off;
-        step[i] = p.Mtot * 8;
-        loff[i] = SA + u * 1024u;
-      } else {
-        const unsigned j = t - (A_N + M_N), panel = j >> 3, kr = 8u * (j & 7u) + (lane >> 3);
-        const unsigned cs = (lane & 7u) ^ b_swz(kr);
-        int gc = n0 + (int)(64u * panel + 8u * cs);
-        gc = gc <= p.N - 8 ? gc : p.N - 8;
-        src[i] = reinterpret_cast<const char*>(B + (size_t)kr * p.N + gc);
-        step[i] = (size_t)64 * p.N * 2;
-        loff[i] = SA + SM_ + panel * 8192u + (j & 7u) * 1024u;
-      }
-    }
-    const bool ktail = (p.K & 63) != 0;
-    auto stage = [&](int kt, int buf) {
-      char* base = smem + buf * STAGE;
-#pragma unroll
-      for (int i = 0; i < SL; ++i) {
-        const unsigned t = lw + (unsigned)NL * i;  // wave-uniform
-        if (t >= (unsigned)W) continue;
-        gptr_t* gp = (gptr_t*)(src[i] + (size_t)kt * step[i]);
-        lptr_t* lp = (lptr_t*)(base + loff[i]);
-        if (ktail && kt == nkt - 1 && t >= (unsigned)(A_N + M_N)) {  // B rows of the K tail: zeros
-          const unsigned kr = 8u * ((t - (unsigned)(A_N + M_N)) & 7u) + (lane >> 3);
-          if (kt * 64 + (int)kr >= p.K) gp = (gptr_t*)(sm_zero_page + 16u * (lane & 7u));
-        }
-        __builtin_amdgcn_global_load_lds(gp, lp, 16, 0, 0);
-      }
-    };
-    // prologue: stages 0, 1; iteration kt = -1 .. nkt-1: stage kt+1 landed | barrier kt | issue stage kt+3
-    if (0 < nkt) stage(0, 0);
-    if (1 < nkt) stage(1, 1);
-    int fill = 2;
-    for (int kt = -1; kt < nkt; ++kt) {
-      // outstanding: stages kt+1 and (if it exists) kt+2; the older one must have landed
-      if (kt + 2 < nkt) wait_dma_and_barrier<LPS>();
-      else wait_dma_and_barrier<0>();
-      if (kt + 3 < nkt) stage(kt + 3, fill);
-      fill = fill + 1 == NS ? 0 : fill + 1;
-    }
-  } else {
-    // ------------------------------------------------------------------ consumer wave
-    const unsigned g = lane >> 4, r = lane & 15u;
-    struct Frag {
-      u4 af[FM];
-      int idx[FM];
-      s4 b0, b1, b2, b3;
-    };
-    const unsigned smem_addr = (unsigned)(uintptr_t)(lds_char*)smem;
-    unsigned a_off_[FM], m_off_[FM];
-#pragma unroll
-    for (int i = 0; i < FM; ++i) {
-      const unsigned row = wm * TM + i * 16 + r;
-      a_off_[i] = row * 64u + 16u * (g ^ a64_swz(row));
-      m_off_[i] = SA + row * 8u + 2u * g;
-    }
-    const unsigned bq = r >> 2, bpp = r & 3u;
-    unsigned bj_off[FN];
-#pragma unroll
-    for (int j = 0; j < FN; ++j) bj_off[j] = SA + SM_ + b_off<64>(8u * g + bq, wn * TN + j * 16 + 4u * bpp);
-    auto issue_b = [&](unsigned base, int j, s4& v0, s4& v1, s4& v2, s4& v3) {
-      const unsigned a = base + bj_off[j];
-      asm volatile("ds_read_b64_tr_b16 %0, %4\n\tds_read_b64_tr_b16 %1, %4 offset:512\n\t"
-                   "ds_read_b64_tr_b16 %2, %4 offset:4096\n\tds_read_b64_tr_b16 %3, %4 offset:4608"
-                   : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3) : "v"(a) : "memory");
-    };
-    auto issue_a = [&](unsigned base, Frag& f) {  // 2 FM reads, then B fragment 0: 2 FM + 4 in all
-#pragma unroll
-      for (int i = 0; i < FM; ++i) {
-        const unsigned aa = base + a_off_[i], ma = base + m_off_[i];
-        asm volatile("ds_read_b128 %0, %2\n\tds_read_u16 %1, %3" : "=&v"(f.af[i]), "=&v"(f.idx[i]) : "v"(aa), "v"(ma) : "memory");
-      }
-      issue_b(base, 0, f.b0, f.b1, f.b2, f.b3);
-    };
-    // one stage: F holds (or has in flight) this stage's A fragments and B fragment 0; G receives the next stage's
-    auto compute = [&](Frag& F, unsigned base, bool has_next, unsigned next_base, Frag& G) {
-      s4 t0[2], t1[2], t2[2], t3[2];
-      t0[0] = F.b0; t1[0] = F.b1; t2[0] = F.b2; t3[0] = F.b3;
-#pragma unroll
-      for (int j = 0; j < FN; ++j) {
-        const int c = j & 1, n = c ^ 1;
-        if (j + 1 < FN) {
-          issue_b(base, j + 1, t0[n], t1[n], t2[n], t3[n]);
-          asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(t0[c]), "+v"(t1[c]), "+v"(t2[c]), "+v"(t3[c]) :: "memory");
-        } else if (has_next) {
-          issue_a(next_base, G);
-          asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(t0[c]), "+v"(t1[c]), "+v"(t2[c]), "+v"(t3[c]) : "n"(2 * FM + 4) : "memory");
-        } else {
-          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t0[c]), "+v"(t1[c]), "+v"(t2[c]), "+v"(t3[c]) :: "memory");
-        }
-        if (j == 0) {  // everything older than the reads just issued has arrived: the A fragments too
-#pragma unroll
-          for (int i = 0; i < FM; ++i) asm volatile("" : "+v"(F.af[i]), "+v"(F.idx[i]) :: "memory");
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        typedef short s16 __attribute__((ext_vector_type(16)));
-        const s16 all = {t0[c][0], t0[c][1], t0[c][2], t0[c][3], t1[c][0], t1[c][1], t1[c][2], t1[c][3],
-                         t2[c][0], t2[c][1], t2[c][2], t2[c][3], t3[c][0], t3[c][1], t3[c][2], t3[c][3]};
-        const h16 bf = __builtin_bit_cast(h16, all);
-#pragma unroll
-        for (int i = 0; i < FM; ++i) acc[i][j] = smfmac16<BF>(__builtin_bit_cast(h8, F.af[i]), bf, acc[i][j], F.idx[i] & 0xffff);
-      }
-    };
-    Frag F, G;
-    wait_dma_and_barrier<0>();  // barrier -1: stage 0 has landed
-    if (nkt > 0) issue_a(smem_addr, F);
-    int cur = 0;
-    for (int kt = 0; kt < nkt; kt += 2) {
-      wait_dma_and_barrier<0>();  // barrier kt: stage kt + 1 has landed, every wave is done with stage kt - 1
-      const int nx1 = cur + 1 == NS ? 0 : cur + 1;
-      compute(F, smem_addr + cur * STAGE, kt + 1 < nkt, smem_addr + nx1 * STAGE, G);
-      if (kt + 1 >= nkt) break;
-      wait_dma_and_barrier<0>();  // barrier kt + 1
-      const int nx2 = nx1 + 1 == NS ? 0 : nx1 + 1;
-      compute(G, smem_addr + nx1 * STAGE, kt + 2 < nkt, smem_addr + nx2 * STAGE, F);
-      cur = nx2;
-    }
-  }
-  __syncthreads();  // both roles; nothing is in flight (the last loader iterations issued no DMA)
-  store_c_tile<BM, BN, FM, FN, 64 * NW, BF>(smem, C, acc, wave < (unsigned)NC, wm * TM, wn * TN, m0, n0, p.Mrows, p.N, p.alpha, p.beta, tid);
-}
-
-template <int BM, int BN, int WM, int WN, int NL, bool BF = false>
-static int launch_pc2(const SpmmaArgs& a0, hipStream_t st) {
-  SpmmaArgs a = a0;
-  a.tiles_m = (a.Mrows + BM - 1) / BM;
-  a.tiles_n = (a.N + BN - 1) / BN;
-  const size_t nwg = (size_t)a.tiles_m * a.tiles_n * a.batch;
-  if (nwg == 0) return SM_STATUS_SUCCESS;
-  if (nwg > 0x7fffffffu) {
-    set_error("spmma_f16: grid too large");
-    return SM_STATUS_NOT_SUPPORTED;
-  }
-  constexpr size_t lds_main = 4 * ((size_t)BM * 72 + (size_t)64 * BN * 2);
-  constexpr size_t lds_epi = (size_t)BM * (BN * 2 + 16);
-  constexpr size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
-  static_assert(lds <= 160 * 1024, "ring of 4 must fit LDS");
-  static LdsOptIn lds_optin;
-  if (lds > 64 * 1024) {
-    if (const int rc = ensure_dyn_lds(lds_optin, reinterpret_cast<const void*>(&spmma_f16_pc2_kernel<BM, BN, WM, WN, NL, BF>), lds, "spmma_f16_pc2_kernel")) return rc;
-  }
-  spmma_f16_pc2_kernel<BM, BN, WM, WN, NL, BF><<<dim3((unsigned)nwg), dim3(64 * (WM * WN + NL)), lds, st>>>(a);
-  return check_launch("spmma_f16_pc2_kernel");
-}
-
+// (A variant of this kernel with the consumers' operand reads pipelined across stages -- ring of 4, the next stage's A
+// fragments and first B fragment fetched under the current stage's last SMFMACs, B fragments two ahead -- was built and
+// measured in round 2: bit-identical, and 1.4 x SLOWER on every few-tile shape (196x512x4608: 51 vs 37 us,
+// profiles/tune_pc2_r02i.txt), with or without the deeper look-ahead.  Exposed LDS latency in the consumers is therefore
+// not what bounds this kernel; the variant is in the git history, not in the library.)
 template <int BM, int BN, int WM, int WN, int NL, int NS, bool BF = false>
 static int launch_pc(const SpmmaArgs& a0, hipStream_t st) {
   SpmmaArgs a = a0;
@@ -902,14 +694,6 @@ static int spmma16(const void* blob, const void* B, void* C, size_t m, size_t n,
       return pns >= 4 ? launch_pc<256, 128, 4, 2, 4, 4, BF>(a, st) : (pns == 3 ? launch_pc<256, 128, 4, 2, 4, 3, BF>(a, st) : launch_pc<256, 128, 4, 2, 4, 2, BF>(a, st));
     }
 #ifdef SM_TUNING
-    if (const char* pc2 = tuning_env("SM_SPMMA_PC2")) {  // "<tile>x<loaders>": tile 128 or 256 rows, 4 or 8 loader waves
-      int tl = 128, nl2 = 4;
-      sscanf(pc2, "%dx%d", &tl, &nl2);
-      if (n > 64 && k >= 128) {
-        if (tl == 256) return nl2 == 8 ? launch_pc2<256, 128, 4, 2, 8, BF>(a, st) : launch_pc2<256, 128, 4, 2, 4, BF>(a, st);
-        return nl2 == 8 ? launch_pc2<128, 128, 2, 2, 8, BF>(a, st) : launch_pc2<128, 128, 2, 2, 4, BF>(a, st);
-      }
-    }
     if (pc_env && n > 64) {  // deep rings / more loaders / 8 consumer waves on 128 x 128 tiles: "<nl>x<ns>x<c>", c = 4 or 8 consumers
       int cw = 4;
       sscanf(pc_env, "%*dx%*dx%d", &cw);
