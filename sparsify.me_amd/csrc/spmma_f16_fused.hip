@@ -44,9 +44,10 @@ struct FusedArgs {
 // so every row of A is selected exactly once -- by the lane that feeds it to the SMFMAC (smfmac_stage_dense_a).
 // The data in flight are LDS buffers, not registers: 2 x 24 KiB per workgroup, two workgroups per CU at n = 64.
 // ---------------------------------------------------------------------------------------------
-template <int BN, int NS, bool BF = false>
+template <int BN, int NS, bool BF = false, int BM = 128>
 __global__ __launch_bounds__(256) void spmma_f16_fused_direct_kernel(const FusedArgs p) {
-  constexpr int BM = 128, NW = 4, TM = 32, FM = 2, FN = BN / 16;
+  static_assert(BM == 128 || BM == 64, "row tile");
+  constexpr int NW = 4, TM = BM / 4, FM = TM / 16, FN = BN / 16;
   constexpr int SA = BM * 128, SB = 64 * BN * 2, STAGE = SA + SB;
   constexpr int A_N = BM / 8, B_N = BN / 8, W = A_N + B_N;  // 1 KiB DMA wave-instructions per stage
   static_assert(W % NW == 0, "equal DMA share per wave");
@@ -136,10 +137,10 @@ __global__ __launch_bounds__(256) void spmma_f16_fused_direct_kernel(const Fused
         d[0] = tv; d[1] = tb; d[2] = ti; d[3] = tc; d[4] = sloop - sstart; d[5] = se - sloop; })
 }
 
-template <int BN, int NS, bool BF = false>
+template <int BN, int NS, bool BF = false, int BM = 128>
 static int launch_fused_direct(const FusedArgs& a0, hipStream_t st) {
   FusedArgs a = a0;
-  a.tiles_m = (a.Mrows + 127) / 128;
+  a.tiles_m = (a.Mrows + BM - 1) / BM;
   a.tiles_n = (a.N + BN - 1) / BN;
   const size_t nwg = (size_t)a.tiles_m * a.tiles_n * a.batch;
   if (nwg == 0) return SM_STATUS_SUCCESS;
@@ -148,15 +149,15 @@ static int launch_fused_direct(const FusedArgs& a0, hipStream_t st) {
     return SM_STATUS_NOT_SUPPORTED;
   }
   // a single-stage problem (k = 64) never touches the ring's other buffers: without them more workgroups share a CU
-  constexpr size_t stage_bytes = 128 * 128 + 64 * BN * 2;
+  constexpr size_t stage_bytes = BM * 128 + 64 * BN * 2;
   const size_t lds_main = ((size_t)(a.K / 64) < (size_t)NS ? (size_t)(a.K / 64) : (size_t)NS) * stage_bytes;
-  constexpr size_t lds_epi = (size_t)128 * (BN * 2 + 16);
+  constexpr size_t lds_epi = (size_t)BM * (BN * 2 + 16);
   const size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
   // the opt-in records the most this instantiation can ever ask for, the launch below only what this K touches
   constexpr size_t lds_max = NS * stage_bytes > lds_epi ? NS * stage_bytes : lds_epi;
   static LdsOptIn lds_optin;
   if (lds_max > 64 * 1024) {
-    if (const int rc = ensure_dyn_lds(lds_optin, reinterpret_cast<const void*>(&spmma_f16_fused_direct_kernel<BN, NS, BF>), lds_max, "spmma_f16_fused_direct_kernel")) return rc;
+    if (const int rc = ensure_dyn_lds(lds_optin, reinterpret_cast<const void*>(&spmma_f16_fused_direct_kernel<BN, NS, BF, BM>), lds_max, "spmma_f16_fused_direct_kernel")) return rc;
   }
 #ifdef SM_STAMP
   {
@@ -166,7 +167,7 @@ static int launch_fused_direct(const FusedArgs& a0, hipStream_t st) {
     if (cnt > cap) { if (dbg) (void)hipFree(dbg); (void)hipMalloc((void**)&dbg, cnt * 8); cap = cnt; }
     (void)hipMemset(dbg, 0, cnt * 8);
     a.dbg = dbg;
-    spmma_f16_fused_direct_kernel<BN, NS, BF><<<dim3((unsigned)nwg), dim3(256), lds, st>>>(a);
+    spmma_f16_fused_direct_kernel<BN, NS, BF, BM><<<dim3((unsigned)nwg), dim3(256), lds, st>>>(a);
     (void)hipDeviceSynchronize();
     std::vector<unsigned long long> h(cnt);
     (void)hipMemcpy(h.data(), dbg, cnt * 8, hipMemcpyDeviceToHost);
@@ -179,7 +180,7 @@ static int launch_fused_direct(const FusedArgs& a0, hipStream_t st) {
     return check_launch("spmma_f16_fused_direct_kernel");
   }
 #endif
-  spmma_f16_fused_direct_kernel<BN, NS, BF><<<dim3((unsigned)nwg), dim3(256), lds, st>>>(a);
+  spmma_f16_fused_direct_kernel<BN, NS, BF, BM><<<dim3((unsigned)nwg), dim3(256), lds, st>>>(a);
   return check_launch("spmma_f16_fused_direct_kernel");
 }
 
@@ -709,6 +710,12 @@ static int spmma_fused16(const void* A, const void* B, void* C, size_t m, size_t
   static const int direct_env = tuning_int("SM_FUSED_DIRECT", 2);
   static const int wide_env = tuning_int("SM_FUSED_WIDE", 0);  // tuning aid: force the wide kernel
   if (!wide_env && (n <= 128 || (n <= 256 && k <= 64))) {
+#ifdef SM_TUNING
+    if (tuning_int("SM_FUSED_BM", 128) == 64) {  // 64-row tiles: 32 KiB (n = 64) of LDS per workgroup, five workgroups per CU
+      if (n <= 64) return launch_fused_direct<64, 2, BF, 64>(a, st);
+      return launch_fused_direct<128, 2, BF, 64>(a, st);
+    }
+#endif
     if (n <= 64) return direct_env >= 3 ? launch_fused_direct<64, 3, BF>(a, st) : launch_fused_direct<64, 2, BF>(a, st);
     return direct_env >= 3 ? launch_fused_direct<128, 3, BF>(a, st) : launch_fused_direct<128, 2, BF>(a, st);
   }
