@@ -178,8 +178,8 @@ constexpr int CSR_J = 16;
 __global__ __launch_bounds__(256) void spmm_csr_kernel(size_t A_rows, size_t A_cols, size_t n, const int* __restrict__ ws,
                                                        const int* __restrict__ colsidx, const float* __restrict__ vals,
                                                        const float* __restrict__ B, float* __restrict__ C, float alpha,
-                                                       float beta) {
-  if (ws[0] != 0) return;  // unsorted input: the atomic kernel handles it
+                                                       float beta, int gate) {
+  if (ws[0] != gate) return;  // unsorted input: the atomic kernel handles it
   const int* row_ptr = ws + 1;
   const size_t r = blockIdx.x * (size_t)256 + threadIdx.x;
   const size_t j0 = (size_t)blockIdx.y * CSR_J, b = blockIdx.z;
@@ -222,10 +222,10 @@ __global__ __launch_bounds__(64 * LDS_WAVES) void spmm_csr_lds_kernel(size_t A_r
                                                                       const int* __restrict__ colsidx,
                                                                       const float* __restrict__ vals,
                                                                       const float* __restrict__ B, float* __restrict__ C,
-                                                                      float alpha, float beta) {
+                                                                      float alpha, float beta, int gate) {
   constexpr int QL = J / 4;    // lanes across the vectors (one 16-byte LDS read = four vectors each)
   constexpr int EL = 64 / QL;  // non-zeros a wave takes per step
-  if (ws[0] != 0) return;  // unsorted input: the atomic kernel handles it
+  if (ws[0] != gate) return;  // 0: row-sorted input (1: the atomic kernel's case; 2 in the v2 path: columns unsorted within rows)
   extern __shared__ __attribute__((aligned(16))) float Xs[];  // [A_cols][J]
   const int* row_ptr = ws + 1;
   const size_t v0 = (size_t)blockIdx.x * J;
@@ -321,20 +321,20 @@ __global__ __launch_bounds__(64 * LDS_WAVES) void spmm_csr_lds_kernel(size_t A_r
 
 template <int J>
 static int launch_csr_lds(size_t A_rows, size_t A_cols, size_t nv, const int* ws, const int* cols, const float* vals,
-                           const float* B, float* C, float alpha, float beta, hipStream_t st) {
+                           const float* B, float* C, float alpha, float beta, hipStream_t st, int gate) {
   static LdsOptIn lds_optin;
   if (const int rc = ensure_dyn_lds(lds_optin, reinterpret_cast<const void*>(&spmm_csr_lds_kernel<J>), (144 * 1024), "spmm_csr_lds_kernel")) return rc;
   // enough workgroups for the chip: split the rows when there are few vector groups (>= 256 rows per split)
   const size_t groups = ceil_div(nv, (size_t)J);
   size_t rsplit = 1;
   while (groups * rsplit < 1024 && A_rows / (rsplit * 2) >= 256) rsplit *= 2;
-  spmm_csr_lds_kernel<J><<<dim3((unsigned)groups, (unsigned)rsplit), 64 * LDS_WAVES, A_cols * J * sizeof(float), st>>>(A_rows, A_cols, nv, ws, cols, vals, B, C, alpha, beta);
+  spmm_csr_lds_kernel<J><<<dim3((unsigned)groups, (unsigned)rsplit), 64 * LDS_WAVES, A_cols * J * sizeof(float), st>>>(A_rows, A_cols, nv, ws, cols, vals, B, C, alpha, beta, gate);
   return SM_STATUS_SUCCESS;
 }
 
 // atomic fallback gated on the flag (runs only when the rows were NOT sorted)
 __global__ __launch_bounds__(256) void scale_if_unsorted_kernel(const int* ws, float* C, size_t count, float beta) {
-  if (ws[0] == 0) return;
+  if ((ws[0] & 1) == 0) return;
   for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256)
     C[i] = beta != 0.0f ? beta * C[i] : 0.0f;
 }
@@ -343,13 +343,51 @@ __global__ __launch_bounds__(256) void spmm_coo_if_unsorted_kernel(const int* ws
                                                                    const int* __restrict__ colsidx,
                                                                    const float* __restrict__ vals,
                                                                    const float* __restrict__ B, float* C, float alpha) {
-  if (ws[0] == 0) return;  // sorted input was served by the CSR kernel: this (small, grid-stride) launch costs nothing
+  if ((ws[0] & 1) == 0) return;  // sorted input was served by a CSR kernel: this (small, grid-stride) launch costs nothing
   for (size_t v = blockIdx.y; v < nv; v += gridDim.y)
     for (size_t e = blockIdx.x * (size_t)256 + threadIdx.x; e < nnz; e += (size_t)gridDim.x * 256) {
       const size_t r = (size_t)rows[e], c = (size_t)colsidx[e];
       if (r >= A_rows || c >= A_cols) continue;
       atomicAdd(C + v * A_rows + r, alpha * vals[e] * B[v * A_cols + c]);
     }
+}
+
+// (A second form -- lanes along the dense vectors, the non-zeros wave-uniform in SGPRs through scalar loads of a pre-packed
+// {LDS offset, value} stream, a row panel's partial sums in registers across 128-column chunks -- was built, tested bit for
+// bit against the oracle and measured in round 2: 3 VALU / LDS instructions per 128 multiply-adds in the inner loop, and
+// still 0.42-0.93 ms against 0.39-0.57 ms for the kernel above (profiles/spmm_probe_r02l_second_form.txt): with ~13
+// non-zeros per (row, chunk) segment every segment pays two dependent scalar-load latencies, and lgkmcnt is shared
+// between scalar loads and LDS reads.  Removed again (git history).)
+// the row-parallel CSR kernels (vectors staged in LDS when they fit) followed by the gated atomic fallback; the CSR
+// kernels run iff ws[0] == gate, the atomic ones iff ws[0] & 1
+static int launch_csr_and_fallback(size_t A_num_rows, size_t A_num_cols, size_t A_nnz, size_t B_num_cols, size_t num_batches,
+                                   const int* ws, const int* rows, const int* cols, const float* vals, const float* B, float* C,
+                                   float alpha, float beta, hipStream_t st, int gate) {
+  const size_t count = A_num_rows * B_num_cols * num_batches;
+  const size_t nv = B_num_cols * num_batches, col_bytes = A_num_cols * sizeof(float);
+  static const int lds_env = tuning_int("SM_SPMM_LDS", -1);  // tuning aid: 0 = off, 8/16/32 = J
+  // as many vectors per workgroup as keep two workgroups on a CU (72 KB each): more FMAs per loaded non-zero
+  int J = col_bytes * 32 <= 72 * 1024 ? 32 : (col_bytes * 16 <= 144 * 1024 ? 16 : 8);
+  if (lds_env == 8 || lds_env == 16 || lds_env == 32) J = lds_env;
+  if (lds_env != 0 && col_bytes * J <= 144 * 1024 && ceil_div(nv, (size_t)J) <= 0x7fffffffull) {
+    int rc;
+    if (J == 32) rc = launch_csr_lds<32>(A_num_rows, A_num_cols, nv, ws, cols, vals, B, C, alpha, beta, st, gate);
+    else if (J == 16) rc = launch_csr_lds<16>(A_num_rows, A_num_cols, nv, ws, cols, vals, B, C, alpha, beta, st, gate);
+    else rc = launch_csr_lds<8>(A_num_rows, A_num_cols, nv, ws, cols, vals, B, C, alpha, beta, st, gate);
+    if (rc != SM_STATUS_SUCCESS) return rc;
+  } else {
+    dim3 grid((unsigned)ceil_div(A_num_rows, 256), (unsigned)ceil_div(B_num_cols, CSR_J), (unsigned)num_batches);
+    spmm_csr_kernel<<<grid, dim3(256), 0, st>>>(A_num_rows, A_num_cols, B_num_cols, ws, cols, vals, B, C, alpha, beta, gate);
+  }
+  scale_if_unsorted_kernel<<<(unsigned)(ceil_div(count, (size_t)256) < 1024 ? ceil_div(count, (size_t)256) : 1024), 256, 0, st>>>(ws, C, count, beta);
+  if (A_nnz) {
+    // a capped grid with grid-stride loops: when the input is sorted (the flag is clear) these blocks exit at once,
+    // and millions of empty blocks would cost more than the product itself
+    const size_t gx = ceil_div(A_nnz, (size_t)256), gy = B_num_cols * num_batches;
+    dim3 g2((unsigned)(gx < 64 ? gx : 64), (unsigned)(gy < 64 ? gy : 64));
+    spmm_coo_if_unsorted_kernel<<<g2, dim3(256), 0, st>>>(ws, A_num_rows, A_num_cols, A_nnz, B_num_cols * num_batches, rows, cols, vals, B, C, alpha);
+  }
+  return check_launch("spmm_csr_kernel");
 }
 
 }  // namespace sm
@@ -499,30 +537,7 @@ int sm_spmm_coo_f32_ws(size_t A_num_rows, size_t A_num_cols, size_t A_nnz, size_
   int* ws = (int*)workspace;
   if (hipMemsetAsync(ws, 0, sizeof(int), st) != hipSuccess) return check_launch("hipMemsetAsync");
   coo_rowptr_kernel<<<(unsigned)ceil_div(A_num_rows + 1, 256), 256, 0, st>>>(rows, A_nnz, A_num_rows, ws);
-  const size_t nv = B_num_cols * num_batches, col_bytes = A_num_cols * sizeof(float);
-  static const int lds_env = tuning_int("SM_SPMM_LDS", -1);  // tuning aid: 0 = off, 8/16/32 = J
-  // as many vectors per workgroup as keep two workgroups on a CU (72 KB each): more FMAs per loaded non-zero
-  int J = col_bytes * 32 <= 72 * 1024 ? 32 : (col_bytes * 16 <= 144 * 1024 ? 16 : 8);
-  if (lds_env == 8 || lds_env == 16 || lds_env == 32) J = lds_env;
-  if (lds_env != 0 && col_bytes * J <= 144 * 1024 && ceil_div(nv, (size_t)J) <= 0x7fffffffull) {
-    int rc;
-    if (J == 32) rc = launch_csr_lds<32>(A_num_rows, A_num_cols, nv, ws, cols, vals, B, C, alpha, beta, st);
-    else if (J == 16) rc = launch_csr_lds<16>(A_num_rows, A_num_cols, nv, ws, cols, vals, B, C, alpha, beta, st);
-    else rc = launch_csr_lds<8>(A_num_rows, A_num_cols, nv, ws, cols, vals, B, C, alpha, beta, st);
-    if (rc != SM_STATUS_SUCCESS) return rc;
-  } else {
-    dim3 grid((unsigned)ceil_div(A_num_rows, 256), (unsigned)ceil_div(B_num_cols, CSR_J), (unsigned)num_batches);
-    spmm_csr_kernel<<<grid, dim3(256), 0, st>>>(A_num_rows, A_num_cols, B_num_cols, ws, cols, vals, B, C, alpha, beta);
-  }
-  scale_if_unsorted_kernel<<<(unsigned)(ceil_div(count, (size_t)256) < 1024 ? ceil_div(count, (size_t)256) : 1024), 256, 0, st>>>(ws, C, count, beta);
-  if (A_nnz) {
-    // a capped grid with grid-stride loops: when the input is sorted (the flag is clear) these blocks exit at once,
-    // and millions of empty blocks would cost more than the product itself
-    const size_t gx = ceil_div(A_nnz, (size_t)256), gy = B_num_cols * num_batches;
-    dim3 g2((unsigned)(gx < 64 ? gx : 64), (unsigned)(gy < 64 ? gy : 64));
-    spmm_coo_if_unsorted_kernel<<<g2, dim3(256), 0, st>>>(ws, A_num_rows, A_num_cols, A_nnz, B_num_cols * num_batches, rows, cols, vals, B, C, alpha);
-  }
-  return check_launch("spmm_csr_kernel");
+  return launch_csr_and_fallback(A_num_rows, A_num_cols, A_nnz, B_num_cols, num_batches, ws, rows, cols, vals, B, C, alpha, beta, st, 0);
 }
 
 }  // extern "C"

@@ -833,9 +833,9 @@ def test_spmm_coo_config5_resnet50_shapes(gpu, orc, shape, order):
     gpu.fill_uniform(dC, 0xC0C + m, -1.0, 1.0)
     C0 = dC.clone()
     nb = ctypes.c_size_t(0)
+    dr, dc, dv = to_dev(r), to_dev(c), to_dev(v)
     assert gpu.lib().sm_spmm_coo_workspace_size(m, ctypes.byref(nb)) == 0
     ws = torch.full((nb.value,), 0x5A, dtype=torch.uint8, device="cuda")   # a stale workspace must not matter
-    dr, dc, dv = to_dev(r), to_dev(c), to_dev(v)
     rc = gpu.lib().sm_spmm_coo_f32_ws(m, k, nnz, n, batches, dr.data_ptr(), dc.data_ptr(), dv.data_ptr(), dB.data_ptr(),
                                       dC.data_ptr(), alpha, beta, ws.data_ptr(), None)
     assert rc == 0, gpu.lib().sm_last_error()
@@ -864,6 +864,41 @@ def test_spmm_coo_config5_resnet50_shapes(gpu, orc, shape, order):
     if empty.size:
         e = int(empty[0])
         assert np.array_equal(host(dC).reshape(batches, n, m)[:, :, e], (np.float32(beta) * C0h[:, :, e]).astype(np.float32))
+
+
+@pytest.mark.parametrize("shape", [(150, 33, 90, 3), (64, 9, 48, 2), (300, 130, 260, 1), (17, 5, 129, 4), (129, 64, 128, 2)],
+                         ids=lambda s_: "x".join(map(str, s_)))
+@pytest.mark.parametrize("order", ["sorted", "cols_shuffled_within_rows", "shuffled", "duplicates"])
+def test_spmm_coo_ws_orders_vs_oracle(gpu, orc, shape, order):
+    """sm_spmm_coo_f32_ws on small shapes against the oracle on every entry: row-sorted input (columns sorted or not,
+    duplicates included) takes the CSR kernel, fully shuffled input the atomic kernels; all four must agree."""
+    import ctypes
+    import torch
+    m, n, k, batches = shape
+    r, c, v, rng = _coo_problem(m, k, m * 7 + k, 0.15)
+    if order == "duplicates":
+        r, c = np.concatenate([r, r[::7]]), np.concatenate([c, c[::7]])
+        v = np.concatenate([v, rng.uniform(-1, 1, r.size - v.size).astype(np.float32)])
+        o = np.lexsort((c, r))
+        r, c, v = r[o].copy(), c[o].copy(), v[o].copy()
+    elif order == "cols_shuffled_within_rows":
+        o = np.lexsort((rng.permutation(r.size), r))
+        r, c, v = r[o].copy(), c[o].copy(), v[o].copy()
+    elif order == "shuffled":
+        o = rng.permutation(r.size)
+        r, c, v = r[o].copy(), c[o].copy(), v[o].copy()
+    B = rng.uniform(-1, 1, batches * k * n).astype(np.float32)
+    C0 = rng.uniform(-1, 1, batches * m * n).astype(np.float32)
+    want = C0.copy()
+    orc.spmm_coo(m, k, r.size, n, batches, r, c, v, B, want, 1.5, -0.75)
+    nb = ctypes.c_size_t(0)
+    assert gpu.lib().sm_spmm_coo_workspace_size(m, ctypes.byref(nb)) == 0
+    ws = torch.full((nb.value,), 0xA5, dtype=torch.uint8, device="cuda")
+    dC, dr, dc, dv, dB = to_dev(C0.copy()), to_dev(r), to_dev(c), to_dev(v), to_dev(B)
+    rc = gpu.lib().sm_spmm_coo_f32_ws(m, k, r.size, n, batches, dr.data_ptr(), dc.data_ptr(), dv.data_ptr(), dB.data_ptr(),
+                                      dC.data_ptr(), 1.5, -0.75, ws.data_ptr(), None)
+    assert rc == 0, gpu.lib().sm_last_error()
+    assert np.allclose(host(dC), want, rtol=2e-5, atol=2e-5), f"max diff {np.abs(host(dC) - want).max():.3e}"
 
 
 def test_spmm_coo_rejects_nothing_but_routes_bad_rows_to_the_atomic_kernel(gpu, orc):
