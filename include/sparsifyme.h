@@ -12,7 +12,8 @@
  *   - every pointer is a DEVICE pointer unless the comment says host;
  *   - `stream` is a hipStream_t passed as void* (NULL = the default stream);
  *   - functions only enqueue work on `stream` (no allocation, no synchronisation), so a caller
- *     may capture them into a hipGraph; they return SM_STATUS_* (0 = success) and never throw;
+ *     may capture them into a hipGraph (one exception, stated at sm_spmm_bell_batched_f32); they
+ *     return SM_STATUS_* (0 = success) and never throw;
  *   - fp16 data are IEEE binary16 bit patterns (`_Float16` / `__half` / uint16_t storage).
  *
  * 2:4 compressed blob (produced by sm_compress24_*, consumed by sm_spmma_* / sm_decompress24_*),
@@ -175,7 +176,10 @@ int sm_spmm_bell_f32_ws(const float* values, const uint64_t* column_indices, siz
 
 /* All batches of the reference's spmm() loop (spmm.hxx:90-101) in one submission: `values`, `column_indices` and `C`
  * are HOST arrays of `batch` device pointers (every A has the same rows/cols/block_size/ell_cols, B is shared --
- * exactly what the reference's driver builds).  Workspace: sm_spmm_bell_batched_workspace_size() bytes, required. */
+ * exactly what the reference's driver builds).  Workspace: sm_spmm_bell_batched_workspace_size() bytes, required.
+ * NOT hipGraph-capturable, unlike every other entry point: the three pointer tables are copied from the caller's HOST
+ * arrays onto the stream (a synchronously staged copy from pageable memory); capture the per-matrix
+ * sm_spmm_bell_f32_ws instead, or keep the host arrays alive and unchanged for the lifetime of the graph. */
 int sm_spmm_bell_batched_workspace_size(size_t rows, size_t cols, size_t batch, size_t* bytes /*host*/);
 int sm_spmm_bell_batched_f32(const float* const* values, const uint64_t* const* column_indices, size_t rows,
                              size_t cols, size_t block_size, size_t ell_cols, const float* B, float* const* C,
