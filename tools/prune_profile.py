@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Runs the prune-step kernels (STRIP prune, TILE prune, check, compress) once per unique ResNet-50 shape at b = 32
+"""Runs the prune-step kernels (STRIP prune, TILE prune, check, compress, one-pass prune+check+compress) once per unique ResNet-50 shape at b = 32
 (fp16), for rocprofv3 passes: tools/prune_profile.py [reps].  Used by tools/gpu_round.sh to report the prune step's
 HBM GB/s from the PMC counters (north_star: "rocprof-reported HBM GB/s for the prune step")."""
 import csv
@@ -25,4 +25,5 @@ for (m, n, k) in sorted(set(rows)):
         sm.prune24(A, O, b * m, k, k, 0)   # TILE
         sm.prune24_check(O, b * m, k, k, valid)
         sm.compress24(A, m, k, k, b, m * k, blob)
+        sm.prune24_compress24(A, O, m, k, k, b, m * k, blob, valid, sm.PRUNE_TILE)    # one pass (spmma()'s sequence)
     torch.cuda.synchronize()
