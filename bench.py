@@ -204,7 +204,9 @@ def main():
         sm.spmma(L["blob"], L["B"], L["C"], L["m"], L["n"], L["k"], L["b"], 0)
 
     def use_fused(L):
-        return (not f32) and args.path == "auto" and L["k"] % 64 == 0 and (L["n"] <= args.fused_max_n or L["k"] <= args.fused_max_k_wide)
+        if f32:  # sm_spmma_fused_f32: the STRIP rule in the registers of the dense fp32 MFMA kernel (no blob, no compress pass)
+            return args.path == "auto" and L["k"] % 32 == 0 and L["n"] % 4 == 0
+        return args.path == "auto" and L["k"] % 64 == 0 and (L["n"] <= args.fused_max_n or L["k"] <= args.fused_max_k_wide)
 
     # (f-1) the fused kernel computes the same C bit for bit straight from the dense A (the 2:4 selection
     # and compaction happen in registers / LDS; no blob goes to HBM)
@@ -285,7 +287,8 @@ def main():
     nfused = sum(use_fused(L) for L in layers)
     sfx = args.dtype
     if f32:
-        path_desc = "sm_compress24_f32 + sm_spmma_f32 on every layer"
+        path_desc = ("auto: sm_spmma_fused_f32 on %d layers (k %% 32 == 0), sm_compress24_f32 + sm_spmma_f32 on %d" % (nfused, len(layers) - nfused)
+                     if args.path == "auto" else "staged: sm_compress24_f32 + sm_spmma_f32 on every layer")
     elif args.path == "auto":
         path_desc = ("auto: sm_spmma_fused_%s on %d layers (n <= %d or k <= %d), sm_compress24_%s + sm_spmma_%s on %d"
                      % (sfx, nfused, args.fused_max_n, args.fused_max_k_wide, sfx, sfx, len(layers) - nfused))
@@ -351,7 +354,7 @@ def extras(args, sm, torch, dev, layers, flops, t_full, Forked, make_runner, tim
     t_mul, t_cmp = sec_per_call(spmma_only), sec_per_call(compress_only)
     t_drm = sec_per_call(dense_rowmajor)
     t_dcm = sec_per_call(dense_batched) if has_batched else None
-    t_staged = t_full if (args.path == "staged" or f32) else sec_per_call(Forked(lambda L: (
+    t_staged = t_full if args.path == "staged" else sec_per_call(Forked(lambda L: (
         sm.compress24(L["A"], L["m"], L["k"], L["k"], L["b"], L["m"] * L["k"], L["blob"]),
         sm.spmma(L["blob"], L["B"], L["C"], L["m"], L["n"], L["k"], L["b"], 0))))
     out["stages"] = {
@@ -361,7 +364,7 @@ def extras(args, sm, torch, dev, layers, flops, t_full, Forked, make_runner, tim
         "speedup_mul_vs_dense_rowmajor": t_drm / t_mul, "speedup_mul_vs_dense_batched": t_dcm / t_mul if t_dcm else None,
         "speedup_full_vs_dense_rowmajor": t_drm / t_full, "speedup_full_vs_dense_batched": t_dcm / t_full if t_dcm else None,
         "full_path_staged_gfs": gfs(t_staged), "full_path_staged_ms": t_staged * 1e3,
-        "timed_path": "staged" if f32 else args.path, "timed_path_ms": t_full * 1e3,
+        "timed_path": args.path, "timed_path_ms": t_full * 1e3,
         # what 2:4 can buy on these shapes when both products are HBM-bound (fp16: they are): the ratio of
         # the algorithmic bytes, dense (A + B + C) over sparse (9/16 A + B + C)
         "hbm_bound_speedup_ceiling": sum(L["b"] * s * (L["m"] * L["k"] + L["m"] * L["n"]) + s * L["k"] * L["n"] for L in layers)
@@ -406,11 +409,14 @@ def extras(args, sm, torch, dev, layers, flops, t_full, Forked, make_runner, tim
     A_fu = lambda L: L["b"] * s * (L["m"] * L["k"] + L["m"] * L["n"]) + s * L["k"] * L["n"]
     fam = {}
     if f32:
-        fam["spmma_f32"] = dict(names=["spmma_f32_dma_kernel", "spmma_f32_kernel"], layers=layers,
+        staged = [L for L in layers if not use_fused(L)]
+        fam["spmma_f32"] = dict(names=["spmma_f32_dma_kernel", "spmma_f32_kernel"], layers=staged,
                                 call=lambda L: sm.spmma(L["blob"], L["B"], L["C"], L["m"], L["n"], L["k"], L["b"], 0), bytes=A_sp)
-        fam["compress"] = dict(names=["compress_kernel"], layers=layers,
+        fam["compress"] = dict(names=["compress_kernel"], layers=staged,
                                call=lambda L: sm.compress24(L["A"], L["m"], L["k"], L["k"], L["b"], L["m"] * L["k"], L["blob"]),
                                bytes=lambda L: L["b"] * L["m"] * L["k"] * (s + s / 2 + 1 / 8))
+        fam["spmma_f32_fused"] = dict(names=["gemm_f32_dma_kernel"], layers=[L for L in layers if use_fused(L)],
+                                      call=lambda L: sm.spmma_fused(L["A"], L["B"], L["C"], L["m"], L["n"], L["k"], batch=L["b"]), bytes=A_fu)
     else:
         staged = [L for L in layers if not use_fused(L)]
         fam["spmma_f16"] = dict(names=["spmma_f16_dma_kernel", "spmma_f16_pc_kernel", "spmma_f16_kernel", "spmma_f16_splitk_kernel"],
@@ -457,11 +463,13 @@ def extras(args, sm, torch, dev, layers, flops, t_full, Forked, make_runner, tim
     fams_out = {n_: {"ms_per_step": r_["seconds"] * 1e3, "launches": r_["launches"], "GBs": r_["GBs"], "frac_of_hbm_peak": r_["GBs"] / HBM_PEAK_GBS,
                      "hbm_traffic_per_launch": r_["traffic"]} for n_, r_ in rows.items()}
     if f32:
-        r_ = rows["spmma_f32"]
+        domf = max((n_ for n_ in rows if n_.startswith("spmma_f32")), key=lambda n_: rows[n_]["seconds"])
+        r_ = rows[domf]
         out["roofline"] = {"bound": "mfma", "achieved": r_["TFs"], "peak": F32_MATRIX_PEAK_TFS, "unit": "TFLOP/s",
-                           "frac": r_["TFs"] / F32_MATRIX_PEAK_TFS, "traffic": r_["traffic"], "traffic_source": tsrc, "kernel": "spmma_f32",
+                           "frac": r_["TFs"] / F32_MATRIX_PEAK_TFS, "traffic": r_["traffic"], "traffic_source": tsrc if r_["traffic"] is not None else None,
+                           "kernel": domf,
                            "launches_per_step": r_["launches"], "avg_launch_us": r_["seconds"] / r_["launches"] * 1e6,
-                           "algorithmic_flops_per_launch": sum(2.0 * L["m"] * L["n"] * L["k"] * L["b"] for L in layers) / r_["launches"],
+                           "algorithmic_flops_per_launch": r_["TFs"] * 1e12 * r_["seconds"] / r_["launches"],
                            "note": "the fp32 2:4 kernel expands to dense fp32 MFMA (no fp32 sparse matrix instruction exists): executed = dense-equivalent flops",
                            "measured": "single stream, HIP events on the launch stream, hipGraph replay", "families": fams_out}
     else:

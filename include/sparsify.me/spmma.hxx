@@ -36,6 +36,9 @@ template <typename T>
 struct spmma_fns;
 template <>
 struct spmma_fns<float> {
+  static int fused(float* A, float* B, float* C, std::size_t m, std::size_t n, std::size_t k, std::size_t b, float al, float be) {
+    return sm_spmma_fused_f32(A, B, C, m, n, k, k, b, m * k, k * n, m * n, al, be, nullptr);
+  }
   static int prune_check_compress(float*, std::size_t, std::size_t, std::size_t, void*, int*) { return SM_STATUS_NOT_SUPPORTED; }
   static int prune_check_compress_on(float*, std::size_t, std::size_t, std::size_t, void*, hipStream_t) { return SM_STATUS_NOT_SUPPORTED; }
   static int prune(float* A, std::size_t m, std::size_t k) { return sm_prune24_f32(A, A, m, k, k, SM_PRUNE_TILE, nullptr); }
@@ -200,13 +203,12 @@ std::vector<float> spmma(type_t* dA,
 // of compress(STRIP) + multiply on the UNPRUNED A -- C = alpha * prune_strip_2:4(A) * B + beta * C -- in ONE kernel
 // straight from the dense A: nothing is pruned in place (A is left as it is), no blob is built, A is read from HBM
 // once.  Bit-identical to spmma() only for an A that already is 2:4 (spmma() prunes with the TILE rule first: for a
-// dense A the two rules keep different elements).  fp16 and bfloat16; needs k % 64 == 0, n % 8 == 0.  Returns the
-// elapsed milliseconds.  A shape the fused kernels cannot take (SM_STATUS_NOT_SUPPORTED) runs as sm_compress24 +
+// dense A the two rules keep different elements).  fp16 / bfloat16 (needs k % 64 == 0, n % 8 == 0) and fp32 (k % 32 == 0,
+// n % 4 == 0: the rule applied in the registers of the dense fp32 MFMA kernel).  Returns the elapsed milliseconds.  A shape the fused kernels cannot take (SM_STATUS_NOT_SUPPORTED) runs as sm_compress24 +
 // sm_spmma with a temporary blob: the same C bit for bit, so callers need no shape logic.
 template <typename type_t>
 float spmma_fused(type_t* dA, type_t* dB, type_t* dC, std::size_t m, std::size_t n, std::size_t k, std::size_t batch_size,
                   float alpha = 1.0f, float beta = 0.0f) {
-  static_assert(sizeof(type_t) == 2, "the fused kernels are fp16 / bfloat16");
   using fns = detail::spmma_fns<type_t>;
   if (batch_size == 0) batch_size = 1;
   util::timer_t timer;

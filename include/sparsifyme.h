@@ -131,6 +131,12 @@ int sm_spmma_fused_f16(const void* A, const void* B, void* C, size_t m, size_t n
                        size_t batch, size_t strideA, size_t strideB, size_t strideC, float alpha,
                        float beta, sm_stream_t stream);
 
+/* fp32 form: the STRIP rule applied to the A fragments in registers of the dense fp32 MFMA kernel (there is no fp32 sparse
+ * matrix instruction).  Equals sm_gemm_rowmajor_f32 of the STRIP-pruned A bit for bit; agrees with sm_compress24_f32 +
+ * sm_spmma_f32 to fp32 accumulation order.  Needs k % 32 == 0, n % 4 == 0, 16-byte aligned rows. */
+int sm_spmma_fused_f32(const float* A, const float* B, float* C, size_t m, size_t n, size_t k, size_t lda, size_t batch,
+                       size_t strideA, size_t strideB, size_t strideC, float alpha, float beta, sm_stream_t stream);
+
 /* ---- (a5) dense batched GEMM: replaces cublas{H,S,D}gemmBatched (gemm.hxx:80-81, 133-134,
  *      186-187).  COLUMN-major, lda = m, ldb = k, ldc = m as the reference passes them;
  *      A_ptrs/B_ptrs/C_ptrs are device arrays of `batch` device pointers (examples/gemm.cu:65-90).

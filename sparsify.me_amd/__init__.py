@@ -47,6 +47,8 @@ _SIGS = {
     "sm_spmma_f32": [_c_ptr, _c_ptr, _c_ptr, _c_size, _c_size, _c_size, _c_size, _c_size, _c_size, _c_f, _c_f, _c_ptr],
     "sm_spmma_fused_f16": [_c_ptr, _c_ptr, _c_ptr, _c_size, _c_size, _c_size, _c_size, _c_size, _c_size, _c_size, _c_size,
                            _c_f, _c_f, _c_ptr],
+    "sm_spmma_fused_f32": [_c_ptr, _c_ptr, _c_ptr, _c_size, _c_size, _c_size, _c_size, _c_size, _c_size, _c_size, _c_size,
+                           _c_f, _c_f, _c_ptr],
     "sm_gemm_batched_f16": [_c_ptr, _c_ptr, _c_ptr, _c_size, _c_size, _c_size, _c_size, _c_i, _c_i, _c_f, _c_f, _c_ptr],
     "sm_gemm_batched_f32": [_c_ptr, _c_ptr, _c_ptr, _c_size, _c_size, _c_size, _c_size, _c_i, _c_i, _c_f, _c_f, _c_ptr],
     "sm_gemm_batched_f64": [_c_ptr, _c_ptr, _c_ptr, _c_size, _c_size, _c_size, _c_size, _c_i, _c_i,

@@ -239,7 +239,10 @@ __device__ __forceinline__ unsigned b32_off(unsigned kr, unsigned col) {  // byt
   return (col >> 5) * 4096u + kr * 128u + 16u * (((col & 31u) >> 2) ^ (4u * ((kr >> 3) & 1u))) + 4u * (col & 3u);
 }
 
-template <int BM, int BN, int WM, int WN, int NS, bool BKM>
+// P24 (sm_spmma_fused_f32): the 2:4 STRIP rule is applied to each stage's A image in LDS, in place, before the MFMA reads
+// it -- so C = prune24_strip(A) * B without a blob and without a compress pass.  fp32 has no sparse matrix instruction: the matrix work is the dense
+// kernel's, what is saved is the 2.06 ms compress pass and the blob round trip of the staged pair (ResNet-18 table).
+template <int BM, int BN, int WM, int WN, int NS, bool BKM, bool P24 = false>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_dma_kernel(const Gemm32Args p) {
   constexpr int NW = WM * WN, TM = BM / WM, TN = BN / WN, FM = TM / 16, FN = TN / 16;
   constexpr int SA = BM * 128, SB = BN * 128, STAGE = SA + SB;
@@ -317,6 +320,21 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_dma_kernel(const Gemm32
     if (kt + NS - 1 < nkt) stage(kt + NS - 1, fill);
     const char* As = smem + cur * STAGE;
     const char* Bs = As + SA;
+    if constexpr (P24) {
+      // the stage's A image pruned in place, once, by all threads: every 16-byte chunk of the image is one strip (4
+      // consecutive k of a row, wherever the swizzle put it).  In the MFMA-feeding lanes' registers the same selection
+      // ran once per wave column and cost 40 % over the dense kernel (profiles/bench_f32_r02m_regmask.json).
+      char* Aw = smem + cur * STAGE;
+      for (unsigned q = tid; q < (unsigned)(BM * 8); q += 64u * NW) {
+        f4 v = *reinterpret_cast<const f4*>(Aw + q * 16u);
+        const u4 kk = __builtin_bit_cast(u4, v);
+        const unsigned mk = strip_keepmask(key_of(kk[0]), key_of(kk[1]), key_of(kk[2]), key_of(kk[3]));
+#pragma unroll
+        for (int t = 0; t < 4; ++t) v[t] = (mk >> t) & 1u ? v[t] : 0.0f;
+        *reinterpret_cast<f4*>(Aw + q * 16u) = v;
+      }
+      __syncthreads();
+    }
     f4 alo[FM], ahi[FM];
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
@@ -375,7 +393,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_dma_kernel(const Gemm32
     }
 }
 
-template <int BM, int BN, int WM, int WN, int NS, bool BKM>
+template <int BM, int BN, int WM, int WN, int NS, bool BKM, bool P24 = false>
 static int launch32_dma(const Gemm32Args& a0, hipStream_t st) {
   Gemm32Args a = a0;
   a.tiles_m = (a.M + BM - 1) / BM;
@@ -389,9 +407,9 @@ static int launch32_dma(const Gemm32Args& a0, hipStream_t st) {
   constexpr size_t lds = (size_t)NS * (BM + BN) * 128;
   static LdsOptIn lds_optin;
   if (lds > 64 * 1024) {
-    if (const int rc = ensure_dyn_lds(lds_optin, reinterpret_cast<const void*>(&gemm_f32_dma_kernel<BM, BN, WM, WN, NS, BKM>), lds, "gemm_f32_dma_kernel")) return rc;
+    if (const int rc = ensure_dyn_lds(lds_optin, reinterpret_cast<const void*>(&gemm_f32_dma_kernel<BM, BN, WM, WN, NS, BKM, P24>), lds, "gemm_f32_dma_kernel")) return rc;
   }
-  gemm_f32_dma_kernel<BM, BN, WM, WN, NS, BKM><<<dim3((unsigned)nwg), dim3(64 * WM * WN), lds, st>>>(a);
+  gemm_f32_dma_kernel<BM, BN, WM, WN, NS, BKM, P24><<<dim3((unsigned)nwg), dim3(64 * WM * WN), lds, st>>>(a);
   return check_launch("gemm_f32_dma_kernel");
 }
 
@@ -825,6 +843,37 @@ int sm_gemm_rowmajor_f32(const float* A, const float* B, float* C, size_t m, siz
     a.batch = 1;
   }
   return dispatch32<0>(a, (hipStream_t)stream);
+}
+
+int sm_spmma_fused_f32(const float* A, const float* B, float* C, size_t m, size_t n, size_t k, size_t lda, size_t batch,
+                       size_t strideA, size_t strideB, size_t strideC, float alpha, float beta, sm_stream_t stream) {
+  if (!A || !B || !C || lda < k) {
+    set_error("sm_spmma_fused_f32: invalid argument");
+    return SM_STATUS_INVALID_VALUE;
+  }
+  if (m == 0 || n == 0 || batch == 0) return SM_STATUS_SUCCESS;
+  if (m * batch > 0x7fffffffull || n > 0x7fffffffull || k > 0x7fffffffull || lda > 0x7fffffffull) {
+    set_error("sm_spmma_fused_f32: dimension exceeds 2^31-1");
+    return SM_STATUS_NOT_SUPPORTED;
+  }
+  // whole 32-deep stages of 16-byte aligned rows only (the LDS-DMA pipeline); anything else: sm_compress24_f32 + sm_spmma_f32
+  if (k % 32 != 0 || n % 4 != 0 || lda % 4 != 0 || strideA % 4 != 0 || strideB % 4 != 0 || !aligned16(A) || !aligned16(B)) {
+    set_error("sm_spmma_fused_f32: needs k %% 32 == 0, n %% 4 == 0 and 16-byte aligned rows (use the staged path)");
+    return SM_STATUS_NOT_SUPPORTED;
+  }
+  Gemm32Args a = {};
+  a.A = A; a.B = B; a.C = C;
+  a.M = (int)m; a.N = (int)n; a.K = (int)k;
+  a.lda = (int)lda; a.ldb = (int)n; a.ldc = (int)n;
+  a.sA = strideA; a.sB = strideB; a.sC = strideC;
+  a.batch = (int)batch; a.alpha = alpha; a.beta = beta;
+  if (batch > 1 && strideB == 0 && strideA == m * lda && strideC == m * n) {
+    a.M = (int)(m * batch);
+    a.batch = 1;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (a.M <= 64) return a.N <= 64 ? launch32_dma<64, 64, 2, 2, 2, false, true>(a, st) : launch32_dma<64, 128, 1, 4, 2, false, true>(a, st);
+  return a.N <= 128 ? launch32_dma<128, 64, 4, 1, 2, false, true>(a, st) : launch32_dma<128, 128, 4, 4, 2, false, true>(a, st);
 }
 
 int sm_gemm_batched_f32(const float* const* A_ptrs, const float* const* B_ptrs, float* const* C_ptrs, size_t m, size_t n,

@@ -564,6 +564,46 @@ def test_spmma_f32_vs_oracle(gpu, orc, shape):
     check_close(host(C), Cref, scale, FP32_TOL, f"spmma_f32 {shape}", k, "f32")
 
 
+@pytest.mark.parametrize("shape", [(128, 64, 64, 1), (196, 512, 256, 2), (130, 72, 224, 1), (512, 512, 512, 1), (33, 12, 32, 3), (300, 136, 160, 2),
+                                   (40, 200, 96, 1)])
+@pytest.mark.parametrize("ab", [(1.0, 0.0), (0.5, -2.0)])
+def test_spmma_fused_f32(gpu, orc, shape, ab):
+    """sm_spmma_fused_f32 (STRIP rule on the A fragments in the dense fp32 MFMA kernel's registers): bit-identical to the
+    dense kernel on the pruned operand, within the tight bound of the oracle's compress -> spmma; ties and specials."""
+    import torch
+    m, n, k, batch = shape
+    alpha, beta = ab
+    rng = np.random.default_rng(m * 3 + n + k * 7)
+    A = rand(rng, batch * m * k, np.float32, "ties" if m % 2 else "uniform")
+    if m == 196:
+        A[:8] = np.array([1.0, np.nan, np.inf, 2.0, -0.0, 0.0, -0.0, 0.0], dtype=np.float32)
+    B, C0 = rand(rng, k * n, np.float32), rand(rng, batch * m * n, np.float32)
+    dA, dB = to_dev(A), to_dev(B)
+    Cf, Cd = to_dev(C0.copy()), to_dev(C0.copy())
+    gpu.spmma_fused(dA, dB, Cf, m, n, k, batch=batch, alpha=alpha, beta=beta)
+    P = dA.clone()
+    gpu.prune24(P, P, batch * m, k, k, gpu.PRUNE_STRIP)
+    gpu.gemm_rowmajor(P, dB, Cd, m, n, k, batch=batch, alpha=alpha, beta=beta)
+    assert np.array_equal(bits(host(Cf)), bits(host(Cd))), "fused fp32 differs from the dense kernel on the pruned operand"
+    if m != 196:   # (the specials row multiplies NaN / inf: compared bit for bit above only)
+        ob = orc.compress24(bits(A), m, k, k, batch)
+        Cref = C0.copy()
+        orc.spmma(ob, B, Cref, m, n, k, batch, 0, alpha=alpha, beta=beta)
+        Pm = np.abs(host(P).astype(np.float64)).reshape(batch * m, k)
+        scale = abs(alpha) * (Pm @ np.abs(B.astype(np.float64)).reshape(k, n)).reshape(-1) + abs(beta) * np.abs(C0.astype(np.float64))
+        check_close(host(Cf), Cref, scale, FP32_TOL, f"spmma_fused_f32 {shape}", k, "f32")
+
+
+def test_spmma_fused_f32_rejects_what_it_cannot_take(gpu):
+    import torch
+    x = torch.zeros(4096, dtype=torch.float32, device="cuda")
+    L_ = gpu.lib()
+    call = lambda m, n, k, lda: L_.sm_spmma_fused_f32(x.data_ptr(), x.data_ptr(), x.data_ptr(), m, n, k, lda, 1, m * lda, 0, m * n, 1.0, 0.0, None)
+    assert call(8, 8, 147, 147) == 2      # k % 32 != 0 -> NOT_SUPPORTED (the staged pair serves it)
+    assert call(8, 6, 32, 32) == 2        # n % 4 != 0
+    assert call(8, 8, 32, 16) == 1        # lda < k -> INVALID_VALUE
+
+
 @pytest.mark.parametrize("sfx,dtype,tol", [("f32", np.float32, FP32_TOL), ("f64", np.float64, 1e-12)])
 @pytest.mark.parametrize("shape", [(128, 64, 64, 2), (196, 512, 100, 2), (130, 72, 200, 3)])
 def test_gemm_batched_column_major_f32_f64(gpu, orc, sfx, dtype, tol, shape):
@@ -764,6 +804,11 @@ def test_full_size_properties_resnet18_f32(gpu, orc, shape):
     gpu.spmma(blob, dB, C, m, n, k, batch)
     Cd = torch.full_like(C, -2.0)
     gpu.gemm_rowmajor(P, dB, Cd, m, n, k, batch=batch)
+    if k % 32 == 0:   # the one-kernel fp32 form: the STRIP rule in the registers of the dense MFMA kernel -> the same bits as Cd
+        Cf = torch.full_like(C, -4.0)
+        gpu.spmma_fused(dA, dB, Cf, m, n, k, batch=batch)
+        assert torch.equal(Cf.view(torch.int32), Cd.view(torch.int32)), "sm_spmma_fused_f32 != sm_gemm_rowmajor_f32(prune_strip(A))"
+        del Cf
     # same products, fp32 accumulation in two different orders: |C - Cd| <= 2 k u sum|ab| = 2 k u Cd  (u = 2^-24)
     worst = ((C - Cd).abs() / Cd.clamp_min(1e-30)).max().item()
     assert worst <= 2 * k * 2.0 ** -24, f"spmma_f32 vs gemm_f32(prune): {worst:.3e} relative to sum|ab|"
