@@ -386,6 +386,10 @@ def extras(args, sm, torch, dev, layers, flops, t_full, Forked, make_runner, tim
         for L in layers:
             del L["Aapi"]
 
+    if not f32 and os.path.basename(args.tables.split(",")[0] if args.tables else (args.table or "resnet50")).startswith("resnet50"):
+        out["stages"]["conv_path"] = conv_path_stage(sm, torch, dev, args.dtype)
+        out["stages"]["config5_coo_spmm"] = config5_stage(sm, torch, dev)
+
     if not f32:
         # matrix-pipe view of the 2:4 matmul (north_star: "MFMA utilisation for the matmul against chip peak"):
         # dense-equivalent rate of the matmul-only pass against 2 x the dense fp16 peak (v_smfmac does a 16x16x64
@@ -480,6 +484,66 @@ def extras(args, sm, torch, dev, layers, flops, t_full, Forked, make_runner, tim
                            "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],
                            "measured": "single stream, one kernel family at a time, HIP events on the launch stream, hipGraph replay",
                            "families": fams_out}
+
+
+def conv_path_stage(sm, torch, dev, dtype):
+    """The 3 x 3 convolution layers of the ResNet-50 table through the implicit-GEMM kernel (sm_conv_spmma_fused_*: NCHW
+    activations in, C out, neither the 9 x larger A nor its blob in HBM), stride 1 / padding 1 so that m = H * W, b = 32.
+    Own roofline: bytes = activations + B + C; bound = max(bytes / HBM peak, dense-equivalent flops / 2 x 2.5 PF).  Not part
+    of `value`: the headline step is defined on the reference's (m, n, k) operands."""
+    tdt = torch.float16 if dtype == "f16" else torch.bfloat16
+    N = 32
+    rows, tot_ms, tot_fl, tot_by, tot_roof = [], 0.0, 0.0, 0.0, 0.0
+    for Cin, HW, n, cnt in [(64, 112, 64, 3), (128, 56, 128, 4), (256, 28, 256, 6), (512, 14, 512, 3)]:
+        L, K = HW * HW, Cin * 9
+        X = torch.empty(N * Cin * L, dtype=tdt, device=dev)
+        sm.fill_uniform(X, 7 + Cin, -1.0, 1.0)
+        B = torch.empty(K * n, dtype=tdt, device=dev)
+        sm.fill_uniform(B, 9 + n, -1.0, 1.0)
+        C = torch.empty(N * L * n, dtype=tdt, device=dev)
+        ms = sm.graph_time_ms(lambda: sm.conv_spmma_fused(X, B, C, N, Cin, HW, HW, 3, 3, 1, 1, 1, n), iters=10)
+        fl, by = 2.0 * N * L * n * K, 2.0 * (N * Cin * L + K * n + N * L * n)
+        roof = max(by / (HBM_PEAK_GBS * 1e9), fl / 5.0e15)
+        rows.append({"m": L, "n": n, "k": K, "count": cnt, "ms": ms, "GBs": by / ms / 1e6, "eff_TFs": fl / ms / 1e9, "frac": roof * 1e3 / ms})
+        tot_ms += ms * cnt; tot_fl += fl * cnt; tot_by += by * cnt; tot_roof += roof * cnt
+        del X, C
+    return {"kernel": "conv_spmma_fused_kernel", "layers": rows, "table_weighted_ms": tot_ms, "eff_TFs": tot_fl / tot_ms / 1e9,
+            "roofline": {"bound": "hbm", "achieved": tot_by / tot_ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": tot_by / tot_ms / 1e6 / HBM_PEAK_GBS, "frac_of_per_layer_roofline": tot_roof * 1e3 / tot_ms},
+            "note": "bytes = activations + B + C (no A); DESIGN.md 4.4: bound by the selection / gather instruction stream, not by HBM"}
+
+
+def config5_stage(sm, torch, dev):
+    """BASELINE config 5: 90 %-sparse COO (one A, density 0.1, values U(-1,1)) x dense, fp32, on four ResNet-50 shapes at
+    b = 32 through sm_spmm_coo_f32_ws; HBM GB/s of the algorithmic bytes (B read once + C written once + A) vs the peak."""
+    import ctypes
+    L_ = sm.lib()
+    rows = []
+    g = torch.Generator(device=dev).manual_seed(5)
+    for (m, n, k, b) in [(784, 256, 2304, 32), (12544, 64, 576, 32), (196, 512, 4608, 32), (3136, 128, 1152, 32)]:
+        dense = torch.rand(m, k, generator=g, device=dev) < 0.1
+        idx = dense.nonzero()            # row-major scan: sorted by row, then column
+        r, c = idx[:, 0].to(torch.int32).contiguous(), idx[:, 1].to(torch.int32).contiguous()
+        nnz = int(r.numel())
+        v = (torch.rand(nnz, generator=g, device=dev) * 2 - 1).float()
+        B = torch.empty(b * k * n, dtype=torch.float32, device=dev)
+        sm.fill_uniform(B, 55 + n, -1.0, 1.0)
+        C = torch.empty(b * m * n, dtype=torch.float32, device=dev)
+        nb = ctypes.c_size_t(0)
+        L_.sm_spmm_coo_workspace_size(m, ctypes.byref(nb))
+        ws = torch.zeros(nb.value, dtype=torch.uint8, device=dev)
+
+        def call():
+            rc = L_.sm_spmm_coo_f32_ws(m, k, nnz, n, b, r.data_ptr(), c.data_ptr(), v.data_ptr(), B.data_ptr(), C.data_ptr(), 1.0, 0.0,
+                                       ws.data_ptr(), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+            if rc != 0:
+                raise RuntimeError(L_.sm_last_error().decode())
+        ms = sm.graph_time_ms(call, iters=5)
+        by = nnz * 8.0 + (m + 1) * 4.0 + 4.0 * b * (k * n + m * n)
+        rows.append({"m": m, "n": n, "k": k, "b": b, "nnz": nnz, "ms": ms, "GBs": by / ms / 1e6, "frac": by / ms / 1e6 / HBM_PEAK_GBS,
+                     "TFs": 2.0 * nnz * n * b / ms / 1e9})
+    return {"kernel": "spmm_csr_lds_kernel", "shapes": rows, "unit": "GB/s of algorithmic bytes (SURVEY.md 8(d): nnz*(s+4) + (m+1)*4 + b*s*(k*n + m*n))",
+            "peak": HBM_PEAK_GBS}
 
 
 def cpu_baseline(ge, shapes):
