@@ -36,7 +36,7 @@ def main():
     sm = ge.load_package()
     sm.device_check()
     dev = torch.device("cuda", 0)
-    path = os.path.join(ROOT, "datasets", args.table + ".csv")
+    path = args.table if args.table.endswith(".csv") else os.path.join(ROOT, "datasets", args.table + ".csv")
     rows = [tuple(int(x) for x in r[:4]) for r in list(csv.reader(open(path)))[1:] if r]
     if args.unique:
         seen, uniq = set(), []
