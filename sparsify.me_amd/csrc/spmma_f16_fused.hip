@@ -211,180 +211,9 @@ struct BTileDma {
   }
 };
 
-// ---------------------------------------------------------------------------------------------
-// n <= 128, REGISTER-A form (tuning builds: SM_FUSED_REGA=<PF>): as the direct kernel, but the dense A never touches LDS.
-// A lane of the SMFMAC wants 32 contiguous bytes of "its" row per 64-k stage (row 16 i + lane % 16 of the wave's 32 rows,
-// k 16 (lane / 16) ...): it loads exactly those with two plain 16-byte loads per row fragment, PF stages ahead in
-// registers (the compiler's counted vmcnt guards each use: loads and B DMA are issued in one fixed order per iteration,
-// stage indices beyond the last are clamped instead of skipped so that no path issues fewer), selects in place and
-// multiplies.  Only the B tile goes through LDS (two slots, one barrier per stage; plain loads PF stages ahead and a
-// 16-byte LDS write, NOT LDS-DMA: with DMA and plain loads mixed in one wave the compiler guards every use with
-// vmcnt(0)), so a workgroup holds 18 KiB (n = 64) and occupancy is set by registers, with PF x 16 KiB of A in flight.
-// Same selection, same operand maps, same k order: bit-identical to the other forms.
-// ---------------------------------------------------------------------------------------------
-template <int FM, int FN, bool BF>
-__device__ __forceinline__ void smfmac_stage_sel(const h8 (&af)[FM], const int (&idx)[FM], const char* Bs, unsigned col0,
-                                                 unsigned lane, f4 (&acc)[FM][FN]) {
-  const unsigned g = lane >> 4, r = lane & 15u;
-  const unsigned bs_addr = (unsigned)(uintptr_t)(lds_char*)Bs;
-  s4 t0[2], t1[2], t2[2], t3[2];
-  auto issue = [&](int j, s4& v0, s4& v1, s4& v2, s4& v3) {
-    const unsigned c0 = col0 + j * 16, q = r >> 2, pp = r & 3u;
-    const unsigned a = bs_addr + b_off<64>(8u * g + q, c0 + 4u * pp);
-    asm volatile("ds_read_b64_tr_b16 %0, %4\n\tds_read_b64_tr_b16 %1, %4 offset:512\n\t"
-                 "ds_read_b64_tr_b16 %2, %4 offset:4096\n\tds_read_b64_tr_b16 %3, %4 offset:4608"
-                 : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3) : "v"(a) : "memory");
-  };
-  issue(0, t0[0], t1[0], t2[0], t3[0]);
-#pragma unroll
-  for (int j = 0; j < FN; ++j) {
-    const int c = j & 1, n = c ^ 1;
-    if (j + 1 < FN) {
-      issue(j + 1, t0[n], t1[n], t2[n], t3[n]);
-      asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(t0[c]), "+v"(t1[c]), "+v"(t2[c]), "+v"(t3[c]) :: "memory");
-    } else {
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t0[c]), "+v"(t1[c]), "+v"(t2[c]), "+v"(t3[c]) :: "memory");
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    typedef short s16 __attribute__((ext_vector_type(16)));
-    const s16 all = {t0[c][0], t0[c][1], t0[c][2], t0[c][3], t1[c][0], t1[c][1], t1[c][2], t1[c][3],
-                     t2[c][0], t2[c][1], t2[c][2], t2[c][3], t3[c][0], t3[c][1], t3[c][2], t3[c][3]};
-    const h16 bf = __builtin_bit_cast(h16, all);
-#pragma unroll
-    for (int i = 0; i < FM; ++i) acc[i][j] = smfmac16<BF>(af[i], bf, acc[i][j], idx[i]);
-  }
-}
-
-template <int BN, int PF, bool BF = false>
-__global__ __launch_bounds__(256) void spmma_f16_fused_rega_kernel(const FusedArgs p) {
-  constexpr int BM = 128, NW = 4, TM = 32, FM = 2, FN = BN / 16;
-  constexpr int SB = 64 * BN * 2;
-  constexpr int B_N = BN / 8, SLB = B_N / NW;  // 1 KiB B wave-loads per stage / per wave
-  static_assert(B_N % NW == 0 && PF >= 2 && PF <= 3, "shape");
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-
-  const unsigned tid = threadIdx.x, lane = tid & 63u;
-  const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const unsigned tiles = (unsigned)p.tiles_m * (unsigned)p.tiles_n;
-  const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
-  const unsigned b = lid / tiles, trem = lid - b * tiles;
-  const unsigned tile_m = trem / (unsigned)p.tiles_n, tile_n = trem - tile_m * (unsigned)p.tiles_n;
-  const int m0 = (int)tile_m * BM, n0 = (int)tile_n * BN;
-  const int nkt = p.K / 64, klast = nkt - 1;
-  const half_t* A = p.A + (size_t)b * p.sA;
-  const half_t* B = p.B + (size_t)b * p.sB;
-  half_t* C = p.C + (size_t)b * p.sC;
-  const int mlast = p.Mrows - 1;
-  const unsigned g = lane >> 4, r = lane & 15u;
-
-  // B: the direct kernel's DMA mapping (wave-load j: k-rows 8 (j & 7) + lane / 8 of panel j >> 3, LDS chunk lane % 8 holds
-  // source chunk (lane % 8) ^ swizzle), as a plain load now and a 16-byte LDS write one stage later
-  const char* bsrc[SLB];
-  unsigned bdst[SLB];
-  const size_t bstep = (size_t)64 * p.N * 2;
-#pragma unroll
-  for (int i = 0; i < SLB; ++i) {
-    const unsigned j = wave + (unsigned)NW * i, panel = j >> 3, kr = 8u * (j & 7u) + (lane >> 3);
-    const unsigned cs = (lane & 7u) ^ b_swz(kr);
-    int gc = n0 + (int)(64u * panel + 8u * cs);
-    gc = gc <= p.N - 8 ? gc : p.N - 8;
-    bsrc[i] = reinterpret_cast<const char*>(B + (size_t)kr * p.N + gc);
-    bdst[i] = panel * 8192u + (j & 7u) * 1024u + lane * 16u;
-  }
-  const half_t* pa[FM];
-#pragma unroll
-  for (int i = 0; i < FM; ++i) {
-    int gr = m0 + (int)(wave * TM + 16u * i + r);
-    gr = gr < mlast ? gr : mlast;
-    pa[i] = A + (size_t)gr * p.lda + 16u * g;
-  }
-  u4 ra[PF][2 * FM], rb[PF][SLB];
-  auto load_a = [&](int kt, u4 (&d)[2 * FM]) {
-    kt = kt < klast ? kt : klast;
-#pragma unroll
-    for (int i = 0; i < FM; ++i) {
-      d[2 * i] = __builtin_nontemporal_load(reinterpret_cast<const u4*>(pa[i] + (size_t)kt * 64));
-      d[2 * i + 1] = __builtin_nontemporal_load(reinterpret_cast<const u4*>(pa[i] + (size_t)kt * 64 + 8));
-    }
-    __builtin_amdgcn_sched_barrier(0);
-  };
-  auto load_b = [&](int kt, u4 (&d)[SLB]) {
-    kt = kt < klast ? kt : klast;
-#pragma unroll
-    for (int i = 0; i < SLB; ++i) d[i] = *reinterpret_cast<const u4*>(bsrc[i] + (size_t)kt * bstep);
-    __builtin_amdgcn_sched_barrier(0);
-  };
-  auto write_b = [&](int slot, const u4 (&d)[SLB]) {
-#pragma unroll
-    for (int i = 0; i < SLB; ++i) *reinterpret_cast<u4*>(smem + slot * SB + bdst[i]) = d[i];
-    __builtin_amdgcn_sched_barrier(0);
-  };
-
-  f4 acc[FM][FN];
-#pragma unroll
-  for (int i = 0; i < FM; ++i)
-#pragma unroll
-    for (int j = 0; j < FN; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
-
-  // stage s of A lives in ra[s % PF], of B in rb[s % PF]; B(s) is written to LDS slot s % 2 during iteration s - 1
-#pragma unroll
-  for (int s = 0; s < PF; ++s) {
-    load_a(s, ra[s]);
-    load_b(s, rb[s]);
-  }
-  write_b(0, rb[0]);
-  load_b(PF, rb[0]);
-  auto step = [&](int kt, u4 (&rr)[2 * FM], u4 (&bb)[SLB]) {
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // B(kt) complete in slot kt % 2; slot (kt + 1) % 2 free
-    __builtin_amdgcn_sched_barrier(0);
-    h8 af[FM];
-    int idx[FM];
-#pragma unroll
-    for (int i = 0; i < FM; ++i) {
-      uint32_t k0, k1, k2, k3, n0_, n1_, n2_, n3_;
-      strip_select_f16(rr[2 * i][0], rr[2 * i][1], k0, n0_);
-      strip_select_f16(rr[2 * i][2], rr[2 * i][3], k1, n1_);
-      strip_select_f16(rr[2 * i + 1][0], rr[2 * i + 1][1], k2, n2_);
-      strip_select_f16(rr[2 * i + 1][2], rr[2 * i + 1][3], k3, n3_);
-      af[i] = __builtin_bit_cast(h8, u4{k0, k1, k2, k3});
-      idx[i] = (int)(n0_ | (n1_ << 4) | (n2_ << 8) | (n3_ << 12));
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    load_a(kt + PF, rr);
-    smfmac_stage_sel<FM, FN, BF>(af, idx, smem + (kt & 1) * SB, 0, lane, acc);
-    __builtin_amdgcn_sched_barrier(0);
-    write_b((kt + 1) & 1, bb);  // B(kt + 1): every wave finished reading this slot (stage kt - 1) before this iteration's barrier
-    load_b(kt + 1 + PF, bb);
-  };
-  int kt0 = 0;
-  for (; kt0 + PF <= nkt; kt0 += PF) {
-#pragma unroll
-    for (int u = 0; u < PF; ++u) step(kt0 + u, ra[u], rb[(u + 1) % PF]);
-  }
-#pragma unroll
-  for (int u = 0; u < PF - 1; ++u)
-    if (kt0 + u < nkt) step(kt0 + u, ra[u], rb[(u + 1) % PF]);
-  __syncthreads();
-  store_c_tile<BM, BN, FM, FN, 64 * NW, BF>(smem, C, acc, true, wave * TM, 0, m0, n0, p.Mrows, p.N, p.alpha, p.beta, tid);
-}
-
-template <int BN, int PF, bool BF = false>
-static int launch_fused_rega(const FusedArgs& a0, hipStream_t st) {
-  FusedArgs a = a0;
-  a.tiles_m = (a.Mrows + 127) / 128;
-  a.tiles_n = (a.N + BN - 1) / BN;
-  const size_t nwg = (size_t)a.tiles_m * a.tiles_n * a.batch;
-  if (nwg == 0) return SM_STATUS_SUCCESS;
-  if (nwg > 0x7fffffffu) {
-    set_error("sm_spmma_fused_f16: grid too large");
-    return SM_STATUS_NOT_SUPPORTED;
-  }
-  constexpr size_t lds_ring = 2 * 64 * BN * 2, lds_epi = (size_t)128 * (BN * 2 + 16);
-  constexpr size_t lds = lds_ring > lds_epi ? lds_ring : lds_epi;
-  static_assert(lds <= 64 * 1024, "no opt-in needed");
-  spmma_f16_fused_rega_kernel<BN, PF, BF><<<dim3((unsigned)nwg), dim3(256), lds, st>>>(a);
-  return check_launch("spmma_f16_fused_rega_kernel");
-}
+// (A register-A form of the direct kernel -- each SMFMAC lane loading the 32 bytes of its row straight from global memory,
+// PF stages ahead in registers, only B through LDS -- was built in round 2: bit-identical, 1.3x slower on every n <= 128 layer
+// (profiles/tune_rega_r02q.txt; 164 VGPRs, half-line wave loads).  Removed again; DESIGN.md 4.5, git history.)
 
 template <int BN, int WM, int WN, int NLB, int PF, int NSB, bool BF = false>
 __global__ __launch_bounds__(64 * (WM * WN + 4 + NLB)) void spmma_f16_fused_wide_kernel(const FusedArgs p) {
@@ -889,12 +718,6 @@ static int spmma_fused16(const void* A, const void* B, void* C, size_t m, size_t
     if (tuning_int("SM_FUSED_BM", 128) == 64) {  // 64-row tiles: 32 KiB (n = 64) of LDS per workgroup, five workgroups per CU
       if (n <= 64) return launch_fused_direct<64, 2, BF, 64>(a, st);
       return launch_fused_direct<128, 2, BF, 64>(a, st);
-    }
-#endif
-#ifdef SM_TUNING
-    if (const int pf = tuning_int("SM_FUSED_REGA", 0)) {  // register-A form, PF stages of A in flight per lane
-      if (n <= 64) return pf >= 3 ? launch_fused_rega<64, 3, BF>(a, st) : launch_fused_rega<64, 2, BF>(a, st);
-      return pf >= 3 ? launch_fused_rega<128, 3, BF>(a, st) : launch_fused_rega<128, 2, BF>(a, st);
     }
 #endif
     if (n <= 64) return direct_env >= 3 ? launch_fused_direct<64, 3, BF>(a, st) : launch_fused_direct<64, 2, BF>(a, st);
