@@ -44,10 +44,11 @@ struct FusedArgs {
 // so every row of A is selected exactly once -- by the lane that feeds it to the SMFMAC (smfmac_stage_dense_a).
 // The data in flight are LDS buffers, not registers: 2 x 24 KiB per workgroup, two workgroups per CU at n = 64.
 // ---------------------------------------------------------------------------------------------
-template <int BN, int NS, bool BF = false, int BM = 128>
-__global__ __launch_bounds__(256) void spmma_f16_fused_direct_kernel(const FusedArgs p) {
+template <int BN, int NS, bool BF = false, int BM = 128, int NWV = 4>
+__global__ __launch_bounds__(64 * NWV) void spmma_f16_fused_direct_kernel(const FusedArgs p) {
   static_assert(BM == 128 || BM == 64, "row tile");
-  constexpr int NW = 4, TM = BM / 4, FM = TM / 16, FN = BN / 16;
+  static_assert(NWV == 4 || (NWV == 8 && BM == 128), "waves per workgroup");
+  constexpr int NW = NWV, TM = BM / NW, FM = TM / 16, FN = BN / 16;
   constexpr int SA = BM * 128, SB = 64 * BN * 2, STAGE = SA + SB;
   constexpr int A_N = BM / 8, B_N = BN / 8, W = A_N + B_N;  // 1 KiB DMA wave-instructions per stage
   static_assert(W % NW == 0, "equal DMA share per wave");
@@ -137,7 +138,7 @@ __global__ __launch_bounds__(256) void spmma_f16_fused_direct_kernel(const Fused
         d[0] = tv; d[1] = tb; d[2] = ti; d[3] = tc; d[4] = sloop - sstart; d[5] = se - sloop; })
 }
 
-template <int BN, int NS, bool BF = false, int BM = 128>
+template <int BN, int NS, bool BF = false, int BM = 128, int NWV = 4>
 static int launch_fused_direct(const FusedArgs& a0, hipStream_t st) {
   FusedArgs a = a0;
   a.tiles_m = (a.Mrows + BM - 1) / BM;
@@ -157,17 +158,17 @@ static int launch_fused_direct(const FusedArgs& a0, hipStream_t st) {
   constexpr size_t lds_max = NS * stage_bytes > lds_epi ? NS * stage_bytes : lds_epi;
   static LdsOptIn lds_optin;
   if (lds_max > 64 * 1024) {
-    if (const int rc = ensure_dyn_lds(lds_optin, reinterpret_cast<const void*>(&spmma_f16_fused_direct_kernel<BN, NS, BF, BM>), lds_max, "spmma_f16_fused_direct_kernel")) return rc;
+    if (const int rc = ensure_dyn_lds(lds_optin, reinterpret_cast<const void*>(&spmma_f16_fused_direct_kernel<BN, NS, BF, BM, NWV>), lds_max, "spmma_f16_fused_direct_kernel")) return rc;
   }
 #ifdef SM_STAMP
   {
     static unsigned long long* dbg = nullptr;
     static size_t cap = 0;
-    const size_t cnt = nwg * 4 * 8;
+    const size_t cnt = nwg * NWV * 8;
     if (cnt > cap) { if (dbg) (void)hipFree(dbg); (void)hipMalloc((void**)&dbg, cnt * 8); cap = cnt; }
     (void)hipMemset(dbg, 0, cnt * 8);
     a.dbg = dbg;
-    spmma_f16_fused_direct_kernel<BN, NS, BF, BM><<<dim3((unsigned)nwg), dim3(256), lds, st>>>(a);
+    spmma_f16_fused_direct_kernel<BN, NS, BF, BM, NWV><<<dim3((unsigned)nwg), dim3(64 * NWV), lds, st>>>(a);
     (void)hipDeviceSynchronize();
     std::vector<unsigned long long> h(cnt);
     (void)hipMemcpy(h.data(), dbg, cnt * 8, hipMemcpyDeviceToHost);
@@ -180,7 +181,7 @@ static int launch_fused_direct(const FusedArgs& a0, hipStream_t st) {
     return check_launch("spmma_f16_fused_direct_kernel");
   }
 #endif
-  spmma_f16_fused_direct_kernel<BN, NS, BF, BM><<<dim3((unsigned)nwg), dim3(256), lds, st>>>(a);
+  spmma_f16_fused_direct_kernel<BN, NS, BF, BM, NWV><<<dim3((unsigned)nwg), dim3(64 * NWV), lds, st>>>(a);
   return check_launch("spmma_f16_fused_direct_kernel");
 }
 
@@ -715,6 +716,10 @@ static int spmma_fused16(const void* A, const void* B, void* C, size_t m, size_t
   static const int wide_env = tuning_int("SM_FUSED_WIDE", 0);  // tuning aid: force the wide kernel
   if (!wide_env && (n <= 128 || (n <= 256 && k <= 64))) {
 #ifdef SM_TUNING
+    if (tuning_int("SM_FUSED_NW", 4) == 8) {  // eight waves of 16 rows per workgroup: the same LDS, twice the waves per SIMD
+      if (n <= 64) return launch_fused_direct<64, 2, BF, 128, 8>(a, st);
+      return launch_fused_direct<128, 2, BF, 128, 8>(a, st);
+    }
     if (tuning_int("SM_FUSED_BM", 128) == 64) {  // 64-row tiles: 32 KiB (n = 64) of LDS per workgroup, five workgroups per CU
       if (n <= 64) return launch_fused_direct<64, 2, BF, 64>(a, st);
       return launch_fused_direct<128, 2, BF, 64>(a, st);

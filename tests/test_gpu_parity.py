@@ -1602,3 +1602,68 @@ def test_fused_rejects_what_it_cannot_take(gpu):
     C = torch.zeros(16 * 64, dtype=torch.float16, device="cuda")
     with pytest.raises(gpu.SparsifymeError):
         gpu.spmma_fused(A, B, C, 16, 64, 147)   # k % 64 != 0: caller must use compress + spmma
+
+
+# ---------------------------------------------------------------------------------------------
+# empty problems: every entry point is a successful no-op for a zero extent, and a zero-length k leaves
+# C = beta * C (the sum over k is empty) -- the reference's vendor calls accept these sizes
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("zero", ["m", "n", "batch"])
+def test_empty_extents_are_noops(gpu, zero):
+    import torch
+    m, n, k, b = 64, 64, 128, 2
+    dims = {"m": m, "n": n, "batch": b}
+    dims[zero] = 0
+    m, n, b = dims["m"], dims["n"], dims["batch"]
+    sentinel = 3.25
+    for tdt in (torch.float16, torch.bfloat16, torch.float32):
+        A = torch.ones(max(1, b * m * k), dtype=tdt, device="cuda")
+        B = torch.ones(max(1, b * k * n), dtype=tdt, device="cuda")
+        C = torch.full((max(1, 2 * 64 * 64),), sentinel, dtype=tdt, device="cuda")
+        gpu.gemm_rowmajor(A, B, C, m, n, k, batch=b, strideA=m * k, strideB=k * n, strideC=m * n)
+        gpu.spmma_fused(A, B, C, m, n, k, batch=b, strideA=m * k, strideB=k * n, strideC=m * n)
+        esz = A.element_size()
+        blob = torch.zeros(max(16, gpu.compress24_size(m, k, esz, b)), dtype=torch.uint8, device="cuda")
+        if zero != "n":
+            gpu.compress24(A, m, k, k, b, m * k, blob)
+            gpu.decompress24(blob, m, k, k, b, m * k, A)
+        gpu.spmma(blob, B, C, m, n, k, batch=b, strideB=k * n, strideC=m * n)
+        assert bool((C == sentinel).all()), (zero, tdt)
+    # prune / check / one-pass / transpose on an empty matrix
+    A16 = torch.ones(16, dtype=torch.float16, device="cuda")
+    O16 = torch.full((16,), sentinel, dtype=torch.float16, device="cuda")
+    valid = torch.full((1,), 7, dtype=torch.int32, device="cuda")
+    blob = torch.zeros(64, dtype=torch.uint8, device="cuda")
+    gpu.prune24(A16, O16, 0, 64, 64, gpu.PRUNE_TILE)
+    gpu.prune24(A16, O16, 0, 64, 64, gpu.PRUNE_STRIP)
+    gpu.prune24_compress24(A16, O16, 0, 64, 64, 1, 0, blob, valid, gpu.PRUNE_TILE)
+    gpu.transpose(A16, O16, 0, 8)
+    gpu.transpose(A16, O16, 8, 0)
+    assert bool((O16 == sentinel).all())
+    # an empty matrix is trivially 2:4: both the one-pass call above and the check write "valid" (0) over the stale flag
+    assert int(host(valid)[0]) == 0
+    valid.fill_(7)
+    gpu.prune24_check(A16, 0, 64, 64, valid)
+    assert int(host(valid)[0]) == 0
+
+
+@pytest.mark.parametrize("tname", ["f16", "bf16", "f32"])
+def test_zero_length_k_scales_c_by_beta(gpu, tname):
+    import torch
+    tdt = {"f16": torch.float16, "bf16": torch.bfloat16, "f32": torch.float32}[tname]
+    m, n, b = 96, 72, 2
+    A = torch.ones(8, dtype=tdt, device="cuda")
+    B = torch.ones(8, dtype=tdt, device="cuda")
+    blob = torch.zeros(16, dtype=torch.uint8, device="cuda")
+    C0 = torch.arange(b * m * n, device="cuda").remainder(17).to(tdt)
+    for call in ("gemm", "spmma", "fused"):
+        for beta in (0.0, 0.5):
+            C = C0.clone()
+            if call == "gemm":
+                gpu.gemm_rowmajor(A, B, C, m, n, 0, lda=8, batch=b, strideA=0, strideB=0, strideC=m * n, alpha=2.0, beta=beta)
+            elif call == "spmma":
+                gpu.spmma(blob, B, C, m, n, 0, batch=b, strideB=0, strideC=m * n, alpha=2.0, beta=beta)
+            else:
+                gpu.spmma_fused(A, B, C, m, n, 0, lda=8, batch=b, strideA=0, strideB=0, strideC=m * n, alpha=2.0, beta=beta)
+            want = (C0.float() * beta).to(tdt)
+            assert torch.equal(C, want), (call, beta, tname)
