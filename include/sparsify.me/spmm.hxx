@@ -100,12 +100,14 @@ float strided_coo(std::size_t A_num_rows,
   util::timer_t t;
   util::range_t range("strided-COO-SpMM");
   t.begin();  // the reference times its buffer allocation too (spmm.hxx:155-156,183)
+  // the packed form's workspace (the counterpart of cusparseSpMM's buffer, spmm.hxx:178-183); the call itself picks the
+  // kernel: packed CSR for row-sorted input that fits, the row-pointer form or the atomic kernels otherwise
   std::size_t ws_bytes = 0;
-  (void)sm_spmm_coo_workspace_size(A_num_rows, &ws_bytes);
+  (void)sm_spmm_coo_packed_workspace_size(A_num_rows, A_nnz, &ws_bytes);
   device_vector<unsigned char> ws(ws_bytes);
-  const int rc = sm_spmm_coo_f32_ws(A_num_rows, A_num_cols, A_nnz, B_num_cols, num_batches, dA_rows, dA_cols,
-                                    reinterpret_cast<const float*>(dA_values), reinterpret_cast<const float*>(dB),
-                                    reinterpret_cast<float*>(dC), alpha, beta, ws.data().get(), nullptr);
+  const int rc = sm_spmm_coo_f32_packed(A_num_rows, A_num_cols, A_nnz, B_num_cols, num_batches, dA_rows, dA_cols,
+                                        reinterpret_cast<const float*>(dA_values), reinterpret_cast<const float*>(dB),
+                                        reinterpret_cast<float*>(dC), alpha, beta, ws.data().get(), ws_bytes, nullptr);
   t.end();
   if (rc != SM_STATUS_SUCCESS) std::cerr << "sparsifyme::batched::strided_coo: " << sm_last_error() << std::endl;
   return t.milliseconds();

@@ -201,6 +201,21 @@ int sm_spmm_coo_f32_ws(size_t A_num_rows, size_t A_num_cols, size_t A_nnz, size_
                        const float* B, float* C, float alpha, float beta, void* workspace,
                        sm_stream_t stream);
 
+/* COO, packed form (replaces the same cusparseSpMM call, spmm.hxx:164-187): the rows of A are first copied, on the
+ * device and once per call, into one stream of {LDS offset, value} entries padded per row, so that the product kernel
+ * (csrc/spmm.hip: spmm_csr_packed_kernel) carries no per-entry predicates, clamps or scattered stores -- the work
+ * cusparseSpMM does behind its buffer (spmm.hxx:178-183).  Workspace: sm_spmm_coo_packed_workspace_size(rows, nnz) bytes
+ * (16-byte aligned), its size passed back in `workspace_bytes`.  Taken when the rows are sorted (decided on the device,
+ * no synchronisation; unsorted input runs the atomic kernels) and (cols + 1) * 64 bytes fit the LDS (cols <= 2559);
+ * otherwise, or with
+ * a workspace that is too small (then treated as sm_spmm_coo_f32_ws's, or as none), sm_spmm_coo_f32_ws /
+ * sm_spmm_coo_f32 produce the same result.  Bitwise reproducible on the sorted path; hipGraph-capturable. */
+int sm_spmm_coo_packed_workspace_size(size_t A_num_rows, size_t A_nnz, size_t* bytes /*host*/);
+int sm_spmm_coo_f32_packed(size_t A_num_rows, size_t A_num_cols, size_t A_nnz, size_t B_num_cols,
+                           size_t num_batches, const int* rows, const int* cols, const float* vals,
+                           const float* B, float* C, float alpha, float beta, void* workspace,
+                           size_t workspace_bytes, sm_stream_t stream);
+
 /* ---- support: counter-based uniform fill (replaces the Thrust RNG transform of
  *      include/sparsify.me/util/gen.hxx:12-20); element i depends only on (seed, i). */
 int sm_fill_uniform_f16(void* out, size_t count, uint64_t seed, float lo, float hi, sm_stream_t stream);

@@ -67,6 +67,9 @@ _SIGS = {
     "sm_spmm_bell_batched_f32": [_c_ptr, _c_ptr, _c_size, _c_size, _c_size, _c_size, _c_ptr, _c_ptr, _c_size, _c_size, _c_f,
                                  _c_f, _c_ptr, _c_ptr],
     "sm_spmm_coo_workspace_size": [_c_size, ctypes.POINTER(_c_size)],
+    "sm_spmm_coo_packed_workspace_size": [_c_size, _c_size, ctypes.POINTER(_c_size)],
+    "sm_spmm_coo_f32_packed": [_c_size, _c_size, _c_size, _c_size, _c_size, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_f, _c_f,
+                               _c_ptr, _c_size, _c_ptr],
     "sm_spmm_coo_f32_ws": [_c_size, _c_size, _c_size, _c_size, _c_size, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_f, _c_f,
                            _c_ptr, _c_ptr],
     "sm_fill_uniform_f16": [_c_ptr, _c_size, ctypes.c_uint64, _c_f, _c_f, _c_ptr],

@@ -18,6 +18,7 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h16 __attribute__((ext_vector_type(16)));
 typedef short s4 __attribute__((ext_vector_type(4)));
 typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f2 __attribute__((ext_vector_type(2)));
 typedef float f16x __attribute__((ext_vector_type(16)));
 typedef unsigned int u4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u2 __attribute__((ext_vector_type(2)));

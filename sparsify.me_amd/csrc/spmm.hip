@@ -174,6 +174,15 @@ __global__ __launch_bounds__(256) void coo_rowptr_kernel(const int* __restrict__
   if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(ws, 1);
 }
 
+// grid: the row-pointer search needs A_rows + 1 threads, the sortedness scan strides over the non-zeros with the whole
+// grid -- sized by the rows alone it left 90 000 entries to one workgroup on a 196-row matrix (240 us)
+static void launch_coo_rowptr(const int* rows, size_t nnz, size_t A_rows, int* ws, hipStream_t st) {
+  size_t blocks = ceil_div(A_rows + 1 > nnz ? A_rows + 1 : nnz, (size_t)256);
+  const size_t need = ceil_div(A_rows + 1, (size_t)256);
+  if (blocks > 4096) blocks = 4096 > need ? 4096 : need;
+  coo_rowptr_kernel<<<(unsigned)blocks, 256, 0, st>>>(rows, nnz, A_rows, ws);
+}
+
 constexpr int CSR_J = 16;
 __global__ __launch_bounds__(256) void spmm_csr_kernel(size_t A_rows, size_t A_cols, size_t n, const int* __restrict__ ws,
                                                        const int* __restrict__ colsidx, const float* __restrict__ vals,
@@ -390,6 +399,238 @@ static int launch_csr_and_fallback(size_t A_num_rows, size_t A_num_cols, size_t 
   return check_launch("spmm_csr_kernel");
 }
 
+
+
+// ---------------------------------------------------------------------------------------------
+// COO, PACKED form (sm_spmm_coo_f32_packed): the CSR-with-vectors-in-LDS kernel above with its per-entry bookkeeping
+// moved into a re-ordering pass that runs once per call.  That kernel spends ~17 instructions per wave step (256
+// multiply-adds): two loads, their predicates, the column clamps, the address, four FMAs, and per row a 16-shuffle
+// reduction and 16 scattered 4-byte stores.  Here the rows are first copied into one stream of packed entries
+// {LDS byte offset of the column's slab row, value}, each row padded to a multiple of 32 entries with {zero row, 0.0f}
+// (an out-of-range column becomes such a pad: it is skipped, as before).  The product then needs per step one 8-byte
+// load (the stream is contiguous across the rows a wave owns, so the next 32 entries are requested before the
+// current ones are used), one add, one ds_read_b128 and two packed FMAs; no predicates, no clamps.  Per row the
+// partial sums are folded with row-rotate DPP adds inside 16 lanes and two xor-shuffles across them; a lane keeps the
+// totals of "its" row (row index mod the entries-per-step) and C is written every 64 / QL rows as 64-byte runs along
+// the rows of column-major C.  Deterministic (no atomics; fixed summation order).  Taken iff the rows are sorted --
+// decided on the device: ws[0] 0 -> 4 -- else the atomic kernels run.
+// ---------------------------------------------------------------------------------------------
+constexpr int PK_PAD = 32;  // entries: a multiple of the entries-per-step of every J
+
+struct PkPlan {  // int offsets into the workspace
+  size_t o_prow, o_ent, total_ints;
+};
+static PkPlan pk_plan(size_t m, size_t nnz) {
+  PkPlan p;
+  size_t o = m + 2;  // [0] flag, [1 .. m+1] row_ptr
+  p.o_prow = o; o += m + 1;
+  o = round_up(o, 4);
+  p.o_ent = o; o += 2 * (nnz + (PK_PAD - 1) * m + 6 * PK_PAD);  // + slack: the kernel requests units past the last
+  p.total_ints = o;
+  return p;
+}
+
+// one workgroup: exclusive scan of the padded row lengths
+__global__ __launch_bounds__(1024) void pk_scan_kernel(int* __restrict__ ws, int* __restrict__ prow, size_t A_rows) {
+  if (ws[0] != 0) return;
+  const int* row_ptr = ws + 1;
+  __shared__ int part[1024];
+  __shared__ int carry;
+  const unsigned tid = threadIdx.x;
+  if (tid == 0) carry = 0;
+  __syncthreads();
+  for (size_t r0 = 0; r0 < A_rows; r0 += 1024) {
+    const size_t r = r0 + tid;
+    const int len = r < A_rows ? (row_ptr[r + 1] - row_ptr[r] + PK_PAD - 1) / PK_PAD * PK_PAD : 0;
+    part[tid] = len;
+    __syncthreads();
+    for (unsigned d = 1; d < 1024; d <<= 1) {
+      const int add = tid >= d ? part[tid - d] : 0;
+      __syncthreads();
+      part[tid] += add;
+      __syncthreads();
+    }
+    if (r < A_rows) prow[r] = carry + part[tid] - len;
+    __syncthreads();
+    if (tid == 1023) carry += part[1023];
+    __syncthreads();
+  }
+  if (tid == 0) {
+    prow[A_rows] = carry;
+    ws[0] = 4;  // the packed kernel takes the call
+  }
+}
+
+// one wave per row: entries in input order, then the pads
+__global__ __launch_bounds__(256) void pk_pack_kernel(const int* __restrict__ ws, const int* __restrict__ colsidx,
+                                                      const float* __restrict__ vals, size_t A_rows, size_t A_cols,
+                                                      unsigned row_bytes, const int* __restrict__ prow, u2* __restrict__ ent) {
+  if (ws[0] != 4) return;
+  const int* row_ptr = ws + 1;
+  const unsigned lane = threadIdx.x & 63u;
+  const size_t r = blockIdx.x * (size_t)4 + (threadIdx.x >> 6);
+  if (r >= A_rows) return;
+  const int e0 = row_ptr[r], n = row_ptr[r + 1] - e0, p0 = prow[r], pn = prow[r + 1] - p0;
+  const unsigned zero_off = (unsigned)A_cols * row_bytes;
+  for (int i = (int)lane; i < pn; i += 64) {
+    u2 o = u2{zero_off, 0u};
+    if (i < n) {
+      const size_t c = (size_t)colsidx[e0 + i];
+      if (c < A_cols) o = u2{(unsigned)c * row_bytes, __builtin_bit_cast(unsigned, vals[e0 + i])};
+    }
+    ent[p0 + i] = o;
+  }
+}
+
+template <int N>
+__device__ __forceinline__ float row_ror_add(float x) {  // x + (x rotated right by N inside each row of 16 lanes): one instruction
+  float y;
+  // (s_nop 1: a DPP read of a VGPR needs two wait states after the VALU write; inside inline asm nobody else inserts them)
+  asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_ror:%2 row_mask:0xf bank_mask:0xf" : "=v"(y) : "v"(x), "n"(N));
+  return y;
+}
+
+template <int J>  // vectors per workgroup: 8, 16 or 32 (LDS = (A_cols + 1) * J * 4 bytes)
+__global__ __launch_bounds__(64 * LDS_WAVES) void spmm_csr_packed_kernel(size_t A_rows, size_t A_cols, size_t NV,
+                                                                          const int* __restrict__ ws, const int* __restrict__ prow,
+                                                                          const u2* __restrict__ ent, const float* __restrict__ B,
+                                                                          float* __restrict__ C, float alpha, float beta) {
+  constexpr int QL = J / 4;        // lanes across the vectors (one 16-byte LDS read = four vectors each)
+  constexpr int EL = 64 / QL;      // entries a wave takes per step, and rows per store group
+  constexpr int SPU = PK_PAD / EL; // steps per 32-entry unit
+  if (ws[0] != 4) return;
+  extern __shared__ __attribute__((aligned(16))) float Xs[];  // [A_cols + 1][J], the last row zeros
+  const size_t v0 = (size_t)blockIdx.x * J;
+  const unsigned tid = threadIdx.x, lane = tid & 63u;
+  const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // stage (as spmm_csr_lds_kernel): a thread gathers element c of four vectors into one 16-byte store
+  const size_t n_it = A_cols * QL;
+  for (size_t i0 = tid; i0 < n_it; i0 += 4 * 64 * LDS_WAVES) {
+    f4 x[4];
+#pragma unroll
+    for (unsigned u = 0; u < 4; ++u) {
+      const size_t i = i0 + u * 64 * LDS_WAVES;
+      const size_t c = i / QL;
+      const unsigned h = (unsigned)(i % QL);
+#pragma unroll
+      for (unsigned t = 0; t < 4; ++t) {
+        const size_t v = v0 + 4u * h + t;
+        x[u][t] = (i < n_it && v < NV) ? B[v * A_cols + c] : 0.0f;
+      }
+    }
+#pragma unroll
+    for (unsigned u = 0; u < 4; ++u) {
+      const size_t i = i0 + u * 64 * LDS_WAVES;
+      if (i < n_it) *reinterpret_cast<f4*>(Xs + (i / QL) * J + 4u * (unsigned)(i % QL)) = x[u];
+    }
+  }
+  if (tid < (unsigned)J) Xs[A_cols * J + tid] = 0.0f;
+  __syncthreads();
+  const unsigned e = lane / QL, q = lane % QL;
+  // blockIdx.y splits the rows; inside a split every wave owns a contiguous run of rows, i.e. one contiguous piece of
+  // the entry stream, which it walks in 32-entry units, PD units requested ahead of the one in use
+  constexpr int PD = 4;
+  const size_t rows_per = (A_rows + gridDim.y - 1) / gridDim.y, r_begin = blockIdx.y * rows_per;
+  const size_t r_end = r_begin + rows_per < A_rows ? r_begin + rows_per : A_rows;
+  const size_t rpw = (r_end - r_begin + LDS_WAVES - 1) / LDS_WAVES;
+  const size_t rw0 = r_begin + (size_t)wave * rpw;
+  if (rw0 >= r_end) return;
+  const size_t rw1 = rw0 + rpw < r_end ? rw0 + rpw : r_end;
+  const char* xs = reinterpret_cast<const char*>(Xs) + 16u * q;
+  const int pos0 = __builtin_amdgcn_readfirstlane(prow[rw0]);
+  const int pos1 = __builtin_amdgcn_readfirstlane(prow[rw1]);
+  const u2* eb = ent + pos0 + (int)e;
+  const int units = (pos1 - pos0) / PK_PAD;
+  u2 ring[PD][SPU];
+#pragma unroll
+  for (int d = 0; d < PD; ++d)
+#pragma unroll
+    for (int s = 0; s < SPU; ++s) ring[d][s] = eb[d * PK_PAD + s * EL];  // past the wave's piece: other rows or the slack
+  // row bookkeeping in 32-bit scalars (the wave's rows are rw0 + ri)
+  const int nrows = (int)(rw1 - rw0), rw0m = (int)(rw0 % EL);
+  int ri = 0;
+  auto row_end = [&](int i) {
+    const size_t rr = rw0 + (size_t)i + 1;
+    return __builtin_amdgcn_readfirstlane(prow[rr <= A_rows ? rr : A_rows]) - pos0;
+  };
+  int pend = row_end(0), pend1 = row_end(1), pend2 = row_end(2);  // in entries from pos0; two rows ahead
+  f4 acc = f4{0.f, 0.f, 0.f, 0.f}, keep = f4{0.f, 0.f, 0.f, 0.f};
+  const int bp16 = (int)((lane ^ 16u) * 4u), bp32 = (int)((lane ^ 32u) * 4u);  // ds_bpermute addresses of the xor partners
+  auto flush = [&](int last) {  // rows [group base, last] of this wave are in `keep`, lane e <-> row % EL
+    const int slot = (rw0m + last) % EL, i = last - slot + (int)e;  // wave-relative index of lane e's row
+    if (i >= 0 && i <= last) {
+      const size_t rr = rw0 + (size_t)i;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const size_t v = v0 + 4u * q + t;
+        if (v < NV) {
+          float* d = C + v * A_rows + rr;
+          *d = beta != 0.0f ? alpha * keep[t] + beta * *d : alpha * keep[t];
+        }
+      }
+    }
+  };
+  auto finish_rows = [&](int done) {  // every row that ends at `done` entries (empty rows included)
+    while (ri < nrows && pend <= done) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        float x = acc[t];
+        if (QL <= 2) x = row_ror_add<2>(x);
+        if (QL <= 4) x = row_ror_add<4>(x);
+        x = row_ror_add<8>(x);
+        x += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(bp16, __builtin_bit_cast(int, x)));
+        x += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(bp32, __builtin_bit_cast(int, x)));
+        acc[t] = x;
+      }
+      const int slot = (rw0m + ri) % EL;
+      if ((int)e == slot) keep = acc;
+      if (slot == EL - 1 || ri + 1 == nrows) flush(ri);
+      acc = f4{0.f, 0.f, 0.f, 0.f};
+      ++ri;
+      pend = pend1;
+      pend1 = pend2;
+      pend2 = row_end(ri + 2);
+    }
+  };
+  finish_rows(0);  // leading empty rows
+  for (int u0 = 0; u0 < units; u0 += PD) {
+#pragma unroll
+    for (int d = 0; d < PD; ++d) {
+      const int u = u0 + d;
+      if (u < units) {
+        u2 cur[SPU];
+#pragma unroll
+        for (int s = 0; s < SPU; ++s) cur[s] = ring[d][s];
+#pragma unroll
+        for (int s = 0; s < SPU; ++s) ring[d][s] = eb[(u + PD) * PK_PAD + s * EL];
+#pragma unroll
+        for (int s = 0; s < SPU; ++s) {
+          const f4 x = *reinterpret_cast<const f4*>(xs + cur[s][0]);
+          const unsigned ab = cur[s][1];
+          const float a = __builtin_bit_cast(float, ab);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) acc[t] = fmaf(a, x[t], acc[t]);
+        }
+        finish_rows((u + 1) * PK_PAD);
+      }
+    }
+  }
+}
+
+template <int J>
+static int launch_csr_packed(size_t A_rows, size_t A_cols, size_t nv, const int* ws, const PkPlan& p, const float* B, float* C,
+                             float alpha, float beta, hipStream_t st) {
+  const size_t lds = (A_cols + 1) * J * sizeof(float);
+  static LdsOptIn lds_optin;
+  if (const int rc = ensure_dyn_lds(lds_optin, reinterpret_cast<const void*>(&spmm_csr_packed_kernel<J>), (160 * 1024), "spmm_csr_packed_kernel")) return rc;
+  const size_t groups = ceil_div(nv, (size_t)J);
+  size_t rsplit = 1;
+  while (groups * rsplit < 1024 && A_rows / (rsplit * 2) >= 256) rsplit *= 2;
+  spmm_csr_packed_kernel<J><<<dim3((unsigned)groups, (unsigned)rsplit), 64 * LDS_WAVES, lds, st>>>(
+      A_rows, A_cols, nv, ws, ws + p.o_prow, reinterpret_cast<const u2*>(ws + p.o_ent), B, C, alpha, beta);
+  return check_launch("spmm_csr_packed_kernel");
+}
+
 }  // namespace sm
 
 using namespace sm;
@@ -536,8 +777,61 @@ int sm_spmm_coo_f32_ws(size_t A_num_rows, size_t A_num_cols, size_t A_nnz, size_
   hipStream_t st = (hipStream_t)stream;
   int* ws = (int*)workspace;
   if (hipMemsetAsync(ws, 0, sizeof(int), st) != hipSuccess) return check_launch("hipMemsetAsync");
-  coo_rowptr_kernel<<<(unsigned)ceil_div(A_num_rows + 1, 256), 256, 0, st>>>(rows, A_nnz, A_num_rows, ws);
+  launch_coo_rowptr(rows, A_nnz, A_num_rows, ws, st);
   return launch_csr_and_fallback(A_num_rows, A_num_cols, A_nnz, B_num_cols, num_batches, ws, rows, cols, vals, B, C, alpha, beta, st, 0);
+}
+
+
+int sm_spmm_coo_packed_workspace_size(size_t A_num_rows, size_t A_nnz, size_t* bytes) {
+  if (!bytes) {
+    set_error("sm_spmm_coo_packed_workspace_size: null output");
+    return SM_STATUS_INVALID_VALUE;
+  }
+  *bytes = round_up(pk_plan(A_num_rows, A_nnz).total_ints * sizeof(int), 256);
+  return SM_STATUS_SUCCESS;
+}
+
+int sm_spmm_coo_f32_packed(size_t A_num_rows, size_t A_num_cols, size_t A_nnz, size_t B_num_cols, size_t num_batches,
+                           const int* rows, const int* cols, const float* vals, const float* B, float* C, float alpha,
+                           float beta, void* workspace, size_t workspace_bytes, sm_stream_t stream) {
+  const PkPlan p = pk_plan(A_num_rows, A_nnz);
+  const size_t nv = B_num_cols * num_batches, row_bytes_max = (A_num_cols + 1) * sizeof(float);
+  // as many vectors per workgroup as the slab (columns + a zero row) leaves room for: 32 while two workgroups share a CU
+  const int J = row_bytes_max * 32 <= 80 * 1024 ? 32 : (row_bytes_max * 16 <= 160 * 1024 ? 16 : 8);
+  const bool can = workspace && workspace_bytes >= p.total_ints * sizeof(int) && A_nnz > 0 && aligned16(workspace) &&
+                   J >= 16 /* 8 vectors per workgroup: measured slower than the row-pointer form (445 vs 339 us) */ &&
+                   row_bytes_max * J <= 160 * 1024 && A_nnz + PK_PAD * (A_num_rows + 2) <= 0x7fffffffull &&
+                   A_num_rows <= 0x7ffffff0ull && ceil_div(nv, (size_t)J) <= 0x7fffffffull;
+  if (!can) {
+    size_t small = 0;
+    (void)sm_spmm_coo_workspace_size(A_num_rows, &small);
+    return sm_spmm_coo_f32_ws(A_num_rows, A_num_cols, A_nnz, B_num_cols, num_batches, rows, cols, vals, B, C, alpha, beta,
+                              workspace && workspace_bytes >= small ? workspace : nullptr, stream);
+  }
+  if (!B || !C || !rows || !cols || !vals) {
+    set_error("sm_spmm_coo_f32_packed: invalid argument");
+    return SM_STATUS_INVALID_VALUE;
+  }
+  const size_t count = A_num_rows * nv;
+  if (count == 0) return SM_STATUS_SUCCESS;
+  hipStream_t st = (hipStream_t)stream;
+  int* ws = (int*)workspace;
+  if (hipMemsetAsync(ws, 0, sizeof(int), st) != hipSuccess) return check_launch("hipMemsetAsync");
+  launch_coo_rowptr(rows, A_nnz, A_num_rows, ws, st);
+  pk_scan_kernel<<<1, 1024, 0, st>>>(ws, ws + p.o_prow, A_num_rows);
+  pk_pack_kernel<<<(unsigned)ceil_div(A_num_rows, (size_t)4), 256, 0, st>>>(ws, cols, vals, A_num_rows, A_num_cols, (unsigned)(J * sizeof(float)),
+                                                                            ws + p.o_prow, reinterpret_cast<u2*>(ws + p.o_ent));
+  if (check_launch("sm_spmm_coo_f32_packed: re-ordering") != SM_STATUS_SUCCESS) return SM_STATUS_LAUNCH_FAILED;
+  int rc;
+  if (J == 32) rc = launch_csr_packed<32>(A_num_rows, A_num_cols, nv, ws, p, B, C, alpha, beta, st);
+  else rc = launch_csr_packed<16>(A_num_rows, A_num_cols, nv, ws, p, B, C, alpha, beta, st);
+  if (rc != SM_STATUS_SUCCESS) return rc;
+  // rows not sorted (flag odd): the atomic kernels
+  scale_if_unsorted_kernel<<<(unsigned)(ceil_div(count, (size_t)256) < 1024 ? ceil_div(count, (size_t)256) : 1024), 256, 0, st>>>(ws, C, count, beta);
+  const size_t gx = ceil_div(A_nnz, (size_t)256);
+  dim3 g2((unsigned)(gx < 64 ? gx : 64), (unsigned)(nv < 64 ? nv : 64));
+  spmm_coo_if_unsorted_kernel<<<g2, dim3(256), 0, st>>>(ws, A_num_rows, A_num_cols, A_nnz, nv, rows, cols, vals, B, C, alpha);
+  return check_launch("sm_spmm_coo_f32_packed");
 }
 
 }  // extern "C"

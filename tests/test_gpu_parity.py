@@ -854,10 +854,32 @@ def _coo_problem(m, k, seed, density=0.1):
     return r.astype(np.int32), c.astype(np.int32), v, rng
 
 
+
+def _coo_call(gpu, entry, m, k, nnz, n, batches, dr, dc, dv, dB, dC, alpha, beta, fill=0x5A):
+    """sm_spmm_coo_f32_ws (row-pointer workspace) or sm_spmm_coo_f32_packed (padded, packed copy of A); the workspace is
+    pre-filled with garbage: a stale one must not matter."""
+    import ctypes
+    import torch
+    nb = ctypes.c_size_t(0)
+    if entry == "ws":
+        assert gpu.lib().sm_spmm_coo_workspace_size(m, ctypes.byref(nb)) == 0
+        ws = torch.full((nb.value,), fill, dtype=torch.uint8, device="cuda")
+        rc = gpu.lib().sm_spmm_coo_f32_ws(m, k, nnz, n, batches, dr.data_ptr(), dc.data_ptr(), dv.data_ptr(), dB.data_ptr(),
+                                          dC.data_ptr(), alpha, beta, ws.data_ptr(), None)
+    else:
+        assert gpu.lib().sm_spmm_coo_packed_workspace_size(m, nnz, ctypes.byref(nb)) == 0
+        ws = torch.full((nb.value,), fill, dtype=torch.uint8, device="cuda")
+        rc = gpu.lib().sm_spmm_coo_f32_packed(m, k, nnz, n, batches, dr.data_ptr(), dc.data_ptr(), dv.data_ptr(), dB.data_ptr(),
+                                               dC.data_ptr(), alpha, beta, ws.data_ptr(), nb.value, None)
+    assert rc == 0, gpu.lib().sm_last_error()
+    return ws
+
+
+@pytest.mark.parametrize("entry", ["ws", "packed"])
 @pytest.mark.parametrize("shape", [(784, 256, 2304), (12544, 64, 576), (196, 512, 4608), (3136, 128, 1152)],
                          ids=lambda s: "x".join(map(str, s)))
 @pytest.mark.parametrize("order", ["sorted", "shuffled"])
-def test_spmm_coo_config5_resnet50_shapes(gpu, orc, shape, order):
+def test_spmm_coo_config5_resnet50_shapes(gpu, orc, shape, order, entry):
     """sm_spmm_coo_f32_ws at config 5's sizes: A m x k with ~10 % non-zeros shared by b = 32 batches, B_b k x n and
     C_b m x n column-major (spmm.hxx:164-187).  Row-sorted input takes the CSR kernels (the shapes pick J = 32 / 16 / 8
     vectors per workgroup and the row split), shuffled input the atomic fallback.  Sampled (row, column, batch) entries
@@ -877,13 +899,11 @@ def test_spmm_coo_config5_resnet50_shapes(gpu, orc, shape, order):
     dC = torch.empty(batches * m * n, dtype=torch.float32, device="cuda")
     gpu.fill_uniform(dC, 0xC0C + m, -1.0, 1.0)
     C0 = dC.clone()
-    nb = ctypes.c_size_t(0)
     dr, dc, dv = to_dev(r), to_dev(c), to_dev(v)
-    assert gpu.lib().sm_spmm_coo_workspace_size(m, ctypes.byref(nb)) == 0
-    ws = torch.full((nb.value,), 0x5A, dtype=torch.uint8, device="cuda")   # a stale workspace must not matter
-    rc = gpu.lib().sm_spmm_coo_f32_ws(m, k, nnz, n, batches, dr.data_ptr(), dc.data_ptr(), dv.data_ptr(), dB.data_ptr(),
-                                      dC.data_ptr(), alpha, beta, ws.data_ptr(), None)
-    assert rc == 0, gpu.lib().sm_last_error()
+    ws = _coo_call(gpu, entry, m, k, nnz, n, batches, dr, dc, dv, dB, dC, alpha, beta)
+    if entry == "packed":   # the device-side decision: 4 = packed kernel (sorted rows), 1 = atomic fallback; k = 4608 is
+        # beyond the packed form's LDS slab and runs as the row-pointer form (flag 0)
+        assert int(host(ws[:4].view(torch.int32))[0]) == ((4 if k <= 2559 else 0) if order == "sorted" else 1)
     # sub-problem: sampled rows (first, last, random) x sampled vectors (batch, column)
     rs = np.unique(np.concatenate([[0, m - 1], rng.integers(0, m, 30)]))
     vecs = [(0, 0), (batches - 1, n - 1)] + [(int(rng.integers(0, batches)), int(rng.integers(0, n))) for _ in range(14)]
@@ -911,10 +931,11 @@ def test_spmm_coo_config5_resnet50_shapes(gpu, orc, shape, order):
         assert np.array_equal(host(dC).reshape(batches, n, m)[:, :, e], (np.float32(beta) * C0h[:, :, e]).astype(np.float32))
 
 
-@pytest.mark.parametrize("shape", [(150, 33, 90, 3), (64, 9, 48, 2), (300, 130, 260, 1), (17, 5, 129, 4), (129, 64, 128, 2)],
+@pytest.mark.parametrize("shape", [(150, 33, 90, 3), (64, 9, 48, 2), (300, 130, 260, 1), (17, 5, 129, 4), (129, 64, 128, 2), (50, 70, 1000, 3), (33, 300, 52, 1)],
                          ids=lambda s_: "x".join(map(str, s_)))
 @pytest.mark.parametrize("order", ["sorted", "cols_shuffled_within_rows", "shuffled", "duplicates"])
-def test_spmm_coo_ws_orders_vs_oracle(gpu, orc, shape, order):
+@pytest.mark.parametrize("entry", ["ws", "packed"])
+def test_spmm_coo_ws_orders_vs_oracle(gpu, orc, shape, order, entry):
     """sm_spmm_coo_f32_ws on small shapes against the oracle on every entry: row-sorted input (columns sorted or not,
     duplicates included) takes the CSR kernel, fully shuffled input the atomic kernels; all four must agree."""
     import ctypes
@@ -936,17 +957,13 @@ def test_spmm_coo_ws_orders_vs_oracle(gpu, orc, shape, order):
     C0 = rng.uniform(-1, 1, batches * m * n).astype(np.float32)
     want = C0.copy()
     orc.spmm_coo(m, k, r.size, n, batches, r, c, v, B, want, 1.5, -0.75)
-    nb = ctypes.c_size_t(0)
-    assert gpu.lib().sm_spmm_coo_workspace_size(m, ctypes.byref(nb)) == 0
-    ws = torch.full((nb.value,), 0xA5, dtype=torch.uint8, device="cuda")
     dC, dr, dc, dv, dB = to_dev(C0.copy()), to_dev(r), to_dev(c), to_dev(v), to_dev(B)
-    rc = gpu.lib().sm_spmm_coo_f32_ws(m, k, r.size, n, batches, dr.data_ptr(), dc.data_ptr(), dv.data_ptr(), dB.data_ptr(),
-                                      dC.data_ptr(), 1.5, -0.75, ws.data_ptr(), None)
-    assert rc == 0, gpu.lib().sm_last_error()
+    _coo_call(gpu, entry, m, k, r.size, n, batches, dr, dc, dv, dB, dC, 1.5, -0.75, fill=0xA5)
     assert np.allclose(host(dC), want, rtol=2e-5, atol=2e-5), f"max diff {np.abs(host(dC) - want).max():.3e}"
 
 
-def test_spmm_coo_rejects_nothing_but_routes_bad_rows_to_the_atomic_kernel(gpu, orc):
+@pytest.mark.parametrize("entry", ["ws", "packed"])
+def test_spmm_coo_rejects_nothing_but_routes_bad_rows_to_the_atomic_kernel(gpu, orc, entry):
     """Row indices outside [0, rows) (the cuSPARSE call would be undefined) are skipped entry by entry, never used as
     CSR row pointers: a negative index in an otherwise sorted list must not displace valid entries."""
     import ctypes
@@ -960,14 +977,9 @@ def test_spmm_coo_rejects_nothing_but_routes_bad_rows_to_the_atomic_kernel(gpu, 
     want = np.zeros(batches * m * n, dtype=np.float32)
     ok = (r2 >= 0) & (r2 < m)
     orc.spmm_coo(m, k, int(ok.sum()), n, batches, r2[ok].copy(), c[ok].copy(), v[ok].copy(), B, want, 1.0, 0.0)
-    nb = ctypes.c_size_t(0)
-    assert gpu.lib().sm_spmm_coo_workspace_size(m, ctypes.byref(nb)) == 0
-    ws = torch.zeros(nb.value, dtype=torch.uint8, device="cuda")
     dC = torch.full((batches * m * n,), 5.0, dtype=torch.float32, device="cuda")
     dr, dc, dv, dB = to_dev(r2), to_dev(c), to_dev(v), to_dev(B)
-    rc = gpu.lib().sm_spmm_coo_f32_ws(m, k, r2.size, n, batches, dr.data_ptr(), dc.data_ptr(), dv.data_ptr(), dB.data_ptr(),
-                                      dC.data_ptr(), 1.0, 0.0, ws.data_ptr(), None)
-    assert rc == 0
+    _coo_call(gpu, entry, m, k, r2.size, n, batches, dr, dc, dv, dB, dC, 1.0, 0.0, fill=0)
     assert np.allclose(host(dC), want, rtol=1e-5, atol=1e-5)
 
 
@@ -1667,3 +1679,68 @@ def test_zero_length_k_scales_c_by_beta(gpu, tname):
                 gpu.spmma_fused(A, B, C, m, n, 0, lda=8, batch=b, strideA=0, strideB=0, strideC=m * n, alpha=2.0, beta=beta)
             want = (C0.float() * beta).to(tdt)
             assert torch.equal(C, want), (call, beta, tname)
+
+
+def test_spmm_coo_packed_dense_rows_and_bad_columns(gpu, orc):
+    """Sixteen half-dense rows among sparse ones (row lengths far from the pad unit), and column indices outside [0, cols),
+    which are skipped as in the CSR kernels."""
+    import torch
+    m, k, n, batches = 48, 256, 40, 2
+    rng = np.random.default_rng(99)
+    dense = rng.random((m, k)) < 0.1
+    dense[0:16, 0:128] = True
+    r, c = np.nonzero(dense)
+    r, c = r.astype(np.int32), c.astype(np.int32)
+    v = rng.uniform(-1, 1, r.size).astype(np.float32)
+    B = rng.uniform(-1, 1, batches * k * n).astype(np.float32)
+    C0 = rng.uniform(-1, 1, batches * m * n).astype(np.float32)
+    want = C0.copy()
+    orc.spmm_coo(m, k, r.size, n, batches, r, c, v, B, want, 0.5, 2.0)
+    dC, dr, dc, dv, dB = to_dev(C0.copy()), to_dev(r), to_dev(c), to_dev(v), to_dev(B)
+    ws = _coo_call(gpu, "packed", m, k, r.size, n, batches, dr, dc, dv, dB, dC, 0.5, 2.0)
+    assert int(host(ws[:4].view(torch.int32))[0]) == 4
+    assert np.allclose(host(dC), want, rtol=2e-5, atol=2e-5)
+    # a sparse problem with two out-of-range columns: skipped, the rest exact
+    r2, c2, v2, rng = _coo_problem(m, k, 5, 0.08)
+    c3 = c2.copy()
+    c3[3] = k + 7
+    c3[-2] = -1
+    ok = (c3 >= 0) & (c3 < k)
+    want = C0.copy()
+    orc.spmm_coo(m, k, int(ok.sum()), n, batches, r2[ok].copy(), c3[ok].copy(), v2[ok].copy(), B, want, 1.0, 1.0)
+    dC = to_dev(C0.copy())
+    ws = _coo_call(gpu, "packed", m, k, r2.size, n, batches, to_dev(r2), to_dev(c3), to_dev(v2), dB, dC, 1.0, 1.0)
+    assert int(host(ws[:4].view(torch.int32))[0]) == 4
+    assert np.allclose(host(dC), want, rtol=2e-5, atol=2e-5)
+
+
+def test_spmm_coo_packed_is_deterministic_and_graph_capturable(gpu):
+    """Same input, same bits (a row's products are added in input order, chunk by chunk; no atomics on the sorted path), also
+    when the whole call -- preprocessing included -- is replayed from a hipGraph."""
+    import ctypes
+    import torch
+    m, k, n, batches = 784, 2304, 24, 2
+    r, c, v, rng = _coo_problem(m, k, 4242)
+    dr, dc, dv = to_dev(r), to_dev(c), to_dev(v)
+    dB = torch.empty(batches * k * n, dtype=torch.float32, device="cuda")
+    gpu.fill_uniform(dB, 17, -1.0, 1.0)
+    nb = ctypes.c_size_t(0)
+    assert gpu.lib().sm_spmm_coo_packed_workspace_size(m, r.size, ctypes.byref(nb)) == 0
+    ws = torch.zeros(nb.value, dtype=torch.uint8, device="cuda")
+    outs = []
+    for _ in range(2):
+        dC = torch.zeros(batches * m * n, dtype=torch.float32, device="cuda")
+        assert gpu.lib().sm_spmm_coo_f32_packed(m, k, r.size, n, batches, dr.data_ptr(), dc.data_ptr(), dv.data_ptr(), dB.data_ptr(),
+                                                 dC.data_ptr(), 1.0, 0.0, ws.data_ptr(), nb.value, None) == 0
+        outs.append(host(dC).copy())
+    assert np.array_equal(bits(outs[0]), bits(outs[1]))
+    dC = torch.zeros(batches * m * n, dtype=torch.float32, device="cuda")
+    side = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    torch.cuda.synchronize()
+    with torch.cuda.graph(g, stream=side):
+        assert gpu.lib().sm_spmm_coo_f32_packed(m, k, r.size, n, batches, dr.data_ptr(), dc.data_ptr(), dv.data_ptr(), dB.data_ptr(),
+                                                 dC.data_ptr(), 1.0, 0.0, ws.data_ptr(), nb.value,
+                                                 ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
+    g.replay()
+    assert np.array_equal(bits(host(dC)), bits(outs[0]))
