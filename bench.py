@@ -75,6 +75,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--settle-ms", type=float, default=300.0,
+                    help="setup, before the W warm-up steps: untimed replays of the step for this long (clock ramp after an idle "
+                         "GPU, first-use state of a fresh graph); 0 = none.  Stated in config.launch")
     ap.add_argument("--tables", default=None,
                     help="comma-separated shape tables (names under datasets/ or paths), concatenated into one work list; "
                          "default resnet50 (fp16 / bf16) or resnet18 (f32: BASELINE config 2); "
@@ -278,6 +281,12 @@ def main():
         return e0.elapsed_time(e1) * 1e-3 / reps
 
     run_full = make_runner(step_full)
+    if args.settle_ms > 0:  # part of the setup, like the buffer fills and the graph capture: not one of the K timed steps
+        t_end = time.perf_counter() + args.settle_ms * 1e-3
+        while time.perf_counter() < t_end:
+            for _ in range(8):
+                run_full()
+            torch.cuda.synchronize()
     wall = timed(run_full, args.steps, args.warmup)
     tot_flops, wall_max = mg.rollup(flops * args.steps, wall, None if args.rehearse_gloo else dev)
     ms_per_step = wall_max / args.steps * 1e3
@@ -308,7 +317,8 @@ def main():
                    "path": path_desc,
                    "layers": len(shapes), "layers_this_rank": len(layers), "batch": shapes[0][3],
                    "dense_equiv_gflop_per_step": tot_flops / args.steps / 1e9,
-                   "launch": "eager" if args.eager else ("hipGraph replay, one linear graph per stream" if args.graphs == "per-stream" else "hipGraph replay of one step"),
+                   "launch": ("eager" if args.eager else ("hipGraph replay, one linear graph per stream" if args.graphs == "per-stream" else "hipGraph replay of one step"))
+                             + (f"; setup runs {args.settle_ms:.0f} ms of untimed replays before the W warm-up steps" if args.settle_ms > 0 else ""),
                    "streams": args.streams, "sched": args.sched,
                    "parallelism": f"{args.scaling} x{world}: {split}; no data-path collective, one all-reduce of "
                                   "{sum flops, max seconds}"},

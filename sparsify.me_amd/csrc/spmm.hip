@@ -430,33 +430,31 @@ static PkPlan pk_plan(size_t m, size_t nnz) {
   return p;
 }
 
-// one workgroup: exclusive scan of the padded row lengths
+// one workgroup: exclusive scan of the padded row lengths (a thread sums a contiguous run of rows, one scan of the 1024
+// run totals, then the thread walks its run again)
 __global__ __launch_bounds__(1024) void pk_scan_kernel(int* __restrict__ ws, int* __restrict__ prow, size_t A_rows) {
   if (ws[0] != 0) return;
   const int* row_ptr = ws + 1;
   __shared__ int part[1024];
-  __shared__ int carry;
   const unsigned tid = threadIdx.x;
-  if (tid == 0) carry = 0;
+  const size_t run = (A_rows + 1023) / 1024, r0 = tid * run, r1 = r0 + run < A_rows ? r0 + run : A_rows;
+  int tot = 0;
+  for (size_t r = r0; r < r1; ++r) tot += (row_ptr[r + 1] - row_ptr[r] + PK_PAD - 1) / PK_PAD * PK_PAD;
+  part[tid] = tot;
   __syncthreads();
-  for (size_t r0 = 0; r0 < A_rows; r0 += 1024) {
-    const size_t r = r0 + tid;
-    const int len = r < A_rows ? (row_ptr[r + 1] - row_ptr[r] + PK_PAD - 1) / PK_PAD * PK_PAD : 0;
-    part[tid] = len;
+  for (unsigned d = 1; d < 1024; d <<= 1) {  // inclusive scan
+    const int add = tid >= d ? part[tid - d] : 0;
     __syncthreads();
-    for (unsigned d = 1; d < 1024; d <<= 1) {
-      const int add = tid >= d ? part[tid - d] : 0;
-      __syncthreads();
-      part[tid] += add;
-      __syncthreads();
-    }
-    if (r < A_rows) prow[r] = carry + part[tid] - len;
-    __syncthreads();
-    if (tid == 1023) carry += part[1023];
+    part[tid] += add;
     __syncthreads();
   }
-  if (tid == 0) {
-    prow[A_rows] = carry;
+  int at = part[tid] - tot;
+  for (size_t r = r0; r < r1; ++r) {
+    prow[r] = at;
+    at += (row_ptr[r + 1] - row_ptr[r] + PK_PAD - 1) / PK_PAD * PK_PAD;
+  }
+  if (tid == 1023) {
+    prow[A_rows] = part[1023];
     ws[0] = 4;  // the packed kernel takes the call
   }
 }
