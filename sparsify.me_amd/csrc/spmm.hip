@@ -795,9 +795,12 @@ int sm_spmm_coo_f32_packed(size_t A_num_rows, size_t A_num_cols, size_t A_nnz, s
   const PkPlan p = pk_plan(A_num_rows, A_nnz);
   const size_t nv = B_num_cols * num_batches, row_bytes_max = (A_num_cols + 1) * sizeof(float);
   // as many vectors per workgroup as the slab (columns + a zero row) leaves room for: 32 while two workgroups share a CU
-  const int J = row_bytes_max * 32 <= 80 * 1024 ? 32 : (row_bytes_max * 16 <= 160 * 1024 ? 16 : 8);
+  int J = row_bytes_max * 32 <= 80 * 1024 ? 32 : (row_bytes_max * 16 <= 160 * 1024 ? 16 : 8);
+  static const int pk_j_env = tuning_int("SM_SPMM_PK_J", 0);  // tuning aid: 8 / 16 / 32 vectors per workgroup
+  const bool forced = pk_j_env == 8 || pk_j_env == 16 || pk_j_env == 32;
+  if (forced) J = pk_j_env;
   const bool can = workspace && workspace_bytes >= p.total_ints * sizeof(int) && A_nnz > 0 && aligned16(workspace) &&
-                   J >= 16 /* 8 vectors per workgroup: measured slower than the row-pointer form (445 vs 339 us) */ &&
+                   (J >= 16 || forced) /* 8 vectors per workgroup: measured slower than the row-pointer form (445 vs 339 us) */ &&
                    row_bytes_max * J <= 160 * 1024 && A_nnz + PK_PAD * (A_num_rows + 2) <= 0x7fffffffull &&
                    A_num_rows <= 0x7ffffff0ull && ceil_div(nv, (size_t)J) <= 0x7fffffffull;
   if (!can) {
@@ -822,7 +825,8 @@ int sm_spmm_coo_f32_packed(size_t A_num_rows, size_t A_num_cols, size_t A_nnz, s
   if (check_launch("sm_spmm_coo_f32_packed: re-ordering") != SM_STATUS_SUCCESS) return SM_STATUS_LAUNCH_FAILED;
   int rc;
   if (J == 32) rc = launch_csr_packed<32>(A_num_rows, A_num_cols, nv, ws, p, B, C, alpha, beta, st);
-  else rc = launch_csr_packed<16>(A_num_rows, A_num_cols, nv, ws, p, B, C, alpha, beta, st);
+  else if (J == 16) rc = launch_csr_packed<16>(A_num_rows, A_num_cols, nv, ws, p, B, C, alpha, beta, st);
+  else rc = launch_csr_packed<8>(A_num_rows, A_num_cols, nv, ws, p, B, C, alpha, beta, st);
   if (rc != SM_STATUS_SUCCESS) return rc;
   // rows not sorted (flag odd): the atomic kernels
   scale_if_unsorted_kernel<<<(unsigned)(ceil_div(count, (size_t)256) < 1024 ? ceil_div(count, (size_t)256) : 1024), 256, 0, st>>>(ws, C, count, beta);
