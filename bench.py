@@ -106,7 +106,7 @@ def main():
                     help="HIP streams the independent layers of a step are spread over (fork/join inside the step)")
     ap.add_argument("--graphs", choices=["single", "per-stream"], default="single",
                     help="hipGraph form of a step: one graph holding every chain (default) or one linear graph per stream")
-    ap.add_argument("--sched", choices=["rr", "split"], default="rr",
+    ap.add_argument("--sched", choices=["rr", "split", "lpt"], default="rr",
                     help="layer -> stream assignment: round-robin, or chip-filling layers (>= 784 row tiles) on the first half "
                          "of the streams and the under-filling ones on the second half")
     ap.add_argument("--rehearse-gloo", action="store_true",
@@ -175,6 +175,15 @@ def main():
             w = (0 if big == 0 else half[0]) + cnt[big] % half[big]
             cnt[big] += 1
         chains[w].append(L)
+    if args.sched == "lpt":  # longest chain first by the layers' bytes (A + B + C: what the kernels stream), largest layers first
+        def cost(L):
+            return L["b"] * (L["m"] * L["k"] + L["m"] * L["n"]) + L["k"] * L["n"]
+        chains = [[] for _ in range(nstreams)]
+        load = [0] * nstreams
+        for L in sorted(layers, key=cost, reverse=True):
+            w = load.index(min(load))
+            chains[w].append(L)
+            load[w] += cost(L)
 
     class Forked:
         """A step whose layers are spread over the streams: fork, one chain of layers per stream, join."""
@@ -493,6 +502,9 @@ def extras(args, sm, torch, dev, layers, flops, t_full, Forked, make_runner, tim
                            "kernel": dom, "launches_per_step": d["launches"], "avg_launch_us": d["seconds"] / d["launches"] * 1e6,
                            "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],
                            "measured": "single stream, one kernel family at a time, HIP events on the launch stream, hipGraph replay",
+                           "yardstick": {"device_copy_GBs": 5150.0, "frac_of_device_copy": GBs / 5150.0,
+                                         "source": "profiles/copy_yardstick_r01.txt: a plain 1 GiB device-to-device copy (read + write) on this part; "
+                                                   "context only -- `frac` is against the 8 TB/s specification"},
                            "families": fams_out}
 
 

@@ -1744,3 +1744,23 @@ def test_spmm_coo_packed_is_deterministic_and_graph_capturable(gpu):
                                                  ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
     g.replay()
     assert np.array_equal(bits(host(dC)), bits(outs[0]))
+
+
+@pytest.mark.parametrize("entry", ["ws", "packed"])
+def test_spmm_coo_without_non_zeros_scales_c_by_beta(gpu, entry):
+    """nnz = 0: C = beta * C (beta = 0 must also clear a NaN); zero rows / vectors: a successful no-op."""
+    import torch
+    m, k, n, batches = 40, 64, 12, 2
+    dr = torch.zeros(4, dtype=torch.int32, device="cuda")
+    dv = torch.zeros(4, dtype=torch.float32, device="cuda")
+    dB = torch.ones(batches * k * n, dtype=torch.float32, device="cuda")
+    for beta in (0.0, -2.0):
+        dC = torch.arange(batches * m * n, device="cuda").remainder(9).float()
+        dC[3] = float("nan") if beta == 0.0 else 1.0
+        want = torch.zeros_like(dC) if beta == 0.0 else dC * beta
+        _coo_call(gpu, entry, m, k, 0, n, batches, dr, dr, dv, dB, dC, 1.0, beta)
+        assert torch.equal(dC, want), (entry, beta)
+    dC = torch.full((16,), 7.0, device="cuda")
+    _coo_call(gpu, entry, 0, k, 0, n, batches, dr, dr, dv, dB, dC, 1.0, 0.0)
+    _coo_call(gpu, entry, m, k, 0, 0, batches, dr, dr, dv, dB, dC, 1.0, 0.0)
+    assert bool((dC == 7.0).all())
