@@ -83,9 +83,11 @@ def main():
                          "default resnet50 (fp16 / bf16) or resnet18 (f32: BASELINE config 2); "
                          "config 4 = resnet50,resnet101,resnet152")
     ap.add_argument("--table", default=None, help="one shape table (alias of --tables)")
-    ap.add_argument("--scaling", choices=["weak", "strong", "lpt"], default="weak",
+    ap.add_argument("--scaling", choices=["weak", "strong", "lpt", "hybrid"], default=None,
                     help="multi-GPU partitioning of the (layer, batch) units: weak = every rank the whole table on its own "
-                         "batch; strong = batch split b/G per layer; lpt = whole layers by longest-processing-time")
+                         "batch; strong = batch split b/G per layer; lpt = whole layers by longest-processing-time; hybrid = "
+                         "batch split where a rank's share still fills the chip, whole layers (LPT) elsewhere.  Default: total "
+                         "work fixed as N grows -- hybrid on one table, lpt on several (--tables); N = 1: all the same")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the per-stage / denominator passes")
     ap.add_argument("--eager", action="store_true", help="launch from Python instead of replaying a hipGraph")
@@ -113,6 +115,12 @@ def main():
                     help="multi-rank rehearsal on a ONE-GPU box: gloo backend, every rank on cuda:0 (control flow only; "
                          "the ranks share the device, so the numbers mean nothing)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("bench: --gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: this process becomes the launcher of N ranks.  It has not imported torch and
+        # never touches a GPU; the ranks are child processes (no exec), rank 0's JSON line and the exit code are relayed.
+        raise SystemExit(launch_ranks(args))
 
     import torch
     import torch.distributed as dist
@@ -121,6 +129,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:  # a launcher that realised another rank count than asked for must not pass as an N-GPU run
+        raise SystemExit(f"bench: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} "
+                         f"(or run `python bench.py --gpus {args.gpus}`, which starts its own ranks)")
+    if world > 1 and not args.rehearse_gloo and torch.cuda.device_count() < world:
+        raise SystemExit(f"bench: {world} ranks asked for, {torch.cuda.device_count()} GPU(s) visible "
+                         "(--rehearse-gloo rehearses the control flow on one GPU)")
+    if args.scaling is None:
+        ntab = len((args.tables or args.table or "x").split(","))
+        args.scaling = "weak" if world == 1 else ("lpt" if ntab > 1 else "hybrid")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -314,7 +331,9 @@ def main():
         path_desc = "staged: sm_compress24_%s + sm_spmma_%s on every layer" % (sfx, sfx)
     split = {"weak": f"every rank runs all {len(shapes)} layers on its own batch (rank r = global batch indices [r*b, (r+1)*b))",
              "strong": f"batch split: rank g runs batch indices [g*b/{world}, (g+1)*b/{world}) of every layer, B replicated",
-             "lpt": f"whole layers by longest-processing-time over {len(shapes)} layer instances"}[args.scaling]
+             "lpt": f"whole layers by longest-processing-time over {len(shapes)} layer instances",
+             "hybrid": f"batch split [g*b/{world}, (g+1)*b/{world}) of the layers whose per-rank share keeps >= {mg.HYBRID_FILL_ROWS} rows, "
+                       f"the other layers whole by longest-processing-time (this rank: {len(layers)} units)"}[args.scaling]
     out = {
         "metric": "effective GF/s (2:4 spmma vs dense gemm) on ResNet-50 layer shapes",
         "value": value, "unit": "GF/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -328,7 +347,7 @@ def main():
                    "dense_equiv_gflop_per_step": tot_flops / args.steps / 1e9,
                    "launch": ("eager" if args.eager else ("hipGraph replay, one linear graph per stream" if args.graphs == "per-stream" else "hipGraph replay of one step"))
                              + (f"; setup runs {args.settle_ms:.0f} ms of untimed replays before the W warm-up steps" if args.settle_ms > 0 else ""),
-                   "streams": args.streams, "sched": args.sched,
+                   "streams": args.streams, "sched": args.sched, "partition": args.scaling,
                    "parallelism": f"{args.scaling} x{world}: {split}; no data-path collective, one all-reduce of "
                                   "{sum flops, max seconds}"},
     }
@@ -344,6 +363,35 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out))
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks (one per GPU) under torch.distributed.run as a CHILD
+    process, relay what rank 0 prints and return the exit code; non-zero when the job fails or does not report N ranks."""
+    import socket
+    import subprocess
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)  # stderr goes straight through
+    sys.stdout.write(res.stdout)
+    sys.stdout.flush()
+    if res.returncode != 0:
+        sys.stderr.write(f"bench: the {args.gpus}-rank job exited with {res.returncode}\n")
+        return res.returncode
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    try:
+        ok = len(lines) == 1 and json.loads(lines[0])["n_gpus"] == args.gpus
+    except Exception:
+        ok = False
+    if not ok:
+        sys.stderr.write(f"bench: expected one JSON line with n_gpus == {args.gpus}\n")
+        return 3
+    return 0
 
 
 def extras(args, sm, torch, dev, layers, flops, t_full, Forked, make_runner, timed, event_seconds, use_fused, out):

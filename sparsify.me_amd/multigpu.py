@@ -9,7 +9,12 @@ range is in GLOBAL batch indices.  Operand data are generated per (layer, global
 so a sharded run multiplies exactly the matrices the unsharded run does, whatever the world size."""
 import os
 
-MODES = ("weak", "strong", "lpt")
+MODES = ("weak", "strong", "lpt", "hybrid")
+
+# hybrid: a layer is split by batch index only while a rank's share still covers the chip with row tiles: 256 CUs x one
+# 128-row tile.  Below that a tile's time is set by its K stages, not by its rows (DESIGN.md 4.1: 128 tiles of a
+# 784 x 256 x 2304 layer take the time of 256), so a batch slice of such a layer costs every rank the whole layer's time.
+HYBRID_FILL_ROWS = 256 * 128
 
 
 def env_world():
@@ -35,7 +40,11 @@ def plan_units(shapes, world, rank, mode="weak"):
     weak  : all layers, global batch indices [rank*b, (rank+1)*b)
     strong: all layers, [g*b/G, (g+1)*b/G) of each layer's batch (SURVEY.md 8(e) primary partitioning; B replicated)
     lpt   : whole layers, greedy longest-processing-time assignment by 2*m*n*k*b (SURVEY.md 8(e) alternative; the
-            config-4 sweep over several tables), deterministic: ties by layer index, equal loads to the lower rank"""
+            config-4 sweep over several tables), deterministic: ties by layer index, equal loads to the lower rank
+    hybrid: strong scaling (total work fixed) with the granularity chosen per layer: a layer whose per-rank batch share
+            still has >= HYBRID_FILL_ROWS rows is split by batch index as in `strong`; a smaller one stays whole and goes
+            to the least-loaded rank (LPT by the layer's A + B + C bytes on top of the split layers' equal shares).  What
+            `bench.py --gpus N` uses by default on one table"""
     if mode not in MODES:
         raise ValueError(mode)
     if world < 1 or not (0 <= rank < world):
@@ -49,6 +58,24 @@ def plan_units(shapes, world, rank, mode="weak"):
             if hi > lo:
                 out.append((l, lo, hi))
         return out
+    if mode == "hybrid":
+        by = lambda m, n, k, b: b * (m * k + m * n) + k * n  # elements streamed: the layers are HBM-bound
+        out, whole, load = [], [], [0.0] * world
+        for l, (m, n, k, b) in enumerate(shapes):
+            if world > 1 and (b < world or m * (b // world) < HYBRID_FILL_ROWS):
+                whole.append(l)
+                continue
+            for r in range(world):
+                lo, hi = _split(b, world, r)
+                load[r] += by(m, n, k, hi - lo)
+                if r == rank and hi > lo:
+                    out.append((l, lo, hi))
+        for l in sorted(whole, key=lambda l: (-by(*shapes[l]), l)):
+            g = min(range(world), key=lambda r: (load[r], r))
+            load[g] += by(*shapes[l])
+            if g == rank:
+                out.append((l, 0, shapes[l][3]))
+        return sorted(out)
     cost = [2.0 * m * n * k * b for (m, n, k, b) in shapes]
     order = sorted(range(len(shapes)), key=lambda l: (-cost[l], l))
     load = [0.0] * world

@@ -22,5 +22,42 @@ def test_bench_two_ranks_complete_and_roll_up():
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, "exactly one JSON line (rank 0)"
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak"
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "strong" and d["config"]["partition"] == "hybrid"
     assert d["value"] > 0 and "roofline" in d and "stages" in d and "cpu_baseline" not in d
+
+
+@pytest.mark.gpu
+def test_bench_gpus2_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with NO launcher around it: the process starts two ranks itself (child processes),
+    relays rank 0's line and reports n_gpus == 2 (it used to run one rank silently)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--rehearse-gloo",
+           "--no-extras", "--settle-ms", "0"]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
+    # total work fixed: the two ranks together ran every (layer, batch index) of the table exactly once
+    assert abs(d["config"]["dense_equiv_gflop_per_step"] - 931.6) < 1.0
+
+
+def test_bench_refuses_a_rank_count_it_was_not_asked_for():
+    """A launcher that realised another world size than --gpus must not pass as an N-GPU run (exits before any GPU call)."""
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1"], cwd=ROOT, env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and "WORLD_SIZE=2" in out.stderr and not out.stdout.strip()
+
+
+def test_bench_self_launch_fails_loudly_without_gpus():
+    """No GPU in the CPU container: `bench.py --gpus 2` must start its ranks, see them fail and exit non-zero with no JSON."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], cwd=ROOT,
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]

@@ -40,7 +40,7 @@ def _worker(rank, world, port, out):
     # the real tables: every rank's planned flops, summed by the same all-reduce bench.py uses
     shapes = _tables(["resnet50", "resnet101", "resnet152"])
     sums = {}
-    for mode in ("strong", "lpt"):
+    for mode in ("strong", "lpt", "hybrid"):
         mine = mg.unit_flops(shapes, mg.plan_units(shapes, world, rank, mode))
         sums[mode], _ = mg.rollup(mine, 1.0)
     out[rank] = (len(weak), weak[0], strong[0], tot, tmax, sums, mg.unit_flops(shapes, [(l, 0, s_[3]) for l, s_ in enumerate(shapes)]))
@@ -61,7 +61,7 @@ def test_rollup_and_sharding_world2():
         assert s0 == (0, 16 * rank, 16 * rank + 16)
         assert tot == 3000.0 and tmax == 5.0  # every rank sees sum(flops) and max(time)
         # sharded flops, summed over the ranks by the roll-up, are the unsharded sweep's (config 4: 5,645.7 GFLOP)
-        assert sums["strong"] == table_flops and sums["lpt"] == table_flops
+        assert sums["strong"] == table_flops and sums["lpt"] == table_flops and sums["hybrid"] == table_flops
         assert abs(table_flops / 1e9 - 5645.7) < 0.1
 
 
@@ -91,7 +91,7 @@ def test_plans_cover_every_layer_batch_unit_exactly_once():
     every = sorted((l, bi) for l, s_ in enumerate(shapes) for bi in range(s_[3]))
     total = mg.unit_flops(shapes, [(l, 0, s_[3]) for l, s_ in enumerate(shapes)])
     for world in (1, 2, 4, 8, 3):
-        for mode in ("strong", "lpt"):
+        for mode in ("strong", "lpt", "hybrid"):
             seen, fl, loads = [], 0.0, []
             for rank in range(world):
                 units = mg.plan_units(shapes, world, rank, mode)
@@ -105,9 +105,15 @@ def test_plans_cover_every_layer_batch_unit_exactly_once():
                 assert max(loads) == min(loads)
             if mode == "lpt":
                 assert max(loads) <= 1.02 * total / world
+            if mode == "hybrid":  # whole small layers on top of equal batch shares: within 5 % of the mean (flops; it balances bytes)
+                assert max(loads) <= 1.05 * total / world
+                for rank in range(world):  # no rank is handed a batch slice that leaves the chip under-filled
+                    for l, lo, hi in mg.plan_units(shapes, world, rank, mode):
+                        assert hi - lo == shapes[l][3] or shapes[l][0] * (hi - lo) >= mg.HYBRID_FILL_ROWS
     # N = 1: both plans are the whole table in order
     assert mg.plan_units(shapes, 1, 0, "strong") == [(l, 0, s_[3]) for l, s_ in enumerate(shapes)]
     assert mg.plan_units(shapes, 1, 0, "lpt") == [(l, 0, s_[3]) for l, s_ in enumerate(shapes)]
+    assert mg.plan_units(shapes, 1, 0, "hybrid") == [(l, 0, s_[3]) for l, s_ in enumerate(shapes)]
     # weak: disjoint GLOBAL batch ranges per rank (rank r = batch indices [r*b, (r+1)*b) of a world*b batch)
     w = [mg.plan_units(shapes[:3], 4, r, "weak") for r in range(4)]
     assert [u[0][1:] for u in w] == [(0, 32), (32, 64), (64, 96), (96, 128)]
