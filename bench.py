@@ -61,6 +61,14 @@ def file_tag(path):
                        "the committed file is replayed here, the counters are not collected by bench.py itself"}
 
 
+def library_tag(sm):
+    """Which shared library this process loaded (SPARSIFYME_LIB can redirect it): path, version string, content hash."""
+    with open(sm.LIB_PATH, "rb") as fh:
+        h = hashlib.sha256(fh.read()).hexdigest()[:16]
+    return {"lib_path": os.path.relpath(sm.LIB_PATH, ROOT) if sm.LIB_PATH.startswith(ROOT) else sm.LIB_PATH,
+            "sm_version": sm.version(), "sha256_16": h, "redirected_by_env": bool(os.environ.get("SPARSIFYME_LIB"))}
+
+
 def fused_variant(n, k):
     """Which kernel sm_spmma_fused_f16 dispatches a (n, k) layer to (csrc/spmma_f16_fused.hip: spmma_fused16)."""
     if n <= 128 or (n <= 256 and k <= 64):
@@ -111,6 +119,10 @@ def main():
     ap.add_argument("--sched", choices=["rr", "split", "lpt"], default="rr",
                     help="layer -> stream assignment: round-robin, or chip-filling layers (>= 784 row tiles) on the first half "
                          "of the streams and the under-filling ones on the second half")
+    ap.add_argument("--group", choices=["on", "off"], default="on",
+                    help="on (default): the fused layers of one (m, n, k, b) shape run as ONE grouped launch per 8 instances "
+                         "(sm_spmma_fused_*_grouped: same kernels, same C bit for bit; the instances share the chip instead of each "
+                         "paying its own last partial round of workgroups); off: one launch per layer")
     ap.add_argument("--rehearse-gloo", action="store_true",
                     help="multi-rank rehearsal on a ONE-GPU box: gloo backend, every rank on cuda:0 (control flow only; "
                          "the ranks share the device, so the numbers mean nothing)")
@@ -245,7 +257,45 @@ def main():
         else:
             layer_staged(L)
 
-    step_full = Forked(layer_path)
+    # Work items of the timed step: with --group on the fused layers of one shape are one item (a grouped launch per 8
+    # instances), every other layer is its own item; items are spread over the streams longest-first by their bytes.
+    def layer_bytes(L):
+        return L["b"] * (L["m"] * L["k"] + L["m"] * L["n"]) + L["k"] * L["n"]
+
+    def fused_groups(Ls):
+        """[(shape key, [layers])] of the fused layers in Ls, in table order of first appearance"""
+        g = {}
+        for L in Ls:
+            g.setdefault((L["m"], L["n"], L["k"], L["b"]), []).append(L)
+        return list(g.items())
+
+    def run_group(Ls):
+        L0 = Ls[0]
+        sm.spmma_fused_grouped([L["A"] for L in Ls], [L["B"] for L in Ls], [L["C"] for L in Ls], L0["m"], L0["n"], L0["k"], batch=L0["b"])
+
+    grouped = args.group == "on" and not f32
+    if grouped:
+        items = [("group", Ls) for _, Ls in fused_groups([L for L in layers if use_fused(L)])]
+        items += [("single", [L]) for L in layers if not use_fused(L)]
+        items.sort(key=lambda it: -sum(layer_bytes(L) for L in it[1]))
+        ichains, iload = [[] for _ in range(nstreams)], [0] * nstreams
+        for it in items:
+            w = iload.index(min(iload))
+            ichains[w].append(it)
+            iload[w] += sum(layer_bytes(L) for L in it[1])
+
+        class ForkedItems(Forked):
+            def chain(self, w):
+                for kind, Ls in ichains[w]:
+                    if kind == "group":
+                        run_group(Ls)
+                    else:
+                        layer_path(Ls[0])
+
+        step_full = ForkedItems(layer_path)
+        n_launch_groups = sum((len(Ls) + 7) // 8 for kind, Ls in items if kind == "group")
+    else:
+        step_full = Forked(layer_path)
 
     def barrier():
         if world > 1:
@@ -334,6 +384,9 @@ def main():
              "lpt": f"whole layers by longest-processing-time over {len(shapes)} layer instances",
              "hybrid": f"batch split [g*b/{world}, (g+1)*b/{world}) of the layers whose per-rank share keeps >= {mg.HYBRID_FILL_ROWS} rows, "
                        f"the other layers whole by longest-processing-time (this rank: {len(layers)} units)"}[args.scaling]
+    if grouped:
+        path_desc += ("; the fused layers run as %d grouped launches (sm_spmma_fused_%s_grouped: one grid per <= 8 same-shape instances, "
+                      "same kernels, same C)" % (n_launch_groups, sfx))
     out = {
         "metric": "effective GF/s (2:4 spmma vs dense gemm) on ResNet-50 layer shapes",
         "value": value, "unit": "GF/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -348,12 +401,14 @@ def main():
                    "launch": ("eager" if args.eager else ("hipGraph replay, one linear graph per stream" if args.graphs == "per-stream" else "hipGraph replay of one step"))
                              + (f"; setup runs {args.settle_ms:.0f} ms of untimed replays before the W warm-up steps" if args.settle_ms > 0 else ""),
                    "streams": args.streams, "sched": args.sched, "partition": args.scaling,
+                   "library": library_tag(sm),
                    "parallelism": f"{args.scaling} x{world}: {split}; no data-path collective, one all-reduce of "
                                   "{sum flops, max seconds}"},
     }
 
     if rank == 0 and not args.no_extras:
-        extras(args, sm, torch, dev, layers, flops, wall / args.steps, Forked, make_runner, timed, event_seconds, use_fused, out)
+        extras(args, sm, torch, dev, layers, flops, wall / args.steps, Forked, make_runner, timed, event_seconds, use_fused, out,
+               (fused_groups, run_group) if grouped else None)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(ge, shapes)
@@ -394,7 +449,7 @@ def launch_ranks(args):
     return 0
 
 
-def extras(args, sm, torch, dev, layers, flops, t_full, Forked, make_runner, timed, event_seconds, use_fused, out):
+def extras(args, sm, torch, dev, layers, flops, t_full, Forked, make_runner, timed, event_seconds, use_fused, out, grouping=None):
     """Rank 0 only: per-stage times, the dense denominators, the API-faithful sequence and the roofline of the
     dominant kernel family."""
     f32 = args.dtype == "f32"
@@ -456,6 +511,9 @@ def extras(args, sm, torch, dev, layers, flops, t_full, Forked, make_runner, tim
     if not f32 and os.path.basename(args.tables.split(",")[0] if args.tables else (args.table or "resnet50")).startswith("resnet50"):
         out["stages"]["conv_path"] = conv_path_stage(sm, torch, dev, args.dtype)
         out["stages"]["config5_coo_spmm"] = config5_stage(sm, torch, dev)
+        out["stages"]["bell_spmm"] = bell_stage(sm, torch, dev)
+    if not args.no_cpu_baseline:
+        out["stages"]["config1_cpu"] = config1_cpu(ge_mod())
 
     if not f32:
         # matrix-pipe view of the 2:4 matmul (north_star: "MFMA utilisation for the matmul against chip peak"):
@@ -513,15 +571,24 @@ def extras(args, sm, torch, dev, layers, flops, t_full, Forked, make_runner, tim
         if not f["layers"]:
             continue
 
-        def serial(f=f):
-            for L in f["layers"]:
-                f["call"](L)
+        nlaunch = len(f["layers"])
+        if grouping and name.startswith("spmma_f16_fused"):  # the family as the timed step launches it: one grid per <= 8 instances of a shape
+            gl = grouping[0](f["layers"])
+            nlaunch = sum((len(Ls) + 7) // 8 for _, Ls in gl)
+
+            def serial(gl=gl):
+                for _, Ls in gl:
+                    grouping[1](Ls)
+        else:
+            def serial(f=f):
+                for L in f["layers"]:
+                    f["call"](L)
         t = event_seconds(make_runner(serial), R)
         by = sum(f["bytes"](L) for L in f["layers"])
         fl = sum(2.0 * L["m"] * L["n"] * L["k"] * L["b"] for L in f["layers"])
         tb = [(traffic_tab[n]["hbm_bytes_per_launch"], traffic_tab[n]["launches_profiled"]) for n in f["names"] if n in traffic_tab]
         traffic = sum(b_ * c_ for b_, c_ in tb) / sum(c_ for _, c_ in tb) if tb else None
-        rows[name] = dict(seconds=t, launches=len(f["layers"]), bytes=by, GBs=by / t / 1e9, TFs=fl / t / 1e12, traffic=traffic)
+        rows[name] = dict(seconds=t, launches=nlaunch, layers=len(f["layers"]), bytes=by, GBs=by / t / 1e9, TFs=fl / t / 1e12, traffic=traffic)
     # the fused variants are one family for the "dominant kernel" choice (they are one entry point), reported each
     groups = {}
     for n_, r_ in rows.items():
@@ -531,7 +598,7 @@ def extras(args, sm, torch, dev, layers, flops, t_full, Forked, make_runner, tim
                                        if all(r["traffic"] is not None for r in rs) else None)) for g, rs in groups.items()}
     dom = max(gsum, key=lambda g: gsum[g]["seconds"])
     d = gsum[dom]
-    fams_out = {n_: {"ms_per_step": r_["seconds"] * 1e3, "launches": r_["launches"], "GBs": r_["GBs"], "frac_of_hbm_peak": r_["GBs"] / HBM_PEAK_GBS,
+    fams_out = {n_: {"ms_per_step": r_["seconds"] * 1e3, "launches": r_["launches"], "layers": r_["layers"], "GBs": r_["GBs"], "frac_of_hbm_peak": r_["GBs"] / HBM_PEAK_GBS,
                      "hbm_traffic_per_launch": r_["traffic"]} for n_, r_ in rows.items()}
     if f32:
         domf = max((n_ for n_ in rows if n_.startswith("spmma_f32")), key=lambda n_: rows[n_]["seconds"])
@@ -545,14 +612,28 @@ def extras(args, sm, torch, dev, layers, flops, t_full, Forked, make_runner, tim
                            "measured": "single stream, HIP events on the launch stream, hipGraph replay", "families": fams_out}
     else:
         GBs = d["bytes"] / d["seconds"] / 1e9
+        # yardstick measured in THIS process: sm_copy_bytes (16-byte non-temporal loads + stores) moving the timed step's own
+        # algorithmic byte count (half read, half written), same event timing as the families above
+        step_bytes = sum((A_fu(L) if use_fused(L) else A_sp(L) + L["b"] * L["m"] * L["k"] * (s + s / 2 + 1 / 8)) for L in layers)
+        half = int(step_bytes / 2) // 4096 * 4096
+        ysrc = torch.empty(half, dtype=torch.uint8, device=dev)
+        ydst = torch.empty(half, dtype=torch.uint8, device=dev)
+        sm.fill_uniform(ysrc.view(torch.float16), 0xC0B1, 0.0, 1.0)
+        t_copy = event_seconds(make_runner(lambda: sm.copy_bytes(ysrc, ydst)), R)
+        copy_GBs = 2.0 * half / t_copy / 1e9
+        del ysrc, ydst
         out["roofline"] = {"bound": "hbm", "achieved": GBs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": GBs / HBM_PEAK_GBS, "traffic": d["traffic"], "traffic_source": tsrc if d["traffic"] is not None else None,
                            "kernel": dom, "launches_per_step": d["launches"], "avg_launch_us": d["seconds"] / d["launches"] * 1e6,
                            "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],
                            "measured": "single stream, one kernel family at a time, HIP events on the launch stream, hipGraph replay",
-                           "yardstick": {"device_copy_GBs": 5150.0, "frac_of_device_copy": GBs / 5150.0,
-                                         "source": "profiles/copy_yardstick_r01.txt: a plain 1 GiB device-to-device copy (read + write) on this part; "
-                                                   "context only -- `frac` is against the 8 TB/s specification"},
+                           "yardstick": {"device_copy_GBs": copy_GBs, "frac_of_device_copy": GBs / copy_GBs,
+                                         "copy_bytes": 2 * half, "copy_ms": t_copy * 1e3,
+                                         "step_algorithmic_bytes": step_bytes, "step_GBs": step_bytes / t_full / 1e9,
+                                         "step_frac_of_device_copy": step_bytes / t_full / 1e9 / copy_GBs,
+                                         "source": "measured in this run: sm_copy_bytes (16-byte streaming copy kernel of libsparsifyme.so) over the "
+                                                   "timed step's own algorithmic byte count, half read + half written; context only -- `frac` is "
+                                                   "against the 8 TB/s specification"},
                            "families": fams_out}
 
 
@@ -626,6 +707,103 @@ def config5_stage(sm, torch, dev):
             "peak": HBM_PEAK_GBS}
 
 
+def ge_mod():
+    import __graft_entry__ as ge
+    return ge
+
+
+def bell_stage(sm, torch, dev):
+    """batched::spmm on Blocked-ELL operands (the reference's only recorded sparse number, examples/compare.csv column
+    `spmm`; call spmm.hxx:94-111) as examples/spmm.cu builds them: 2 x 2 blocks, half of the block columns present, one A per
+    batch index, B shared, fp32, b = 32, all batches in one submission (sm_spmm_bell_batched_f32).  Bytes = stored values +
+    block indices + B + C; the kernel pair expands the blocks and runs the dense fp32 MFMA product, so the binding roofline is
+    max(bytes / HBM peak, dense flops / fp32 matrix peak).  Host pointer tables: not graph-capturable, wall clock over 5 calls."""
+    import ctypes
+    L_ = sm.lib()
+    rows = []
+    g = torch.Generator(device=dev).manual_seed(11)
+    for (m, n, k, b) in [(784, 256, 2304, 32), (12544, 64, 576, 32), (196, 512, 4608, 32), (3136, 128, 1152, 32)]:
+        bs, ell_cols = 2, k // 2
+        bcols = ell_cols // bs
+        vals, idxs = [], []
+        for _ in range(b):
+            ci = torch.rand(m // bs, k // bs, generator=g, device=dev).argsort(dim=1)[:, :bcols].sort(dim=1).values
+            idxs.append(ci.to(torch.int64).contiguous().view(-1))
+            v = torch.empty(m * ell_cols, dtype=torch.float32, device=dev)
+            sm.fill_uniform(v, 77 + len(vals), -0.5, 0.5)
+            vals.append(v)
+        B = torch.empty(k * n, dtype=torch.float32, device=dev)
+        sm.fill_uniform(B, 78, -0.5, 0.5)
+        Cs = [torch.empty(m * n, dtype=torch.float32, device=dev) for _ in range(b)]
+        nb = ctypes.c_size_t(0)
+        L_.sm_spmm_bell_batched_workspace_size(m, k, b, ctypes.byref(nb))
+        ws = torch.empty(nb.value, dtype=torch.uint8, device=dev)
+        PA = ctypes.c_void_p * b
+        pv, pi, pc = PA(*[v.data_ptr() for v in vals]), PA(*[i.data_ptr() for i in idxs]), PA(*[c.data_ptr() for c in Cs])
+
+        def call():
+            rc = L_.sm_spmm_bell_batched_f32(pv, pi, m, k, bs, ell_cols, B.data_ptr(), pc, n, b, 1.0, 0.0, ws.data_ptr(),
+                                             ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+            if rc != 0:
+                raise RuntimeError(L_.sm_last_error().decode())
+        call()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            call()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / 5 * 1e3
+        by = b * (m * ell_cols * 4.0 + (m // bs) * bcols * 8.0 + m * n * 4.0) + k * n * 4.0
+        fl = 2.0 * m * n * k * b  # what the expanded fp32 MFMA product executes (stored-value flops are half of it)
+        roof_ms = max(by / (HBM_PEAK_GBS * 1e9), fl / (F32_MATRIX_PEAK_TFS * 1e12)) * 1e3
+        rows.append({"m": m, "n": n, "k": k, "b": b, "block": bs, "ell_cols": ell_cols, "ms": ms, "bytes": by, "GBs": by / ms / 1e6,
+                     "executed_TFs": fl / ms / 1e9, "stored_value_TFs": fl / 2 / ms / 1e9,
+                     "bound": "mfma" if fl / (F32_MATRIX_PEAK_TFS * 1e12) > by / (HBM_PEAK_GBS * 1e9) else "hbm", "frac": roof_ms / ms})
+        del vals, idxs, Cs, ws
+    return {"kernel": "bell_expand_rows_kernel + gemm_f32_dma_kernel (sm_spmm_bell_batched_f32, one submission for all batches)",
+            "shapes": rows, "frac": "roofline time / measured time, roofline = max(algorithmic bytes / 8 TB/s, executed dense flops / 157.3 TF/s)",
+            "timing": "wall clock over 5 calls after one warm-up (host pointer tables: the entry point is not graph-capturable)"}
+
+
+def config1_cpu(ge):
+    """BASELINE config 1 (examples/sparsify.cu:43-47 path, no GPU): one 512 x 512 x 512 fp32 layer on the host, timed in
+    full -- the positional sparsify, the magnitude prune to 2:4 (STRIP), compress, the dense GEMM and the 2:4 product, all the
+    oracle's arithmetic (`port`).  Seeded U(0,1) operands; best of 5 after one warm-up each."""
+    import numpy as np
+    orc = ge.load_oracle()
+    m = n = k = 512
+    rng = np.random.default_rng(0x5EED)
+    A = rng.uniform(0, 1, m * k).astype(np.float32)
+    B = rng.uniform(0, 1, k * n).astype(np.float32)
+    C = np.zeros(m * n, dtype=np.float32)
+
+    def best(fn, reps=5):
+        fn()
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+        return min(ts) * 1e3
+
+    w, mask = A.copy(), np.ones(m * k, dtype=np.uint64)
+    t_pos = best(lambda: orc.sparsify_positional(w, mask, m, k, 0.5))
+    Au = A.view(np.uint32)
+    t_prune = best(lambda: orc.prune24(Au, m, k, k, orc.STRIP))
+    P = orc.prune24(Au, m, k, k, orc.STRIP)
+    t_cmp = best(lambda: orc.compress24(P, m, k, k))
+    t_gemm = best(lambda: orc.cpu_gemm_f32(A, B, C, m, n, k))
+    t_sp = best(lambda: orc.cpu_spmma_f32(A, B, C, m, n, k))
+    fl = 2.0 * m * n * k
+    return {"m": m, "n": n, "k": k, "b": 1, "dtype": "f32", "kind": "port", "cores": orc.num_threads(),
+            "threads": "dense GEMM and 2:4 product: OpenMP over rows on `cores` threads; sparsify / prune / compress: 1 thread",
+            "sparsify_positional_ms": t_pos, "prune24_strip_ms": t_prune, "compress24_ms": t_cmp,
+            "dense_gemm_ms": t_gemm, "dense_gemm_gfs": fl / t_gemm / 1e6,
+            "spmma_2to4_ms": t_sp, "spmma_2to4_eff_gfs": fl / t_sp / 1e6,
+            "prune_compress_dense_gemm_ms": t_prune + t_cmp + t_gemm,
+            "note": "untuned restatement (naive loops, no cache blocking): a reported baseline, not a target"}
+
+
 def cpu_baseline(ge, shapes):
     """The oracle's arithmetic ('port': fp32 accumulate, OpenMP over rows) on the host cores, on a
     bounded sample: one batch (b = 1) of every unique (m,n,k) of the table, repeated; both the dense
@@ -653,7 +831,7 @@ def cpu_baseline(ge, shapes):
         fl += 2.0 * r * n * k * reps
     return {"value": fl / t_sparse / 1e9, "unit": "GF/s", "cores": orc.num_threads(), "kind": "port",
             "dense_value": fl / t_dense / 1e9,
-            "sample": f"oracle sm_cpu_spmma_f32 (2:4 path) / sm_cpu_gemm_f32 (dense_value), fp32, one batch (b=1) of each of "
+            "sample": f"UNTUNED port (naive row-parallel loops, no cache blocking): oracle sm_cpu_spmma_f32 (2:4 path) / sm_cpu_gemm_f32 (dense_value), fp32, one batch (b=1) of each of "
                       f"the {len(uniq)} unique shapes of the table x {reps} repetitions ({fl / 1e9:.1f} dense-equivalent GFLOP, "
                       f"{t_dense + t_sparse:.1f} s of CPU work); effective GF/s = dense-equivalent flops / time"}
 

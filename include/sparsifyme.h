@@ -131,6 +131,17 @@ int sm_spmma_fused_f16(const void* A, const void* B, void* C, size_t m, size_t n
                        size_t batch, size_t strideA, size_t strideB, size_t strideC, float alpha,
                        float beta, sm_stream_t stream);
 
+/* Grouped form (extension; round 3): `count` same-shape problems -- host arrays of device pointers A[i], B[i], C[i], the way
+ * the reference's batched::spmm takes its As / Cs (spmm.hxx:30-33) -- in one grid per 8 problems instead of one per problem:
+ * the 3-6 instances of one layer shape in a network then share the chip (the last partial round of one instance is filled by
+ * the next).  Same kernels and the same C, bit for bit, as `count` calls of sm_spmma_fused_f16; C operands 16-byte aligned. */
+int sm_spmma_fused_f16_grouped(size_t count, const void* const* A, const void* const* B, void* const* C, size_t m, size_t n,
+                               size_t k, size_t lda, size_t batch, size_t strideA, size_t strideB, size_t strideC,
+                               float alpha, float beta, sm_stream_t stream);
+int sm_spmma_fused_bf16_grouped(size_t count, const void* const* A, const void* const* B, void* const* C, size_t m, size_t n,
+                                size_t k, size_t lda, size_t batch, size_t strideA, size_t strideB, size_t strideC,
+                                float alpha, float beta, sm_stream_t stream);
+
 /* fp32 form: the STRIP rule applied to the A fragments in registers of the dense fp32 MFMA kernel (there is no fp32 sparse
  * matrix instruction).  Equals sm_gemm_rowmajor_f32 of the STRIP-pruned A bit for bit; agrees with sm_compress24_f32 +
  * sm_spmma_f32 to fp32 accumulation order.  Needs k % 32 == 0, n % 4 == 0, 16-byte aligned rows. */
@@ -220,6 +231,10 @@ int sm_spmm_coo_f32_packed(size_t A_num_rows, size_t A_num_cols, size_t A_nnz, s
  *      include/sparsify.me/util/gen.hxx:12-20); element i depends only on (seed, i). */
 int sm_fill_uniform_f16(void* out, size_t count, uint64_t seed, float lo, float hi, sm_stream_t stream);
 int sm_fill_uniform_f32(float* out, size_t count, uint64_t seed, float lo, float hi, sm_stream_t stream);
+
+/* ---- support: plain streaming device-to-device copy (16-byte accesses; src, dst 16-byte aligned, bytes % 16 == 0).  No
+ *      reference counterpart: the bandwidth yardstick bench.py times next to the step (roofline.yardstick), in-process. */
+int sm_copy_bytes(const void* src, void* dst, size_t bytes, sm_stream_t stream);
 
 /* ---- transposed operands of sparsifyme::spmma (spmma.hxx:30-31,67-69: transpose_a / transpose_b go to the vendor's matmul
  *      descriptor).  out[b][c * ld_out + r] = in[b][r * ld_in + c] for `batch` row-major rows x cols matrices of 2-, 4- or

@@ -49,6 +49,10 @@ _SIGS = {
                            _c_f, _c_f, _c_ptr],
     "sm_spmma_fused_f32": [_c_ptr, _c_ptr, _c_ptr, _c_size, _c_size, _c_size, _c_size, _c_size, _c_size, _c_size, _c_size,
                            _c_f, _c_f, _c_ptr],
+    "sm_spmma_fused_f16_grouped": [_c_size, _c_ptr, _c_ptr, _c_ptr, _c_size, _c_size, _c_size, _c_size, _c_size, _c_size, _c_size,
+                                   _c_size, _c_f, _c_f, _c_ptr],
+    "sm_spmma_fused_bf16_grouped": [_c_size, _c_ptr, _c_ptr, _c_ptr, _c_size, _c_size, _c_size, _c_size, _c_size, _c_size, _c_size,
+                                    _c_size, _c_f, _c_f, _c_ptr],
     "sm_gemm_batched_f16": [_c_ptr, _c_ptr, _c_ptr, _c_size, _c_size, _c_size, _c_size, _c_i, _c_i, _c_f, _c_f, _c_ptr],
     "sm_gemm_batched_f32": [_c_ptr, _c_ptr, _c_ptr, _c_size, _c_size, _c_size, _c_size, _c_i, _c_i, _c_f, _c_f, _c_ptr],
     "sm_gemm_batched_f64": [_c_ptr, _c_ptr, _c_ptr, _c_size, _c_size, _c_size, _c_size, _c_i, _c_i,
@@ -74,6 +78,7 @@ _SIGS = {
                            _c_ptr, _c_ptr],
     "sm_fill_uniform_f16": [_c_ptr, _c_size, ctypes.c_uint64, _c_f, _c_f, _c_ptr],
     "sm_fill_uniform_f32": [_c_ptr, _c_size, ctypes.c_uint64, _c_f, _c_f, _c_ptr],
+    "sm_copy_bytes": [_c_ptr, _c_ptr, _c_size, _c_ptr],
 }
 _SIGS["sm_prune24_compress24_f16"] = [_c_ptr, _c_ptr, _c_size, _c_size, _c_size, _c_size, _c_size, _c_ptr, _c_ptr, _c_i, _c_ptr]
 _SIGS["sm_prune24_compress24_bf16"] = _SIGS["sm_prune24_compress24_f16"]
@@ -304,6 +309,25 @@ def spmma_fused(A, B, C, m, n, k, lda=None, batch=1, strideA=None, strideB=0, st
            "sm_spmma_fused")
 
 
+def _ptr_table(tensors):
+    arr = (ctypes.c_void_p * len(tensors))(*[_dev(t).value for t in tensors])
+    return arr
+
+
+def spmma_fused_grouped(As, Bs, Cs, m, n, k, lda=None, batch=1, strideA=None, strideB=0, strideC=None, alpha=1.0, beta=0.0):
+    """len(As) same-shape problems in one grid per 8 (sm_spmma_fused_*_grouped): the same C as len(As) spmma_fused calls."""
+    if not (len(As) == len(Bs) == len(Cs)):
+        raise SparsifymeError("spmma_fused_grouped: operand lists differ in length")
+    if not As:
+        return
+    lda = k if lda is None else lda
+    strideA = m * lda if strideA is None else strideA
+    strideC = m * n if strideC is None else strideC
+    fn = getattr(lib(), "sm_spmma_fused_%s_grouped" % _sfx(As[0]))
+    _check(fn(len(As), _ptr_table(As), _ptr_table(Bs), _ptr_table(Cs), m, n, k, lda, batch, strideA, strideB, strideC,
+              float(alpha), float(beta), _stream()), "sm_spmma_fused_grouped")
+
+
 def transpose(src, dst, rows, cols, ld_in=None, ld_out=None, batch=1, stride_in=None, stride_out=None):
     """dst[b][c][r] = src[b][r][c] (row-major, out of place): the transposed operands of sparsifyme::spmma."""
     ld_in = cols if ld_in is None else ld_in
@@ -347,6 +371,14 @@ def gemm_rowmajor(A, B, C, m, n, k, lda=None, batch=1, strideA=None, strideB=0, 
     fn = getattr(lib(), "sm_gemm_rowmajor_" + _sfx(A))
     _check(fn(_dev(A), _dev(B), _dev(C), m, n, k, lda, batch, strideA, strideB, strideC, float(alpha), float(beta),
               _stream()), "sm_gemm_rowmajor")
+
+
+def copy_bytes(src, dst):
+    """Streaming device-to-device copy of src's bytes into dst (bandwidth yardstick of bench.py)."""
+    nbytes = src.numel() * src.element_size()
+    if dst.numel() * dst.element_size() < nbytes:
+        raise SparsifymeError("copy_bytes: destination smaller than the source")
+    _check(lib().sm_copy_bytes(_dev(src), _dev(dst), nbytes, _stream()), "sm_copy_bytes")
 
 
 def fill_uniform(out, seed, lo=0.0, hi=1.0):

@@ -83,9 +83,35 @@ static int launch_fill(void* out, size_t count, uint64_t seed, float lo, float h
   return check_launch("fill_uniform_kernel");
 }
 
+// Plain streaming copy (16-byte non-temporal loads and stores, grid-stride): the yardstick bench.py times in the same
+// process as the step -- what HBM delivers to the simplest possible kernel on this part, on this day.
+__global__ __launch_bounds__(256) void copy_bytes_kernel(const u4* __restrict__ src, u4* __restrict__ dst, size_t n16) {
+  const size_t stride = (size_t)gridDim.x * 256 * 4;
+  for (size_t i = (size_t)blockIdx.x * 256 * 4 + threadIdx.x; i < n16; i += stride) {
+    u4 v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (i + (size_t)j * 256 < n16) v[j] = __builtin_nontemporal_load(src + i + (size_t)j * 256);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (i + (size_t)j * 256 < n16) __builtin_nontemporal_store(v[j], dst + i + (size_t)j * 256);
+  }
+}
+
 }  // namespace sm
 
 extern "C" {
+
+int sm_copy_bytes(const void* src, void* dst, size_t bytes, sm_stream_t s) {
+  if (bytes == 0) return SM_STATUS_SUCCESS;
+  if (!src || !dst || (bytes & 15u) || !sm::aligned16(src) || !sm::aligned16(dst)) {
+    sm::set_error("sm_copy_bytes: needs non-null 16-byte aligned buffers and a byte count that is a multiple of 16");
+    return SM_STATUS_INVALID_VALUE;
+  }
+  const size_t n16 = bytes / 16;
+  sm::copy_bytes_kernel<<<sm::stream_grid((n16 + 3) / 4, 256), 256, 0, (hipStream_t)s>>>((const sm::u4*)src, (sm::u4*)dst, n16);
+  return sm::check_launch("copy_bytes_kernel");
+}
 
 const char* sm_version(void) { return "sparsifyme-amd 0.1.0 (gfx950)"; }
 

@@ -24,13 +24,18 @@
 
 namespace sm {
 
+// A launch serves up to MAXG same-shape problems (the grouped entry points: the 3-6 instances of one layer shape in a
+// network run as ONE grid, so the tail of one instance is filled by the next and few-tile shapes stop paying whole
+// rounds of 256 CUs per instance); problem g = (A[g], B[g], C[g]), every other field shared.  A plain call is ngroup = 1.
+constexpr int MAXG = 8;
 struct FusedArgs {
-  const half_t* A;
-  const half_t* B;
-  half_t* C;
+  const half_t* A[MAXG];
+  const half_t* B[MAXG];
+  half_t* C[MAXG];
   size_t sA, sB, sC;  // batch strides (elements)
   int Mrows, N, K, lda;
   int batch, tiles_m, tiles_n;
+  int ngroup;
   float alpha, beta;
 #ifdef SM_STAMP
   unsigned long long* dbg;  // diagnostic build only: per-wave cycle sums (never in the product library)
@@ -59,13 +64,14 @@ __global__ __launch_bounds__(64 * NWV) void spmma_f16_fused_direct_kernel(const 
   const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const unsigned tiles = (unsigned)p.tiles_m * (unsigned)p.tiles_n;
   const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
-  const unsigned b = lid / tiles, trem = lid - b * tiles;
+  const unsigned gb = lid / tiles, trem = lid - gb * tiles;
+  const unsigned grp = gb / (unsigned)p.batch, b = gb - grp * (unsigned)p.batch;
   const unsigned tile_m = trem / (unsigned)p.tiles_n, tile_n = trem - tile_m * (unsigned)p.tiles_n;
   const int m0 = (int)tile_m * BM, n0 = (int)tile_n * BN;
   const int nkt = p.K / 64;
-  const half_t* A = p.A + (size_t)b * p.sA;
-  const half_t* B = p.B + (size_t)b * p.sB;
-  half_t* C = p.C + (size_t)b * p.sC;
+  const half_t* A = p.A[grp] + (size_t)b * p.sA;
+  const half_t* B = p.B[grp] + (size_t)b * p.sB;
+  half_t* C = p.C[grp] + (size_t)b * p.sC;
   const int mlast = p.Mrows - 1;
 
   const char* src[SL];
@@ -143,7 +149,7 @@ static int launch_fused_direct(const FusedArgs& a0, hipStream_t st) {
   FusedArgs a = a0;
   a.tiles_m = (a.Mrows + BM - 1) / BM;
   a.tiles_n = (a.N + BN - 1) / BN;
-  const size_t nwg = (size_t)a.tiles_m * a.tiles_n * a.batch;
+  const size_t nwg = (size_t)a.tiles_m * a.tiles_n * a.batch * a.ngroup;
   if (nwg == 0) return SM_STATUS_SUCCESS;
   if (nwg > 0x7fffffffu) {
     set_error("sm_spmma_fused_f16: grid too large");
@@ -232,11 +238,12 @@ __global__ __launch_bounds__(64 * (WM * WN + 4 + NLB)) void spmma_f16_fused_wide
   const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const unsigned tiles = (unsigned)p.tiles_m * (unsigned)p.tiles_n;
   const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
-  const unsigned b = lid / tiles, trem = lid - b * tiles;
+  const unsigned gb = lid / tiles, trem = lid - gb * tiles;
+  const unsigned grp = gb / (unsigned)p.batch, b = gb - grp * (unsigned)p.batch;
   const unsigned tile_m = trem / (unsigned)p.tiles_n, tile_n = trem - tile_m * (unsigned)p.tiles_n;
   const int m0 = (int)tile_m * BM, n0 = (int)tile_n * BN;
   const int nkt = p.K / 64;
-  half_t* C = p.C + (size_t)b * p.sC;
+  half_t* C = p.C[grp] + (size_t)b * p.sC;
 
   f4 acc[FM][FN];
 #pragma unroll
@@ -248,7 +255,7 @@ __global__ __launch_bounds__(64 * (WM * WN + 4 + NLB)) void spmma_f16_fused_wide
   if (NLB > 0 && wave >= (unsigned)(NC + NLA)) {
     // ------------------------------------------------------------------ B loader wave: LDS-DMA only
     BTileDma<BN, NBW> bd;
-    bd.setup(p.B + (size_t)b * p.sB, p.N, n0, wave - (NC + NLA), lane, BRING);
+    bd.setup(p.B[grp] + (size_t)b * p.sB, p.N, n0, wave - (NC + NLA), lane, BRING);
     auto issue = [&](int kt, int buf) {
 #if defined(SM_ABLATE) && (SM_ABLATE & 4)
       return;  /* diagnostic timing builds only: 1 = no consumer compute, 2 = no selection, 4 = no B DMA, 8 = no A loads in the loop */
@@ -283,7 +290,7 @@ __global__ __launch_bounds__(64 * (WM * WN + 4 + NLB)) void spmma_f16_fused_wide
   } else if (wave >= (unsigned)NC) {
     // ------------------------------------------------------------------ A loader wave: load, select, ds_write
     const unsigned lw = wave - NC;
-    const half_t* A = p.A + (size_t)b * p.sA;
+    const half_t* A = p.A[grp] + (size_t)b * p.sA;
     const int mlast = p.Mrows - 1;
     // load i of this wave = rows 8*(4*lw + i) + lane/8, dense chunk c = lane % 8 (k 8c .. 8c+7 of the stage)
     const unsigned c8 = lane & 7u;
@@ -374,7 +381,7 @@ __global__ __launch_bounds__(64 * (WM * WN + 4 + NLB)) void spmma_f16_fused_wide
     BTileDma<BN, NBW> bd;
     int nb = NSB - 1;
     if (NLB == 0) {
-      bd.setup(p.B + (size_t)b * p.sB, p.N, n0, wave, lane, BRING);
+      bd.setup(p.B[grp] + (size_t)b * p.sB, p.N, n0, wave, lane, BRING);
 #pragma unroll
       for (int s = 0; s < NSB - 1; ++s)
         if (s < nkt) bd.issue(smem, s, (unsigned)(s * SB));
@@ -415,7 +422,7 @@ static int launch_fused_wide(const FusedArgs& a0, hipStream_t st) {
   FusedArgs a = a0;
   a.tiles_m = (a.Mrows + 127) / 128;
   a.tiles_n = (a.N + BN - 1) / BN;
-  const size_t nwg = (size_t)a.tiles_m * a.tiles_n * a.batch;
+  const size_t nwg = (size_t)a.tiles_m * a.tiles_n * a.batch * a.ngroup;
   if (nwg == 0) return SM_STATUS_SUCCESS;
   if (nwg > 0x7fffffffu) {
     set_error("sm_spmma_fused_f16: grid too large");
@@ -487,7 +494,8 @@ __global__ __launch_bounds__(64 * 16) void spmma_f16_fused_astat_kernel(const Fu
   const int nkt = p.K / 64;
   const unsigned per_batch = (unsigned)p.tiles_m * (unsigned)nsplit;
   const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
-  const unsigned b = lid / per_batch, trem = lid - b * per_batch;
+  const unsigned gb = lid / per_batch, trem = lid - gb * per_batch;
+  const unsigned grp = gb / (unsigned)p.batch, b = gb - grp * (unsigned)p.batch;
   const unsigned tile_m = trem / (unsigned)nsplit, split = trem - tile_m * (unsigned)nsplit;
   const int m0 = (int)tile_m * BM;
   const int nt0 = (int)split * tiles_per_split;
@@ -495,12 +503,12 @@ __global__ __launch_bounds__(64 * 16) void spmma_f16_fused_astat_kernel(const Fu
   const int T = (nt1 - nt0) * nkt;  // stage iterations of this workgroup (>= nkt: the launcher never makes empty splits)
   char* const Bring = smem + nkt * ASTG;
   char* const Cpatch = Bring + NSB * SB;
-  half_t* C = p.C + (size_t)b * p.sC;
+  half_t* C = p.C[grp] + (size_t)b * p.sC;
 
   // B loader state (waves NC+NLA ..): set up first so that their ring prologue is in flight during phase 1
   const bool is_b = wave >= (unsigned)(NC + NLA);
   const unsigned lwb = is_b ? wave - (NC + NLA) : 0u;
-  const char* Bb = reinterpret_cast<const char*>(p.B + (size_t)b * p.sB);
+  const char* Bb = reinterpret_cast<const char*>(p.B[grp] + (size_t)b * p.sB);
   unsigned b_kr[B_WI], b_col[B_WI], b_dst[B_WI];
 #pragma unroll
   for (int i = 0; i < B_WI; ++i) {
@@ -534,7 +542,7 @@ __global__ __launch_bounds__(64 * 16) void spmma_f16_fused_astat_kernel(const Fu
   // ---- phase 1, all 16 waves: the 2:4 image of the row panel for the whole K.  Wave w owns rows 8w .. 8w+7: one
   // 16-byte load per lane and stage, all stages in flight at once (K <= 512: at most 8 loads), then selection.
   {
-    const half_t* A = p.A + (size_t)b * p.sA;
+    const half_t* A = p.A[grp] + (size_t)b * p.sA;
     const unsigned row = 8u * wave + (lane >> 3), c8 = lane & 7u;
     int gr = m0 + (int)row;
     gr = gr < p.Mrows - 1 ? gr : p.Mrows - 1;
@@ -657,7 +665,7 @@ static int launch_fused_astat(const FusedArgs& a0, hipStream_t st) {
   // its A panel, so no more than needed: 784 x 1024 x 256, b = 32: 29 / 33 / 41 us with 1 / 2 / 4 splits); >= 2 tiles
   // per split
   const int cus = device_cu_count();
-  const size_t panels = (size_t)a.tiles_m * a.batch;
+  const size_t panels = (size_t)a.tiles_m * a.batch * a.ngroup;
   static const int nsplit_env = tuning_int("SM_FUSED_NSPLIT", 0);  // tuning aid
   int nsplit = 1;
   while (!nsplit_env && panels * nsplit * 4 < (size_t)3 * cus && (a.tiles_n + 2 * nsplit - 1) / (2 * nsplit) >= 2) nsplit *= 2;
@@ -683,17 +691,31 @@ static int launch_fused_astat(const FusedArgs& a0, hipStream_t st) {
 using namespace sm;
 
 template <bool BF>
-static int spmma_fused16(const void* A, const void* B, void* C, size_t m, size_t n, size_t k, size_t lda,
+static int spmma_fused16(size_t ngroup, const void* const* Ag, const void* const* Bg, void* const* Cg, size_t m, size_t n, size_t k, size_t lda,
                          size_t batch, size_t strideA, size_t strideB, size_t strideC, float alpha, float beta,
                          sm_stream_t stream) {
-  if (!A || !B || !C || lda < k) {
+  if (ngroup == 0) return SM_STATUS_SUCCESS;
+  if (!Ag || !Bg || !Cg || lda < k || ngroup > (size_t)MAXG) {
     set_error("sm_spmma_fused_{f16,bf16}: invalid argument");
     return SM_STATUS_INVALID_VALUE;
   }
+  bool all_aligned = true, c_aligned = true;
+  for (size_t g = 0; g < ngroup; ++g) {
+    if (!Ag[g] || !Bg[g] || !Cg[g]) {
+      set_error("sm_spmma_fused_{f16,bf16}: invalid argument (null operand)");
+      return SM_STATUS_INVALID_VALUE;
+    }
+    all_aligned = all_aligned && aligned16(Ag[g]) && aligned16(Bg[g]);
+    c_aligned = c_aligned && aligned16(Cg[g]);
+  }
   if (m == 0 || n == 0 || batch == 0) return SM_STATUS_SUCCESS;
   // whole 64-deep stages of 16-byte aligned rows only; anything else: sm_compress24_f16 + sm_spmma_f16
-  if (k % 64 != 0 || lda % 8 != 0 || strideA % 8 != 0 || n % 8 != 0 || strideB % 8 != 0 || !aligned16(A) || !aligned16(B)) {
+  if (k % 64 != 0 || lda % 8 != 0 || strideA % 8 != 0 || n % 8 != 0 || strideB % 8 != 0 || !all_aligned) {
     set_error("sm_spmma_fused_{f16,bf16}: needs k %% 64 == 0, n %% 8 == 0 and 16-byte aligned rows (use the staged path)");
+    return SM_STATUS_NOT_SUPPORTED;
+  }
+  if (ngroup > 1 && !c_aligned) {  // (the kernels' scalar C path keys on the pointer: one decision per launch)
+    set_error("sm_spmma_fused_{f16,bf16}_grouped: needs 16-byte aligned C operands");
     return SM_STATUS_NOT_SUPPORTED;
   }
   if (m * batch > 0x7fffffffull || n > 0x7fffffffull || k > 0x7fffffffull || lda > 0x7fffffffull) {
@@ -701,7 +723,12 @@ static int spmma_fused16(const void* A, const void* B, void* C, size_t m, size_t
     return SM_STATUS_NOT_SUPPORTED;
   }
   FusedArgs a = {};
-  a.A = (const half_t*)A; a.B = (const half_t*)B; a.C = (half_t*)C;
+  for (size_t g = 0; g < (size_t)MAXG; ++g) {  // unused slots repeat problem 0 (never indexed: grp < ngroup)
+    const size_t s_ = g < ngroup ? g : 0;
+    a.A[g] = (const half_t*)Ag[s_]; a.B[g] = (const half_t*)Bg[s_]; a.C[g] = (half_t*)Cg[s_];
+  }
+  a.ngroup = (int)ngroup;
+  void* const C = Cg[0];
   a.sA = strideA; a.sB = strideB; a.sC = strideC;
   a.Mrows = (int)m; a.N = (int)n; a.K = (int)k; a.lda = (int)lda;
   a.batch = (int)batch; a.alpha = alpha; a.beta = beta;
@@ -743,10 +770,37 @@ static int spmma_fused16(const void* A, const void* B, void* C, size_t m, size_t
 extern "C" int sm_spmma_fused_f16(const void* A, const void* B, void* C, size_t m, size_t n, size_t k, size_t lda,
                                   size_t batch, size_t strideA, size_t strideB, size_t strideC, float alpha, float beta,
                                   sm_stream_t stream) {
-  return spmma_fused16<false>(A, B, C, m, n, k, lda, batch, strideA, strideB, strideC, alpha, beta, stream);
+  return spmma_fused16<false>(1, &A, &B, &C, m, n, k, lda, batch, strideA, strideB, strideC, alpha, beta, stream);
 }
 extern "C" int sm_spmma_fused_bf16(const void* A, const void* B, void* C, size_t m, size_t n, size_t k, size_t lda,
                                    size_t batch, size_t strideA, size_t strideB, size_t strideC, float alpha, float beta,
                                    sm_stream_t stream) {
-  return spmma_fused16<true>(A, B, C, m, n, k, lda, batch, strideA, strideB, strideC, alpha, beta, stream);
+  return spmma_fused16<true>(1, &A, &B, &C, m, n, k, lda, batch, strideA, strideB, strideC, alpha, beta, stream);
+}
+
+// Grouped forms: `count` same-shape problems (host arrays of device pointers, as the reference's batched::spmm takes its
+// As / Cs, spmm.hxx:30-33) in as few grids as possible (MAXG problems per launch).  Same kernels, same C bit for bit.
+template <bool BF>
+static int spmma_fused16_grouped(size_t count, const void* const* A, const void* const* B, void* const* C, size_t m, size_t n, size_t k,
+                                 size_t lda, size_t batch, size_t strideA, size_t strideB, size_t strideC, float alpha, float beta,
+                                 sm_stream_t stream) {
+  if (count && (!A || !B || !C)) {
+    set_error("sm_spmma_fused_{f16,bf16}_grouped: invalid argument");
+    return SM_STATUS_INVALID_VALUE;
+  }
+  for (size_t i = 0; i < count; i += (size_t)MAXG) {
+    const size_t ng = count - i < (size_t)MAXG ? count - i : (size_t)MAXG;
+    if (const int rc = spmma_fused16<BF>(ng, A + i, B + i, C + i, m, n, k, lda, batch, strideA, strideB, strideC, alpha, beta, stream)) return rc;
+  }
+  return SM_STATUS_SUCCESS;
+}
+extern "C" int sm_spmma_fused_f16_grouped(size_t count, const void* const* A, const void* const* B, void* const* C, size_t m, size_t n,
+                                          size_t k, size_t lda, size_t batch, size_t strideA, size_t strideB, size_t strideC,
+                                          float alpha, float beta, sm_stream_t stream) {
+  return spmma_fused16_grouped<false>(count, A, B, C, m, n, k, lda, batch, strideA, strideB, strideC, alpha, beta, stream);
+}
+extern "C" int sm_spmma_fused_bf16_grouped(size_t count, const void* const* A, const void* const* B, void* const* C, size_t m, size_t n,
+                                           size_t k, size_t lda, size_t batch, size_t strideA, size_t strideB, size_t strideC,
+                                           float alpha, float beta, sm_stream_t stream) {
+  return spmma_fused16_grouped<true>(count, A, B, C, m, n, k, lda, batch, strideA, strideB, strideC, alpha, beta, stream);
 }

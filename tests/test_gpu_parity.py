@@ -1039,6 +1039,31 @@ def test_cpp_drivers_cli_contract(gpu):
             assert "Matches spmma(): yes" in out.stdout
 
 
+def test_values_through_the_cpp_headers_vs_oracle(gpu):
+    """Row b of the scope table, by VALUE: tests/cpp/header_parity runs sparsify<2,2>, batched::gemm (N,N and T,N),
+    batched::spmm, batched::strided_coo and spmma<half / float> (N,N and T,N) through include/sparsify.me/*.hxx on a 3-row
+    table and compares every result with the oracle (bit-exact masks / pruned A, the tight GEMM bound for the products).
+    `--swap` then rotates the C pointer table handed to batched::gemm / batched::spmm: every such check must notice, i.e. a
+    swapped pointer inside a header would turn this test red."""
+    import os
+    import subprocess
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tests", "cpp", "bin", "header_parity")
+    subprocess.run(["make", "-C", os.path.join(root, "tests", "cpp")], check=True, capture_output=True)
+    with tempfile.TemporaryDirectory() as td:
+        tab = os.path.join(td, "three.csv")
+        with open(tab, "w") as fh:
+            fh.write("m,n,k,b\n196,64,128,3\n64,40,72,2\n130,24,64,4\n")
+        out = subprocess.run([exe, tab], capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stdout[-4000:] + out.stderr[-2000:]
+        assert "MISMATCH" not in out.stdout and "Incorrect pruning" not in out.stderr
+        assert out.stdout.count(" ok") >= 3 * (3 + 2 + 1 + 1 + 4 + 4)
+        sw = subprocess.run([exe, tab, "--swap"], capture_output=True, text=True, timeout=600)
+        assert sw.returncode == 0, sw.stdout[-4000:] + sw.stderr[-2000:]
+        assert sw.stdout.count("rotated pointer table detected") == 3 * 3 and "did not notice" not in sw.stdout
+
+
 # ---------------------------------------------------------------------------------------------
 # (f-2) transposed operands of spmma (reference spmma.hxx:30-31,67-69)
 # ---------------------------------------------------------------------------------------------
@@ -1146,6 +1171,55 @@ def test_fused_equals_staged(gpu, orc, shape, shared_b):
     scale = np.stack([np.abs(A.astype(np.float64)).reshape(batch, m, k)[b] @ np.abs(B.astype(np.float64)).reshape(nb, k, n)[b if not shared_b else 0]
                       for b in range(batch)]).reshape(-1)
     check_close(host(C2), Cref.view(np.float16), scale, FP16_TOL, f"fused {shape}", k)
+
+
+@pytest.mark.parametrize("shape", [(196, 64, 128, 2), (784, 256, 1024, 1), (300, 520, 128, 2), (260, 520, 576, 1), (3136, 128, 512, 1),
+                                   (130, 72, 192, 1)])
+@pytest.mark.parametrize("count", [1, 3, 8, 11])
+def test_fused_grouped_equals_individual_calls(gpu, shape, count):
+    """sm_spmma_fused_f16_grouped over `count` same-shape problems (one grid per 8) writes, into every C[i], exactly the bits
+    of a plain sm_spmma_fused_f16 call on (A[i], B[i]) -- every kernel variant (direct, wide, A-stationary), ragged tiles,
+    more problems than one launch holds.  bf16 rides the same kernels (one case)."""
+    import torch
+    m, n, k, batch = shape
+    rng = np.random.default_rng(count * 1000 + m + n + k)
+    As = [to_dev(rand(rng, batch * m * k, np.float16, "ties" if i % 3 == 2 else "uniform")) for i in range(count)]
+    Bs = [to_dev(rand(rng, k * n, np.float16)) for _ in range(count)]
+    want = []
+    for i in range(count):
+        C = torch.full((batch * m * n,), 3.0, dtype=torch.float16, device="cuda")
+        gpu.spmma_fused(As[i], Bs[i], C, m, n, k, batch=batch)
+        want.append(bits(host(C)))
+    Cs = [torch.full((batch * m * n,), 5.0, dtype=torch.float16, device="cuda") for _ in range(count)]
+    gpu.spmma_fused_grouped(As, Bs, Cs, m, n, k, batch=batch)
+    for i in range(count):
+        assert np.array_equal(bits(host(Cs[i])), want[i]), f"grouped problem {i} of {count} differs from its own call"
+    if count == 3:
+        Ab = [a.view(torch.int16).view(torch.bfloat16) for a in As]
+        Bb = [b.view(torch.int16).view(torch.bfloat16) for b in Bs]
+        Cb = [torch.zeros(batch * m * n, dtype=torch.bfloat16, device="cuda") for _ in range(count)]
+        gpu.spmma_fused_grouped(Ab, Bb, Cb, m, n, k, batch=batch)
+        for i in range(count):
+            C = torch.zeros(batch * m * n, dtype=torch.bfloat16, device="cuda")
+            gpu.spmma_fused(Ab[i], Bb[i], C, m, n, k, batch=batch)
+            torch.cuda.synchronize()
+            assert torch.equal(C.view(torch.int16), Cb[i].view(torch.int16))
+
+
+def test_fused_grouped_rejects_bad_arguments(gpu):
+    import ctypes
+    import torch
+    L = gpu.lib()
+    A = torch.zeros(128 * 64, dtype=torch.float16, device="cuda")
+    C = torch.zeros(128 * 64 + 8, dtype=torch.float16, device="cuda")
+    tab = lambda *ts: (ctypes.c_void_p * len(ts))(*[t if isinstance(t, int) else t.data_ptr() for t in ts])
+    z = ctypes.c_void_p(0)
+    # a null operand in the table
+    assert L.sm_spmma_fused_f16_grouped(2, tab(A, 0), tab(A, A), tab(C, C), 128, 64, 64, 64, 1, 128 * 64, 0, 128 * 64, 1.0, 0.0, z) != 0
+    # a misaligned C in a group of two
+    assert L.sm_spmma_fused_f16_grouped(2, tab(A, A), tab(A, A), tab(C, C.data_ptr() + 2), 128, 64, 64, 64, 1, 128 * 64, 0, 128 * 64, 1.0, 0.0, z) != 0
+    # count == 0 is a no-op
+    assert L.sm_spmma_fused_f16_grouped(0, None, None, None, 128, 64, 64, 64, 1, 128 * 64, 0, 128 * 64, 1.0, 0.0, z) == 0
 
 
 # ---------------------------------------------------------------------------------------------

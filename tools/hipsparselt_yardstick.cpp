@@ -251,7 +251,7 @@ int main(int argc, char** argv) {
   fprintf(out, "# hipSPARSELt yardstick (tools/hipsparselt_yardstick.cpp): libhipsparselt next to %s\n", sm_version());
   fprintf(out, "# (a) semantics of hipsparseLtSpMMAPrune / PruneCheck vs sm_prune24_f16 / sm_prune24_check_f16\n");
   if (!semantics(out, 3136, 512)) fprintf(out, "semantics: vendor library refused (see stderr)\n");
-  if (!semantics(out, 196, 4608)) fprintf(out, "semantics: vendor library refused (see stderr)\n");
+  if (!semantics(out, 784, 4608)) fprintf(out, "semantics: vendor library refused (see stderr)\n");
   // (b) time, unique shapes of the table with their multiplicity
   std::ifstream f(table);
   if (!f) { fprintf(stderr, "cannot open %s\n", table.c_str()); return 2; }
