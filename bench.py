@@ -497,7 +497,7 @@ def extras(args, sm, torch, dev, layers, flops, t_full, Forked, make_runner, tim
     # TILE prune -> prune check -> compress -> multiply.  The prune reads the step's dense A and writes the pruned
     # operand to a second buffer (the bytes of the in-place prune, without turning the bench's operand into an already
     # pruned one for the next step).
-    if hasattr(sm, "api_spmma_step") and not f32:
+    if hasattr(sm, "api_spmma_step"):  # (fp32 too since round 3: sm_prune24_compress24_f32)
         valid = torch.zeros(1, dtype=torch.int32, device=dev)
         for L in layers:
             L["Aapi"] = torch.empty_like(L["A"])

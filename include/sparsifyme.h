@@ -110,6 +110,10 @@ int sm_prune24_compress24_f16(const void* A_in, void* A_out, size_t m, size_t k,
                               void* blob, int* d_valid, int alg, sm_stream_t stream);
 int sm_prune24_compress24_bf16(const void* A_in, void* A_out, size_t m, size_t k, size_t ld, size_t batch, size_t strideA,
                                void* blob, int* d_valid, int alg, sm_stream_t stream);
+/* fp32 form (the type the reference's own driver instantiates, examples/spmma.cu:24): 2:4 on fp32 as everywhere in this
+ * build; same bytes as sm_prune24_f32 + sm_prune24_check_f32 + sm_compress24_f32. */
+int sm_prune24_compress24_f32(const float* A_in, float* A_out, size_t m, size_t k, size_t ld, size_t batch, size_t strideA,
+                              void* blob, int* d_valid, int alg, sm_stream_t stream);
 
 /* ---- (a4) 2:4 sparse x dense matmul: replaces cusparseLtMatmul (spmma.hxx:112-113).
  *      C_b = alpha * A_b * B_b + beta * C_b, row-major, ld(B) = ld(C) = n (spmma.hxx:56-64);

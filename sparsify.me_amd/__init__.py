@@ -82,6 +82,7 @@ _SIGS = {
 }
 _SIGS["sm_prune24_compress24_f16"] = [_c_ptr, _c_ptr, _c_size, _c_size, _c_size, _c_size, _c_size, _c_ptr, _c_ptr, _c_i, _c_ptr]
 _SIGS["sm_prune24_compress24_bf16"] = _SIGS["sm_prune24_compress24_f16"]
+_SIGS["sm_prune24_compress24_f32"] = _SIGS["sm_prune24_compress24_f16"]
 _SIGS["sm_conv_spmma_fused_f16"] = [_c_ptr, _c_ptr, _c_ptr] + [_c_size] * 10 + [_c_f, _c_f, _c_ptr]
 _SIGS["sm_conv_spmma_fused_bf16"] = _SIGS["sm_conv_spmma_fused_f16"]
 _SIGS["sm_transpose"] = [_c_ptr, _c_ptr] + [_c_size] * 8 + [_c_ptr]

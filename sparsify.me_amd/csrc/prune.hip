@@ -605,6 +605,13 @@ int prune_check_accumulate_u16(const void* A, size_t m, size_t k, size_t ld, int
   return check_launch("prune_check_kernel");
 }
 
+int prune_check_accumulate_u32(const void* A, size_t m, size_t k, size_t ld, int* d_valid, hipStream_t st) {
+  if (m == 0 || k == 0) return SM_STATUS_SUCCESS;
+  const bool vec_ok = vec_ok_2d<uint32_t>(A, A, ld, 0);
+  prune_check_kernel<uint32_t><<<stream_grid(m * ceil_div(k, 8), 256), 256, 0, st>>>((const uint32_t*)A, m, k, ld, vec_ok, d_valid);
+  return check_launch("prune_check_kernel");
+}
+
 template <typename T>
 static int launch_compress(const void* A, size_t m, size_t k, size_t ld, size_t batch, size_t strideA, void* blob,
                            hipStream_t st) {

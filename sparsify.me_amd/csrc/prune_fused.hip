@@ -198,6 +198,176 @@ __global__ __launch_bounds__(256) void prune_compress_kernel(const PruneFusedArg
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// fp32 form (round 3): the type the reference's own driver instantiates (examples/spmma.cu:24 -> spmma.hxx:82-104).  Same
+// work item (4 rows x 8 columns = two TILE tiles / eight strips; two 16-byte loads per row and lane), same wave mapping,
+// same blob geometry with 4-byte elements (values [kc/64][M][32] floats, metadata [kc/64][M][8 B]): per item and row
+// 32 bytes of pruned A, one 16-byte piece of kept values, one metadata byte (a lane quad's four bytes leave as one dword).
+// The rules are the fp32 ones of prune.hip: magnitudes = bit patterns with the sign cleared (NaN -> +inf for the TILE
+// sums), STRIP by compare-and-count (strip_keepmask), and the blob of a pruned strip is the STRIP selection of ITS values.
+// ---------------------------------------------------------------------------------------------
+struct PruneFusedArgs32 {
+  const uint32_t* A_in;
+  uint32_t* A_out;
+  uint32_t* vals;
+  unsigned char* meta;
+  int* d_valid;
+  size_t m, ld, strideA, M;
+  unsigned rows, trows, gtr_total, ppr, lpr_log2;
+};
+
+__device__ __forceinline__ float mag_of_f32bits(uint32_t v) {
+  const uint32_t k = v & 0x7fffffffu;
+  return k > 0x7f800000u ? __builtin_inff() : __builtin_bit_cast(float, k);
+}
+
+template <bool TILE, bool FLAT>
+__global__ __launch_bounds__(256) void prune_compress_f32_kernel(const PruneFusedArgs32 p) {
+  bool bad = false;
+  const unsigned lane = threadIdx.x & 63u;
+  const unsigned wave_g = blockIdx.x * 4u + (threadIdx.x >> 6), nwaves = gridDim.x * 4u;
+  const unsigned lg = p.lpr_log2, rw = lane >> lg, pcl = lane & ((1u << lg) - 1u), rpw = 64u >> lg;
+  const unsigned nj = p.ppr >> lg;
+  const unsigned ngroups = (p.gtr_total + rpw - 1u) / rpw;
+
+  struct Pos {
+    size_t aoff, R0;
+    unsigned nrows, pc;
+  };
+  auto locate = [&](unsigned g, unsigned j) {
+    Pos q;
+    const unsigned gtr = g * rpw + rw;
+    q.pc = (j << lg) + pcl;
+    if constexpr (FLAT) {
+      const unsigned r0 = gtr * 4u;
+      q.nrows = gtr < p.gtr_total ? (p.rows - r0 < 4u ? p.rows - r0 : 4u) : 0u;
+      q.aoff = (size_t)r0 * p.ld + (size_t)q.pc * 8u;
+      q.R0 = r0;
+    } else {
+      const unsigned b = gtr / p.trows, tr = gtr - b * p.trows, r0 = tr * 4u;
+      const unsigned left = (unsigned)p.m - r0;
+      q.nrows = gtr < p.gtr_total ? (left < 4u ? left : 4u) : 0u;
+      q.aoff = (size_t)b * p.strideA + (size_t)r0 * p.ld + (size_t)q.pc * 8u;
+      q.R0 = (size_t)b * p.m + r0;
+    }
+    return q;
+  };
+  auto load = [&](const Pos& q, u4 (&v)[4][2]) {
+    const uint32_t* src = p.A_in + q.aoff;
+#pragma unroll
+    for (unsigned r = 0; r < 4; ++r) {
+      if (r < q.nrows) {
+        v[r][0] = __builtin_nontemporal_load(reinterpret_cast<const u4*>(src));
+        v[r][1] = __builtin_nontemporal_load(reinterpret_cast<const u4*>(src) + 1);
+      } else {
+        v[r][0] = v[r][1] = u4{0u, 0u, 0u, 0u};
+      }
+      src += p.ld;
+    }
+  };
+
+  const unsigned long long units = (unsigned long long)ngroups * nj;
+  if (wave_g >= units) return;
+  unsigned g = wave_g / nj, j = wave_g - g * nj;
+  const unsigned dg = nwaves / nj, dj = nwaves - dg * nj;
+  unsigned long long u = wave_g;
+  Pos cur = locate(g, j);
+  u4 v[4][2];
+  load(cur, v);
+  for (;;) {
+    unsigned gn = g + dg, jn = j + dj;
+    if (jn >= nj) {
+      jn -= nj;
+      ++gn;
+    }
+    const bool more = u + nwaves < units;
+    Pos nxt = cur;
+    u4 vn[4][2];
+    if (more) {
+      nxt = locate(gn, jn);
+      load(nxt, vn);
+    }
+
+    unsigned keep[2] = {0u, 0u};  // 16-bit keep masks (bit 4 r + c) of the item's two tiles
+    if constexpr (TILE) {
+#pragma unroll
+      for (unsigned t = 0; t < 2; ++t) {
+        float mag[4][4];
+#pragma unroll
+        for (unsigned r = 0; r < 4; ++r)
+#pragma unroll
+          for (unsigned c = 0; c < 4; ++c) mag[r][c] = mag_of_f32bits(v[r][t][c]);
+        keep[t] = tile_keepmask(mag);
+        __builtin_amdgcn_sched_barrier(0);  // one tile after the other (registers)
+      }
+    } else {
+#pragma unroll
+      for (unsigned t = 0; t < 2; ++t)
+#pragma unroll
+        for (unsigned r = 0; r < 4; ++r)
+          keep[t] |= strip_keepmask(key_of(v[r][t][0]), key_of(v[r][t][1]), key_of(v[r][t][2]), key_of(v[r][t][3])) << (4u * r);
+    }
+    const size_t stage = cur.pc >> 3;
+    const unsigned q2 = cur.pc & 7u;
+    uint32_t* dst = p.A_out ? p.A_out + cur.aoff : nullptr;
+    uint32_t* vdst = p.vals ? p.vals + (stage * p.M + cur.R0) * 32 + q2 * 4 : nullptr;
+    unsigned char* mdst = p.vals ? p.meta + (stage * p.M + cur.R0) * 8 + q2 : nullptr;
+#pragma unroll
+    for (unsigned r = 0; r < 4; ++r) {
+      uint32_t o[2][4], kv[4];
+      unsigned nb[2];
+#pragma unroll
+      for (unsigned t = 0; t < 2; ++t) {
+        const unsigned rm = (keep[t] >> (4u * r)) & 15u;
+        bad |= __builtin_popcount(rm) > 2;  // what is about to be written
+#pragma unroll
+        for (unsigned c = 0; c < 4; ++c) o[t][c] = ((rm >> c) & 1u) ? v[r][t][c] : 0u;
+        // what sm_compress24_f32 stores for the pruned strip: the STRIP selection of ITS values (== rm unless a zero was kept)
+        const unsigned ks = strip_keepmask(key_of(o[t][0]), key_of(o[t][1]), key_of(o[t][2]), key_of(o[t][3]));
+        nb[t] = nibble_of(ks);
+        const unsigned p0 = nb[t] & 3u, p1 = nb[t] >> 2;
+        uint32_t a0 = o[t][0], a1 = o[t][1];
+        a0 = p0 == 1 ? o[t][1] : a0;
+        a0 = p0 == 2 ? o[t][2] : a0;
+        a1 = p1 == 2 ? o[t][2] : a1;
+        a1 = p1 == 3 ? o[t][3] : a1;
+        kv[2 * t] = a0;
+        kv[2 * t + 1] = a1;
+      }
+      const int mb = (int)(nb[0] | (nb[1] << 4));
+      const unsigned b0 = (unsigned)__builtin_amdgcn_update_dpp(0, mb, 0x00, 0xf, 0xf, true);
+      const unsigned b1 = (unsigned)__builtin_amdgcn_update_dpp(0, mb, 0x55, 0xf, 0xf, true);
+      const unsigned b2 = (unsigned)__builtin_amdgcn_update_dpp(0, mb, 0xaa, 0xf, 0xf, true);
+      const unsigned b3 = (unsigned)__builtin_amdgcn_update_dpp(0, mb, 0xff, 0xf, 0xf, true);
+      if (r < cur.nrows) {
+        if (dst) {
+          reinterpret_cast<u4*>(dst)[0] = u4{o[0][0], o[0][1], o[0][2], o[0][3]};
+          reinterpret_cast<u4*>(dst)[1] = u4{o[1][0], o[1][1], o[1][2], o[1][3]};
+        }
+        if (vdst) {
+          __builtin_nontemporal_store(u4{kv[0], kv[1], kv[2], kv[3]}, reinterpret_cast<u4*>(vdst + r * 32));
+          if ((lane & 3u) == 0) *reinterpret_cast<unsigned*>(mdst + r * 8) = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+        }
+      }
+      if (dst) dst += p.ld;
+    }
+    if (!more) break;
+    u += nwaves;
+    g = gn;
+    j = jn;
+    cur = nxt;
+#pragma unroll
+    for (unsigned r = 0; r < 4; ++r) {
+      v[r][0] = vn[r][0];
+      v[r][1] = vn[r][1];
+    }
+  }
+  if (p.d_valid && __any(bad)) {
+    if (lane == 0) atomicOr(p.d_valid, 1);
+  }
+}
+
 }  // namespace sm
 
 using namespace sm;
@@ -295,4 +465,76 @@ extern "C" int sm_prune24_compress24_f16(const void* A_in, void* A_out, size_t m
 extern "C" int sm_prune24_compress24_bf16(const void* A_in, void* A_out, size_t m, size_t k, size_t ld, size_t batch,
                                           size_t strideA, void* blob, int* d_valid, int alg, sm_stream_t stream) {
   return prune_compress16<true>(A_in, A_out, m, k, ld, batch, strideA, blob, d_valid, alg, stream);
+}
+
+// prune.hip
+extern "C" int sm_prune24_f32(const float*, float*, size_t, size_t, size_t, int, sm_stream_t);
+extern "C" int sm_compress24_f32(const float*, size_t, size_t, size_t, size_t, size_t, void*, sm_stream_t);
+namespace sm {
+int prune_check_accumulate_u32(const void* A, size_t m, size_t k, size_t ld, int* d_valid, hipStream_t st);  // ORs into *d_valid
+}
+
+extern "C" int sm_prune24_compress24_f32(const float* A_in, float* A_out, size_t m, size_t k, size_t ld, size_t batch, size_t strideA,
+                                         void* blob, int* d_valid, int alg, sm_stream_t stream) {
+  const char* name = "sm_prune24_compress24_f32";
+  if (!A_in || ld < k || (alg != SM_PRUNE_STRIP && alg != SM_PRUNE_TILE) || (blob && !aligned16(blob))) {
+    set_error("%s: invalid argument", name);
+    return SM_STATUS_INVALID_VALUE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (d_valid && hipMemsetAsync(d_valid, 0, sizeof(int), st) != hipSuccess) return check_launch("hipMemsetAsync(d_valid)");
+  if (m == 0 || k == 0 || batch == 0) return SM_STATUS_SUCCESS;
+  const bool fast = k % 64 == 0 && ld % 4 == 0 && strideA % 4 == 0 && aligned16(A_in) && (!A_out || aligned16(A_out)) &&
+                    batch * ceil_div(m, (size_t)4) < 0x3fffffffull && k / 8 < 0xffffffffull && m * batch < 0xfffffff0ull;
+  if (!fast) {  // the same three steps as separate launches (k % 64 != 0, unaligned rows)
+    int rc = SM_STATUS_SUCCESS;
+    const float* src = A_in;
+    const bool tall = batch == 1 || (strideA == m * ld && (alg == SM_PRUNE_STRIP || m % 4 == 0));
+    const size_t nbm = tall ? 1 : batch, rows = tall ? m * batch : m;
+    if (A_out) {
+      for (size_t b = 0; b < nbm && rc == SM_STATUS_SUCCESS; ++b) rc = sm_prune24_f32(A_in + b * strideA, A_out + b * strideA, rows, k, ld, alg, stream);
+      src = A_out;
+    } else if (alg == SM_PRUNE_TILE && blob) {
+      set_error("%s: TILE + blob without A_out needs k %% 64 == 0 and 16-byte aligned rows", name);
+      return SM_STATUS_NOT_SUPPORTED;
+    }
+    if (rc == SM_STATUS_SUCCESS && d_valid && A_out)
+      for (size_t b = 0; b < nbm && rc == SM_STATUS_SUCCESS; ++b) rc = prune_check_accumulate_u32(A_out + b * strideA, rows, k, ld, d_valid, st);
+    if (rc == SM_STATUS_SUCCESS && blob) rc = sm_compress24_f32(src, m, k, ld, batch, strideA, blob, stream);
+    return rc;
+  }
+  const BlobLayout L = blob_layout(m, k, 4, batch);
+  if (blob) {
+    const size_t vbytes = L.M * (L.kc / 2) * 4, mbytes = L.M * (L.kc / 8);
+    if (L.meta_off > vbytes && hipMemsetAsync((char*)blob + vbytes, 0, L.meta_off - vbytes, st) != hipSuccess) return check_launch("hipMemsetAsync");
+    if (L.total > L.meta_off + mbytes && hipMemsetAsync((char*)blob + L.meta_off + mbytes, 0, L.total - L.meta_off - mbytes, st) != hipSuccess)
+      return check_launch("hipMemsetAsync");
+  }
+  PruneFusedArgs32 a = {};
+  a.A_in = (const uint32_t*)A_in;
+  a.A_out = (uint32_t*)A_out;
+  a.vals = (uint32_t*)blob;
+  a.meta = blob ? (unsigned char*)blob + L.meta_off : nullptr;
+  a.d_valid = d_valid;
+  a.m = m; a.ld = ld; a.strideA = strideA; a.M = L.M;
+  const bool flat = batch == 1 || (strideA == m * ld && m % 4 == 0);
+  a.rows = (unsigned)(flat ? m * batch : 0);
+  a.trows = (unsigned)ceil_div(m, (size_t)4);
+  a.gtr_total = (unsigned)(flat ? ceil_div(m * batch, (size_t)4) : batch * a.trows);
+  a.ppr = (unsigned)(k / 8);
+  a.lpr_log2 = 3;
+  while (a.lpr_log2 < 6 && a.ppr % (2u << a.lpr_log2) == 0) ++a.lpr_log2;
+  const size_t wave_units = ceil_div((size_t)a.gtr_total, (size_t)(64u >> a.lpr_log2));
+  size_t blocks = ceil_div(wave_units, (size_t)4);
+  const size_t cap = (size_t)device_cu_count() * 8;
+  if (blocks > cap) blocks = cap;
+  const unsigned grid = (unsigned)(blocks ? blocks : 1);
+  if (alg == SM_PRUNE_TILE) {
+    if (flat) prune_compress_f32_kernel<true, true><<<grid, 256, 0, st>>>(a);
+    else prune_compress_f32_kernel<true, false><<<grid, 256, 0, st>>>(a);
+  } else {
+    if (flat) prune_compress_f32_kernel<false, true><<<grid, 256, 0, st>>>(a);
+    else prune_compress_f32_kernel<false, false><<<grid, 256, 0, st>>>(a);
+  }
+  return check_launch("prune_compress_f32_kernel");
 }

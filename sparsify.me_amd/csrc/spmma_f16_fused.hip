@@ -49,7 +49,7 @@ struct FusedArgs {
 // so every row of A is selected exactly once -- by the lane that feeds it to the SMFMAC (smfmac_stage_dense_a).
 // The data in flight are LDS buffers, not registers: 2 x 24 KiB per workgroup, two workgroups per CU at n = 64.
 // ---------------------------------------------------------------------------------------------
-template <int BN, int NS, bool BF = false, int BM = 128, int NWV = 4>
+template <int BN, int NS, bool BF = false, int BM = 128, int NWV = 4, bool ANT = true>
 __global__ __launch_bounds__(64 * NWV) void spmma_f16_fused_direct_kernel(const FusedArgs p) {
   static_assert(BM == 128 || BM == 64, "row tile");
   static_assert(NWV == 4 || (NWV == 8 && BM == 128), "waves per workgroup");
@@ -99,9 +99,16 @@ __global__ __launch_bounds__(64 * NWV) void spmma_f16_fused_direct_kernel(const 
   }
   auto stage = [&](int kt, int buf) {
     char* base = smem + buf * STAGE;
+    // A is read exactly once by the whole grid: its DMA carries the non-temporal hint (aux = 2, `nt`); B is re-read by
+    // every row tile and keeps the default policy.  Instruction i of a wave is an A piece iff NW * i < A_N (A_N % NW == 0).
+    static_assert(A_N % NW == 0, "A / B split of the DMA instructions is per instruction index");
 #pragma unroll
-    for (int i = 0; i < SL; ++i)
-      __builtin_amdgcn_global_load_lds((gptr_t*)(src[i] + (size_t)kt * step[i]), (lptr_t*)(base + loff[i]), 16, 0, 0);
+    for (int i = 0; i < SL; ++i) {
+      if (ANT && NW * i < A_N)
+        __builtin_amdgcn_global_load_lds((gptr_t*)(src[i] + (size_t)kt * step[i]), (lptr_t*)(base + loff[i]), 16, 0, 2);
+      else
+        __builtin_amdgcn_global_load_lds((gptr_t*)(src[i] + (size_t)kt * step[i]), (lptr_t*)(base + loff[i]), 16, 0, 0);
+    }
   };
 
   f4 acc[FM][FN];
@@ -144,7 +151,7 @@ __global__ __launch_bounds__(64 * NWV) void spmma_f16_fused_direct_kernel(const 
         d[0] = tv; d[1] = tb; d[2] = ti; d[3] = tc; d[4] = sloop - sstart; d[5] = se - sloop; })
 }
 
-template <int BN, int NS, bool BF = false, int BM = 128, int NWV = 4>
+template <int BN, int NS, bool BF = false, int BM = 128, int NWV = 4, bool ANT = true>
 static int launch_fused_direct(const FusedArgs& a0, hipStream_t st) {
   FusedArgs a = a0;
   a.tiles_m = (a.Mrows + BM - 1) / BM;
@@ -164,7 +171,7 @@ static int launch_fused_direct(const FusedArgs& a0, hipStream_t st) {
   constexpr size_t lds_max = NS * stage_bytes > lds_epi ? NS * stage_bytes : lds_epi;
   static LdsOptIn lds_optin;
   if (lds_max > 64 * 1024) {
-    if (const int rc = ensure_dyn_lds(lds_optin, reinterpret_cast<const void*>(&spmma_f16_fused_direct_kernel<BN, NS, BF, BM, NWV>), lds_max, "spmma_f16_fused_direct_kernel")) return rc;
+    if (const int rc = ensure_dyn_lds(lds_optin, reinterpret_cast<const void*>(&spmma_f16_fused_direct_kernel<BN, NS, BF, BM, NWV, ANT>), lds_max, "spmma_f16_fused_direct_kernel")) return rc;
   }
 #ifdef SM_STAMP
   {
@@ -174,7 +181,7 @@ static int launch_fused_direct(const FusedArgs& a0, hipStream_t st) {
     if (cnt > cap) { if (dbg) (void)hipFree(dbg); (void)hipMalloc((void**)&dbg, cnt * 8); cap = cnt; }
     (void)hipMemset(dbg, 0, cnt * 8);
     a.dbg = dbg;
-    spmma_f16_fused_direct_kernel<BN, NS, BF, BM, NWV><<<dim3((unsigned)nwg), dim3(64 * NWV), lds, st>>>(a);
+    spmma_f16_fused_direct_kernel<BN, NS, BF, BM, NWV, ANT><<<dim3((unsigned)nwg), dim3(64 * NWV), lds, st>>>(a);
     (void)hipDeviceSynchronize();
     std::vector<unsigned long long> h(cnt);
     (void)hipMemcpy(h.data(), dbg, cnt * 8, hipMemcpyDeviceToHost);
@@ -187,7 +194,7 @@ static int launch_fused_direct(const FusedArgs& a0, hipStream_t st) {
     return check_launch("spmma_f16_fused_direct_kernel");
   }
 #endif
-  spmma_f16_fused_direct_kernel<BN, NS, BF, BM, NWV><<<dim3((unsigned)nwg), dim3(64 * NWV), lds, st>>>(a);
+  spmma_f16_fused_direct_kernel<BN, NS, BF, BM, NWV, ANT><<<dim3((unsigned)nwg), dim3(64 * NWV), lds, st>>>(a);
   return check_launch("spmma_f16_fused_direct_kernel");
 }
 
@@ -750,6 +757,12 @@ static int spmma_fused16(size_t ngroup, const void* const* Ag, const void* const
     if (tuning_int("SM_FUSED_BM", 128) == 64) {  // 64-row tiles: 32 KiB (n = 64) of LDS per workgroup, five workgroups per CU
       if (n <= 64) return launch_fused_direct<64, 2, BF, 64>(a, st);
       return launch_fused_direct<128, 2, BF, 64>(a, st);
+    }
+#endif
+#ifdef SM_TUNING
+    if (tuning_int("SM_DIRECT_NT", 1) == 0) {  // A/B of the non-temporal hint on the A DMA
+      if (n <= 64) return launch_fused_direct<64, 2, BF, 128, 4, false>(a, st);
+      return launch_fused_direct<128, 2, BF, 128, 4, false>(a, st);
     }
 #endif
     if (n <= 64) return direct_env >= 3 ? launch_fused_direct<64, 3, BF>(a, st) : launch_fused_direct<64, 2, BF>(a, st);

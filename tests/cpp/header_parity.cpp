@@ -108,6 +108,10 @@ static void check_gemm(size_t m, size_t n, size_t k, size_t b) {
   std::mt19937 gen(0x5eed + (unsigned)(m + n + k));
   std::uniform_real_distribution<float> U(-1.f, 1.f);
   for (int mode = 0; mode < 2; ++mode) {  // (N, N) and (T, N)
+    // the reference always passes lda = m (gemm.hxx:80-81), so a transposed A (k x m stored, leading dimension m) only
+    // exists for m >= k; for the other rows of the table the call is an argument error in the vendor library and here
+    if (mode && m < k) continue;
+    const size_t a_elems = mode ? m * m : m * k;
     const operation_t ta = mode ? operation_t::T : operation_t::N, tb = operation_t::N;
     std::vector<host_vector<float>> hA(b), hC(b);
     host_vector<float> hB(k * n);
@@ -116,7 +120,7 @@ static void check_gemm(size_t m, size_t n, size_t k, size_t b) {
     device_vector<float> dB = hB;
     std::vector<float*> pA(b), pB(b), pC(b);
     for (size_t i = 0; i < b; ++i) {
-      hA[i].resize(m * k);
+      hA[i].resize(a_elems);
       for (auto& x : hA[i]) x = U(gen);
       dA[i] = hA[i];
       dC[i].resize(m * n);
@@ -127,7 +131,7 @@ static void check_gemm(size_t m, size_t n, size_t k, size_t b) {
     device_vector<float*> dpA = pA, dpB = pB, dpC = pC_call;  // device arrays of device pointers (examples/gemm.cu:65-90)
     batched::gemm<float>(dpA.data().get(), dpB.data().get(), dpC.data().get(), m, n, k, b, ta, tb);
     (void)hipDeviceSynchronize();
-    // oracle: column-major, lda = (ta ? k : m), ldb = k, ldc = m
+    // oracle: column-major, lda = m (op(A)(r, l) = A[r * m + l] when transposed, A[l * m + r] otherwise), ldb = k, ldc = m
     bool all = true;
     std::string detail;
     for (size_t i = 0; i < b; ++i) {
@@ -138,7 +142,7 @@ static void check_gemm(size_t m, size_t n, size_t k, size_t b) {
       for (size_t j = 0; j < n; ++j)
         for (size_t r = 0; r < m; ++r) {
           double s = 0;
-          for (size_t l = 0; l < k; ++l) s += std::fabs((double)(mode ? hA[i][r * k + l] : hA[i][l * m + r])) * std::fabs((double)hB[j * k + l]);
+          for (size_t l = 0; l < k; ++l) s += std::fabs((double)(mode ? hA[i][r * m + l] : hA[i][l * m + r])) * std::fabs((double)hB[j * k + l]);
           scale[j * m + r] = s;
         }
       all = close_enough(to_host(dC[i]), ref, scale, std::ldexp(1.0, -22), k, detail) && all;
@@ -245,7 +249,7 @@ static void check_spmma(size_t m, size_t n, size_t k, size_t b, const char* tnam
   auto dec = [](bits_t x) -> float { if constexpr (F32) return x; else return h2f(x); };
   for (int mode = 0; mode < 2; ++mode) {
     const bool ta = mode == 1;
-    std::vector<bits_t> hA(b * m * k), hB(k * n);  // hA in the N form (m x k row-major per batch)
+    std::vector<bits_t> hA(b * m * k), hB(b * k * n);  // hA in the N form (m x k row-major per batch); B per batch (examples/spmma.cu:48-59)
     for (auto& x : hA) x = enc(U(gen));
     for (auto& x : hB) x = enc(U(gen));
     std::vector<bits_t> stored = hA;  // what the caller holds: k x m row-major per batch when transpose_a
@@ -280,8 +284,8 @@ static void check_spmma(size_t m, size_t n, size_t k, size_t b, const char* tnam
     sm_compress24_size_ref(m, k, sizeof(bits_t), b, &bytes);
     std::vector<unsigned char> blob(bytes);
     std::vector<bits_t> cref(b * m * n);
-    if constexpr (F32) { sm_compress24_f32_ref(pr.data(), m, k, k, b, m * k, blob.data()); sm_spmma_f32_ref(blob.data(), hB.data(), cref.data(), m, n, k, b, 0, m * n, 1.f, 0.f); }
-    else { sm_compress24_f16_ref(pr.data(), m, k, k, b, m * k, blob.data()); sm_spmma_f16_ref(blob.data(), hB.data(), cref.data(), m, n, k, b, 0, m * n, 1.f, 0.f); }
+    if constexpr (F32) { sm_compress24_f32_ref(pr.data(), m, k, k, b, m * k, blob.data()); sm_spmma_f32_ref(blob.data(), hB.data(), cref.data(), m, n, k, b, k * n, m * n, 1.f, 0.f); }
+    else { sm_compress24_f16_ref(pr.data(), m, k, k, b, m * k, blob.data()); sm_spmma_f16_ref(blob.data(), hB.data(), cref.data(), m, n, k, b, k * n, m * n, 1.f, 0.f); }
     std::vector<float> got(b * m * n), ref(b * m * n);
     std::vector<double> scale(b * m * n, 0.0);
     const auto gotC = to_host(dC);
@@ -291,7 +295,7 @@ static void check_spmma(size_t m, size_t n, size_t k, size_t b, const char* tnam
         for (size_t l = 0; l < k; ++l) {
           const double a = std::fabs((double)dec(pr[bi * m * k + r * k + l]));
           if (a == 0.0) continue;
-          for (size_t j = 0; j < n; ++j) scale[bi * m * n + r * n + j] += a * std::fabs((double)dec(hB[l * n + j]));
+          for (size_t j = 0; j < n; ++j) scale[bi * m * n + r * n + j] += a * std::fabs((double)dec(hB[bi * k * n + l * n + j]));
         }
     std::string detail;
     // the oracle's C is already rounded to the type: allow one more rounding of the output on top of the accumulation bound
