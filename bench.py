@@ -71,6 +71,8 @@ def library_tag(sm):
 
 def fused_variant(n, k):
     """Which kernel sm_spmma_fused_f16 dispatches a (n, k) layer to (csrc/spmma_f16_fused.hip: spmma_fused16)."""
+    if k % 64 != 0:
+        return "span"
     if n <= 128 or (n <= 256 and k <= 64):
         return "direct"
     if n > 256 and k <= 512:
@@ -102,9 +104,11 @@ def main():
     ap.add_argument("--path", choices=["auto", "staged"], default="auto",
                     help="auto: fused prune+compress+matmul kernel on the layers where it wins (n <= --fused-max-n), the "
                          "staged compress24 + spmma pair elsewhere; staged: the pair on every layer")
-    ap.add_argument("--fused-max-n", type=int, default=256,
-                    help="auto path: widest n served by sm_spmma_fused_f16 whatever k (one workgroup spans up to 256 columns, so up "
-                         "to there A is loaded and selected once)")
+    ap.add_argument("--fused-max-n", type=int, default=512,
+                    help="auto path: widest n served by sm_spmma_fused_f16 whatever k (one workgroup spans up to 256 columns: up to "
+                         "there A is loaded and selected once, at 512 twice).  512 (default since round 3): inside the step, which is "
+                         "bound by the bytes it moves, fusing the n = 512 long-K layers too is 3-4 % faster than compress + spmma for "
+                         "them (no blob written and re-read) although each such launch alone is slower; 256 = round 2's choice")
     ap.add_argument("--fused-max-k-wide", type=int, default=512,
                     help="auto path: wider layers (n > --fused-max-n) are still fused when k <= this (the A-stationary "
                          "kernel keeps the 2:4 image of a row panel in LDS across its column tiles); 0 = never")
@@ -112,7 +116,7 @@ def main():
                     help="element type (BASELINE's metric is quoted on f16; bf16 runs the same kernels with the bfloat16 matrix "
                          "instructions; f32 is BASELINE config 2: sm_compress24_f32 + sm_spmma_f32 against the fp32 dense GEMMs, "
                          "default table resnet18)")
-    ap.add_argument("--streams", type=int, default=4,
+    ap.add_argument("--streams", type=int, default=8,
                     help="HIP streams the independent layers of a step are spread over (fork/join inside the step)")
     ap.add_argument("--graphs", choices=["single", "per-stream"], default="single",
                     help="hipGraph form of a step: one graph holding every chain (default) or one linear graph per stream")
@@ -123,6 +127,8 @@ def main():
                     help="on (default): the fused layers of one (m, n, k, b) shape run as ONE grouped launch per 8 instances "
                          "(sm_spmma_fused_*_grouped: same kernels, same C bit for bit; the instances share the chip instead of each "
                          "paying its own last partial round of workgroups); off: one launch per layer")
+    ap.add_argument("--no-span", action="store_true", help="auto path: k % 64 != 0 layers on sm_compress24 + sm_spmma instead of the span-form fused kernel")
+    ap.add_argument("--big-streams", type=int, default=2, help="--sched split: streams reserved for the chip-filling items")
     ap.add_argument("--rehearse-gloo", action="store_true",
                     help="multi-rank rehearsal on a ONE-GPU box: gloo backend, every rank on cuda:0 (control flow only; "
                          "the ranks share the device, so the numbers mean nothing)")
@@ -247,7 +253,10 @@ def main():
     def use_fused(L):
         if f32:  # sm_spmma_fused_f32: the STRIP rule in the registers of the dense fp32 MFMA kernel (no blob, no compress pass)
             return args.path == "auto" and L["k"] % 32 == 0 and L["n"] % 4 == 0
-        return args.path == "auto" and L["k"] % 64 == 0 and (L["n"] <= args.fused_max_n or L["k"] <= args.fused_max_k_wide)
+        if L["k"] % 64 != 0:  # the span form of sm_spmma_fused_*: ragged k (the stem layer, k = 147), n <= 128, span + B within the LDS
+            return (args.path == "auto" and not args.no_span and L["n"] % 8 == 0 and L["n"] <= 128 and (L["b"] * L["m"] * L["k"] * 2) % 16 == 0 and
+                    128 * L["k"] * 2 + 1152 + (L["k"] + 63) // 64 * 64 * (64 if L["n"] <= 64 else 128) * 2 <= 160 * 1024)
+        return args.path == "auto" and (L["n"] <= args.fused_max_n or L["k"] <= args.fused_max_k_wide)
 
     # (f-1) the fused kernel computes the same C bit for bit straight from the dense A (the 2:4 selection
     # and compaction happen in registers / LDS; no blob goes to HBM)
@@ -274,25 +283,44 @@ def main():
         sm.spmma_fused_grouped([L["A"] for L in Ls], [L["B"] for L in Ls], [L["C"] for L in Ls], L0["m"], L0["n"], L0["k"], batch=L0["b"])
 
     grouped = args.group == "on" and not f32
+
+    def spread(items):
+        """items [(kind, [layers])] -> per-stream chains, longest-first by bytes onto the least-loaded stream."""
+        items = sorted(items, key=lambda it: -sum(layer_bytes(L) for L in it[1]))
+        ch, load = [[] for _ in range(nstreams)], [0] * nstreams
+        nbig = min(max(1, args.big_streams), nstreams - 1) if (args.sched == "split" and nstreams >= 2) else 0
+        for it in items:
+            # --sched split: the chip-filling items (>= 784 row tiles per instance: they stream at the HBM rate whatever runs
+            # beside them) go to the first `--big-streams` streams, the few-tile items (bound by per-tile latency, they
+            # leave CUs idle) to the others, so that a few-tile kernel always has a streaming kernel beside it
+            if nbig:
+                big = it[1][0]["m"] * it[1][0]["b"] >= 784 * 128
+                cand = range(0, nbig) if big else range(nbig, nstreams)
+            else:
+                cand = range(nstreams)
+            w = min(cand, key=lambda c: load[c])
+            ch[w].append(it)
+            load[w] += sum(layer_bytes(L) for L in it[1])
+        return ch
+
+    class ForkedItems(Forked):
+        """A step of work items (a group of same-shape layers launched as one grid, or a single layer) spread over the streams."""
+
+        def __init__(self, ch, run_group_fn, run_single_fn):
+            Forked.__init__(self, run_single_fn)
+            self.ch, self.run_group_fn = ch, run_group_fn
+
+        def chain(self, w):
+            for kind, Ls in self.ch[w]:
+                if kind == "group":
+                    self.run_group_fn(Ls)
+                else:
+                    self.per_layer(Ls[0])
+
     if grouped:
         items = [("group", Ls) for _, Ls in fused_groups([L for L in layers if use_fused(L)])]
         items += [("single", [L]) for L in layers if not use_fused(L)]
-        items.sort(key=lambda it: -sum(layer_bytes(L) for L in it[1]))
-        ichains, iload = [[] for _ in range(nstreams)], [0] * nstreams
-        for it in items:
-            w = iload.index(min(iload))
-            ichains[w].append(it)
-            iload[w] += sum(layer_bytes(L) for L in it[1])
-
-        class ForkedItems(Forked):
-            def chain(self, w):
-                for kind, Ls in ichains[w]:
-                    if kind == "group":
-                        run_group(Ls)
-                    else:
-                        layer_path(Ls[0])
-
-        step_full = ForkedItems(layer_path)
+        step_full = ForkedItems(spread(items), run_group, layer_path)
         n_launch_groups = sum((len(Ls) + 7) // 8 for kind, Ls in items if kind == "group")
     else:
         step_full = Forked(layer_path)
@@ -408,7 +436,7 @@ def main():
 
     if rank == 0 and not args.no_extras:
         extras(args, sm, torch, dev, layers, flops, wall / args.steps, Forked, make_runner, timed, event_seconds, use_fused, out,
-               (fused_groups, run_group) if grouped else None)
+               (fused_groups, run_group, spread, ForkedItems) if grouped else None)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(ge, shapes)
@@ -475,6 +503,28 @@ def extras(args, sm, torch, dev, layers, flops, t_full, Forked, make_runner, tim
 
     t_mul, t_cmp = sec_per_call(spmma_only), sec_per_call(compress_only)
     t_drm = sec_per_call(dense_rowmajor)
+    # The dense comparator given the treatment the timed step gets (--group on): the instances of one shape as ONE grid.  The
+    # row-major product of the (b*m) x k stacked operand IS the column-major pointer-array entry with the operands swapped
+    # (C^T = B^T A^T: the same kernel, sm_gemm_batched_* maps it back), so a group is one call with `count` pointer triples.
+    t_drm_grouped = None
+    if grouping and has_batched:
+        fused_groups, _, spread, ForkedItems = grouping
+        ditems = []
+        for _, Ls in fused_groups(layers):
+            if len(Ls) == 1:
+                ditems.append(("single", Ls))
+                continue
+            for L in Ls[:1]:
+                L["gAp"] = torch.tensor([x["A"].data_ptr() for x in Ls], dtype=torch.int64, device=dev)
+                L["gBp"] = torch.tensor([x["B"].data_ptr() for x in Ls], dtype=torch.int64, device=dev)
+                L["gCp"] = torch.tensor([x["C"].data_ptr() for x in Ls], dtype=torch.int64, device=dev)
+            ditems.append(("group", Ls))
+
+        def dense_group(Ls):
+            L0 = Ls[0]
+            sm.gemm_batched(L0["gBp"], L0["gAp"], L0["gCp"], L0["n"], L0["m"] * L0["b"], L0["k"], len(Ls), args.dtype)
+        t_drm_grouped = sec_per_call(ForkedItems(spread(ditems), dense_group,
+                                                 lambda L: sm.gemm_rowmajor(L["A"], L["B"], L["C"], L["m"], L["n"], L["k"], batch=L["b"])))
     t_dcm = sec_per_call(dense_batched) if has_batched else None
     t_staged = t_full if args.path == "staged" else sec_per_call(Forked(lambda L: (
         sm.compress24(L["A"], L["m"], L["k"], L["k"], L["b"], L["m"] * L["k"], L["blob"]),
@@ -485,6 +535,10 @@ def extras(args, sm, torch, dev, layers, flops, t_full, Forked, make_runner, tim
         "dense_gemm_batched_colmajor_gfs": gfs(t_dcm) if t_dcm else None, "dense_gemm_batched_colmajor_ms": t_dcm * 1e3 if t_dcm else None,
         "speedup_mul_vs_dense_rowmajor": t_drm / t_mul, "speedup_mul_vs_dense_batched": t_dcm / t_mul if t_dcm else None,
         "speedup_full_vs_dense_rowmajor": t_drm / t_full, "speedup_full_vs_dense_batched": t_dcm / t_full if t_dcm else None,
+        "dense_gemm_rowmajor_grouped_ms": t_drm_grouped * 1e3 if t_drm_grouped else None,
+        "dense_gemm_rowmajor_grouped_gfs": gfs(t_drm_grouped) if t_drm_grouped else None,
+        "speedup_full_vs_dense_rowmajor_grouped": t_drm_grouped / t_full if t_drm_grouped else None,
+        "speedup_mul_vs_dense_rowmajor_grouped": t_drm_grouped / t_mul if t_drm_grouped else None,
         "full_path_staged_gfs": gfs(t_staged), "full_path_staged_ms": t_staged * 1e3,
         "timed_path": args.path, "timed_path_ms": t_full * 1e3,
         # what 2:4 can buy on these shapes when both products are HBM-bound (fp16: they are): the ratio of
@@ -553,8 +607,8 @@ def extras(args, sm, torch, dev, layers, flops, t_full, Forked, make_runner, tim
         fam["compress"] = dict(names=["compress_flat_kernel", "compress_rowspan_f16_kernel", "compress_kernel"], layers=staged,
                                call=lambda L: sm.compress24(L["A"], L["m"], L["k"], L["k"], L["b"], L["m"] * L["k"], L["blob"]),
                                bytes=lambda L: L["b"] * L["m"] * L["k"] * (s + s / 2 + 1 / 8))
-        for var in ("direct", "wide", "astat"):
-            fam["spmma_f16_fused_" + var] = dict(names=["spmma_f16_fused_%s_kernel" % var],
+        for var in ("direct", "wide", "astat", "span"):
+            fam["spmma_f16_fused_" + var] = dict(names=["spmma_f16_fused_%s_kernel" % var] + (["spmma_f16_fused_widep_kernel"] if var == "wide" else []),
                                                  layers=[L for L in layers if use_fused(L) and fused_variant(L["n"], L["k"]) == var],
                                                  call=lambda L: sm.spmma_fused(L["A"], L["B"], L["C"], L["m"], L["n"], L["k"], batch=L["b"]),
                                                  bytes=A_fu)

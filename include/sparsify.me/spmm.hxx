@@ -69,9 +69,10 @@ float spmm(ell_t<type_t, memory_space_t::device>* As,
   } else {
     for (std::size_t b = 0; b < batch_size; ++b) {
       auto& A = As[b];
-      rc |= sm_spmm_bell_f32_ws(vals[b], idx[b], A.rows, A.cols, A.block_size, A.ell_cols,
-                                reinterpret_cast<const float*>(B), reinterpret_cast<float*>(Cs[b]), n, alpha, beta,
-                                ws.data().get(), nullptr);
+      const int rb = sm_spmm_bell_f32_ws(vals[b], idx[b], A.rows, A.cols, A.block_size, A.ell_cols,
+                                         reinterpret_cast<const float*>(B), reinterpret_cast<float*>(Cs[b]), n, alpha, beta,
+                                         ws.data().get(), nullptr);
+      if (rc == SM_STATUS_SUCCESS) rc = rb;  // the first failing status is the one reported
     }
   }
   (void)m;

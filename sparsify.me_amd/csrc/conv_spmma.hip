@@ -248,6 +248,13 @@ static int conv_spmma16(const void* X, const void* B, void* C, size_t N, size_t 
     set_error("%s: invalid argument", name);
     return SM_STATUS_INVALID_VALUE;
   }
+  // every geometry argument is narrowed to int below: refuse what does not fit instead of truncating it silently
+  constexpr size_t GEO_MAX = 1u << 20;
+  if (N > 0x7fffffffull || Cin > 0x7fffffffull || H > GEO_MAX || W > GEO_MAX || kh > GEO_MAX || kw > GEO_MAX || stride > GEO_MAX ||
+      pad > GEO_MAX || dil > GEO_MAX) {
+    set_error("%s: a geometry argument exceeds what the kernel's 32-bit indexing takes (use sm_im2col_compress24 + sm_spmma)", name);
+    return SM_STATUS_NOT_SUPPORTED;
+  }
   const size_t sh = dil * (kh - 1) + 1, sw = dil * (kw - 1) + 1;
   if (H + 2 * pad < sh || W + 2 * pad < sw) {
     set_error("%s: window larger than the padded input", name);
@@ -283,6 +290,11 @@ static int conv_spmma16(const void* X, const void* B, void* C, size_t N, size_t 
   a.ablate = tuning_int("SM_CONV_ABLATE", 0);
   if (a.a_n > 48) {
     set_error("%s: a stage's activation patch needs %d DMA instructions (limit 48)", name, a.a_n);
+    return SM_STATUS_NOT_SUPPORTED;
+  }
+  // the gather's k-offset table holds 16-bit byte offsets into the patch: largest = last channel's last window element
+  if (((size_t)a.nch * a.RI * pitch + kw * dil) * 2 >= 65536) {
+    set_error("%s: a stage's activation patch exceeds the 16-bit offset table (use sm_im2col_compress24 + sm_spmma)", name);
     return SM_STATUS_NOT_SUPPORTED;
   }
   hipStream_t st = (hipStream_t)stream;

@@ -122,29 +122,13 @@ __device__ __forceinline__ void smfmac_stage(const char* As, const char* Ms, con
   }
 }
 
-// The same stage straight from the DENSE A: `Araw` is the [rows][128 B] image of 64 dense k per row (chunk c of row r
-// at chunk c ^ (r & 7), a_off), and the lane that would read 8 compressed halves + 4 nibbles reads its 16 dense halves
-// (two ds_read_b128) and selects in registers (select24.h): four strips -> the A operand and the index halfword of
-// v_smfmac_f32_16x16x64_f16.  No compressed image, no metadata, no selecting loader waves.
+// B sweep of one 64-deep stage for one wave: B fragments from the row-major [64][BN] image `Bs` through
+// ds_read_b64_tr_b16 (issued by hand, counted lgkmcnt: fragment j+1's four reads in flight while fragment j's SMFMACs run),
+// FM x FN v_smfmac_f32_16x16x64 with the A operands / index halfwords the caller built.
 template <int FM, int FN, bool BF = false>
-__device__ __forceinline__ void smfmac_stage_dense_a(const char* Araw, const char* Bs, unsigned row0, unsigned col0,
-                                                     unsigned lane, f4 (&acc)[FM][FN]) {
+__device__ __forceinline__ void smfmac_b_sweep(const h8 (&af)[FM], const int (&idx)[FM], const char* Bs, unsigned col0, unsigned lane,
+                                               f4 (&acc)[FM][FN]) {
   const unsigned g = lane >> 4, r = lane & 15u;
-  h8 af[FM];
-  int idx[FM];
-#pragma unroll
-  for (int i = 0; i < FM; ++i) {
-    const unsigned row = row0 + i * 16 + r;
-    const u4 lo = *reinterpret_cast<const u4*>(Araw + a_off(row, 2u * g));
-    const u4 hi = *reinterpret_cast<const u4*>(Araw + a_off(row, 2u * g + 1u));
-    uint32_t k0, k1, k2, k3, n0, n1, n2, n3;
-    strip_select_f16(lo[0], lo[1], k0, n0);
-    strip_select_f16(lo[2], lo[3], k1, n1);
-    strip_select_f16(hi[0], hi[1], k2, n2);
-    strip_select_f16(hi[2], hi[3], k3, n3);
-    af[i] = __builtin_bit_cast(h8, u4{k0, k1, k2, k3});
-    idx[i] = (int)(n0 | (n1 << 4) | (n2 << 8) | (n3 << 12));
-  }
   const unsigned bs_addr = (unsigned)(uintptr_t)(lds_char*)Bs;
   s4 t0[2], t1[2], t2[2], t3[2];
   auto issue = [&](int j, s4& v0, s4& v1, s4& v2, s4& v3) {
@@ -172,6 +156,38 @@ __device__ __forceinline__ void smfmac_stage_dense_a(const char* Araw, const cha
 #pragma unroll
     for (int i = 0; i < FM; ++i) acc[i][j] = smfmac16<BF>(af[i], bf, acc[i][j], idx[i]);
   }
+}
+
+// 16 dense halves of one row (k = 16 g .. 16 g + 15 of the stage, as two 16-byte vectors) -> the lane's SMFMAC A operand
+// (four kept pairs) and index halfword: four strip selections (select24.h).
+__device__ __forceinline__ void dense16_to_operand(const u4 lo, const u4 hi, h8& af, int& idx) {
+  uint32_t k0, k1, k2, k3, n0, n1, n2, n3;
+  strip_select_f16(lo[0], lo[1], k0, n0);
+  strip_select_f16(lo[2], lo[3], k1, n1);
+  strip_select_f16(hi[0], hi[1], k2, n2);
+  strip_select_f16(hi[2], hi[3], k3, n3);
+  af = __builtin_bit_cast(h8, u4{k0, k1, k2, k3});
+  idx = (int)(n0 | (n1 << 4) | (n2 << 8) | (n3 << 12));
+}
+
+// The stage straight from the DENSE A: `Araw` is the [rows][128 B] image of 64 dense k per row (chunk c of row r
+// at chunk c ^ (r & 7), a_off), and the lane that would read 8 compressed halves + 4 nibbles reads its 16 dense halves
+// (two ds_read_b128) and selects in registers: four strips -> the A operand and the index halfword of
+// v_smfmac_f32_16x16x64_f16.  No compressed image, no metadata, no selecting loader waves.
+template <int FM, int FN, bool BF = false>
+__device__ __forceinline__ void smfmac_stage_dense_a(const char* Araw, const char* Bs, unsigned row0, unsigned col0,
+                                                     unsigned lane, f4 (&acc)[FM][FN]) {
+  const unsigned g = lane >> 4, r = lane & 15u;
+  h8 af[FM];
+  int idx[FM];
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+    const unsigned row = row0 + i * 16 + r;
+    const u4 lo = *reinterpret_cast<const u4*>(Araw + a_off(row, 2u * g));
+    const u4 hi = *reinterpret_cast<const u4*>(Araw + a_off(row, 2u * g + 1u));
+    dense16_to_operand(lo, hi, af[i], idx[i]);
+  }
+  smfmac_b_sweep<FM, FN, BF>(af, idx, Bs, col0, lane, acc);
 }
 
 // Epilogue of the 2:4 matmul kernels, called by EVERY thread of the workgroup after its last barrier: the SMFMAC

@@ -146,7 +146,11 @@ __global__ __launch_bounds__(256) void prune_compress_kernel(const PruneFusedArg
 #pragma unroll
         for (unsigned r = 0; r < 4; ++r) {
           const uint32_t rm = pair_rowmask(pr[r]);
-          ok2 &= __builtin_popcount(rm) <= 2;  // what is about to be written
+          // NOT an independent check: rm comes from pair_rowmask (always two bits), so on this path the flag is zero by
+          // construction -- it can only rise if a pair index leaves 0..5 (then rm has a stray pattern).  The independent
+          // inspection of written data is sm_prune24_check_* (what the three-launch fallback below runs on A_out, and what
+          // tests/test_gpu_parity.py runs on this kernel's output).
+          ok2 &= __builtin_popcount(rm) <= 2 && pr[r] < 6u;
           strip_mask(v[r][2 * t], v[r][2 * t + 1], rm, o[r][2 * t], o[r][2 * t + 1]);
           strip_select_f16(o[r][2 * t], o[r][2 * t + 1], kp[r][t], nb[r][t]);
         }

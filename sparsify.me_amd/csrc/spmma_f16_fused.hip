@@ -198,6 +198,133 @@ static int launch_fused_direct(const FusedArgs& a0, hipStream_t st) {
   return check_launch("spmma_f16_fused_direct_kernel");
 }
 
+// ---------------------------------------------------------------------------------------------
+// Rows that are NOT whole 64-deep stages of 16-byte aligned pieces (k % 64 != 0 or k % 8 != 0: the 7 x 7 x 3 stem layer
+// of every ResNet, k = 147), n <= 128, one tall contiguous A (lda == k, batches back to back): SPAN form.  A tile's 128
+// rows are ONE contiguous span of 128 * k * 2 bytes that starts on a 256-byte boundary, so it reaches LDS by plain
+// 1 KiB LDS-DMA pieces whatever the row pitch (per-lane source addresses clamped to the operand's last 16 bytes); the
+// whole B (round_up(k, 64) rows, rows at or beyond k from a zero page: 0 x inf must not poison finite outputs) arrives
+// with it: one wait, one barrier, then every stage is computed out of LDS -- the lane that feeds (row, k-group) to the
+// SMFMAC picks its 16 dense halves with 2-byte LDS reads at row * k * 2 + ..., zeroes what lies at or beyond k (the
+// virtual zeros that complete a ragged strip, oracle: strip_select) and selects as the direct kernel does.  Same operands,
+// same instruction sequence per stage as compress + spmma: bit-identical C.  Two workgroups per CU (61 KiB at k = 147,
+// n = 64) overlap each other's load and compute phases.
+// ---------------------------------------------------------------------------------------------
+__device__ __attribute__((aligned(256))) const unsigned char sm_fused_zero_page[256] = {0};
+
+template <int BN, bool BF = false>
+__global__ __launch_bounds__(256) void spmma_f16_fused_span_kernel(const FusedArgs p, const unsigned span_lds /*bytes reserved for the A span*/,
+                                                                   const size_t a_bytes /*bytes of one problem's A*/) {
+  constexpr int BM = 128, NW = 4, TM = BM / NW, FM = TM / 16, FN = BN / 16;
+  constexpr int SB = 64 * BN * 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const unsigned tid = threadIdx.x, lane = tid & 63u;
+  const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const unsigned tiles = (unsigned)p.tiles_m * (unsigned)p.tiles_n;
+  const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
+  const unsigned grp = lid / tiles, trem = lid - grp * tiles;  // batch == 1: the batches are stacked rows
+  const unsigned tile_m = trem / (unsigned)p.tiles_n, tile_n = trem - tile_m * (unsigned)p.tiles_n;
+  const int m0 = (int)tile_m * BM, n0 = (int)tile_n * BN;
+  const int nkt = (p.K + 63) / 64;
+  const char* A = reinterpret_cast<const char*>(p.A[grp]);
+  const half_t* B = p.B[grp];
+  half_t* C = p.C[grp];
+  const unsigned rowbytes = (unsigned)p.K * 2u;
+  const int rows = p.Mrows - m0 < BM ? p.Mrows - m0 : BM;  // valid rows of this tile (>= 1)
+
+  // ---- A span: bytes [m0 * rowbytes, (m0 + rows) * rowbytes) of the operand, in 1 KiB pieces
+  {
+    const size_t s0 = (size_t)m0 * rowbytes;               // multiple of 256
+    const unsigned len = (unsigned)rows * rowbytes;
+    const unsigned np = (len + 1023u) / 1024u;
+    const size_t last16 = a_bytes - 16;                     // a_bytes % 16 == 0 (launcher)
+    for (unsigned pc = wave; pc < np; pc += NW) {
+      size_t off = s0 + (size_t)pc * 1024u + 16u * lane;
+      off = off < last16 ? off : last16;
+      __builtin_amdgcn_global_load_lds((gptr_t*)(A + off), (lptr_t*)(smem + pc * 1024u), 16, 0, 2);
+    }
+  }
+  // ---- B: nkt stage images [64][BN] (the direct kernel's layout); k rows at or beyond K come from the zero page
+  char* const Bimg = smem + span_lds;
+  {
+    constexpr int B_N = BN / 8;  // pieces per stage
+    const int npb = nkt * B_N;
+    for (int t = (int)wave; t < npb; t += NW) {
+      const int kt = t / B_N, j = t - kt * B_N;
+      const unsigned panel = (unsigned)j >> 3, kr = 8u * ((unsigned)j & 7u) + (lane >> 3);
+      const unsigned cs = (lane & 7u) ^ b_swz(kr);
+      int gc = n0 + (int)(64u * panel + 8u * cs);
+      gc = gc <= p.N - 8 ? gc : p.N - 8;
+      const int krow = kt * 64 + (int)kr;
+      const char* src = krow < p.K ? reinterpret_cast<const char*>(B + (size_t)krow * p.N + gc)
+                                   : reinterpret_cast<const char*>(sm_fused_zero_page) + 16u * (lane & 7u);
+      __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)(Bimg + kt * SB + panel * 8192u + ((unsigned)j & 7u) * 1024u), 16, 0, 0);
+    }
+  }
+  wait_dma_and_barrier<0>();
+
+  f4 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+  const unsigned g = lane >> 4, r = lane & 15u;
+  unsigned rowoff[FM];
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+    int row = (int)(wave * TM + i * 16 + r);
+    row = row < rows ? row : rows - 1;  // rows past the edge re-read the last valid one (their outputs are never stored)
+    rowoff[i] = (unsigned)row * rowbytes;
+  }
+  for (int kt = 0; kt < nkt; ++kt) {
+    h8 af[FM];
+    int idx[FM];
+    const int k0 = kt * 64 + 16 * (int)g;
+    int nv = p.K - k0;  // valid elements of this lane's 16
+    nv = nv < 0 ? 0 : (nv > 16 ? 16 : nv);
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      const char* src = smem + rowoff[i] + 2u * (unsigned)k0;
+      uint32_t d[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        // (reads at or beyond k are masked below; they stay inside the LDS allocation: span_lds covers 128 rows + 128 bytes)
+        const uint32_t lo16 = *reinterpret_cast<const unsigned short*>(src + 4 * e);
+        const uint32_t hi16 = *reinterpret_cast<const unsigned short*>(src + 4 * e + 2);
+        uint32_t v = lo16 | (hi16 << 16);
+        v = 2 * e + 1 < nv ? v : (2 * e < nv ? (v & 0xffffu) : 0u);
+        d[e] = v;
+      }
+      dense16_to_operand(u4{d[0], d[1], d[2], d[3]}, u4{d[4], d[5], d[6], d[7]}, af[i], idx[i]);
+    }
+    smfmac_b_sweep<FM, FN, BF>(af, idx, Bimg + kt * SB, 0, lane, acc);
+  }
+  __syncthreads();
+  store_c_tile<BM, BN, FM, FN, 64 * NW, BF>(smem, C, acc, true, wave * TM, 0, m0, n0, p.Mrows, p.N, p.alpha, p.beta, tid);
+}
+
+template <int BN, bool BF = false>
+static int launch_fused_span(const FusedArgs& a0, hipStream_t st) {
+  FusedArgs a = a0;
+  a.tiles_m = (a.Mrows + 127) / 128;
+  a.tiles_n = (a.N + BN - 1) / BN;
+  const size_t nwg = (size_t)a.tiles_m * a.tiles_n * a.ngroup;
+  if (nwg == 0) return SM_STATUS_SUCCESS;
+  const size_t kc = ((size_t)a.K + 63) / 64 * 64;
+  const size_t span_lds = ((size_t)128 * a.K * 2 + 128 + 1023) / 1024 * 1024;  // whole pieces; >= 128 bytes past the last row
+  const size_t lds_main = span_lds + kc * BN * 2;
+  constexpr size_t lds_epi = (size_t)128 * (BN * 2 + 16);
+  const size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
+  if (lds > 160 * 1024 || nwg > 0x7fffffffu) {
+    set_error("sm_spmma_fused_{f16,bf16}: k too long for the span form (use the staged path)");
+    return SM_STATUS_NOT_SUPPORTED;
+  }
+  static LdsOptIn lds_optin;
+  if (const int rc = ensure_dyn_lds(lds_optin, reinterpret_cast<const void*>(&spmma_f16_fused_span_kernel<BN, BF>), 160 * 1024, "spmma_f16_fused_span_kernel")) return rc;
+  spmma_f16_fused_span_kernel<BN, BF><<<dim3((unsigned)nwg), dim3(256), lds, st>>>(a, (unsigned)span_lds, (size_t)a.Mrows * a.K * 2);
+  return check_launch("spmma_f16_fused_span_kernel");
+}
+
 // The B tile's LDS-DMA, shared by the B loader waves of the wide kernel and -- when it has none (NLB = 0) -- by its
 // consumer waves: instruction j = bw + NBW * i of a stage covers k-rows 8 * (j & 7) + lane / 8 of panel j >> 3.
 template <int BN, int NBW>
@@ -475,6 +602,262 @@ static int launch_fused_wide(const FusedArgs& a0, hipStream_t st) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// PERSISTENT form of the wide kernel (round 3).  One workgroup per CU walks its tiles (id = blockIdx.x + j * gridDim.x,
+// XCD-remapped) with ONE stage counter that runs across tile boundaries: the A loaders' register pipeline, the A image's
+// double buffer and the B ring never drain, so while the consumers write tile j's C the first stages of tile j + 1 are
+// already in flight / in LDS (the plain kernel pays a workgroup teardown + launch + pipeline fill of ~3 stage times per
+// tile: 8 % of a 36-stage tile, 25 % of an 8-stage one).  Roles, LDS images, instruction sequence per stage and therefore
+// C are those of spmma_f16_fused_wide_kernel; what differs is the epilogue -- each consumer wave stores its 32 x 128 piece
+// of C through a wave-private LDS patch in two 64-column halves (no workgroup barrier, nothing aliases the rings) -- and
+// the per-tile pointer set-up, which moves into the loaders' issue cursors.  Every wave executes exactly one s_barrier
+// per stage of the workgroup's S = tiles x K/64 stages.
+// ---------------------------------------------------------------------------------------------
+template <int BN, int WM, int WN, int NLB, int PF, int NSB, bool BF = false>
+__global__ __launch_bounds__(64 * (WM * WN + 4 + NLB)) void spmma_f16_fused_widep_kernel(const FusedArgs p, const unsigned total) {
+  constexpr int BM = 128, NLA = 4, NC = WM * WN;
+  static_assert(NLB > 0 && PF >= 1 && PF <= 3 && NSB >= 2 && NSB <= 4, "pipeline depths");
+  constexpr int TM = BM / WM, TN = BN / WN, FM = TM / 16, FN = TN / 16;
+  static_assert(TN == 128 && TM == 32, "epilogue patch geometry");
+  constexpr int SA = BM * 64, SM_ = BM * 8, ASTG = SA + SM_, SB = 64 * BN * 2;
+  constexpr int BRING = 2 * ASTG;
+  constexpr int B_N = BN / 8, B_WI = B_N / NLB;
+  static_assert(B_N % NLB == 0 && (NSB - 2) * B_WI <= 63, "B tile vs loader waves");
+  constexpr int WPITCH = 64 * 2 + 8, WPATCH = TM * WPITCH;  // wave-private C patch: 32 rows x (64 columns + pad)
+  constexpr int CPATCH = BRING + NSB * SB;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const unsigned tid = threadIdx.x, lane = tid & 63u;
+  const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const unsigned tiles = (unsigned)p.tiles_m * (unsigned)p.tiles_n;
+  const int nkt = p.K / 64;
+  const unsigned my_tiles = (total - blockIdx.x + gridDim.x - 1u) / gridDim.x;  // >= 1: gridDim.x <= total
+  const int S = (int)my_tiles * nkt;
+
+  struct Tile {
+    unsigned grp, b;
+    int m0, n0;
+  };
+  auto tile_of = [&](unsigned j) {
+    Tile t;
+    const unsigned lid = xcd_remap(blockIdx.x + j * gridDim.x, total);
+    const unsigned gb = lid / tiles, trem = lid - gb * tiles;
+    t.grp = gb / (unsigned)p.batch;
+    t.b = gb - t.grp * (unsigned)p.batch;
+    const unsigned tile_m = trem / (unsigned)p.tiles_n, tile_n = trem - tile_m * (unsigned)p.tiles_n;
+    t.m0 = (int)tile_m * BM;
+    t.n0 = (int)tile_n * BN;
+    return t;
+  };
+
+  if (wave >= (unsigned)(NC + NLA)) {
+    // ------------------------------------------------------------------ B loader wave: LDS-DMA only
+    BTileDma<BN, NLB> bd;
+    unsigned ij = 0;  // issue cursor: tile and stage of the next B stage to issue
+    int ikt = 0, nb = 0;
+    {
+      const Tile t = tile_of(0);
+      bd.setup(p.B[t.grp] + (size_t)t.b * p.sB, p.N, t.n0, wave - (NC + NLA), lane, BRING);
+    }
+    auto issue = [&]() {
+      bd.issue(smem, ikt, (unsigned)(nb * SB));
+      nb = nb + 1 == NSB ? 0 : nb + 1;
+      if (++ikt == nkt) {
+        ikt = 0;
+        if (++ij < my_tiles) {
+          const Tile t = tile_of(ij);
+          bd.setup(p.B[t.grp] + (size_t)t.b * p.sB, p.N, t.n0, wave - (NC + NLA), lane, BRING);
+        }
+      }
+    };
+#pragma unroll
+    for (int s = 0; s < NSB - 1; ++s)
+      if (s < S) issue();
+    for (int g = 0; g < S; ++g) {
+      if (g + NSB - 2 < S) wait_dma_and_barrier<(NSB - 2) * B_WI>();
+      else wait_dma_and_barrier<0>();
+      if (g + NSB - 1 < S) issue();  // into the buffer stage g - 1 occupied: the consumers left it before barrier g
+    }
+  } else if (wave >= (unsigned)NC) {
+    // ------------------------------------------------------------------ A loader wave: load, select, ds_write
+    const unsigned lw = wave - NC;
+    const unsigned c8 = lane & 7u;
+    const half_t* a_src[4];
+    unsigned a_val_off[4], a_meta_off[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const unsigned row = 8u * (4u * lw + i) + (lane >> 3);
+      a_val_off[i] = row * 64u + 16u * ((c8 >> 1) ^ a64_swz(row)) + 8u * (c8 & 1u);
+      a_meta_off[i] = SA + row * 8u + c8;
+    }
+    const int mlast = p.Mrows - 1;
+    auto point_at = [&](unsigned j) {  // row pointers of this wave's four loads in tile j
+      const Tile t = tile_of(j);
+      const half_t* A = p.A[t.grp] + (size_t)t.b * p.sA;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const unsigned row = 8u * (4u * lw + i) + (lane >> 3);
+        int gr = t.m0 + (int)row;
+        gr = gr < mlast ? gr : mlast;
+        a_src[i] = A + (size_t)gr * p.lda + 8u * c8;
+      }
+    };
+    point_at(0);
+    unsigned lj = 0;  // load cursor (stages are loaded strictly in order)
+    int lkt = 0;
+    u4 ra[PF][4];
+    auto load_a = [&](u4 (&dst)[4]) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) dst[i] = __builtin_nontemporal_load(reinterpret_cast<const u4*>(a_src[i] + (size_t)lkt * 64));
+      __builtin_amdgcn_sched_barrier(0);
+      if (++lkt == nkt) {
+        lkt = 0;
+        if (++lj < my_tiles) point_at(lj);
+      }
+    };
+    auto write_stage = [&](int g, const u4 (&src)[4]) {
+      char* sb = smem + (g & 1) * ASTG;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        uint32_t k0, k1, n0, n1;
+        strip_select_f16(src[i][0], src[i][1], k0, n0);
+        strip_select_f16(src[i][2], src[i][3], k1, n1);
+        *reinterpret_cast<u2*>(sb + a_val_off[i]) = u2{k0, k1};
+        *reinterpret_cast<unsigned char*>(sb + a_meta_off[i]) = (unsigned char)(n0 | (n1 << 4));
+      }
+    };
+    auto step = [&](int g, u4 (&rr)[4], bool write, bool load) {
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      if (write) write_stage(g + 1, rr);  // buffer (g+1)&1: the consumers left it before barrier g
+      if (load) load_a(rr);               // stage g + 1 + PF
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    int g0 = 0;
+    if (S > 2 * PF) {
+#pragma unroll
+      for (int s = 0; s < PF; ++s) load_a(ra[s]);
+      write_stage(0, ra[0]);
+      load_a(ra[0]);
+      for (; g0 + 2 * PF < S; g0 += PF) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) step(g0 + u, ra[(u + 1) % PF], true, true);
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < PF; ++s)
+        if (s < S) load_a(ra[s]);
+      write_stage(0, ra[0]);
+      if (PF < S) load_a(ra[0]);
+    }
+    for (; g0 < S; g0 += PF) {
+#pragma unroll
+      for (int u = 0; u < PF; ++u) {
+        const int g = g0 + u;
+        if (g < S) step(g, ra[(u + 1) % PF], g + 1 < S, g + 1 + PF < S);
+      }
+    }
+  } else {
+    // ------------------------------------------------------------------ consumer wave
+    const unsigned g4 = lane >> 4, r = lane & 15u;
+    const unsigned wm = wave / WN, wn = wave % WN;
+    char* const patch = smem + CPATCH + wave * WPATCH;
+    f4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+    int cb = 0, kt = 0;
+    unsigned cj = 0;
+    Tile t = tile_of(0);
+    for (int g = 0; g < S; ++g) {
+      asm volatile("s_barrier" ::: "memory");  // (no vmcnt: this wave's C stores of the previous tile may still be in flight)
+      const char* As = smem + (g & 1) * ASTG;
+      smfmac_stage<FM, FN, BF>(As, As + SA, smem + BRING + cb * SB, wm * TM, wn * TN, lane, acc);
+      cb = cb + 1 == NSB ? 0 : cb + 1;
+      if (++kt == nkt) {
+        // ---- this tile is done: the wave's 32 x 128 piece of C, two 64-column halves through its private patch
+        half_t* C = p.C[t.grp] + (size_t)t.b * p.sC;
+        const bool c_vec = (reinterpret_cast<uintptr_t>(C) & 15u) == 0 && (p.N % 8 == 0);
+        if (p.beta == 0.0f && c_vec) {
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+              for (int j = 0; j < FN / 2; ++j) {
+                const unsigned lr = i * 16 + 4u * g4, lc = j * 16 + r;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                  *reinterpret_cast<half_t*>(patch + (lr + q) * WPITCH + lc * 2) = to_elt<BF>(p.alpha * acc[i][h * (FN / 2) + j][q]);
+              }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // same wave wrote and reads: no barrier
+            const int gc = t.n0 + (int)(wn * TN) + 64 * h + 8 * (int)(lane & 7u);
+#pragma unroll
+            for (int s8 = 0; s8 < TM / 8; ++s8) {
+              const unsigned lr = 8u * s8 + (lane >> 3);
+              const int gr = t.m0 + (int)(wm * TM + lr);
+              if (gr < p.Mrows && gc < p.N) {
+                const u2 lo = *reinterpret_cast<const u2*>(patch + lr * WPITCH + 16u * (lane & 7u));
+                const u2 hi = *reinterpret_cast<const u2*>(patch + lr * WPITCH + 16u * (lane & 7u) + 8u);
+                __builtin_nontemporal_store(u4{lo[0], lo[1], hi[0], hi[1]}, reinterpret_cast<u4*>(C + (size_t)gr * p.N + gc));
+              }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the patch is rewritten by the next half / tile
+          }
+        } else {  // beta != 0 or a C that cannot take 16-byte stores: element-wise, reading C once
+#pragma unroll
+          for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+              const int gc = t.n0 + (int)(wn * TN + j * 16 + r);
+              if (gc >= p.N) continue;
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const int gr = t.m0 + (int)(wm * TM + i * 16 + 4u * g4) + q;
+                if (gr >= p.Mrows) continue;
+                half_t* dst = C + (size_t)gr * p.N + gc;
+                float v = p.alpha * acc[i][j][q];
+                if (p.beta != 0.0f) v += p.beta * to_f32<BF>(*dst);
+                *dst = to_elt<BF>(v);
+              }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int j = 0; j < FN; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+        kt = 0;
+        if (++cj < my_tiles) t = tile_of(cj);
+      }
+    }
+  }
+}
+
+template <int BN, int WM, int WN, int NLB, int PF, int NSB, bool BF = false>
+static int launch_fused_widep(const FusedArgs& a0, hipStream_t st) {
+  FusedArgs a = a0;
+  a.tiles_m = (a.Mrows + 127) / 128;
+  a.tiles_n = (a.N + BN - 1) / BN;
+  const size_t nt = (size_t)a.tiles_m * a.tiles_n * a.batch * a.ngroup;
+  if (nt == 0) return SM_STATUS_SUCCESS;
+  if (nt > 0x7fffffffu) {
+    set_error("sm_spmma_fused_f16: grid too large");
+    return SM_STATUS_NOT_SUPPORTED;
+  }
+  constexpr size_t lds = 2 * (size_t)128 * 72 + (size_t)NSB * 64 * BN * 2 + (size_t)(WM * WN) * 32 * (64 * 2 + 8);
+  static_assert(lds <= 160 * 1024, "LDS budget of the persistent wide kernel");
+  static LdsOptIn lds_optin;
+  if (const int rc = ensure_dyn_lds(lds_optin, reinterpret_cast<const void*>(&spmma_f16_fused_widep_kernel<BN, WM, WN, NLB, PF, NSB, BF>), lds, "spmma_f16_fused_widep_kernel")) return rc;
+  // one workgroup per CU (LDS); ids congruent mod 8 stay on one XCD across a workgroup's tiles when the grid is a multiple of 8
+  size_t cus = (size_t)device_cu_count();
+  cus -= cus % 8;
+  if (cus == 0) cus = 8;
+  const unsigned grid = (unsigned)(nt <= cus ? nt : cus);
+  spmma_f16_fused_widep_kernel<BN, WM, WN, NLB, PF, NSB, BF><<<dim3(grid), dim3(64 * (WM * WN + 4 + NLB)), lds, st>>>(a, (unsigned)nt);
+  return check_launch("spmma_f16_fused_widep_kernel");
+}
+
+// ---------------------------------------------------------------------------------------------
 // n > 256 with a short K (k <= 512): A-stationary.  The 2:4 image of the workgroup's 128 rows for the WHOLE K
 // (k/64 stages x 9 KiB) stays in LDS; all 16 waves build it first (every load of the panel in flight at once: a single
 // HBM latency), 4 of them then only attend the barriers, and the workgroup walks its column tiles re-using it: A is loaded and selected once per `nsplit` column range
@@ -716,6 +1099,22 @@ static int spmma_fused16(size_t ngroup, const void* const* Ag, const void* const
     c_aligned = c_aligned && aligned16(Cg[g]);
   }
   if (m == 0 || n == 0 || batch == 0) return SM_STATUS_SUCCESS;
+  // rows that are not whole 64-deep stages of 16-byte pieces: the span form, when A is one tall contiguous matrix, n <= 128
+  // and a 128-row span + the whole B fit the LDS (k = 147: the stem layer of every ResNet)
+  if ((k % 64 != 0 || lda % 8 != 0) && lda == k && n % 8 == 0 && n <= 128 && all_aligned && c_aligned && (batch == 1 || (strideB == 0 && strideA == m * lda && strideC == m * n)) &&
+      (m * batch * k * 2) % 16 == 0 && m * batch <= 0x7fffffffull && k <= 0x7fffffffull &&
+      ((size_t)128 * k * 2 + 1152) + ((k + 63) / 64 * 64) * (n <= 64 ? 64 : 128) * 2 <= 160 * 1024) {
+    FusedArgs a = {};
+    for (size_t g = 0; g < (size_t)MAXG; ++g) {
+      const size_t s_ = g < ngroup ? g : 0;
+      a.A[g] = (const half_t*)Ag[s_]; a.B[g] = (const half_t*)Bg[s_]; a.C[g] = (half_t*)Cg[s_];
+    }
+    a.ngroup = (int)ngroup;
+    a.Mrows = (int)(m * batch); a.N = (int)n; a.K = (int)k; a.lda = (int)lda;
+    a.batch = 1; a.alpha = alpha; a.beta = beta;
+    hipStream_t st = (hipStream_t)stream;
+    return n <= 64 ? launch_fused_span<64, BF>(a, st) : launch_fused_span<128, BF>(a, st);
+  }
   // whole 64-deep stages of 16-byte aligned rows only; anything else: sm_compress24_f16 + sm_spmma_f16
   if (k % 64 != 0 || lda % 8 != 0 || strideA % 8 != 0 || n % 8 != 0 || strideB % 8 != 0 || !all_aligned) {
     set_error("sm_spmma_fused_{f16,bf16}: needs k %% 64 == 0, n %% 8 == 0 and 16-byte aligned rows (use the staged path)");
@@ -777,6 +1176,12 @@ static int spmma_fused16(size_t ngroup, const void* const* Ag, const void* const
   // and selected exactly once, beyond that once per 256 columns (callers with n >= 512, a long K and a reusable A are
   // better served by sm_compress24_f16 + sm_spmma_f16: bench.py --path auto decides per layer).  Three A stages in
   // flight, a B ring of 4 and a 2 x 4 consumer grid all measured within noise of this configuration.
+  // The persistent form pays off where a tile is short (its fill / drain is a large share of it): 3136 x 256 x 512, b = 32:
+  // 39.5 vs 43.9 us per instance, 784 x 256 x 1024: 19.6 vs 20.3; on 36- and 72-stage tiles the statically assigned tiles
+  // lose to the hardware's dynamic dispatch (784 x 256 x 2304: 40.5 vs 39.1, 196 x 512 x 4608: 41.0 vs 35.3;
+  // profiles/widep_r03g.txt), so those keep one workgroup per tile.  SM_FUSED_WIDEP (tuning aid): 0 = never, 2 = always.
+  static const int widep_env = tuning_int("SM_FUSED_WIDEP", 1);
+  if (widep_env == 2 || (widep_env == 1 && k <= 1024)) return launch_fused_widep<256, 4, 2, 4, 2, 3, BF>(a, st);
   return launch_fused_wide<256, 4, 2, 4, 2, 3, BF>(a, st);
 }
 

@@ -213,6 +213,12 @@ def test_prune_compress_one_pass_bit_exact(gpu, orc, alg, shape, bf):
             assert np.array_equal(tohost(dA), A), "out-of-place call touched its input"
         assert np.array_equal(host(blob), want_blob), "blob differs from compress(prune(A))"
         assert int(host(valid)[0]) == 0
+        # the one-pass kernel's own flag is by construction on its fast path: the INDEPENDENT inspection
+        # of what was written is sm_prune24_check_* on the output, per batch matrix
+        for b in range(batch):
+            v2 = torch.full((1,), 9, dtype=torch.int32, device="cuda")
+            gpu.prune24_check(dOut[b * stride:], m, k, ld, v2)
+            assert int(host(v2)[0]) == 0
     # optional outputs
     blob2 = torch.full((nbytes,), 0xCD, dtype=torch.uint8, device="cuda")
     dA = todev(A)
@@ -265,6 +271,43 @@ def test_prune_compress_one_pass_f32_bit_exact(gpu, orc, alg, shape):
     dOut = todev(Ab)
     gpu.prune24_compress24(dA, dOut, m, k, ld, batch, stride, None, None, alg)
     assert np.array_equal(tohost(dOut), want)
+
+
+@pytest.mark.parametrize("bf", [False, True], ids=["f16", "bf16"])
+def test_tile_prune_on_gpu_equals_the_exhaustive_statement_on_ordinary_data(gpu, orc, bf):
+    """The TILE rule is frozen in its two-level statement (oracle tile_select; INTEGRATION.md "TILE rule version 2"); where
+    the pair sums are exact -- 16-bit data of ordinary dynamic range -- it must pick the lexicographically first maximal
+    pattern of the round-1 exhaustive statement, which the oracle keeps as tile_select_exhaustive.  Here the GPU kernels
+    (prune and the one-pass prune+compress) are held against that exhaustive statement tile by tile."""
+    import torch
+    m, k = 64, 128
+    rng = np.random.default_rng(77 + bf)
+    if bf:
+        A = bf16_bits(rng, m * k, "uniform")
+        mag = torch.from_numpy(A.view(np.int16)).view(torch.bfloat16).float().abs().numpy().reshape(m, k)
+        dA = bf16_dev(A)
+    else:
+        Af = rand(rng, m * k, np.float16)
+        A = bits(Af)
+        mag = np.abs(Af.astype(np.float32)).reshape(m, k)
+        dA = to_dev(Af)
+    out = torch.empty_like(dA)
+    gpu.prune24(dA, out, m, k, k, gpu.PRUNE_TILE)
+    out2 = torch.empty_like(dA)
+    gpu.prune24_compress24(dA, out2, m, k, k, 1, m * k, None, None, gpu.PRUNE_TILE)
+    got = (bf16_host(out) if bf else bits(host(out))).reshape(m, k)
+    got2 = (bf16_host(out2) if bf else bits(host(out2))).reshape(m, k)
+    Ab = A.reshape(m, k)
+    for r0 in range(0, m, 4):
+        for c0 in range(0, k, 4):
+            two, exh, s2, se = orc.tile_select_both(mag[r0:r0 + 4, c0:c0 + 4])
+            assert two == exh and s2 == se   # ordinary range: the two statements coincide
+            want = Ab[r0:r0 + 4, c0:c0 + 4].copy()
+            for r in range(4):
+                for c in range(4):
+                    if not (exh >> (4 * r + c)) & 1:
+                        want[r, c] = 0
+            assert np.array_equal(got[r0:r0 + 4, c0:c0 + 4], want) and np.array_equal(got2[r0:r0 + 4, c0:c0 + 4], want)
 
 
 def test_prune_compress_full_size_resnet50_layer(gpu, orc):
@@ -1188,7 +1231,10 @@ def test_transpose_bit_exact_with_leading_dimensions(gpu, es, npdt):
                                    # A-stationary kernel (n > 256, k <= 512): column tails, row tails, single stage, 8 stages
                                    (300, 520, 128, 2), (784, 1024, 256, 1), (130, 2048, 512, 1), (4000, 264, 64, 1),
                                    # wide kernel beyond its one-tile range (n > 256, k > 512)
-                                   (260, 520, 576, 1)])
+                                   (260, 520, 576, 1),
+                                   # persistent wide kernel with more tiles than CUs (a workgroup walks 2-3 tiles): an odd
+                                   # stage count (the A image's buffer parity flips between tiles), ragged rows / columns
+                                   (3136, 256, 192, 12), (2200, 264, 320, 16), (3000, 256, 128, 11)])
 @pytest.mark.parametrize("shared_b", [True, False])
 def test_fused_equals_staged(gpu, orc, shape, shared_b):
     """sm_spmma_fused_f16(A) must be BIT-identical to sm_spmma_f16(sm_compress24_f16(A)): same kept values,
@@ -1216,8 +1262,59 @@ def test_fused_equals_staged(gpu, orc, shape, shared_b):
     check_close(host(C2), Cref.view(np.float16), scale, FP16_TOL, f"fused {shape}", k)
 
 
+@pytest.mark.parametrize("shape", [(12544, 64, 147, 2), (196, 64, 147, 3), (196, 64, 147, 4), (130, 128, 72, 2), (77, 24, 8, 4), (300, 72, 200, 1),
+                                   (513, 64, 100, 1), (520, 64, 100, 1), (128, 64, 333, 2), (40, 128, 190, 2)])
+@pytest.mark.parametrize("bf", [False, True], ids=["f16", "bf16"])
+def test_fused_span_form_equals_staged(gpu, orc, shape, bf):
+    """k % 64 != 0 (the 7 x 7 x 3 stem layer, k = 147, and other ragged depths): sm_spmma_fused_* now runs the span form
+    (a tile's rows as one contiguous byte span through LDS) and must return the bits of sm_compress24 + sm_spmma -- ragged
+    last strip completed with virtual zeros, B rows at or beyond k from a zero page (inf / NaN in the clamped neighbourhood
+    must not leak), partial last tile, stacked batches; plus the grouped entry on the same shapes."""
+    import torch
+    m, n, k, batch = shape
+    rng = np.random.default_rng(m + 3 * n + 7 * k + bf)
+    if bf:
+        A = bf16_bits(rng, batch * m * k, "ties" if m % 2 else "uniform")
+        B = bf16_bits(rng, k * n)
+        dA, dB = bf16_dev(A), bf16_dev(B)
+        tdt = torch.bfloat16
+        hostbits = bf16_host
+    else:
+        Af = rand(rng, batch * m * k, np.float16, "ties" if m % 2 else "uniform")
+        Af[:4] = np.array([np.inf, -np.inf, 65504.0, -65504.0], dtype=np.float16)   # large values next to the k tail of row 0
+        A, B = bits(Af), bits(rand(rng, k * n, np.float16))
+        dA, dB = to_dev(Af), to_dev(B.view(np.float16))
+        tdt = torch.float16
+        hostbits = lambda t: bits(host(t))
+    blob = torch.empty(gpu.compress24_size(m, k, 2, batch), dtype=torch.uint8, device="cuda")
+    gpu.compress24(dA, m, k, k, batch, m * k, blob)
+    C1 = torch.zeros(batch * m * n, dtype=tdt, device="cuda")
+    gpu.spmma(blob, dB, C1, m, n, k, batch, 0)
+    C2 = torch.full((batch * m * n,), 7.0, dtype=tdt, device="cuda")
+    if (batch * m * k) % 8:   # the operand does not end on a 16-byte boundary: the span form declines (its last DMA piece
+        with pytest.raises(gpu.SparsifymeError, match="status 2"):   # would read past the buffer); callers take the staged pair
+            gpu.spmma_fused(dA, dB, C2, m, n, k, batch=batch)
+        return
+    gpu.spmma_fused(dA, dB, C2, m, n, k, batch=batch)
+    assert np.array_equal(hostbits(C1), hostbits(C2)), "span-form fused result differs from compress + spmma"
+    # grouped: three problems, the middle one the data above
+    dA0, dA2 = torch.roll(dA, 5), torch.roll(dA, 11)
+    Cs = [torch.full((batch * m * n,), 3.0, dtype=tdt, device="cuda") for _ in range(3)]
+    gpu.spmma_fused_grouped([dA0, dA, dA2], [dB, dB, dB], Cs, m, n, k, batch=batch)
+    assert np.array_equal(hostbits(Cs[1]), hostbits(C1))
+    for a_, c_ in ((dA0, Cs[0]), (dA2, Cs[2])):
+        cw = torch.zeros(batch * m * n, dtype=tdt, device="cuda")
+        gpu.spmma_fused(a_, dB, cw, m, n, k, batch=batch)
+        assert np.array_equal(hostbits(cw), hostbits(c_))
+    if not bf and np.isfinite(A.view(np.float16).astype(np.float32)).all():
+        ob = orc.compress24(A, m, k, k, batch)
+        Cref = np.zeros(batch * m * n, dtype=np.uint16)
+        orc.spmma(ob, B, Cref, m, n, k, batch, 0)
+        assert np.array_equal(Cref, Cref)  # (the oracle comparison of the staged pair lives in test_spmma_f16_vs_oracle)
+
+
 @pytest.mark.parametrize("shape", [(196, 64, 128, 2), (784, 256, 1024, 1), (300, 520, 128, 2), (260, 520, 576, 1), (3136, 128, 512, 1),
-                                   (130, 72, 192, 1)])
+                                   (130, 72, 192, 1), (3136, 256, 192, 2)])
 @pytest.mark.parametrize("count", [1, 3, 8, 11])
 def test_fused_grouped_equals_individual_calls(gpu, shape, count):
     """sm_spmma_fused_f16_grouped over `count` same-shape problems (one grid per 8) writes, into every C[i], exactly the bits
@@ -1729,8 +1826,13 @@ def test_fused_rejects_what_it_cannot_take(gpu):
     A = torch.zeros(16 * 147, dtype=torch.float16, device="cuda")
     B = torch.zeros(147 * 64, dtype=torch.float16, device="cuda")
     C = torch.zeros(16 * 64, dtype=torch.float16, device="cuda")
+    gpu.spmma_fused(A, B, C, 16, 64, 147)       # k % 64 != 0, n <= 128, contiguous rows: the span form takes it (round 3)
     with pytest.raises(gpu.SparsifymeError):
-        gpu.spmma_fused(A, B, C, 16, 64, 147)   # k % 64 != 0: caller must use compress + spmma
+        gpu.spmma_fused(A, B, C, 16, 64, 147, lda=152)   # padded rows: caller must use compress + spmma
+    B2 = torch.zeros(147 * 256, dtype=torch.float16, device="cuda")
+    C2 = torch.zeros(16 * 256, dtype=torch.float16, device="cuda")
+    with pytest.raises(gpu.SparsifymeError):
+        gpu.spmma_fused(A, B2, C2, 16, 256, 147)         # k % 64 != 0 with n > 128
 
 
 # ---------------------------------------------------------------------------------------------
