@@ -1044,6 +1044,12 @@ __global__ __launch_bounds__(64 * 16) void spmma_f16_fused_astat_kernel(const Fu
   }
 }
 
+// (A PERSISTENT form of this kernel -- one workgroup per CU walking its row panels with two panel images in LDS, the four
+// barrier-only waves building panel j + 1's image during panel j's stages, B ring across panels -- was built in round 3:
+// bit-identical, and 10-18 % SLOWER than one workgroup per panel with either a 1- or a 4-interval prefetch ring
+// (profiles/astatp_r03m.txt: 3136 x 512 x 128 x 4: 158.6 vs 140.2 us; 784 x 1024 x 256 x 6: 147.6 vs 124.9 us).  As with the
+// wide kernel's long-K tiles, statically assigned work loses to the hardware's dynamic dispatch.  Removed again)
+
 static size_t astat_lds_bytes(int nkt, int nsb) { return (size_t)nkt * (128 * 72) + (size_t)nsb * 64 * 128 * 2 + 8 * 32 * (64 * 2 + 8); }
 
 template <bool BF = false>
@@ -1170,8 +1176,9 @@ static int spmma_fused16(size_t ngroup, const void* const* Ag, const void* const
   // n > 256, short K, plain store: A-stationary (the 2:4 image of a row panel stays in LDS across column tiles)
   static const int astat_env = tuning_int("SM_FUSED_ASTAT", 1);  // tuning aid: 0 = off
   if (astat_env && n > 256 && k <= 512 && beta == 0.0f && aligned16(C) && (strideC % 8 == 0) &&
-      astat_lds_bytes((int)(k / 64), 3) <= 160 * 1024)
+      astat_lds_bytes((int)(k / 64), 3) <= 160 * 1024) {
     return launch_fused_astat<BF>(a, st);
+  }
   // wider: 256-column tiles, 8 consumer waves (wave tile 32 x 128), split loaders; for n <= 256 every row of A is loaded
   // and selected exactly once, beyond that once per 256 columns (callers with n >= 512, a long K and a reusable A are
   // better served by sm_compress24_f16 + sm_spmma_f16: bench.py --path auto decides per layer).  Three A stages in

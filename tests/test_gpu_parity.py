@@ -1262,6 +1262,35 @@ def test_fused_equals_staged(gpu, orc, shape, shared_b):
     check_close(host(C2), Cref.view(np.float16), scale, FP16_TOL, f"fused {shape}", k)
 
 
+@pytest.mark.parametrize("shape", [(3136, 512, 128, 24), (2100, 264, 256, 32), (4096, 384, 64, 17), (2049, 520, 192, 32)])
+def test_fused_astat_many_panels_equals_staged(gpu, shape):
+    """The A-stationary kernel at grouped-launch sizes (several rounds of row panels per CU; one- to four-stage panels, ragged
+    rows and columns) must return the bits of sm_compress24 + sm_spmma.  (The staged pair is the one held against the
+    oracle, test_spmma_f16_vs_oracle; at these sizes the CPU product would take minutes.)"""
+    import torch
+    m, n, k, batch = shape
+    dA = torch.empty(batch * m * k, dtype=torch.float16, device="cuda")
+    gpu.fill_uniform(dA, 1234 + m, -1.0, 1.0)
+    dB = torch.empty(k * n, dtype=torch.float16, device="cuda")
+    gpu.fill_uniform(dB, 4321 + n, -1.0, 1.0)
+    blob = torch.empty(gpu.compress24_size(m, k, 2, batch), dtype=torch.uint8, device="cuda")
+    gpu.compress24(dA, m, k, k, batch, m * k, blob)
+    C1 = torch.zeros(batch * m * n, dtype=torch.float16, device="cuda")
+    gpu.spmma(blob, dB, C1, m, n, k, batch, 0)
+    C2 = torch.full((batch * m * n,), 7.0, dtype=torch.float16, device="cuda")
+    gpu.spmma_fused(dA, dB, C2, m, n, k, batch=batch)
+    torch.cuda.synchronize()
+    assert torch.equal(C1.view(torch.int16), C2.view(torch.int16)), "A-stationary result differs from compress + spmma"
+    # and as a grouped launch of two problems
+    dA2 = torch.roll(dA, 3)
+    Cs = [torch.full((batch * m * n,), 5.0, dtype=torch.float16, device="cuda") for _ in range(2)]
+    gpu.spmma_fused_grouped([dA, dA2], [dB, dB], Cs, m, n, k, batch=batch)
+    C3 = torch.zeros_like(C1)
+    gpu.spmma_fused(dA2, dB, C3, m, n, k, batch=batch)
+    torch.cuda.synchronize()
+    assert torch.equal(Cs[0].view(torch.int16), C1.view(torch.int16)) and torch.equal(Cs[1].view(torch.int16), C3.view(torch.int16))
+
+
 @pytest.mark.parametrize("shape", [(12544, 64, 147, 2), (196, 64, 147, 3), (196, 64, 147, 4), (130, 128, 72, 2), (77, 24, 8, 4), (300, 72, 200, 1),
                                    (513, 64, 100, 1), (520, 64, 100, 1), (128, 64, 333, 2), (40, 128, 190, 2)])
 @pytest.mark.parametrize("bf", [False, True], ids=["f16", "bf16"])
