@@ -752,12 +752,25 @@ def config5_stage(sm, torch, dev):
                                             ws2.data_ptr(), nb2.value, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
             if rc != 0:
                 raise RuntimeError(L_.sm_last_error().decode())
+        nb3 = ctypes.c_size_t(0)
+        L_.sm_spmm_coo_fast_workspace_size(m, k, n, b, ctypes.byref(nb3))
+        ws3 = torch.zeros(nb3.value, dtype=torch.uint8, device=dev)
+
+        def call_fast():
+            rc = L_.sm_spmm_coo_f32_fast(m, k, nnz, n, b, r.data_ptr(), c.data_ptr(), v.data_ptr(), B.data_ptr(), C.data_ptr(), 1.0, 0.0,
+                                          ws3.data_ptr(), nb3.value, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+            if rc != 0:
+                raise RuntimeError(L_.sm_last_error().decode())
         ms_rowptr = sm.graph_time_ms(call_rowptr, iters=5)
         ms = sm.graph_time_ms(call_packed, iters=5)
+        ms_fast = sm.graph_time_ms(call_fast, iters=5)
         by = nnz * 8.0 + (m + 1) * 4.0 + 4.0 * b * (k * n + m * n)
         rows.append({"m": m, "n": n, "k": k, "b": b, "nnz": nnz, "ms": ms, "GBs": by / ms / 1e6, "frac": by / ms / 1e6 / HBM_PEAK_GBS,
-                     "TFs": 2.0 * nnz * n * b / ms / 1e9, "ms_rowptr_form": ms_rowptr})
-    return {"kernel": "spmm_csr_packed_kernel (sm_spmm_coo_f32_packed: re-ordering of A + product, whole call); ms_rowptr_form = sm_spmm_coo_f32_ws", "shapes": rows, "unit": "GB/s of algorithmic bytes (SURVEY.md 8(d): nnz*(s+4) + (m+1)*4 + b*s*(k*n + m*n))",
+                     "TFs": 2.0 * nnz * n * b / ms / 1e9, "ms_rowptr_form": ms_rowptr,
+                     "ms_fast_form": ms_fast, "GBs_fast_form": by / ms_fast / 1e6, "frac_fast_form": by / ms_fast / 1e6 / HBM_PEAK_GBS})
+    return {"kernel": "spmm_csr_packed_kernel (sm_spmm_coo_f32_packed: re-ordering of A + product, whole call); ms_rowptr_form = sm_spmm_coo_f32_ws; "
+                      "ms_fast_form = sm_spmm_coo_f32_fast (explicit opt-in: dense operand rounded to fp16, A split hi + lo, fp16 MFMA with fp32 "
+                      "accumulation; result within 2^-11 of sum|a||b|; whole call incl. its conversion / scatter passes)", "shapes": rows, "unit": "GB/s of algorithmic bytes (SURVEY.md 8(d): nnz*(s+4) + (m+1)*4 + b*s*(k*n + m*n))",
             "peak": HBM_PEAK_GBS}
 
 

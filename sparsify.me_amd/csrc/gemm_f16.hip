@@ -29,6 +29,10 @@ struct GemmArgs {
   int lda, ldb, ldc;
   int batch, tiles_m, tiles_n;
   float alpha, beta;
+  // F32OUT instantiation only (sm::gemm_f16_f32out, the dense-MFMA form of the COO SpMM): fp32 C, and an A operand whose
+  // k runs over [0, a_wrap_kt * 64) TWICE (stage kt >= a_wrap_kt re-reads stage kt - a_wrap_kt) against a B of 2 x that depth
+  float* C32;
+  int a_wrap_kt;
 };
 
 // 8 halves starting at p[col]; elements at or beyond `limit` columns read as zero.
@@ -245,7 +249,7 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(const GemmArgs p) {
 // lane-linear for the DMA with the swizzle on the per-lane source address.  Edge rows / columns are
 // clamped to the last valid one (their products land in outputs that are never stored).
 // ---------------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, int NS, bool BF = false>
+template <int BM, int BN, int WM, int WN, int NS, bool BF = false, bool F32OUT = false>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_dma_kernel(const GemmArgs p) {
   constexpr int NW = WM * WN;
   static_assert(NW == 4 || NW == 8 || NW == 16, "4, 8 or 16 waves");
@@ -298,11 +302,14 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_dma_kernel(const GemmAr
   }
   auto stage = [&](int kt, int buf) {
     char* base = smem + buf * STAGE;
+    int kta = kt;
+    if constexpr (F32OUT) kta = (p.a_wrap_kt > 0 && kt >= p.a_wrap_kt) ? kt - p.a_wrap_kt : kt;
 #pragma unroll
     for (int i = 0; i < SL; ++i) {
       const unsigned t = wave + (unsigned)NW * i;
       if (t >= (unsigned)W) continue;
-      __builtin_amdgcn_global_load_lds((gptr_t*)(src[i] + (size_t)kt * step[i]), (lptr_t*)(base + loff[i]), 16, 0, 0);
+      const int ks = (F32OUT && t < (unsigned)A_N) ? kta : kt;
+      __builtin_amdgcn_global_load_lds((gptr_t*)(src[i] + (size_t)ks * step[i]), (lptr_t*)(base + loff[i]), 16, 0, 0);
     }
   };
 
@@ -366,6 +373,34 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_dma_kernel(const GemmAr
   }
   __syncthreads();
 
+  if constexpr (F32OUT) {
+    // fp32 output straight from the accumulators: a lane holds 4 consecutive columns of one row = one 16-byte store
+    // (ldc % 4 == 0 and N % 4 == 0 are the launcher's conditions, so a 4-column piece is all in or all out)
+    float* C32 = p.C32 + (size_t)b * p.sC;
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const int gr = m0 + (int)(wm * TM + i * 16 + r);
+        int gc = n0 + (int)(wn * TN + j * 16 + 4u * g);
+        if (gr >= p.M) continue;
+        const int chunk0 = gc & ~7;  // N % 8 == 4: the clamped last chunk holds the outputs of columns N-8 .. N-1 (see below)
+        if (chunk0 < p.N && chunk0 > p.N - 8) {
+          if ((gc & 4) == 0) continue;  // its lower half duplicates the neighbour's columns
+          gc -= chunk0 - (p.N - 8);
+        }
+        if (gc >= p.N) continue;
+        float* dst = C32 + (size_t)gr * p.ldc + gc;
+        f4 v = {p.alpha * acc[i][j][0], p.alpha * acc[i][j][1], p.alpha * acc[i][j][2], p.alpha * acc[i][j][3]};
+        if (p.beta != 0.0f) {
+          const f4 o = *reinterpret_cast<const f4*>(dst);
+          v = {v[0] + p.beta * o[0], v[1] + p.beta * o[1], v[2] + p.beta * o[2], v[3] + p.beta * o[3]};
+        }
+        __builtin_nontemporal_store(v, reinterpret_cast<f4*>(dst));
+      }
+    return;
+  }
+
   // ---- epilogue: lane holds C[row lane&15][cols 4*(lane>>4) .. +3] of each fragment.
   // N % 8 == 4 (the reference's column-major layout with m = 196): the B loads of the last, half-valid 8-column chunk
   // were clamped to columns N-8 .. N-1, so that chunk of the tile holds THOSE outputs: it is stored at N-8 as well
@@ -420,7 +455,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_dma_kernel(const GemmAr
   }
 }
 
-template <int BM, int BN, int WM, int WN, int NS, bool BF = false>
+template <int BM, int BN, int WM, int WN, int NS, bool BF = false, bool F32OUT = false>
 static int launch_dma(const GemmArgs& a0, hipStream_t st) {
   GemmArgs a = a0;
   a.tiles_m = (a.M + BM - 1) / BM;
@@ -439,9 +474,9 @@ static int launch_dma(const GemmArgs& a0, hipStream_t st) {
   const size_t lds_launch = used > lds_epi ? used : lds_epi;
   static LdsOptIn lds_optin;
   if (lds > 64 * 1024) {
-    if (const int rc = ensure_dyn_lds(lds_optin, reinterpret_cast<const void*>(&gemm_f16_dma_kernel<BM, BN, WM, WN, NS, BF>), lds, "gemm_f16_dma_kernel")) return rc;
+    if (const int rc = ensure_dyn_lds(lds_optin, reinterpret_cast<const void*>(&gemm_f16_dma_kernel<BM, BN, WM, WN, NS, BF, F32OUT>), lds, "gemm_f16_dma_kernel")) return rc;
   }
-  gemm_f16_dma_kernel<BM, BN, WM, WN, NS, BF><<<dim3((unsigned)nwg), dim3(64 * WM * WN), lds_launch, st>>>(a);
+  gemm_f16_dma_kernel<BM, BN, WM, WN, NS, BF, F32OUT><<<dim3((unsigned)nwg), dim3(64 * WM * WN), lds_launch, st>>>(a);
   return check_launch("gemm_f16_dma_kernel");
 }
 
@@ -498,6 +533,36 @@ static int launch_gemm_f16(const GemmArgs& a, hipStream_t st, bool ta = false, b
   if (a.N <= 64) return launch_cfg<128, 64, 4, 1, false, false, BF>(a, vec, st);
   if (a.M <= 64) return launch_cfg<64, 128, 1, 4, false, false, BF>(a, vec, st);
   return launch_cfg<128, 128, 2, 2, false, false, BF>(a, vec, st);
+}
+
+// fp16 x fp16 -> fp32 row-major product for spmm.hip's dense-MFMA COO form: C32[M x N] (ldc) = alpha * A[M x K] (lda) *
+// (B[0 .. K) + B[K .. 2K)) (ldb, the two fp16 planes of one fp32 operand stacked along k) + beta * C32.  K % 64 == 0,
+// N % 4 == 0, N >= 8, leading dimensions multiples of 4, 8-byte aligned bases (the DMA kernel's conditions).
+int gemm_f16_f32out(const void* A, const void* B2, float* C, size_t M, size_t N, size_t K, size_t lda, size_t ldb, size_t ldc, float alpha,
+                    float beta, hipStream_t st) {
+  if (K % 64 != 0 || N % 4 != 0 || N < 8 || lda % 4 != 0 || ldb % 4 != 0 || ldc % 4 != 0 || M > 0x7fffffffull || N > 0x7fffffffull ||
+      2 * K > 0x7fffffffull || (reinterpret_cast<uintptr_t>(A) & 7u) || (reinterpret_cast<uintptr_t>(B2) & 7u) || (reinterpret_cast<uintptr_t>(C) & 15u)) {
+    set_error("gemm_f16_f32out: shape / alignment not served");
+    return SM_STATUS_NOT_SUPPORTED;
+  }
+  GemmArgs a = {};
+  a.A = (const half_t*)A; a.B = (const half_t*)B2; a.C32 = C;
+  a.M = (int)M; a.N = (int)N; a.K = (int)(2 * K);
+  a.lda = (int)lda; a.ldb = (int)ldb; a.ldc = (int)ldc;
+  a.batch = 1; a.alpha = alpha; a.beta = beta;
+  a.a_wrap_kt = (int)(K / 64);
+  if (N <= 64) return launch_dma<128, 64, 4, 1, 2, false, true>(a, st);
+#ifdef SM_TUNING
+  switch (tuning_int("SM_COOFAST_TILE", 0)) {  // A/B of the tile shape of this compute-bound product
+    case 1: return launch_dma<256, 128, 4, 2, 2, false, true>(a, st);
+    case 2: return launch_dma<128, 256, 2, 4, 2, false, true>(a, st);
+    case 3: return launch_dma<256, 128, 4, 2, 3, false, true>(a, st);
+    case 4: return launch_dma<128, 128, 2, 2, 3, false, true>(a, st);
+    case 5: return launch_dma<256, 256, 4, 4, 2, false, true>(a, st);
+    default: break;
+  }
+#endif
+  return launch_dma<128, 128, 2, 2, 2, false, true>(a, st);
 }
 
 }  // namespace sm

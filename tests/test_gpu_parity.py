@@ -1017,6 +1017,117 @@ def test_spmm_coo_config5_resnet50_shapes(gpu, orc, shape, order, entry):
         assert np.array_equal(host(dC).reshape(batches, n, m)[:, :, e], (np.float32(beta) * C0h[:, :, e]).astype(np.float32))
 
 
+def _coo_fast_call(gpu, m, k, nnz, n, batches, dr, dc, dv, dB, dC, alpha, beta):
+    import ctypes
+    import torch
+    nb = ctypes.c_size_t(0)
+    assert gpu.lib().sm_spmm_coo_fast_workspace_size(m, k, n, batches, ctypes.byref(nb)) == 0
+    ws = torch.full((nb.value,), 0x5A, dtype=torch.uint8, device="cuda")   # stale workspace must not matter
+    return gpu.lib().sm_spmm_coo_f32_fast(m, k, nnz, n, batches, dr.data_ptr(), dc.data_ptr(), dv.data_ptr(), dB.data_ptr(), dC.data_ptr(),
+                                          alpha, beta, ws.data_ptr(), nb.value, None)
+
+
+# bound of the dense-MFMA form: the dense operand rounded once to fp16 (2^-11 relative per element), A exact to 2^-22, fp32
+# accumulation over k terms, one fp32 rounding of the result -- all relative to |alpha| sum|a||b| + |beta||c0|
+COO_FAST_TOL = 2.0 ** -11 * 1.02
+
+
+@pytest.mark.parametrize("shape", [(784, 256, 2304), (12544, 64, 576), (196, 512, 4608), (3136, 128, 1152)], ids=lambda s: "x".join(map(str, s)))
+@pytest.mark.parametrize("order", ["sorted", "shuffled"])
+def test_spmm_coo_fast_config5_resnet50_shapes(gpu, orc, shape, order):
+    """sm_spmm_coo_f32_fast (the fp16-split dense-MFMA form, an explicit opt-in) at config 5's sizes, b = 32: sampled entries
+    against the fp64 oracle within COO_FAST_TOL of |alpha| sum|a||b| + |beta||c0| -- half of north_star's 1e-3 for fp32
+    products, asserted exactly here -- for sorted and shuffled input (the scatter does not care), alpha / beta != (1, 0)."""
+    import torch
+    m, n, k = shape
+    batches = 32
+    alpha, beta = 1.25, -0.5
+    r, c, v, rng = _coo_problem(m, k, m + k)
+    nnz = r.size
+    if order == "shuffled":
+        perm = rng.permutation(nnz)
+        r, c, v = r[perm].copy(), c[perm].copy(), v[perm].copy()
+    dB = torch.empty(batches * k * n, dtype=torch.float32, device="cuda")
+    gpu.fill_uniform(dB, 0xC00 + n, -1.0, 1.0)
+    dC = torch.empty(batches * m * n, dtype=torch.float32, device="cuda")
+    gpu.fill_uniform(dC, 0xC0C + m, -1.0, 1.0)
+    C0 = dC.clone()
+    dr, dc, dv = to_dev(r), to_dev(c), to_dev(v)
+    rc = _coo_fast_call(gpu, m, k, nnz, n, batches, dr, dc, dv, dB, dC, alpha, beta)
+    assert rc == 0, gpu.lib().sm_last_error()
+    rs = np.unique(np.concatenate([[0, m - 1], rng.integers(0, m, 30)]))
+    vecs = [(0, 0), (batches - 1, n - 1)] + [(int(rng.integers(0, batches)), int(rng.integers(0, n))) for _ in range(14)]
+    remap = -np.ones(m, dtype=np.int64)
+    remap[rs] = np.arange(rs.size)
+    keep = remap[r] >= 0
+    sr, sc, sv = remap[r[keep]].astype(np.int32), c[keep].copy(), v[keep].copy()
+    Bh = np.concatenate([host(dB[(bb * n + j) * k:(bb * n + j + 1) * k]) for bb, j in vecs])
+    C0h = host(C0).reshape(batches, n, m)
+    Csub = np.stack([C0h[bb, j, rs] for bb, j in vecs]).astype(np.float32).reshape(-1)
+    want = Csub.copy()
+    orc.spmm_coo(rs.size, k, sr.size, len(vecs), 1, sr, sc, sv, Bh, want, alpha, beta)
+    got = np.stack([host(dC).reshape(batches, n, m)[bb, j, rs] for bb, j in vecs]).reshape(-1)
+    absA = np.zeros((rs.size, k))
+    np.add.at(absA, (sr, sc), np.abs(sv.astype(np.float64)))
+    scale = abs(alpha) * (np.abs(Bh.astype(np.float64)).reshape(len(vecs), k) @ absA.T).reshape(-1) + abs(beta) * np.abs(Csub)
+    err = np.abs(got.astype(np.float64) - want.astype(np.float64))
+    worst = float(np.max(err / np.maximum(scale, 1e-30)))
+    assert worst <= COO_FAST_TOL, f"fast coo {shape} {order}: worst error {worst:.3e} of the scale, bound {COO_FAST_TOL:.3e}"
+    assert worst <= 1e-3   # north_star's fp32 tolerance
+    empty = np.setdiff1d(np.arange(m), np.unique(r))
+    if empty.size:   # rows without non-zeros: beta * C0 (+ 0), exactly
+        e = int(empty[0])
+        assert np.array_equal(host(dC).reshape(batches, n, m)[:, :, e], (np.float32(beta) * C0h[:, :, e]).astype(np.float32))
+
+
+@pytest.mark.parametrize("shape", [(8, 8, 64, 1), (132, 33, 128, 3), (300, 130, 256, 2), (20, 5, 192, 4), (128, 64, 64, 2)], ids=lambda s_: "x".join(map(str, s_)))
+@pytest.mark.parametrize("order", ["sorted", "shuffled", "duplicates"])
+def test_spmm_coo_fast_small_vs_oracle(gpu, orc, shape, order):
+    """Every output of the dense-MFMA form on small shapes (ragged tiles, duplicates, an empty matrix, beta = 0) within its
+    bound; shapes it does not take (cols % 64, rows % 4, a short workspace) return SM_STATUS_NOT_SUPPORTED untouched."""
+    import ctypes
+    import torch
+    m, n, k, batches = shape
+    rng = np.random.default_rng(m * 7 + n + k)
+    dens = rng.uniform(0, 1, (m, k)) < 0.15
+    r, c = np.nonzero(dens)
+    r, c = r.astype(np.int32), c.astype(np.int32)
+    if order == "duplicates" and r.size:
+        r, c = np.concatenate([r, r[:50]]), np.concatenate([c, c[:50]])
+    v = rng.uniform(-1, 1, r.size).astype(np.float32)
+    if order == "shuffled":
+        p_ = rng.permutation(r.size)
+        r, c, v = r[p_].copy(), c[p_].copy(), v[p_].copy()
+    B = rng.uniform(-1, 1, batches * k * n).astype(np.float32)
+    for alpha, beta in ((1.0, 0.0), (0.75, 2.0)):
+        C0 = rng.uniform(-1, 1, batches * m * n).astype(np.float32)
+        dC = to_dev(C0.copy())
+        rc = _coo_fast_call(gpu, m, k, r.size, n, batches, to_dev(r) if r.size else torch.zeros(1, dtype=torch.int32, device="cuda"),
+                            to_dev(c) if r.size else torch.zeros(1, dtype=torch.int32, device="cuda"),
+                            to_dev(v) if r.size else torch.zeros(1, dtype=torch.float32, device="cuda"), to_dev(B), dC, alpha, beta)
+        assert rc == 0, gpu.lib().sm_last_error()
+        want = C0.copy()
+        orc.spmm_coo(m, k, r.size, n, batches, r, c, v, B, want, alpha, beta)
+        absA = np.zeros((m, k))
+        np.add.at(absA, (r, c), np.abs(v.astype(np.float64)))
+        scale = np.concatenate([(abs(alpha) * (np.abs(B[bb * k * n:(bb + 1) * k * n].astype(np.float64)).reshape(n, k) @ absA.T)).reshape(-1) for bb in range(batches)])
+        scale = scale + abs(beta) * np.abs(C0)
+        err = np.abs(host(dC).astype(np.float64) - want.astype(np.float64))
+        assert float(np.max(err / np.maximum(scale, 1e-30))) <= COO_FAST_TOL
+    # declined shapes leave C alone
+    L = gpu.lib()
+    nb = ctypes.c_size_t(0)
+    L.sm_spmm_coo_fast_workspace_size(m, k, n, batches, ctypes.byref(nb))
+    ws = torch.zeros(max(nb.value, 16), dtype=torch.uint8, device="cuda")
+    dC = to_dev(C0.copy())
+    z = lambda t: t.data_ptr()
+    dr, dc_, dv = (to_dev(r), to_dev(c), to_dev(v)) if r.size else (torch.zeros(1, dtype=torch.int32, device="cuda"),) * 2 + (torch.zeros(1, dtype=torch.float32, device="cuda"),)
+    dB = to_dev(B)
+    assert L.sm_spmm_coo_f32_fast(m, k + 1, r.size, n, batches, z(dr), z(dc_), z(dv), z(dB), z(dC), 1.0, 0.0, z(ws), nb.value, None) == 2   # cols % 64
+    assert L.sm_spmm_coo_f32_fast(m, k, r.size, n, batches, z(dr), z(dc_), z(dv), z(dB), z(dC), 1.0, 0.0, z(ws), max(nb.value, 16) - 16, None) == 2   # short workspace
+    assert np.array_equal(host(dC), C0)
+
+
 @pytest.mark.parametrize("shape", [(150, 33, 90, 3), (64, 9, 48, 2), (300, 130, 260, 1), (17, 5, 129, 4), (129, 64, 128, 2), (50, 70, 1000, 3), (33, 300, 52, 1)],
                          ids=lambda s_: "x".join(map(str, s_)))
 @pytest.mark.parametrize("order", ["sorted", "cols_shuffled_within_rows", "shuffled", "duplicates"])
