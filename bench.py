@@ -128,6 +128,8 @@ def main():
                          "(sm_spmma_fused_*_grouped: same kernels, same C bit for bit; the instances share the chip instead of each "
                          "paying its own last partial round of workgroups); off: one launch per layer")
     ap.add_argument("--no-span", action="store_true", help="auto path: k % 64 != 0 layers on sm_compress24 + sm_spmma instead of the span-form fused kernel")
+    ap.add_argument("--cost", choices=["bytes", "model"], default="bytes", help="what the longest-first spreading of work items balances")
+    ap.add_argument("--item-order", choices=["big-first", "small-first"], default="big-first", help="order of a stream's items")
     ap.add_argument("--big-streams", type=int, default=2, help="--sched split: streams reserved for the chip-filling items")
     ap.add_argument("--rehearse-gloo", action="store_true",
                     help="multi-rank rehearsal on a ONE-GPU box: gloo backend, every rank on cuda:0 (control flow only; "
@@ -284,9 +286,19 @@ def main():
 
     grouped = args.group == "on" and not f32
 
+    def item_cost(it):
+        """what a work item costs a stream: its bytes (--cost bytes) or those bytes over the rate its kernel family reaches
+        alone (--cost model: direct 4.9, span 2.9, wide 3.0, A-stationary 3.1 TB/s, profiles/bench_r03k.json)"""
+        by = sum(layer_bytes(L) for L in it[1])
+        if args.cost == "bytes" or f32:
+            return by
+        L0 = it[1][0]
+        rate = {"direct": 4.9, "span": 2.9, "wide": 3.0, "astat": 3.1}[fused_variant(L0["n"], L0["k"])] if use_fused(L0) else 3.0
+        return by / rate
+
     def spread(items):
-        """items [(kind, [layers])] -> per-stream chains, longest-first by bytes onto the least-loaded stream."""
-        items = sorted(items, key=lambda it: -sum(layer_bytes(L) for L in it[1]))
+        """items [(kind, [layers])] -> per-stream chains, longest-first onto the least-loaded stream."""
+        items = sorted(items, key=lambda it: -item_cost(it))
         ch, load = [[] for _ in range(nstreams)], [0] * nstreams
         nbig = min(max(1, args.big_streams), nstreams - 1) if (args.sched == "split" and nstreams >= 2) else 0
         for it in items:
@@ -300,7 +312,9 @@ def main():
                 cand = range(nstreams)
             w = min(cand, key=lambda c: load[c])
             ch[w].append(it)
-            load[w] += sum(layer_bytes(L) for L in it[1])
+            load[w] += item_cost(it)
+        if args.item_order == "small-first":  # a stream ends on its chip-filling items: the step's tail is not left to few-tile kernels
+            ch = [list(reversed(c)) for c in ch]
         return ch
 
     class ForkedItems(Forked):

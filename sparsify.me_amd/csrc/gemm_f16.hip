@@ -562,6 +562,14 @@ int gemm_f16_f32out(const void* A, const void* B2, float* C, size_t M, size_t N,
     default: break;
   }
 #endif
+  // 256 x 256 tiles (16 waves, one workgroup per CU) halve the LDS bytes per flop of this compute-bound product; taken when they
+  // still give most CUs a tile and pad N no worse than 128-wide tiles do (profiles/coo_fast_tiles_r03p.txt: 137 vs 157 us on
+  // (2048 x 12544 x 1152), 101 vs 109 on (4096 x 3136 x 2304); 276 vs 199 and 148 vs 116 where the conditions fail)
+  {
+    const size_t t256 = ((M + 255) / 256) * ((N + 255) / 256);
+    const double pad256 = (double)((N + 255) / 256 * 256) / (double)N, pad128 = (double)((N + 127) / 128 * 128) / (double)N;
+    if (t256 >= 192 && pad256 <= 1.1 * pad128) return launch_dma<256, 256, 4, 4, 2, false, true>(a, st);
+  }
   return launch_dma<128, 128, 2, 2, 2, false, true>(a, st);
 }
 
