@@ -1,7 +1,7 @@
 #!/bin/bash
 # One short GPU-box session: selected GPU tests + the bench with and without grouped launches (tools/gpu_quick.sh <tag> [pytest -k expr])
 set -o pipefail
-tag=${1:-rXX}; kexpr="${2:-grouped or fused_equals}"
+tag=${1:-rXX}; kexpr="${2-grouped or fused_equals}"   # pass "" for the whole GPU suite
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
 guard() { rc=$1; what=$2; echo "$what rc=$rc"; if [ "$rc" = 124 ] || [ "$rc" = 137 ]; then echo "$what hit its limit; stopping"; exit 1; fi; }

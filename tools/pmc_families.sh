@@ -11,10 +11,11 @@ run() { name=$1; shift
 run sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE
 run sq2 SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INST_LEVEL_VMEM SQ_ACTIVE_INST_VMEM SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS
 run sq3 SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_INST_LEVEL_LDS SQ_BUSY_CU_CYCLES
-run tcp TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCC_WRITE_REQ_sum TCP_GATE_EN1_sum TCP_TA_TCP_STATE_READ_sum
-run ta TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TA_FLAT_READ_WAVEFRONTS_sum TA_BUFFER_READ_WAVEFRONTS_sum
-run tcc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_LEVEL_sum TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum
-for p in sq1 sq2 sq3 tcp ta tcc; do echo "== pass $p"; python3 tools/pmc_generic.py gpurun_out/${tag}_pmc_${p}; done > gpurun_out/${tag}_pmc_summary.txt 2>&1
+# (a six-counter TCP pass aborts rocprofv3 and every TCC_* pass tried hung until its limit on this pool: two small TCP passes only)
+run tcp1 TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum
+run tcp2 TCP_PENDING_STALL_CYCLES_sum TCP_GATE_EN1_sum
+for p in sq1 sq2 sq3 tcp1 tcp2; do echo "== pass $p"; python3 tools/pmc_generic.py gpurun_out/${tag}_pmc_${p}; done > gpurun_out/${tag}_pmc_summary.txt 2>&1
+python3 tools/pmc_family_table.py gpurun_out/${tag}_pmc_sq1 gpurun_out/${tag}_pmc_sq2 gpurun_out/${tag}_pmc_sq3 gpurun_out/${tag}_pmc_tcp1 gpurun_out/${tag}_pmc_tcp2 > gpurun_out/${tag}_pmc_families.txt 2>&1
 # kernel durations of the same launches (from the first pass's kernel trace)
 python3 - <<PY >> gpurun_out/${tag}_pmc_summary.txt
 import csv, glob, collections

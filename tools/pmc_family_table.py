@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Derived per-kernel figures from the counter passes of tools/pmc_families.sh / tools/gpu_exp3.sh (one representative
+"""Derived per-kernel figures from the counter passes of tools/pmc_families.sh (one representative
 layer per kernel family, b = 32): which limit each family is at.  usage: pmc_family_table.py <dir prefix>... (pass dirs)"""
 import collections, csv, glob, sys
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
