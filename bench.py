@@ -450,7 +450,7 @@ def main():
 
     if rank == 0 and not args.no_extras:
         extras(args, sm, torch, dev, layers, flops, wall / args.steps, Forked, make_runner, timed, event_seconds, use_fused, out,
-               (fused_groups, run_group, spread, ForkedItems) if grouped else None)
+               (fused_groups, run_group, spread, ForkedItems) if grouped else None, step_full)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(ge, shapes)
@@ -491,7 +491,7 @@ def launch_ranks(args):
     return 0
 
 
-def extras(args, sm, torch, dev, layers, flops, t_full, Forked, make_runner, timed, event_seconds, use_fused, out, grouping=None):
+def extras(args, sm, torch, dev, layers, flops, t_full, Forked, make_runner, timed, event_seconds, use_fused, out, grouping=None, step_full=None):
     """Rank 0 only: per-stage times, the dense denominators, the API-faithful sequence and the roofline of the
     dominant kernel family."""
     f32 = args.dtype == "f32"
@@ -560,6 +560,20 @@ def extras(args, sm, torch, dev, layers, flops, t_full, Forked, make_runner, tim
         "hbm_bound_speedup_ceiling": sum(L["b"] * s * (L["m"] * L["k"] + L["m"] * L["n"]) + s * L["k"] * L["n"] for L in layers)
         / sum(L["b"] * (L["m"] * L["k"] * (s / 2 + 1.0 / 8) + s * L["m"] * L["n"]) + s * L["k"] * L["n"] for L in layers),
     }
+
+    # What the per-step join costs (NOT the headline: `value` keeps one fork / join per step).  The steps are independent
+    # batches; here four of them are captured as one graph in which every stream runs its chain four times back to back --
+    # a layer's consecutive executions stay ordered on their stream, nothing waits for another stream between steps -- so one
+    # step's ramp-up and tail (<= 2 kernels active for ~ 25 % of a replayed step, profiles/ktrace_r03f.txt) overlap its neighbours.
+    if step_full is not None and not args.eager:
+        class Pipelined(object):
+            def __call__(self):
+                step_full.fork_join(lambda w: [step_full.chain(w) for _ in range(4)])
+        t_pipe = timed(make_runner(Pipelined()), max(2, R // 2), 2, collective=False) / max(2, R // 2) / 4.0
+        out["stages"]["pipelined_4_steps_ms_per_step"] = t_pipe * 1e3
+        out["stages"]["pipelined_4_steps_gfs"] = gfs(t_pipe)
+        out["stages"]["pipelined_note"] = ("four steps per graph replay, no cross-stream join between them (per-stream order kept); "
+                                           "reported beside the headline, which joins every step")
 
     # The API-faithful sequence of sparsifyme::spmma() (reference spmma.hxx:82-113, include/sparsify.me/spmma.hxx):
     # TILE prune -> prune check -> compress -> multiply.  The prune reads the step's dense A and writes the pruned

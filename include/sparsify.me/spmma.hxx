@@ -190,7 +190,7 @@ std::vector<float> spmma(type_t* dA,
 // of compress(STRIP) + multiply on the UNPRUNED A -- C = alpha * prune_strip_2:4(A) * B + beta * C -- in ONE kernel
 // straight from the dense A: nothing is pruned in place (A is left as it is), no blob is built, A is read from HBM
 // once.  Bit-identical to spmma() only for an A that already is 2:4 (spmma() prunes with the TILE rule first: for a
-// dense A the two rules keep different elements).  fp16 / bfloat16 (needs k % 64 == 0, n % 8 == 0) and fp32 (k % 32 == 0,
+// dense A the two rules keep different elements).  fp16 / bfloat16 (k % 64 == 0, n % 8 == 0; or a ragged k with n <= 128: the span form) and fp32 (k % 32 == 0,
 // n % 4 == 0: the rule applied in the registers of the dense fp32 MFMA kernel).  Returns the elapsed milliseconds.  A shape the fused kernels cannot take (SM_STATUS_NOT_SUPPORTED) runs as sm_compress24 +
 // sm_spmma with a temporary blob: the same C bit for bit, so callers need no shape logic.
 template <typename type_t>

@@ -129,8 +129,10 @@ int sm_spmma_f32(const void* blob, const float* B, float* C, size_t m, size_t n,
 /* ---- (f-1) fused prune -> compress -> matmul: C_b = alpha * prune24_strip(A_b) * B_b + beta * C_b from the
  *      DENSE row-major A (m x k, lda, batch stride strideA) without materialising the compressed blob the
  *      reference rebuilds on every call (spmma.hxx:100-113).  Bit-identical to
- *      sm_compress24_f16 + sm_spmma_f16.  Needs k % 64 == 0, n % 8 == 0 and 16-byte aligned rows;
- *      returns SM_STATUS_NOT_SUPPORTED otherwise (use the staged pair). */
+ *      sm_compress24_f16 + sm_spmma_f16.  Takes k % 64 == 0, n % 8 == 0 and 16-byte aligned rows; or (round 3, the span
+ *      form) any k with n % 8 == 0, n <= 128, lda == k, the batches one contiguous tall matrix that ends on a 16-byte
+ *      boundary and whose 128-row span + B fit the LDS (k = 147, the ResNets' stem layer).  Returns SM_STATUS_NOT_SUPPORTED
+ *      otherwise (use the staged pair). */
 int sm_spmma_fused_f16(const void* A, const void* B, void* C, size_t m, size_t n, size_t k, size_t lda,
                        size_t batch, size_t strideA, size_t strideB, size_t strideC, float alpha,
                        float beta, sm_stream_t stream);
