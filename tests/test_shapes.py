@@ -36,3 +36,23 @@ def test_other_batch_and_image_sizes():
     rows = gen.shapes("resnet18", batch=8, image=128)
     assert rows[0] == (64 * 64, 64, 147, 8)
     assert all(r[3] == 8 for r in rows) and len(rows) == 17
+
+
+def test_bench_serves_every_resnet50_layer_with_a_fused_variant():
+    """bench.py mirrors the C-side dispatch of sm_spmma_fused_f16 (csrc/spmma_f16_fused.hip: spmma_fused16) to label its kernel
+    families; since round 3 every layer of the headline table runs fused: direct (n <= 128), wide (256-column tiles), A-stationary
+    (n > 256, k <= 512) or the span form (k % 64 != 0).  Guards the two dispatch tables against drifting apart."""
+    import collections
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    shapes = bench.read_shapes(os.path.join(root, "datasets", "resnet50.csv"))
+    assert len(shapes) == 49
+    fam = collections.Counter(bench.fused_variant(n, k) for (_, n, k, _) in shapes)
+    assert fam == {"direct": 17, "wide": 18, "astat": 13, "span": 1}
+    # the span form's conditions as bench.py states them hold for the stem layer
+    m, n, k, b = next(s for s in shapes if s[2] % 64)
+    assert (m, n, k, b) == (12544, 64, 147, 32) and (b * m * k * 2) % 16 == 0 and n % 8 == 0 and n <= 128
+    assert 128 * k * 2 + 1152 + (k + 63) // 64 * 64 * 64 * 2 <= 160 * 1024
