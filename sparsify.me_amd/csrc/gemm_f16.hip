@@ -559,6 +559,9 @@ int gemm_f16_f32out(const void* A, const void* B2, float* C, size_t M, size_t N,
     case 3: return launch_dma<256, 128, 4, 2, 3, false, true>(a, st);
     case 4: return launch_dma<128, 128, 2, 2, 3, false, true>(a, st);
     case 5: return launch_dma<256, 256, 4, 4, 2, false, true>(a, st);
+    case 6: return launch_dma<64, 128, 1, 4, 2, false, true>(a, st);
+    case 7: return launch_dma<128, 64, 4, 1, 2, false, true>(a, st);
+    case 8: return launch_dma<64, 128, 1, 4, 3, false, true>(a, st);
     default: break;
   }
 #endif
@@ -569,6 +572,9 @@ int gemm_f16_f32out(const void* A, const void* B2, float* C, size_t M, size_t N,
     const size_t t256 = ((M + 255) / 256) * ((N + 255) / 256);
     const double pad256 = (double)((N + 255) / 256 * 256) / (double)N, pad128 = (double)((N + 127) / 128 * 128) / (double)N;
     if (t256 >= 192 && pad256 <= 1.1 * pad128) return launch_dma<256, 256, 4, 4, 2, false, true>(a, st);
+    // at most one 128 x 128 tile per CU: 64-row tiles put two workgroups on a CU (16384 x 196 x 9216: 181 vs 202 us)
+    const size_t t128 = ((M + 127) / 128) * ((N + 127) / 128);
+    if (t128 <= (size_t)device_cu_count()) return launch_dma<64, 128, 1, 4, 2, false, true>(a, st);
   }
   return launch_dma<128, 128, 2, 2, 2, false, true>(a, st);
 }
