@@ -1201,6 +1201,13 @@ def test_cpp_drivers_cli_contract(gpu):
     lines = out.stdout.strip().splitlines()
     assert out.returncode == 0 and [l.split(":")[0] for l in lines] == ["Pruning Time (ms)", "Compression Time (ms)", "SpMMA Time (ms)"]
     assert "Incorrect pruning" not in out.stderr
+    # the reference's own instantiation (type_t = float, examples/spmma.cu:24): one-pass prune + check + compress since round 3
+    if not os.path.exists(os.path.join(bins, "spmma_f32")):
+        subprocess.run(["make", "-C", os.path.join(root, "examples"), "-j4"], check=True, capture_output=True)
+    out = run("spmma_f32", 196, 64, 128, 4)
+    lines = out.stdout.strip().splitlines()
+    assert out.returncode == 0 and [l.split(":")[0] for l in lines] == ["Pruning Time (ms)", "Compression Time (ms)", "SpMMA Time (ms)"]
+    assert all(float(l.split(":")[1]) > 0.0 for l in lines) and "Incorrect pruning" not in out.stderr
     bad = run("spmma", 1, 2)
     assert bad.returncode != 0 and "Usage: ./spmma m n k b" in bad.stdout
     # int8 driver: stage labels of the fp16 one; its fused kernel must return the staged pair's bytes
