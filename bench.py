@@ -425,7 +425,7 @@ def main():
              "strong": f"batch split: rank g runs batch indices [g*b/{world}, (g+1)*b/{world}) of every layer, B replicated",
              "lpt": f"whole layers by longest-processing-time over {len(shapes)} layer instances",
              "hybrid": f"batch split [g*b/{world}, (g+1)*b/{world}) of the layers whose per-rank share keeps >= {mg.HYBRID_FILL_ROWS} rows, "
-                       f"the other layers whole by longest-processing-time (this rank: {len(layers)} units)"}[args.scaling]
+                       f"the other layers whole, longest modelled time first (this rank: {len(layers)} units)"}[args.scaling]
     if grouped:
         path_desc += ("; the fused layers run as %d grouped launches (sm_spmma_fused_%s_grouped: one grid per <= 8 same-shape instances, "
                       "same kernels, same C)" % (n_launch_groups, sfx))

@@ -11,10 +11,27 @@ import os
 
 MODES = ("weak", "strong", "lpt", "hybrid")
 
-# hybrid: a layer is split by batch index only while a rank's share still covers the chip with row tiles: 256 CUs x one
-# 128-row tile.  Below that a tile's time is set by its K stages, not by its rows (128 tiles of a
-# 784 x 256 x 2304 layer take the time of 256), so a batch slice of such a layer costs every rank the whole layer's time.
-HYBRID_FILL_ROWS = 256 * 128
+# hybrid: a layer is split by batch index only while a rank's share still fills the chip with resident row tiles: 256 CUs x
+# the three 128-row workgroups a CU holds of the kernels that serve the tall layers.  Below that a tile's time is set by
+# its K stages, not by its rows (128 tiles of a 784 x 256 x 2304 layer take the time of 256), so a batch
+# slice of such a layer costs every rank most of the whole layer's time.  Whole layers balance well on their own: the
+# ResNet tables repeat each shape 1-6 times (bytes within 1.2 % at 8 ranks).
+HYBRID_FILL_ROWS = 768 * 128
+
+
+def layer_cost(m, n, k, b):
+    """Modelled time of one layer (arbitrary unit): the elements it streams over the rate its kernel family reaches alone
+    (bench.py `families`: direct 4.9, wide 3.0, A-stationary 3.1, span 2.9 TB/s of algorithmic bytes, round 3)."""
+    by = b * (m * k + m * n) + k * n
+    if k % 64:
+        rate = 2.9
+    elif n <= 128 or (n <= 256 and k <= 64):
+        rate = 4.9
+    elif n > 256 and k <= 512:
+        rate = 3.1
+    else:
+        rate = 3.0
+    return by / rate
 
 
 def env_world():
@@ -43,8 +60,8 @@ def plan_units(shapes, world, rank, mode="weak"):
             config-4 sweep over several tables), deterministic: ties by layer index, equal loads to the lower rank
     hybrid: strong scaling (total work fixed) with the granularity chosen per layer: a layer whose per-rank batch share
             still has >= HYBRID_FILL_ROWS rows is split by batch index as in `strong`; a smaller one stays whole and goes
-            to the least-loaded rank (LPT by the layer's A + B + C bytes on top of the split layers' equal shares).  What
-            `bench.py --gpus N` uses by default on one table"""
+            to the least-loaded rank (LPT by the layer's modelled time, layer_cost(), on top of the split layers' equal shares).
+            What `bench.py --gpus N` uses by default on one table"""
     if mode not in MODES:
         raise ValueError(mode)
     if world < 1 or not (0 <= rank < world):
@@ -59,7 +76,7 @@ def plan_units(shapes, world, rank, mode="weak"):
                 out.append((l, lo, hi))
         return out
     if mode == "hybrid":
-        by = lambda m, n, k, b: b * (m * k + m * n) + k * n  # elements streamed: the layers are HBM-bound
+        by = layer_cost  # modelled time: the layers are HBM-bound, at a rate that depends on the kernel family
         out, whole, load = [], [], [0.0] * world
         for l, (m, n, k, b) in enumerate(shapes):
             if world > 1 and (b < world or m * (b // world) < HYBRID_FILL_ROWS):
