@@ -562,6 +562,9 @@ int gemm_f16_f32out(const void* A, const void* B2, float* C, size_t M, size_t N,
     case 6: return launch_dma<64, 128, 1, 4, 2, false, true>(a, st);
     case 7: return launch_dma<128, 64, 4, 1, 2, false, true>(a, st);
     case 8: return launch_dma<64, 128, 1, 4, 3, false, true>(a, st);
+    case 9: return launch_dma<256, 256, 2, 4, 2, false, true>(a, st);
+    case 10: return launch_dma<256, 128, 2, 2, 2, false, true>(a, st);
+    case 11: return launch_dma<128, 256, 2, 2, 2, false, true>(a, st);
     default: break;
   }
 #endif
