@@ -131,12 +131,20 @@ def main():
     ap.add_argument("--cost", choices=["bytes", "model"], default="bytes", help="what the longest-first spreading of work items balances")
     ap.add_argument("--item-order", choices=["big-first", "small-first"], default="big-first", help="order of a stream's items")
     ap.add_argument("--big-streams", type=int, default=2, help="--sched split: streams reserved for the chip-filling items")
+    ap.add_argument("--emulate-world", type=int, default=0,
+                    help="predict an N-GPU run on ONE GPU: the data path has no collective, so rank r's time is measurable alone. "
+                         "For r = 0..N-1 a fresh child process (started before this process touches a GPU; it never does) runs rank "
+                         "r's units of the --scaling plan; the parent reports max_r t_r, sum(flops) / max t and the spread, labelled "
+                         "'predicted, single-GPU emulation' (no RCCL, no contention between ranks, one box's clock)")
+    ap.add_argument("--emu-rank", type=int, default=None, help=argparse.SUPPRESS)  # child of --emulate-world: whose units to run
     ap.add_argument("--rehearse-gloo", action="store_true",
                     help="multi-rank rehearsal on a ONE-GPU box: gloo backend, every rank on cuda:0 (control flow only; "
                          "the ranks share the device, so the numbers mean nothing)")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("bench: --gpus must be >= 1")
+    if args.emulate_world and args.emu_rank is None:
+        raise SystemExit(emulate_world(args))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: this process becomes the launcher of N ranks.  It has not imported torch and
         # never touches a GPU; the ranks are child processes (no exec), rank 0's JSON line and the exit code are relayed.
@@ -155,9 +163,10 @@ def main():
     if world > 1 and not args.rehearse_gloo and torch.cuda.device_count() < world:
         raise SystemExit(f"bench: {world} ranks asked for, {torch.cuda.device_count()} GPU(s) visible "
                          "(--rehearse-gloo rehearses the control flow on one GPU)")
+    plan_world, plan_rank = (args.emulate_world, args.emu_rank) if args.emu_rank is not None else (world, rank)
     if args.scaling is None:
         ntab = len((args.tables or args.table or "x").split(","))
-        args.scaling = "weak" if world == 1 else ("lpt" if ntab > 1 else "hybrid")
+        args.scaling = "weak" if plan_world == 1 else ("lpt" if ntab > 1 else "hybrid")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -179,7 +188,7 @@ def main():
     tables = (args.tables or args.table or ("resnet18" if f32 else "resnet50")).split(",")
     tables = [table_path(t) for t in tables]
     shapes = [s_ for t in tables for s_ in read_shapes(t)]
-    units = mg.plan_units(shapes, world, rank, args.scaling)
+    units = mg.plan_units(shapes, plan_world, plan_rank, args.scaling)
     tdt = {"f16": torch.float16, "bf16": torch.bfloat16, "f32": torch.float32}[args.dtype]
     es = 4 if f32 else 2
     layers = []
@@ -433,6 +442,7 @@ def main():
         "metric": "effective GF/s (2:4 spmma vs dense gemm) on ResNet-50 layer shapes",
         "value": value, "unit": "GF/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak" if args.scaling == "weak" else "strong",
+        "partition_mode": args.scaling,  # the real mode name (`scaling` keeps the contract's two values: hybrid / lpt fix the total work = strong)
         "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": "datasets/%s: %d conv layers as im2col GEMMs (m,n,k) at b=%d, %s; step = per layer "
                                "2:4 prune(STRIP)+compress+matmul of the unpruned A"
@@ -448,6 +458,8 @@ def main():
                                   "{sum flops, max seconds}"},
     }
 
+    if args.emu_rank is not None:
+        out["emulated"] = {"world": plan_world, "rank": plan_rank, "units": len(units), "dense_equiv_gflop_per_step": flops / 1e9}
     if rank == 0 and not args.no_extras:
         extras(args, sm, torch, dev, layers, flops, wall / args.steps, Forked, make_runner, timed, event_seconds, use_fused, out,
                (fused_groups, run_group, spread, ForkedItems) if grouped else None, step_full)
@@ -460,6 +472,61 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out))
+
+
+def emulate_world(args):
+    """`--emulate-world N`: one child process per emulated rank, each alone on the one GPU; this process never imports torch.
+    A strong (pure batch split) plan with b % N == 0 gives every rank the same shapes: rank 0 is measured and the others
+    are stated to be identical."""
+    import subprocess
+    N = args.emulate_world
+    if N < 1:
+        raise SystemExit("bench: --emulate-world must be >= 1")
+    ntab = len((args.tables or args.table or "x").split(","))
+    mode = args.scaling or ("weak" if N == 1 else ("lpt" if ntab > 1 else "hybrid"))
+    argv = []
+    skip = 0
+    for a in sys.argv[1:]:  # the child's command line: ours without --emulate-world / --scaling / --gpus
+        if skip:
+            skip -= 1
+            continue
+        if a in ("--emulate-world", "--scaling", "--gpus"):
+            skip = 1
+            continue
+        if a.startswith(("--emulate-world=", "--scaling=", "--gpus=")):
+            continue
+        argv.append(a)
+
+    def child(extra):
+        cmd = [sys.executable, os.path.abspath(__file__)] + argv + ["--no-extras", "--no-cpu-baseline"] + extra
+        res = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)
+        lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+        if res.returncode != 0 or len(lines) != 1:
+            raise SystemExit(f"bench --emulate-world: child {extra} failed (rc {res.returncode})")
+        return json.loads(lines[0])
+
+    base = child(["--scaling", "weak"])  # N = 1: the whole table on the one GPU
+    shapes = [s_ for t in (args.tables or args.table or ("resnet18" if args.dtype == "f32" else "resnet50")).split(",") for s_ in read_shapes(table_path(t))]
+    identical = mode == "weak" or (mode == "strong" and all(b % N == 0 for _, _, _, b in shapes))
+    ranks = [0] if identical else list(range(N))
+    per = {r: child(["--scaling", mode, "--emulate-world", str(N), "--emu-rank", str(r)]) for r in ranks}
+    ms = [per[r if not identical else 0]["ms_per_step"] for r in range(N)]
+    gf = [per[r if not identical else 0]["emulated"]["dense_equiv_gflop_per_step"] for r in range(N)]
+    tmax = max(ms)
+    total = sum(gf)
+    out = {"metric": base["metric"], "value": total / (tmax * 1e-3), "unit": "GF/s", "n_gpus": N,
+           "label": "predicted, single-GPU emulation: every rank's units ran ALONE on one MI355X, each in a fresh process; no RCCL, no "
+                    "contention between ranks, one box's clock -- not a measured N-GPU run",
+           "predicted": True, "partition_mode": mode, "scaling": "weak" if mode == "weak" else "strong",
+           "per_rank_ms": ms, "per_rank_gflop": gf, "max_ms": tmax, "min_ms": min(ms),
+           "spread": (max(ms) - min(ms)) / (sum(ms) / len(ms)),
+           "ranks_measured": ranks, "ranks_identical_by_construction": identical,
+           "n1_ms": base["ms_per_step"], "n1_value": base["value"],
+           "predicted_speedup_vs_n1": (total / (tmax * 1e-3)) / base["value"],
+           "steps": args.steps, "warmup": args.warmup, "dtype": args.dtype, "data": "synthetic",
+           "config": {"workload": base["config"]["workload"], "library": base["config"]["library"]}}
+    print(json.dumps(out))
+    return 0
 
 
 def launch_ranks(args):

@@ -125,12 +125,15 @@ __device__ __forceinline__ void smfmac_stage(const char* As, const char* Ms, con
 // B sweep of one 64-deep stage for one wave: B fragments from the row-major [64][BN] image `Bs` through
 // ds_read_b64_tr_b16 (issued by hand, counted lgkmcnt: fragment j+1's four reads in flight while fragment j's SMFMACs run),
 // FM x FN v_smfmac_f32_16x16x64 with the A operands / index halfwords the caller built.
-template <int FM, int FN, bool BF = false>
+template <int FM, int FN, bool BF = false, int D = 1>
 __device__ __forceinline__ void smfmac_b_sweep(const h8 (&af)[FM], const int (&idx)[FM], const char* Bs, unsigned col0, unsigned lane,
                                                f4 (&acc)[FM][FN]) {
+  // D = B fragments requested ahead of the one being multiplied (1: the default; 2: two fragments = eight reads in flight,
+  // for wave tiles with few SMFMACs per fragment, where one fragment's two SMFMACs do not cover the next one's LDS latency)
+  static_assert(D == 1 || D == 2, "fragments in flight");
   const unsigned g = lane >> 4, r = lane & 15u;
   const unsigned bs_addr = (unsigned)(uintptr_t)(lds_char*)Bs;
-  s4 t0[2], t1[2], t2[2], t3[2];
+  s4 t0[D + 1], t1[D + 1], t2[D + 1], t3[D + 1];
   auto issue = [&](int j, s4& v0, s4& v1, s4& v2, s4& v3) {
     const unsigned c0 = col0 + j * 16, q = r >> 2, pp = r & 3u;
     const unsigned a = bs_addr + b_off<64>(8u * g + q, c0 + 4u * pp);
@@ -138,12 +141,16 @@ __device__ __forceinline__ void smfmac_b_sweep(const h8 (&af)[FM], const int (&i
                  "ds_read_b64_tr_b16 %2, %4 offset:4096\n\tds_read_b64_tr_b16 %3, %4 offset:4608"
                  : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3) : "v"(a) : "memory");
   };
-  issue(0, t0[0], t1[0], t2[0], t3[0]);
+#pragma unroll
+  for (int j = 0; j < D; ++j)
+    if (j < FN) issue(j, t0[j], t1[j], t2[j], t3[j]);
 #pragma unroll
   for (int j = 0; j < FN; ++j) {
-    const int c = j & 1, n = c ^ 1;
-    if (j + 1 < FN) {
-      issue(j + 1, t0[n], t1[n], t2[n], t3[n]);
+    const int c = j % (D + 1), n = (j + D) % (D + 1);
+    if (j + D < FN) {
+      issue(j + D, t0[n], t1[n], t2[n], t3[n]);
+      asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(t0[c]), "+v"(t1[c]), "+v"(t2[c]), "+v"(t3[c]) : "n"(4 * D) : "memory");
+    } else if (D == 2 && j + 1 < FN) {
       asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(t0[c]), "+v"(t1[c]), "+v"(t2[c]), "+v"(t3[c]) :: "memory");
     } else {
       asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t0[c]), "+v"(t1[c]), "+v"(t2[c]), "+v"(t3[c]) :: "memory");
@@ -174,7 +181,7 @@ __device__ __forceinline__ void dense16_to_operand(const u4 lo, const u4 hi, h8&
 // at chunk c ^ (r & 7), a_off), and the lane that would read 8 compressed halves + 4 nibbles reads its 16 dense halves
 // (two ds_read_b128) and selects in registers: four strips -> the A operand and the index halfword of
 // v_smfmac_f32_16x16x64_f16.  No compressed image, no metadata, no selecting loader waves.
-template <int FM, int FN, bool BF = false>
+template <int FM, int FN, bool BF = false, int D = 1>
 __device__ __forceinline__ void smfmac_stage_dense_a(const char* Araw, const char* Bs, unsigned row0, unsigned col0,
                                                      unsigned lane, f4 (&acc)[FM][FN]) {
   const unsigned g = lane >> 4, r = lane & 15u;
@@ -187,7 +194,7 @@ __device__ __forceinline__ void smfmac_stage_dense_a(const char* Araw, const cha
     const u4 hi = *reinterpret_cast<const u4*>(Araw + a_off(row, 2u * g + 1u));
     dense16_to_operand(lo, hi, af[i], idx[i]);
   }
-  smfmac_b_sweep<FM, FN, BF>(af, idx, Bs, col0, lane, acc);
+  smfmac_b_sweep<FM, FN, BF, D>(af, idx, Bs, col0, lane, acc);
 }
 
 // Epilogue of the 2:4 matmul kernels, called by EVERY thread of the workgroup after its last barrier: the SMFMAC

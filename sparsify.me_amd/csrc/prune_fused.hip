@@ -324,9 +324,11 @@ __global__ __launch_bounds__(256) void prune_compress_f32_kernel(const PruneFuse
 #pragma unroll
       for (unsigned t = 0; t < 2; ++t) {
         const unsigned rm = (keep[t] >> (4u * r)) & 15u;
-        bad |= __builtin_popcount(rm) > 2;  // what is about to be written
 #pragma unroll
         for (unsigned c = 0; c < 4; ++c) o[t][c] = ((rm >> c) & 1u) ? v[r][t][c] : 0u;
+        // the flag is derived from the VALUES about to be stored, as sm_prune24_check_f32 derives it from the stored matrix
+        // (more than two of a strip's four != 0; -0 counts as zero) -- not from the keep mask, which has two bits by construction
+        bad |= ((key_of(o[t][0]) != 0u) + (key_of(o[t][1]) != 0u) + (key_of(o[t][2]) != 0u) + (key_of(o[t][3]) != 0u)) > 2;
         // what sm_compress24_f32 stores for the pruned strip: the STRIP selection of ITS values (== rm unless a zero was kept)
         const unsigned ks = strip_keepmask(key_of(o[t][0]), key_of(o[t][1]), key_of(o[t][2]), key_of(o[t][3]));
         nb[t] = nibble_of(ks);

@@ -199,6 +199,194 @@ static int launch_fused_direct(const FusedArgs& a0, hipStream_t st) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// BIG form of the direct kernel (round 4): 256-row tiles, eight waves, split rings.  Same ownership as the direct kernel
+// -- wave w owns rows 32 w .. 32 w + 31 of the tile and ALL its BN columns, every row of A is selected exactly once, by
+// the lane that feeds it to the SMFMAC -- but one workgroup per CU with the whole LDS: the dense A stages (256 rows x
+// 128 B = 32 KiB) sit in a ring of NSA = 3 and the B stages (64 x BN halves) in a ring of NSB = 2, so TWO stages of A
+// (the operand that comes from HBM) are in flight per CU while B (served by L2) needs one.  Why: the few-tile families
+//  are bound by the per-stage synchronisation chain at 21-47 lines outstanding per CU; a 256 x 256 tile
+// does twice the work per barrier, halves the B bytes a CU pulls from L2 per A byte (A : B = 1 : 1 instead of 1 : 2) and
+// keeps 64 KiB of HBM reads in flight per CU.  Issue order per iteration: B(kt + NSB - 1) then A(kt + NSA - 1); vmcnt
+// retires in order, so at iteration kt's wait everything up to B(kt) has landed once only the pieces issued after it
+// -- A(kt + 1) when NSA = 3 / NSB = 2 -- remain.  Same operands, same instruction sequence per output element as the
+// direct / wide kernels: bit-identical C.
+// ---------------------------------------------------------------------------------------------
+template <int BN, bool BF = false, int NSA = 3, int NSB = 2, bool ANT = true, int BPF = 1, bool STAG = false>
+__global__ __launch_bounds__(512) void spmma_f16_fused_big_kernel(const FusedArgs p) {
+  constexpr int BM = 256, NW = 8, TM = BM / NW, FM = TM / 16, FN = BN / 16;
+  constexpr int SA = BM * 128, SB = 64 * BN * 2;
+  constexpr int A_N = BM / 8, B_N = BN / 8;  // 1 KiB DMA wave-instructions per stage
+  static_assert(A_N % NW == 0 && B_N % NW == 0, "equal DMA share per wave");
+  static_assert(NSA == 3 && (NSB == 2 || NSB == 3), "ring depths the counted waits below are written for");
+  constexpr int SLA = A_N / NW, SLB = B_N / NW;
+  constexpr int AHEAD = SLA + (NSB == 3 ? SLB : 0);  // pieces issued after B(kt) / A(kt) that may stay in flight at iteration kt
+  constexpr int BRING = NSA * SA;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const unsigned tid = threadIdx.x, lane = tid & 63u;
+  const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const unsigned tiles = (unsigned)p.tiles_m * (unsigned)p.tiles_n;
+  const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
+  const unsigned gb = lid / tiles, trem = lid - gb * tiles;
+  const unsigned grp = gb / (unsigned)p.batch, b = gb - grp * (unsigned)p.batch;
+  const unsigned tile_m = trem / (unsigned)p.tiles_n, tile_n = trem - tile_m * (unsigned)p.tiles_n;
+  const int m0 = (int)tile_m * BM, n0 = (int)tile_n * BN;
+  const int nkt = p.K / 64;
+  const half_t* A = p.A[grp] + (size_t)b * p.sA;
+  const half_t* B = p.B[grp] + (size_t)b * p.sB;
+  half_t* C = p.C[grp] + (size_t)b * p.sC;
+  const int mlast = p.Mrows - 1;
+
+  const char* asrc[SLA];
+  const char* bsrc[SLB];
+  unsigned aoff[SLA], boff[SLB];
+#pragma unroll
+  for (int i = 0; i < SLA; ++i) {  // 8 rows x 128 B: lane -> row 8t + lane/8, LDS chunk lane%8 holds source chunk (lane%8) ^ (row&7)
+    const unsigned t = wave + (unsigned)NW * i;
+    const unsigned row = 8u * t + (lane >> 3), cs = (lane & 7u) ^ (row & 7u);
+    int gr = m0 + (int)row;
+    gr = gr < mlast ? gr : mlast;
+    asrc[i] = reinterpret_cast<const char*>(A + (size_t)gr * p.lda) + 16u * cs;
+    aoff[i] = t * 1024u;
+  }
+#pragma unroll
+  for (int i = 0; i < SLB; ++i) {
+    const unsigned j = wave + (unsigned)NW * i, panel = j >> 3, kr = 8u * (j & 7u) + (lane >> 3);
+    const unsigned cs = (lane & 7u) ^ b_swz(kr);
+    int gc = n0 + (int)(64u * panel + 8u * cs);
+    gc = gc <= p.N - 8 ? gc : p.N - 8;
+    bsrc[i] = reinterpret_cast<const char*>(B + (size_t)kr * p.N + gc);
+    boff[i] = BRING + panel * 8192u + (j & 7u) * 1024u;
+  }
+  const size_t bstep = (size_t)64 * p.N * 2;
+  auto stage_a = [&](int kt, int buf) {  // A is read once by the whole grid when there is one column tile: non-temporal
+#pragma unroll
+    for (int i = 0; i < SLA; ++i) {
+      if (ANT) __builtin_amdgcn_global_load_lds((gptr_t*)(asrc[i] + (size_t)kt * 128), (lptr_t*)(smem + buf * SA + aoff[i]), 16, 0, 2);
+      else __builtin_amdgcn_global_load_lds((gptr_t*)(asrc[i] + (size_t)kt * 128), (lptr_t*)(smem + buf * SA + aoff[i]), 16, 0, 0);
+    }
+  };
+  auto stage_b = [&](int kt, int buf) {
+#pragma unroll
+    for (int i = 0; i < SLB; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t*)(bsrc[i] + (size_t)kt * bstep), (lptr_t*)(smem + buf * SB + boff[i]), 16, 0, 0);
+  };
+
+  f4 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+
+  // prologue = iterations -(NSA-1) .. -1 of the loop's issue pattern
+#pragma unroll
+  for (int j = -(NSA - 1); j < 0; ++j) {
+    if (j + NSB - 1 >= 0 && j + NSB - 1 < nkt) stage_b(j + NSB - 1, j + NSB - 1);
+    if (j + NSA - 1 < nkt) stage_a(j + NSA - 1, j + NSA - 1);
+  }
+  int ca = 0, cb = 0, fa = NSA - 1, fb = NSB - 1;  // current / next-to-fill slots of the two rings
+  SM_T(unsigned long long tv = 0, tb = 0, ti = 0, ts = 0, tc = 0; unsigned long long s0 = sm_stamp(); const unsigned long long sstart = s0;)
+  for (int kt = 0; kt < nkt; ++kt) {
+#ifdef SM_STAMP
+    if (kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AHEAD) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long sv = sm_stamp(); tv += sv - s0;
+    asm volatile("s_barrier" ::: "memory");
+    const unsigned long long sb = sm_stamp(); tb += sb - sv;
+#else
+    if (kt + 1 < nkt) wait_dma_and_barrier<AHEAD>();
+    else wait_dma_and_barrier<0>();
+#endif
+    // STAG: the two waves of a SIMD (w, w + 4) run the same program in lockstep between barriers -- both in the DMA issue,
+    // both in the selection (VALU), both in the B sweep (MFMA) at the same time.  Waves 4-7 therefore issue their A pieces
+    // (two stages ahead: nothing waits for them soon) AFTER their compute: their selection runs beside the partner's DMA
+    // issue, their sweep beside its selection.  Same issue ORDER per wave (B then A), so the counted waits are unchanged.
+    const bool late_a = STAG && wave >= 4u;
+    if (kt + NSB - 1 < nkt) stage_b(kt + NSB - 1, fb);  // the slots stage kt - 1 occupied: every wave left them before this barrier
+    if (!late_a && kt + NSA - 1 < nkt) stage_a(kt + NSA - 1, fa);
+#ifdef SM_STAMP
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned long long si = sm_stamp(); ti += si - sb;
+    {
+      const unsigned g = lane >> 4, r = lane & 15u;
+      const char* Araw = smem + ca * SA;
+      h8 af[FM];
+      int idx[FM];
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        const unsigned row = wave * TM + i * 16 + r;
+        const u4 lo = *reinterpret_cast<const u4*>(Araw + a_off(row, 2u * g));
+        const u4 hi = *reinterpret_cast<const u4*>(Araw + a_off(row, 2u * g + 1u));
+        dense16_to_operand(lo, hi, af[i], idx[i]);
+      }
+#pragma unroll
+      for (int i = 0; i < FM; ++i) asm volatile("" : "+v"(af[i]), "+v"(idx[i]));
+      __builtin_amdgcn_sched_barrier(0);
+      const unsigned long long ss = sm_stamp(); ts += ss - si;
+      smfmac_b_sweep<FM, FN, BF, BPF>(af, idx, smem + BRING + cb * SB, 0, lane, acc);
+      __builtin_amdgcn_sched_barrier(0);
+      s0 = sm_stamp(); tc += s0 - ss;
+    }
+#else
+    smfmac_stage_dense_a<FM, FN, BF, BPF>(smem + ca * SA, smem + BRING + cb * SB, wave * TM, 0, lane, acc);
+#endif
+    if (late_a && kt + NSA - 1 < nkt) stage_a(kt + NSA - 1, fa);
+    ca = ca + 1 == NSA ? 0 : ca + 1;
+    fa = fa + 1 == NSA ? 0 : fa + 1;
+    cb = cb + 1 == NSB ? 0 : cb + 1;
+    fb = fb + 1 == NSB ? 0 : fb + 1;
+  }
+  __syncthreads();
+  SM_T(const unsigned long long sloop = sm_stamp();)
+  store_c_tile<BM, BN, FM, FN, 64 * NW, BF>(smem, C, acc, true, wave * TM, 0, m0, n0, p.Mrows, p.N, p.alpha, p.beta, tid);
+  SM_T(if (p.dbg && lane == 0) { unsigned long long* d = p.dbg + ((size_t)blockIdx.x * NW + wave) * 8; const unsigned long long se = sm_stamp();
+        d[0] = tv; d[1] = tb; d[2] = ti; d[3] = ts; d[4] = tc; d[5] = sloop - sstart; d[6] = se - sloop; })
+}
+
+template <int BN, bool BF = false, int NSA = 3, int NSB = 2, bool ANT = true, int BPF = 1, bool STAG = false>
+static int launch_fused_big(const FusedArgs& a0, hipStream_t st) {
+  constexpr int BM = 256;
+  FusedArgs a = a0;
+  a.tiles_m = (a.Mrows + BM - 1) / BM;
+  a.tiles_n = (a.N + BN - 1) / BN;
+  const size_t nwg = (size_t)a.tiles_m * a.tiles_n * a.batch * a.ngroup;
+  if (nwg == 0) return SM_STATUS_SUCCESS;
+  if (nwg > 0x7fffffffu) {
+    set_error("sm_spmma_fused_f16: grid too large");
+    return SM_STATUS_NOT_SUPPORTED;
+  }
+  constexpr size_t lds_main = (size_t)NSA * BM * 128 + (size_t)NSB * 64 * BN * 2;
+  constexpr size_t lds_epi = (size_t)BM * (BN * 2 + 16);
+  constexpr size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
+  static_assert(lds <= 160 * 1024, "LDS budget of the big direct kernel");
+  static LdsOptIn lds_optin;
+  if (const int rc = ensure_dyn_lds(lds_optin, reinterpret_cast<const void*>(&spmma_f16_fused_big_kernel<BN, BF, NSA, NSB, ANT, BPF, STAG>), lds, "spmma_f16_fused_big_kernel")) return rc;
+#ifdef SM_STAMP
+  {
+    static unsigned long long* dbg = nullptr;
+    static size_t cap = 0;
+    const size_t cnt = nwg * 8 * 8;
+    if (cnt > cap) { if (dbg) (void)hipFree(dbg); (void)hipMalloc((void**)&dbg, cnt * 8); cap = cnt; }
+    (void)hipMemset(dbg, 0, cnt * 8);
+    a.dbg = dbg;
+    spmma_f16_fused_big_kernel<BN, BF, NSA, NSB, ANT, BPF, STAG><<<dim3((unsigned)nwg), dim3(512), lds, st>>>(a);
+    (void)hipDeviceSynchronize();
+    std::vector<unsigned long long> h(cnt);
+    (void)hipMemcpy(h.data(), dbg, cnt * 8, hipMemcpyDeviceToHost);
+    double t[7] = {0, 0, 0, 0, 0, 0, 0};
+    for (size_t i = 0; i < cnt / 8; ++i)
+      for (int j = 0; j < 7; ++j) t[j] += (double)h[i * 8 + j];
+    const double nwv = (double)(cnt / 8), nk = (double)(a.K / 64);
+    fprintf(stderr, "STAMP-FUSED-BIG %dx%dx%d BN=%d NSA=%d NSB=%d tiles=%zu nkt=%d | per wave per stage: vmcnt-wait %.0f barrier %.0f dma-issue %.0f select %.0f b-sweep %.0f | loop %.0f epilogue %.0f cycles per tile\n",
+            a.Mrows, a.N, a.K, BN, NSA, NSB, nwg, a.K / 64, t[0] / nwv / nk, t[1] / nwv / nk, t[2] / nwv / nk, t[3] / nwv / nk, t[4] / nwv / nk, t[5] / nwv, t[6] / nwv);
+    return check_launch("spmma_f16_fused_big_kernel");
+  }
+#endif
+  spmma_f16_fused_big_kernel<BN, BF, NSA, NSB, ANT, BPF, STAG><<<dim3((unsigned)nwg), dim3(512), lds, st>>>(a);
+  return check_launch("spmma_f16_fused_big_kernel");
+}
+
+// ---------------------------------------------------------------------------------------------
 // Rows that are NOT whole 64-deep stages of 16-byte aligned pieces (k % 64 != 0 or k % 8 != 0: the 7 x 7 x 3 stem layer
 // of every ResNet, k = 147), n <= 128, one tall contiguous A (lda == k, batches back to back): SPAN form.  A tile's 128
 // rows are ONE contiguous span of 128 * k * 2 bytes that starts on a 256-byte boundary, so it reaches LDS by plain
@@ -356,7 +544,7 @@ struct BTileDma {
 // PF stages ahead in registers, only B through LDS -- was built in round 2: bit-identical, 1.3x slower on every n <= 128 layer
 // (profiles/tune_rega_r02q.txt; 164 VGPRs, half-line wave loads).  Removed again; DESIGN.md 4.5, git history.)
 
-template <int BN, int WM, int WN, int NLB, int PF, int NSB, bool BF = false>
+template <int BN, int WM, int WN, int NLB, int PF, int NSB, bool BF = false, int APRIO = 0>
 __global__ __launch_bounds__(64 * (WM * WN + 4 + NLB)) void spmma_f16_fused_wide_kernel(const FusedArgs p) {
   constexpr int BM = 128, NLA = 4, NC = WM * WN, NW = NC + NLA + NLB;
   static_assert(PF >= 1 && PF <= 3 && NSB >= 2 && NSB <= 4, "pipeline depths");
@@ -423,6 +611,9 @@ __global__ __launch_bounds__(64 * (WM * WN + 4 + NLB)) void spmma_f16_fused_wide
     SM_T(if (p.dbg && lane == 0) { unsigned long long* d = p.dbg + ((size_t)blockIdx.x * NW + wave) * 8; d[0] = tb; d[1] = ti; d[2] = tv; d[3] = 2; d[6] = nlong; })
   } else if (wave >= (unsigned)NC) {
     // ------------------------------------------------------------------ A loader wave: load, select, ds_write
+    // (its selection is the stage's critical path and shares a SIMD's vector issue with two consumers and a B loader:
+    //  APRIO > 0 raises its priority once -- the branch is wave-uniform, s_setprio ignores EXEC)
+    if (APRIO > 0) __builtin_amdgcn_s_setprio(APRIO);
     const unsigned lw = wave - NC;
     const half_t* A = p.A[grp] + (size_t)b * p.sA;
     const int mlast = p.Mrows - 1;
@@ -551,7 +742,7 @@ __global__ __launch_bounds__(64 * (WM * WN + 4 + NLB)) void spmma_f16_fused_wide
   store_c_tile<BM, BN, FM, FN, 64 * NW, BF>(smem, C, acc, wave < (unsigned)NC, wm * TM, wn * TN, m0, n0, p.Mrows, p.N, p.alpha, p.beta, tid);
 }
 
-template <int BN, int WM, int WN, int NLB, int PF, int NSB, bool BF = false>
+template <int BN, int WM, int WN, int NLB, int PF, int NSB, bool BF = false, int APRIO = 0>
 static int launch_fused_wide(const FusedArgs& a0, hipStream_t st) {
   FusedArgs a = a0;
   a.tiles_m = (a.Mrows + 127) / 128;
@@ -567,7 +758,7 @@ static int launch_fused_wide(const FusedArgs& a0, hipStream_t st) {
   constexpr size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
   static LdsOptIn lds_optin;
   if (lds > 64 * 1024) {
-    if (const int rc = ensure_dyn_lds(lds_optin, reinterpret_cast<const void*>(&spmma_f16_fused_wide_kernel<BN, WM, WN, NLB, PF, NSB, BF>), lds, "spmma_f16_fused_wide_kernel")) return rc;
+    if (const int rc = ensure_dyn_lds(lds_optin, reinterpret_cast<const void*>(&spmma_f16_fused_wide_kernel<BN, WM, WN, NLB, PF, NSB, BF, APRIO>), lds, "spmma_f16_fused_wide_kernel")) return rc;
   }
 #ifdef SM_STAMP
   {
@@ -578,7 +769,7 @@ static int launch_fused_wide(const FusedArgs& a0, hipStream_t st) {
     if (cnt > cap) { if (dbg) (void)hipFree(dbg); (void)hipMalloc((void**)&dbg, cnt * 8); cap = cnt; }
     (void)hipMemset(dbg, 0, cnt * 8);
     a.dbg = dbg;
-    spmma_f16_fused_wide_kernel<BN, WM, WN, NLB, PF, NSB, BF><<<dim3((unsigned)nwg), dim3(64 * NWV), lds, st>>>(a);
+    spmma_f16_fused_wide_kernel<BN, WM, WN, NLB, PF, NSB, BF, APRIO><<<dim3((unsigned)nwg), dim3(64 * NWV), lds, st>>>(a);
     (void)hipDeviceSynchronize();
     std::vector<unsigned long long> h(cnt);
     (void)hipMemcpy(h.data(), dbg, cnt * 8, hipMemcpyDeviceToHost);
@@ -597,7 +788,7 @@ static int launch_fused_wide(const FusedArgs& a0, hipStream_t st) {
     return check_launch("spmma_f16_fused_wide_kernel");
   }
 #endif
-  spmma_f16_fused_wide_kernel<BN, WM, WN, NLB, PF, NSB, BF><<<dim3((unsigned)nwg), dim3(64 * (WM * WN + 4 + NLB)), lds, st>>>(a);
+  spmma_f16_fused_wide_kernel<BN, WM, WN, NLB, PF, NSB, BF, APRIO><<<dim3((unsigned)nwg), dim3(64 * (WM * WN + 4 + NLB)), lds, st>>>(a);
   return check_launch("spmma_f16_fused_wide_kernel");
 }
 
@@ -1153,6 +1344,32 @@ static int spmma_fused16(size_t ngroup, const void* const* Ag, const void* const
   // registers, ring of 2 so that three workgroups share a CU.  SM_FUSED_DIRECT=3 (tuning aid): ring of 3.
   static const int direct_env = tuning_int("SM_FUSED_DIRECT", 2);
   static const int wide_env = tuning_int("SM_FUSED_WIDE", 0);  // tuning aid: force the wide kernel
+#ifdef SM_TUNING
+  // occupancy of the last round of workgroups when `tiles` one-per-CU workgroups run on `cus` CUs
+  auto round_eff = [](size_t tiles, size_t cus) { const size_t r = (tiles + cus - 1) / cus; return r ? (double)tiles / (double)(r * cus) : 1.0; };
+  if (tuning_int("SM_FUSED_BIG", 0) == 8 && n > 128 && k > 64) {  // the rule that would ship: big where its rounds fill the chip at least as well
+    const size_t cus = (size_t)device_cu_count(), nb = (size_t)a.batch * a.ngroup;
+    const size_t t_big = ((size_t)a.Mrows + 255) / 256 * ((n + 255) / 256) * nb, t_wide = ((size_t)a.Mrows + 127) / 128 * ((n + 255) / 256) * nb;
+    const bool astat_shape = n > 256 && k <= 512 && beta == 0.0f;
+    bool big = round_eff(t_big, cus) >= round_eff(t_wide, cus);
+    if (astat_shape) {
+      const size_t panels = ((size_t)a.Mrows + 127) / 128 * nb;
+      size_t ns = 1, tn = (n + 127) / 128;
+      while (panels * ns * 4 < 3 * cus && (tn + 2 * ns - 1) / (2 * ns) >= 2) ns *= 2;
+      big = round_eff(t_big, cus) > round_eff(panels * ns, cus) + 0.1;
+    }
+    if (big) return n <= 256 ? launch_fused_big<256, BF, 3, 2, true>(a, st) : launch_fused_big<256, BF, 3, 2, false>(a, st);
+  }
+  {  // A/B of the 256-row big form: bit 0 = n >= 256 (k > 64), bit 1 = 64 < n <= 128, bit 2 = n <= 256 with k <= 64; SM_FUSED_BIG_NSB = 2 / 3
+    const int big_env = tuning_int("SM_FUSED_BIG", 0), nsb = tuning_int("SM_FUSED_BIG_NSB", 2), bpf = tuning_int("SM_FUSED_BIG_PF", 1);
+    if (big_env < 8 && (big_env & 1) && n > 128 && k > 64 && tuning_int("SM_FUSED_BIG_STAG", 0)) return n <= 256 ? launch_fused_big<256, BF, 3, 2, true, 1, true>(a, st) : launch_fused_big<256, BF, 3, 2, false, 1, true>(a, st);
+    if (big_env < 8 && (big_env & 2) && n > 64 && n <= 128 && tuning_int("SM_FUSED_BIG_STAG", 0)) return launch_fused_big<128, BF, 3, 2, true, 1, true>(a, st);
+    if (big_env < 8 && (big_env & 1) && n > 128 && k > 64 && bpf == 2) return n <= 256 ? launch_fused_big<256, BF, 3, 2, true, 2>(a, st) : launch_fused_big<256, BF, 3, 2, false, 2>(a, st);
+    if (big_env < 8 && (big_env & 1) && n > 128 && k > 64) return n <= 256 ? launch_fused_big<256, BF, 3, 2, true>(a, st) : launch_fused_big<256, BF, 3, 2, false>(a, st);
+    if (big_env < 8 && (big_env & 4) && n > 128 && n <= 256 && k <= 64) return launch_fused_big<256, BF, 3, 2, true>(a, st);
+    if (big_env < 8 && (big_env & 2) && n > 64 && n <= 128) return nsb == 3 ? launch_fused_big<128, BF, 3, 3, true>(a, st) : launch_fused_big<128, BF, 3, 2, true>(a, st);
+  }
+#endif
   if (!wide_env && (n <= 128 || (n <= 256 && k <= 64))) {
 #ifdef SM_TUNING
     if (tuning_int("SM_FUSED_NW", 4) == 8) {  // eight waves of 16 rows per workgroup: the same LDS, twice the waves per SIMD
@@ -1189,6 +1406,10 @@ static int spmma_fused16(size_t ngroup, const void* const* Ag, const void* const
   // profiles/widep_r03g.txt), so those keep one workgroup per tile.  SM_FUSED_WIDEP (tuning aid): 0 = never, 2 = always.
   static const int widep_env = tuning_int("SM_FUSED_WIDEP", 1);
   if (widep_env == 2 || (widep_env == 1 && k <= 1024)) return launch_fused_widep<256, 4, 2, 4, 2, 3, BF>(a, st);
+#ifdef SM_TUNING
+  if (tuning_int("SM_FUSED_APRIO", 0) > 0) return launch_fused_wide<256, 4, 2, 4, 2, 3, BF, 2>(a, st);
+  if (tuning_int("SM_FUSED_WIDE_PF", 2) == 3) return launch_fused_wide<256, 4, 2, 4, 3, 3, BF>(a, st);
+#endif
   return launch_fused_wide<256, 4, 2, 4, 2, 3, BF>(a, st);
 }
 

@@ -115,11 +115,13 @@ def unit_seed(base, layer, batch_index):
     return (int(base) + 0x9E3779B1 * (layer + 1) + 0x85EBCA77 * (batch_index + 1)) & 0xFFFFFFFFFFFF
 
 
-def rollup(flops_done, seconds, device=None):
-    """(total flops over ranks, max seconds over ranks).  No-op without an initialised process group."""
+def rollup(flops_done, seconds, device=None, force_collective=False):
+    """(total flops over ranks, max seconds over ranks).  No-op without an initialised process group, and -- unless
+    `force_collective` -- with a group of one rank (force_collective: run the two all-reduces anyway, so that a one-GPU
+    box can put the RCCL path of an N-GPU run through the backend: tests/test_bench_multirank.py)."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not force_collective):
         return float(flops_done), float(seconds)
     f = torch.tensor([float(flops_done)], dtype=torch.float64, device=device)
     t = torch.tensor([float(seconds)], dtype=torch.float64, device=device)

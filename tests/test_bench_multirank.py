@@ -43,6 +43,30 @@ def test_bench_gpus2_starts_its_own_ranks():
     assert abs(d["config"]["dense_equiv_gflop_per_step"] - 931.6) < 1.0
 
 
+@pytest.mark.gpu
+def test_rollup_runs_through_rccl_at_world_size_one():
+    """The only collective of an N-GPU run -- multigpu.rollup's two all-reduces -- executed by the `nccl` (= RCCL) backend on
+    the one GPU of the box: world size 1, device-bound process group exactly as bench.py initialises it (bench.py: init_process_group
+    ("nccl", device_id=...)).  In a child process, so that the group's state never meets the test process's."""
+    code = (
+        "import os, sys, json, torch, torch.distributed as dist\n"
+        "sys.path.insert(0, %r)\n"
+        "import __graft_entry__ as ge\n"
+        "mg = ge.load_package_module('multigpu')\n"
+        "os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29547', RANK='0', WORLD_SIZE='1', HSA_ENABLE_IPC_MODE_LEGACY='0')\n"
+        "torch.cuda.set_device(0)\n"
+        "dist.init_process_group('nccl', device_id=torch.device('cuda', 0))\n"
+        "dev = torch.device('cuda', 0)\n"
+        "tot, tmax = mg.rollup(931.6e9, 1.5e-3, dev, force_collective=True)\n"
+        "x = torch.arange(8, dtype=torch.float64, device=dev); dist.all_reduce(x); torch.cuda.synchronize()\n"
+        "print(json.dumps({'backend': dist.get_backend(), 'tot': tot, 'tmax': tmax, 'x': x.tolist()}))\n"
+        "dist.barrier(); dist.destroy_process_group()\n") % ROOT
+    out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["backend"] == "nccl" and d["tot"] == 931.6e9 and d["tmax"] == 1.5e-3 and d["x"] == [float(i) for i in range(8)]
+
+
 def test_bench_refuses_a_rank_count_it_was_not_asked_for():
     """A launcher that realised another world size than --gpus must not pass as an N-GPU run (exits before any GPU call)."""
     env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
