@@ -69,15 +69,29 @@ def library_tag(sm):
             "sm_version": sm.version(), "sha256_16": h, "redirected_by_env": bool(os.environ.get("SPARSIFYME_LIB"))}
 
 
-def fused_variant(n, k):
-    """Which kernel sm_spmma_fused_f16 dispatches a (n, k) layer to (csrc/spmma_f16_fused.hip: spmma_fused16)."""
+def fused_variant(n, k, m=None, b=None, count=1, cus=256):
+    """Which kernel sm_spmma_fused_f16[_grouped] dispatches a layer to (csrc/spmma_f16_fused.hip: spmma_fused16).  With m, b and
+    the instance count of the launch given, the round-4 rule for the 256-row big form is applied too (it depends on how many
+    tiles the launch has); without them the (n, k)-only families of rounds 1-3 are returned."""
     if k % 64 != 0:
         return "span"
     if n <= 128 or (n <= 256 and k <= 64):
         return "direct"
-    if n > 256 and k <= 512:
-        return "astat"
-    return "wide"
+    astat = n > 256 and k <= 512
+    if m is not None:
+        rows = m * b                       # the batches of a shared-B launch are one tall matrix
+        eff = lambda t: t / (-(-t // cus) * cus)
+        t_big = -(-rows // 256) * -(-n // 256) * count
+        t_wide = -(-rows // 128) * -(-n // 256) * count
+        big = eff(t_big) >= eff(t_wide)
+        if astat:
+            panels, ns, tn = -(-rows // 128) * count, 1, -(-n // 128)
+            while panels * ns * 4 < 3 * cus and -(-tn // (2 * ns)) >= 2:
+                ns *= 2
+            big = eff(t_big) > eff(panels * ns) + 0.1
+        if big:
+            return "big"
+    return "astat" if astat else "wide"
 
 
 def main():
@@ -302,7 +316,7 @@ def main():
         if args.cost == "bytes" or f32:
             return by
         L0 = it[1][0]
-        rate = {"direct": 4.9, "span": 2.9, "wide": 3.0, "astat": 3.1}[fused_variant(L0["n"], L0["k"])] if use_fused(L0) else 3.0
+        rate = {"direct": 4.9, "span": 2.9, "wide": 3.0, "astat": 3.1, "big": 3.2}[fused_variant(L0["n"], L0["k"])] if use_fused(L0) else 3.0
         return by / rate
 
     def spread(items):
@@ -458,6 +472,32 @@ def main():
                                   "{sum flops, max seconds}"},
     }
 
+    # What was timed, checked (not timed): C of one layer per kernel family, as the last timed step left it, against
+    # sm_compress24 + sm_spmma on the same operands, bit for bit (the fused kernels' contract; tests/test_gpu_parity.py holds
+    # the full matrix of cases).  A mismatch fails the run: a fast step with different results is not a measurement.
+    if not f32 and args.path == "auto":
+        checked, ok = [], True
+        seen = set()
+        for L in layers:
+            if not use_fused(L):
+                continue
+            fam = fused_variant(L["n"], L["k"], L["m"], L["b"],
+                                min(8, sum(1 for X in layers if (X["m"], X["n"], X["k"], X["b"]) == (L["m"], L["n"], L["k"], L["b"]))) if args.group == "on" else 1)
+            if fam in seen:
+                continue
+            seen.add(fam)
+            Cref = torch.empty_like(L["C"])
+            sm.compress24(L["A"], L["m"], L["k"], L["k"], L["b"], L["m"] * L["k"], L["blob"])
+            sm.spmma(L["blob"], L["B"], Cref, L["m"], L["n"], L["k"], L["b"], 0)
+            same = bool(torch.equal(Cref.view(torch.int16), L["C"].view(torch.int16)))
+            ok = ok and same
+            checked.append({"family": fam, "m": L["m"], "n": L["n"], "k": L["k"], "b": L["b"], "bit_identical_to_compress_plus_spmma": same})
+            del Cref
+        out["verified"] = ok
+        out["verified_layers"] = checked
+        if not ok:
+            sys.stderr.write("bench: the timed step's C differs from compress + spmma: " + json.dumps(checked) + "\n")
+            raise SystemExit(4)
     if args.emu_rank is not None:
         out["emulated"] = {"world": plan_world, "rank": plan_rank, "units": len(units), "dense_equiv_gflop_per_step": flops / 1e9}
     if rank == 0 and not args.no_extras:
@@ -654,6 +694,14 @@ def extras(args, sm, torch, dev, layers, flops, t_full, Forked, make_runner, tim
         out["stages"]["api_spmma_ms"] = t_api * 1e3
         out["stages"]["api_spmma_gfs"] = gfs(t_api)
         out["stages"]["api_spmma_sequence"] = sm.API_SPMMA_SEQUENCE
+        if not f32 and hasattr(sm, "api_spmma_step_fused"):
+            # round 4: the same sequence as ONE kernel (sm_prune24_spmma_*: TILE prune written to the second buffer, flag, multiply,
+            # no blob) on the layers it takes (n <= 128, k % 64 == 0, m % 4 == 0); the two-launch pair on the others
+            t_api1 = sec_per_call(Forked(lambda L: sm.api_spmma_step_fused(L["A"], L["Aapi"], L["B"], L["C"], L["blob"], valid, L["m"], L["n"], L["k"], L["b"])))
+            n_one = sum(1 for L in layers if L["n"] <= 128 and L["n"] % 8 == 0 and L["k"] % 64 == 0 and L["m"] % 4 == 0)
+            out["stages"]["api_spmma_one_kernel_ms"] = t_api1 * 1e3
+            out["stages"]["api_spmma_one_kernel_gfs"] = gfs(t_api1)
+            out["stages"]["api_spmma_one_kernel_layers"] = n_one
         for L in layers:
             del L["Aapi"]
 
@@ -702,9 +750,18 @@ def extras(args, sm, torch, dev, layers, flops, t_full, Forked, make_runner, tim
         fam["compress"] = dict(names=["compress_flat_kernel", "compress_rowspan_f16_kernel", "compress_kernel"], layers=staged,
                                call=lambda L: sm.compress24(L["A"], L["m"], L["k"], L["k"], L["b"], L["m"] * L["k"], L["blob"]),
                                bytes=lambda L: L["b"] * L["m"] * L["k"] * (s + s / 2 + 1 / 8))
-        for var in ("direct", "wide", "astat", "span"):
+        shape_count = {}
+        for L in layers:
+            if use_fused(L):
+                key = (L["m"], L["n"], L["k"], L["b"])
+                shape_count[key] = shape_count.get(key, 0) + 1
+
+        def variant_of(L):  # the kernel the timed step's (grouped) launch of this layer's shape runs
+            cnt = min(8, shape_count[(L["m"], L["n"], L["k"], L["b"])]) if grouping else 1
+            return fused_variant(L["n"], L["k"], L["m"], L["b"], cnt)
+        for var in ("direct", "big", "wide", "astat", "span"):
             fam["spmma_f16_fused_" + var] = dict(names=["spmma_f16_fused_%s_kernel" % var] + (["spmma_f16_fused_widep_kernel"] if var == "wide" else []),
-                                                 layers=[L for L in layers if use_fused(L) and fused_variant(L["n"], L["k"]) == var],
+                                                 layers=[L for L in layers if use_fused(L) and variant_of(L) == var],
                                                  call=lambda L: sm.spmma_fused(L["A"], L["B"], L["C"], L["m"], L["n"], L["k"], batch=L["b"]),
                                                  bytes=A_fu)
     traffic_tab, tsrc = {}, None

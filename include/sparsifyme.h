@@ -115,6 +115,20 @@ int sm_prune24_compress24_bf16(const void* A_in, void* A_out, size_t m, size_t k
 int sm_prune24_compress24_f32(const float* A_in, float* A_out, size_t m, size_t k, size_t ld, size_t batch, size_t strideA,
                               void* blob, int* d_valid, int alg, sm_stream_t stream);
 
+/* ---- (a2 + a4 in ONE kernel, round 4) the whole call sequence of sparsifyme::spmma() (spmma.hxx:82-113: prune TILE in place,
+ *      check, compress, multiply) without a compressed blob: reads A_in once, writes the pruned operand to A_out (A_in itself:
+ *      in place, what the reference does; or a second buffer), raises *d_valid (NULL: not wanted; 0 iff every strip written
+ *      holds <= 2 non-zeros, derived from the stored values) and computes C_b = alpha * prune24(A_b) * B_b + beta * C_b.
+ *      A_out is bit-identical to sm_prune24_*(A_in, alg), C to sm_spmma_*(sm_compress24_*(A_out)).  Takes n <= 128, n % 8 == 0,
+ *      k % 64 == 0, m % 4 == 0 and 16-byte aligned rows; SM_STATUS_NOT_SUPPORTED otherwise (then: sm_prune24_compress24_* +
+ *      sm_spmma_*, which is what include/sparsify.me/spmma.hxx falls back to). */
+int sm_prune24_spmma_f16(const void* A_in, void* A_out, const void* B, void* C, size_t m, size_t n, size_t k, size_t lda,
+                         size_t batch, size_t strideA, size_t strideB, size_t strideC, int alg, int* d_valid, float alpha,
+                         float beta, sm_stream_t stream);
+int sm_prune24_spmma_bf16(const void* A_in, void* A_out, const void* B, void* C, size_t m, size_t n, size_t k, size_t lda,
+                          size_t batch, size_t strideA, size_t strideB, size_t strideC, int alg, int* d_valid, float alpha,
+                          float beta, sm_stream_t stream);
+
 /* ---- (a4) 2:4 sparse x dense matmul: replaces cusparseLtMatmul (spmma.hxx:112-113).
  *      C_b = alpha * A_b * B_b + beta * C_b, row-major, ld(B) = ld(C) = n (spmma.hxx:56-64);
  *      B_b = B + b*strideB (strideB = 0: one shared B), C_b = C + b*strideC (elements).

@@ -19,6 +19,8 @@ LIB_PATH = os.environ.get("SPARSIFYME_LIB") or os.path.join(_HERE, "libsparsifym
 
 PRUNE_TILE = 0
 PRUNE_STRIP = 1
+# include/sparsifyme.h: SM_STATUS_*
+STATUS_SUCCESS, STATUS_INVALID_VALUE, STATUS_NOT_SUPPORTED, STATUS_LAUNCH_FAILED, STATUS_NO_DEVICE = 0, 1, 2, 3, 4
 
 _lib = None
 
@@ -85,6 +87,8 @@ _SIGS = {
 }
 _SIGS["sm_prune24_compress24_f16"] = [_c_ptr, _c_ptr, _c_size, _c_size, _c_size, _c_size, _c_size, _c_ptr, _c_ptr, _c_i, _c_ptr]
 _SIGS["sm_prune24_compress24_bf16"] = _SIGS["sm_prune24_compress24_f16"]
+_SIGS["sm_prune24_spmma_f16"] = [_c_ptr, _c_ptr, _c_ptr, _c_ptr] + [_c_size] * 8 + [_c_i, _c_ptr, _c_f, _c_f, _c_ptr]
+_SIGS["sm_prune24_spmma_bf16"] = _SIGS["sm_prune24_spmma_f16"]
 _SIGS["sm_prune24_compress24_f32"] = _SIGS["sm_prune24_compress24_f16"]
 _SIGS["sm_conv_spmma_fused_f16"] = [_c_ptr, _c_ptr, _c_ptr] + [_c_size] * 10 + [_c_f, _c_f, _c_ptr]
 _SIGS["sm_conv_spmma_fused_bf16"] = _SIGS["sm_conv_spmma_fused_f16"]
@@ -254,6 +258,27 @@ def api_spmma_step(A, Apruned, B, C, blob, d_valid, m, n, k, batch):
     an in-place prune without destroying the bench's operand), check, compress, multiply."""
     prune24_compress24(A, Apruned, m, k, k, batch, m * k, blob, d_valid, PRUNE_TILE)
     spmma(blob, B, C, m, n, k, batch, 0)
+
+
+def prune24_spmma(A_in, A_out, B, C, m, n, k, lda=None, batch=1, strideA=None, strideB=0, strideC=None, alg=PRUNE_TILE, d_valid=None,
+                  alpha=1.0, beta=0.0, check=True):
+    """sparsifyme::spmma()'s whole sequence in one kernel (spmma.hxx:82-113): prune A_in -> A_out (may be A_in), flag, multiply.
+    Returns the status (check=False: SM_STATUS_NOT_SUPPORTED is returned, not raised, so that callers can fall back)."""
+    lda = k if lda is None else lda
+    strideA = m * lda if strideA is None else strideA
+    strideC = m * n if strideC is None else strideC
+    fn = getattr(lib(), "sm_prune24_spmma_" + _sfx(A_in))
+    rc = fn(_dev(A_in), _dev(A_out), _dev(B), _dev(C), m, n, k, lda, batch, strideA, strideB, strideC, alg,
+            _dev(d_valid) if d_valid is not None else None, alpha, beta, _stream())
+    if check or rc not in (0, STATUS_NOT_SUPPORTED):
+        _check(rc, "sm_prune24_spmma")
+    return rc
+
+
+def api_spmma_step_fused(A, Apruned, B, C, blob, d_valid, m, n, k, batch):
+    """api_spmma_step with the one-kernel form where it applies (n <= 128, k % 64 == 0, m % 4 == 0), the two-launch pair elsewhere."""
+    if prune24_spmma(A, Apruned, B, C, m, n, k, batch=batch, d_valid=d_valid, check=False) == STATUS_NOT_SUPPORTED:
+        api_spmma_step(A, Apruned, B, C, blob, d_valid, m, n, k, batch)
 
 
 def decompress24(blob, m, k, ld, batch, strideA, A):

@@ -13,33 +13,6 @@
 
 namespace sm {
 
-// magnitudes of the two 16-bit elements of a dword as fp32 for the TILE sums; NaN -> +inf: the magnitude bits are
-// clamped to the infinity pattern (integer min) before the conversion.  (Written on scalar halves: extracting element 1
-// of a packed 16-bit min result is miscompiled by this toolchain -- the high half's conversion disappears.)
-template <bool BF>
-__device__ __forceinline__ void mag2(uint32_t d, float& lo, float& hi) {
-  constexpr uint32_t LIM = BF ? 0x7f80u : 0x7c00u;
-  const uint32_t a = d & 0x7fff7fffu;
-  uint32_t l = a & 0xffffu, h = a >> 16;
-  l = l < LIM ? l : LIM;
-  h = h < LIM ? h : LIM;
-  if constexpr (BF) {
-    lo = __builtin_bit_cast(float, l << 16);
-    hi = __builtin_bit_cast(float, h << 16);
-  } else {
-    lo = (float)__builtin_bit_cast(_Float16, (uint16_t)l);
-    hi = (float)__builtin_bit_cast(_Float16, (uint16_t)h);
-  }
-}
-
-// AND-mask a strip {d0 = x1:x0, d1 = x3:x2} with its 4-bit keep-mask (pruned positions become +0)
-__device__ __forceinline__ void strip_mask(uint32_t d0, uint32_t d1, uint32_t rm, uint32_t& o0, uint32_t& o1) {
-  const uint32_t m0 = (uint32_t)__builtin_amdgcn_sbfe((int)rm, 0, 1), m1 = (uint32_t)__builtin_amdgcn_sbfe((int)rm, 1, 1);
-  const uint32_t m2 = (uint32_t)__builtin_amdgcn_sbfe((int)rm, 2, 1), m3 = (uint32_t)__builtin_amdgcn_sbfe((int)rm, 3, 1);
-  o0 = d0 & __builtin_amdgcn_perm(m1, m0, 0x07060100u);
-  o1 = d1 & __builtin_amdgcn_perm(m3, m2, 0x07060100u);
-}
-
 struct PruneFusedArgs {
   const uint16_t* A_in;
   uint16_t* A_out;      // may be null (no pruned copy wanted) or alias A_in

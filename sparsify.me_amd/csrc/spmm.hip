@@ -768,7 +768,9 @@ int sm_spmm_coo_f32_ws(size_t A_num_rows, size_t A_num_cols, size_t A_nnz, size_
   }
   const size_t count = A_num_rows * B_num_cols * num_batches;
   if (count == 0) return SM_STATUS_SUCCESS;
-  if (B_num_cols * num_batches > 65535 || num_batches > 65535 || A_nnz > 0x7fffffffull) {
+  // (the CSR kernels index their vector groups by grid x and the fallback by (rows, column groups, batches): no limit on
+  //  B_num_cols * num_batches -- 196 x 2048 x 512 at b = 32 has 65 536 vectors; round 4)
+  if (ceil_div(B_num_cols, (size_t)CSR_J) > 65535 || num_batches > 65535 || A_nnz > 0x7fffffffull) {
     set_error("sm_spmm_coo_f32_ws: shape not supported");
     return SM_STATUS_NOT_SUPPORTED;
   }

@@ -1344,13 +1344,17 @@ static int spmma_fused16(size_t ngroup, const void* const* Ag, const void* const
   // registers, ring of 2 so that three workgroups share a CU.  SM_FUSED_DIRECT=3 (tuning aid): ring of 3.
   static const int direct_env = tuning_int("SM_FUSED_DIRECT", 2);
   static const int wide_env = tuning_int("SM_FUSED_WIDE", 0);  // tuning aid: force the wide kernel
-#ifdef SM_TUNING
-  // occupancy of the last round of workgroups when `tiles` one-per-CU workgroups run on `cus` CUs
+  // (round 4) n > 128: the 256-row BIG form where its one-per-CU workgroups fill the chip's rounds at least as well as the
+  // 128-row kernels' do (profiles/ab_big_r04a.txt: it then wins 3-10 %: 784 x 256 x 1024 x 5, 3136 x 256 x 512, 196 x 512 x 4608 x 3,
+  // 784 x 512 x 1024; it loses where halving the tile count empties the last round: 784 x 256 x 2304 x 6 = 588 tiles = 2.3
+  // rounds against 4.6, 196 x 512 x 2048 x 2 = 100 tiles against 196).  Against the A-stationary kernel (n > 256, k <= 512) it
+  // needs a clear margin (196 x 2048 x 512 x 3: 59 vs 68 us; 784 x 1024 x 256 x 6: 126 vs 111).  SM_FUSED_BIG (tuning): 0 = never.
+  const int big_rule = tuning_int("SM_FUSED_BIG", 8);
   auto round_eff = [](size_t tiles, size_t cus) { const size_t r = (tiles + cus - 1) / cus; return r ? (double)tiles / (double)(r * cus) : 1.0; };
-  if (tuning_int("SM_FUSED_BIG", 0) == 8 && n > 128 && k > 64) {  // the rule that would ship: big where its rounds fill the chip at least as well
+  if (big_rule == 8 && !wide_env && n > 128 && k > 64) {
     const size_t cus = (size_t)device_cu_count(), nb = (size_t)a.batch * a.ngroup;
     const size_t t_big = ((size_t)a.Mrows + 255) / 256 * ((n + 255) / 256) * nb, t_wide = ((size_t)a.Mrows + 127) / 128 * ((n + 255) / 256) * nb;
-    const bool astat_shape = n > 256 && k <= 512 && beta == 0.0f;
+    const bool astat_shape = n > 256 && k <= 512 && beta == 0.0f && aligned16(C) && (strideC % 8 == 0);
     bool big = round_eff(t_big, cus) >= round_eff(t_wide, cus);
     if (astat_shape) {
       const size_t panels = ((size_t)a.Mrows + 127) / 128 * nb;
@@ -1360,6 +1364,7 @@ static int spmma_fused16(size_t ngroup, const void* const* Ag, const void* const
     }
     if (big) return n <= 256 ? launch_fused_big<256, BF, 3, 2, true>(a, st) : launch_fused_big<256, BF, 3, 2, false>(a, st);
   }
+#ifdef SM_TUNING
   {  // A/B of the 256-row big form: bit 0 = n >= 256 (k > 64), bit 1 = 64 < n <= 128, bit 2 = n <= 256 with k <= 64; SM_FUSED_BIG_NSB = 2 / 3
     const int big_env = tuning_int("SM_FUSED_BIG", 0), nsb = tuning_int("SM_FUSED_BIG_NSB", 2), bpf = tuning_int("SM_FUSED_BIG_PF", 1);
     if (big_env < 8 && (big_env & 1) && n > 128 && k > 64 && tuning_int("SM_FUSED_BIG_STAG", 0)) return n <= 256 ? launch_fused_big<256, BF, 3, 2, true, 1, true>(a, st) : launch_fused_big<256, BF, 3, 2, false, 1, true>(a, st);

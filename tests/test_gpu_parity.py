@@ -610,6 +610,71 @@ def test_full_size_properties_resnet50(gpu, orc, shape):
     check_close(got, Cref.view(np.float16), scale, FP16_TOL, f"sampled batch {shape}", k)
 
 
+PRUNE_SPMMA_SHAPES = [(128, 64, 64, 1), (196, 128, 256, 2), (132, 72, 192, 3), (4, 8, 64, 1), (260, 128, 128, 2), (3136, 128, 512, 2), (12544, 64, 576, 1)]
+
+
+@pytest.mark.parametrize("alg", [0, 1], ids=["tile", "strip"])
+@pytest.mark.parametrize("shape", PRUNE_SPMMA_SHAPES, ids=lambda s_: "x".join(map(str, s_)))
+@pytest.mark.parametrize("bf", [False, True], ids=["f16", "bf16"])
+@pytest.mark.parametrize("kind", ["uniform", "ties"])
+def test_prune_spmma_one_kernel(gpu, orc, alg, shape, bf, kind):
+    """sm_prune24_spmma_* -- sparsifyme::spmma()'s whole sequence (spmma.hxx:82-113: prune in place, check, compress, multiply) as
+    one kernel with no blob: the pruned operand it writes is bit-identical to sm_prune24_* (itself held against the oracle,
+    test_prune24 / test_prune24_bf16_vs_oracle; on the small shapes also against the oracle here), C is bit-identical to
+    sm_spmma(sm_compress24(pruned)), the flag is clear and the independent sm_prune24_check agrees; in place and out of place;
+    alpha / beta."""
+    import torch
+    m, n, k, batch = shape
+    tdt = torch.bfloat16 if bf else torch.float16
+    rng = np.random.default_rng(m * 7 + n * 3 + k + batch + alg)
+    if kind == "ties":
+        Ah = rng.integers(-3, 4, batch * m * k).astype(np.float32)
+    else:
+        Ah = rng.uniform(-1, 1, batch * m * k).astype(np.float32)
+    dA = torch.from_numpy(Ah).cuda().to(tdt)
+    dB = torch.empty(k * n, dtype=tdt, device="cuda")
+    gpu.fill_uniform(dB, 0xB1 + n, -1.0, 1.0)
+    C0 = torch.empty(batch * m * n, dtype=tdt, device="cuda")
+    gpu.fill_uniform(C0, 0xC1 + m, -1.0, 1.0)
+    # the staged reference on the GPU: prune -> compress -> spmma
+    P = dA.clone()
+    gpu.prune24(P, P, batch * m, k, k, alg)
+    blob = torch.empty(gpu.compress24_size(m, k, 2, batch), dtype=torch.uint8, device="cuda")
+    gpu.compress24(P, m, k, k, batch, m * k, blob)
+    for (alpha, beta, inplace) in [(1.0, 0.0, False), (0.5, -2.0, True)]:
+        Cref = C0.clone()
+        gpu.spmma(blob, dB, Cref, m, n, k, batch, alpha=alpha, beta=beta)
+        Ain = dA.clone()
+        Aout = Ain if inplace else torch.full_like(Ain, 7.0)
+        C = C0.clone()
+        valid = torch.full((1,), 5, dtype=torch.int32, device="cuda")
+        gpu.prune24_spmma(Ain, Aout, dB, C, m, n, k, batch=batch, alg=alg, d_valid=valid, alpha=alpha, beta=beta)
+        assert torch.equal(Aout.view(torch.int16), P.view(torch.int16)), "pruned operand differs from sm_prune24"
+        assert torch.equal(C.view(torch.int16), Cref.view(torch.int16)), "C differs from spmma(compress(prune(A)))"
+        assert int(valid.item()) == 0
+        if not inplace:
+            assert torch.equal(Ain.view(torch.int16), dA.view(torch.int16)), "A_in was modified by the out-of-place form"
+        chk = torch.ones(1, dtype=torch.int32, device="cuda")
+        gpu.prune24_check(Aout, batch * m, k, k, chk)
+        assert int(chk.item()) == 0
+    if batch * m * k <= 200000 and not bf:  # small: the pruned operand against the oracle directly
+        want = orc.prune24(bits(host(dA)), batch * m, k, k, orc.TILE if alg == 0 else orc.STRIP)
+        assert np.array_equal(bits(host(P)), want)
+
+
+def test_prune_spmma_rejects_what_it_cannot_take(gpu):
+    import torch
+    A = torch.zeros(200 * 256, dtype=torch.float16, device="cuda")
+    B = torch.zeros(256 * 256, dtype=torch.float16, device="cuda")
+    C = torch.zeros(200 * 256, dtype=torch.float16, device="cuda")
+    NS = gpu.STATUS_NOT_SUPPORTED
+    assert gpu.prune24_spmma(A, A, B, C, 196, 256, 256, check=False) == NS       # n > 128: two column tiles would both rewrite A
+    assert gpu.prune24_spmma(A, A, B, C, 196, 64, 72, check=False) == NS         # k % 64 != 0
+    assert gpu.prune24_spmma(A, A, B, C, 130, 64, 64, check=False) == NS         # m % 4 != 0: a 4 x 4 tile would straddle two batches
+    with pytest.raises(gpu.SparsifymeError):
+        gpu.prune24_spmma(A, A, B, C, 196, 64, 64, alg=7)
+
+
 def _resnet50_groups():
     """(m, n, k, count) of datasets/resnet50.csv: the grouped launches of bench.py's timed step (one grid per shape)"""
     import collections
@@ -1245,6 +1310,12 @@ def test_cpp_drivers_cli_contract(gpu):
     lines = out.stdout.strip().splitlines()
     assert out.returncode == 0 and [l.split(":")[0] for l in lines] == ["Pruning Time (ms)", "Compression Time (ms)", "SpMMA Time (ms)"]
     assert "Incorrect pruning" not in out.stderr
+    # this shape runs as ONE kernel (sm_prune24_spmma_f16): one measured time, reported first; nothing compressed, no separate multiply
+    vals = [float(l.split(":")[1]) for l in lines]
+    assert vals[0] > 0.0 and vals[1] == 0.0 and vals[2] == 0.0
+    out = run("spmma", 196, 256, 128, 4)   # n > 128: one-pass prune + check + compress, then the multiply -- three measured values
+    vals = [float(l.split(":")[1]) for l in out.stdout.strip().splitlines()]
+    assert out.returncode == 0 and all(v > 0.0 for v in vals) and "Incorrect pruning" not in out.stderr
     # the reference's own instantiation (type_t = float, examples/spmma.cu:24): one-pass prune + check + compress since round 3
     if not os.path.exists(os.path.join(bins, "spmma_f32")):
         subprocess.run(["make", "-C", os.path.join(root, "examples"), "-j4"], check=True, capture_output=True)
@@ -1279,6 +1350,8 @@ def test_cpp_drivers_cli_contract(gpu):
         assert rows[0][7:10] == ["spmma_prune", "spmma_compress", "spmma_mul"]
         assert len(rows) == 4 and [r[:4] for r in rows[1:]] == [["784", "64", "128", "4"], ["196", "128", "256", "2"], ["392", "72", "64", "3"]]
         assert all(float(x) > 0.0 for r in rows[1:] for x in r[4:10])
+        # round 4: one spmma() call as callers get it (the one-kernel form on these shapes) beside the three staged stages
+        assert rows[0][12] == "spmma_call" and all(0.0 < float(r[12]) for r in rows[1:])
     # cached-plan form (row f-1): compress once, multiply many; the driver compares its C with spmma()'s bit for bit
     for argv in [(196, 64, 128, 4), (784, 256, 1152, 2), (130, 72, 200, 3)]:
         for tool in ("spmma_plan", "spmma_plan_bf16"):

@@ -118,6 +118,14 @@ def test_bench_serves_every_resnet50_layer_with_a_fused_variant():
     assert len(shapes) == 49
     fam = collections.Counter(bench.fused_variant(n, k) for (_, n, k, _) in shapes)
     assert fam == {"direct": 17, "wide": 18, "astat": 13, "span": 1}
+    # round 4: with the launch's tile count known (grouped launches of the table's instance counts at b = 32) the 256-row big form
+    # takes the shapes whose rounds it fills at least as well -- mirror of the rule in spmma_fused16
+    cnt = collections.Counter(shapes)
+    fam = collections.Counter(bench.fused_variant(n, k, m, b, cnt[(m, n, k, b)]) for (m, n, k, b) in shapes)
+    assert fam == {"direct": 17, "span": 1, "big": 13, "wide": 8, "astat": 10}
+    assert bench.fused_variant(256, 2304, 784, 32, 6) == "wide" and bench.fused_variant(256, 1024, 784, 32, 5) == "big"
+    assert bench.fused_variant(2048, 512, 196, 32, 3) == "big" and bench.fused_variant(1024, 256, 784, 32, 6) == "astat"
+    assert bench.fused_variant(256, 2304, 784, 32, 1) == "wide"   # a single instance: 98 big tiles would fill 0.38 of a round
     # the span form's conditions as bench.py states them hold for the stem layer
     m, n, k, b = next(s for s in shapes if s[2] % 64)
     assert (m, n, k, b) == (12544, 64, 147, 32) and (b * m * k * 2) % 16 == 0 and n % 8 == 0 and n <= 128
