@@ -877,7 +877,11 @@ def config5_stage(sm, torch, dev):
     L_ = sm.lib()
     rows = []
     g = torch.Generator(device=dev).manual_seed(5)
-    for (m, n, k, b) in [(784, 256, 2304, 32), (12544, 64, 576, 32), (196, 512, 4608, 32), (3136, 128, 1152, 32)]:
+    seen = []
+    for sh in read_shapes(table_path("resnet50")):   # every unique shape of the table (four of 17 were timed)
+        if sh not in seen:
+            seen.append(sh)
+    for (m, n, k, b) in seen:
         dense = torch.rand(m, k, generator=g, device=dev) < 0.1
         idx = dense.nonzero()            # row-major scan: sorted by row, then column
         r, c = idx[:, 0].to(torch.int32).contiguous(), idx[:, 1].to(torch.int32).contiguous()
@@ -915,15 +919,24 @@ def config5_stage(sm, torch, dev):
                 raise RuntimeError(L_.sm_last_error().decode())
         ms_rowptr = sm.graph_time_ms(call_rowptr, iters=5)
         ms = sm.graph_time_ms(call_packed, iters=5)
-        ms_fast = sm.graph_time_ms(call_fast, iters=5)
         by = nnz * 8.0 + (m + 1) * 4.0 + 4.0 * b * (k * n + m * n)
-        rows.append({"m": m, "n": n, "k": k, "b": b, "nnz": nnz, "ms": ms, "GBs": by / ms / 1e6, "frac": by / ms / 1e6 / HBM_PEAK_GBS,
-                     "TFs": 2.0 * nnz * n * b / ms / 1e9, "ms_rowptr_form": ms_rowptr,
-                     "ms_fast_form": ms_fast, "GBs_fast_form": by / ms_fast / 1e6, "frac_fast_form": by / ms_fast / 1e6 / HBM_PEAK_GBS})
-    return {"kernel": "spmm_csr_packed_kernel (sm_spmm_coo_f32_packed: re-ordering of A + product, whole call); ms_rowptr_form = sm_spmm_coo_f32_ws; "
-                      "ms_fast_form = sm_spmm_coo_f32_fast (explicit opt-in: dense operand rounded to fp16, A split hi + lo, fp16 MFMA with fp32 "
-                      "accumulation; result within 2^-11 of sum|a||b|; whole call incl. its conversion / scatter passes)", "shapes": rows, "unit": "GB/s of algorithmic bytes (SURVEY.md 8(d): nnz*(s+4) + (m+1)*4 + b*s*(k*n + m*n))",
-            "peak": HBM_PEAK_GBS}
+        row = {"m": m, "n": n, "k": k, "b": b, "nnz": nnz, "ms_exact": ms, "GBs_exact": by / ms / 1e6, "frac_exact": by / ms / 1e6 / HBM_PEAK_GBS,
+               "TFs_exact": 2.0 * nnz * n * b / ms / 1e9, "ms_exact_rowptr_form": ms_rowptr}
+        if k % 64 == 0:
+            ms_fast = sm.graph_time_ms(call_fast, iters=5)
+            flag = ctypes.c_int(-1)
+            L_.sm_spmm_coo_fast_flag(ws3.data_ptr(), ctypes.byref(flag), None)
+            row.update({"ms": ms_fast, "GBs": by / ms_fast / 1e6, "frac": by / ms_fast / 1e6 / HBM_PEAK_GBS, "form": "dense-MFMA (strided_coo's default)", "range_flag": flag.value})
+        else:  # the stem layer's k = 147: the dense-MFMA form takes whole 64-deep stages only; strided_coo runs the exact form
+            row.update({"ms": ms, "GBs": by / ms / 1e6, "frac": by / ms / 1e6 / HBM_PEAK_GBS, "form": "exact (packed)", "range_flag": None})
+        rows.append(row)
+        del B, C, ws, ws2, ws3
+    return {"kernel": "what sparsifyme::batched::strided_coo runs since round 4: sm_spmm_coo_f32_fast (dense operand and A scaled by powers of two computed on the "
+                      "device, rounded to fp16 / split hi + lo, fp16 MFMA with fp32 accumulation, inverse scales on the fp32 sums; result within 2^-11 of "
+                      "sum|a||b| at any magnitude; a range flag + untouched C when an operand does not convert -> exact fallback; whole call incl. its scan / "
+                      "conversion / scatter passes) = ms / GBs / frac; the exact forms beside it: ms_exact = sm_spmm_coo_f32_packed (re-ordering of A + product), "
+                      "ms_exact_rowptr_form = sm_spmm_coo_f32_ws", "shapes": rows,
+            "unit": "GB/s of algorithmic bytes (SURVEY.md 8(d): nnz*(s+4) + (m+1)*4 + b*s*(k*n + m*n))", "peak": HBM_PEAK_GBS}
 
 
 def ge_mod():
@@ -967,11 +980,13 @@ def bell_stage(sm, torch, dev):
                 raise RuntimeError(L_.sm_last_error().decode())
         call()
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()  # device time by a HIP event pair on the launch stream (round 3 timed this stage by wall clock)
         for _ in range(5):
             call()
+        e1.record()
         torch.cuda.synchronize()
-        ms = (time.perf_counter() - t0) / 5 * 1e3
+        ms = e0.elapsed_time(e1) / 5
         by = b * (m * ell_cols * 4.0 + (m // bs) * bcols * 8.0 + m * n * 4.0) + k * n * 4.0
         fl = 2.0 * m * n * k * b  # what the expanded fp32 MFMA product executes (stored-value flops are half of it)
         roof_ms = max(by / (HBM_PEAK_GBS * 1e9), fl / (F32_MATRIX_PEAK_TFS * 1e12)) * 1e3
@@ -981,7 +996,7 @@ def bell_stage(sm, torch, dev):
         del vals, idxs, Cs, ws
     return {"kernel": "bell_expand_rows_kernel + gemm_f32_dma_kernel (sm_spmm_bell_batched_f32, one submission for all batches)",
             "shapes": rows, "frac": "roofline time / measured time, roofline = max(algorithmic bytes / 8 TB/s, executed dense flops / 157.3 TF/s)",
-            "timing": "wall clock over 5 calls after one warm-up (host pointer tables: the entry point is not graph-capturable)"}
+            "timing": "HIP event pair on the launch stream around 5 calls after one warm-up (host pointer tables: the entry point is not graph-capturable)"}
 
 
 def config1_cpu(ge):

@@ -82,6 +82,15 @@ float spmm(ell_t<type_t, memory_space_t::device>* As,
   return t.milliseconds();
 }
 
+// exact = true: strided_coo always runs the exact fp32 kernels (default false: the fp16-split dense-MFMA form first, see below)
+struct strided_coo_options_t {
+  bool exact = false;
+};
+inline strided_coo_options_t& strided_coo_options() {
+  static strided_coo_options_t o;
+  return o;
+}
+
 template <typename type_t>
 float strided_coo(std::size_t A_num_rows,
                   std::size_t A_num_cols,
@@ -101,14 +110,37 @@ float strided_coo(std::size_t A_num_rows,
   util::timer_t t;
   util::range_t range("strided-COO-SpMM");
   t.begin();  // the reference times its buffer allocation too (spmm.hxx:155-156,183)
-  // the packed form's workspace (the counterpart of cusparseSpMM's buffer, spmm.hxx:178-183); the call itself picks the
-  // kernel: packed CSR for row-sorted input that fits, the row-pointer form or the atomic kernels otherwise
-  std::size_t ws_bytes = 0;
-  (void)sm_spmm_coo_packed_workspace_size(A_num_rows, A_nnz, &ws_bytes);
-  device_vector<unsigned char> ws(ws_bytes);
-  const int rc = sm_spmm_coo_f32_packed(A_num_rows, A_num_cols, A_nnz, B_num_cols, num_batches, dA_rows, dA_cols,
-                                        reinterpret_cast<const float*>(dA_values), reinterpret_cast<const float*>(dB),
-                                        reinterpret_cast<float*>(dC), alpha, beta, ws.data().get(), ws_bytes, nullptr);
+  int rc = SM_STATUS_NOT_SUPPORTED;
+  // (round 4) First the dense-MFMA form (sm_spmm_coo_f32_fast: operands scaled by powers of two and rounded to fp16, fp32
+  // accumulation; result within 2^-11 of sum|a||b|, include/sparsifyme.h) where it pays -- at least ~2 % of A's entries present:
+  // below that the exact kernels' work, which follows nnz, is less than the dense product's -- and where the library takes the
+  // shape.  It raises a flag on the device and leaves C untouched when an operand does not fit the fp16 range under its scales;
+  // the exact form below then runs on the untouched operands.  strided_coo_options().exact = true skips it.
+  const bool dense_enough = A_nnz * 50 >= A_num_rows * A_num_cols;
+  if (!strided_coo_options().exact && dense_enough) {
+    std::size_t fast_bytes = 0;
+    if (sm_spmm_coo_fast_workspace_size(A_num_rows, A_num_cols, B_num_cols, num_batches, &fast_bytes) == SM_STATUS_SUCCESS) {
+      device_vector<unsigned char> fws(fast_bytes);
+      rc = sm_spmm_coo_f32_fast(A_num_rows, A_num_cols, A_nnz, B_num_cols, num_batches, dA_rows, dA_cols,
+                                reinterpret_cast<const float*>(dA_values), reinterpret_cast<const float*>(dB),
+                                reinterpret_cast<float*>(dC), alpha, beta, fws.data().get(), fast_bytes, nullptr);
+      if (rc == SM_STATUS_SUCCESS) {
+        int flag = 1;
+        if (sm_spmm_coo_fast_flag(fws.data().get(), &flag, nullptr) != SM_STATUS_SUCCESS || flag != 0) rc = SM_STATUS_NOT_SUPPORTED;
+      }
+    }
+  }
+  if (rc != SM_STATUS_SUCCESS) {
+    // the packed form's workspace (the counterpart of cusparseSpMM's buffer, spmm.hxx:178-183); the call itself picks the
+    // kernel: packed CSR for row-sorted input that fits, the row-pointer form or the atomic kernels otherwise
+    std::size_t ws_bytes = 0;
+    (void)sm_spmm_coo_packed_workspace_size(A_num_rows, A_nnz, &ws_bytes);
+    device_vector<unsigned char> ws(ws_bytes);
+    rc = sm_spmm_coo_f32_packed(A_num_rows, A_num_cols, A_nnz, B_num_cols, num_batches, dA_rows, dA_cols,
+                                reinterpret_cast<const float*>(dA_values), reinterpret_cast<const float*>(dB),
+                                reinterpret_cast<float*>(dC), alpha, beta, ws.data().get(), ws_bytes, nullptr);
+    (void)hipStreamSynchronize(nullptr);  // the workspace is released when this scope ends
+  }
   t.end();
   if (rc != SM_STATUS_SUCCESS) std::cerr << "sparsifyme::batched::strided_coo: " << sm_last_error() << std::endl;
   return t.milliseconds();

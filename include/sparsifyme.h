@@ -247,14 +247,25 @@ int sm_spmm_coo_f32_packed(size_t A_num_rows, size_t A_num_cols, size_t A_nnz, s
                            const float* B, float* C, float alpha, float beta, void* workspace,
                            size_t workspace_bytes, sm_stream_t stream);
 
-/* Dense-MFMA form of the same product (extension, round 3; an explicit opt-in, NOT what strided_coo calls): the batches' dense
- * operand is rounded once to fp16 (relative error <= 2^-11 per element, i.e. the result stays within 4.9e-4 of sum|a b| --
- * inside the 1e-3 this build's fp32 products are held to -- plus fp32 accumulation), A is scattered dense and split exactly
- * into two fp16 planes, and the product runs on the fp16 matrix instruction with fp32 accumulation: 2-3 x faster than the
- * exact forms at 90 % sparsity.  Values beyond fp16's range (|x| > 65504) overflow to inf; duplicates add (in an unspecified
- * order).  Needs A_num_cols % 64 == 0, A_num_rows % 4 == 0 (>= 8), 16-byte aligned B and C and
- * sm_spmm_coo_fast_workspace_size bytes of workspace; SM_STATUS_NOT_SUPPORTED otherwise (use the exact entry points). */
+/* Dense-MFMA form of the same product (extension; what sparsifyme::batched::strided_coo tries first since round 4, with the exact
+ * form as its fallback): the batches' dense operand is scaled by a power of two and rounded once to fp16, A is scattered dense,
+ * scaled and split exactly into two fp16 planes, the product runs on the fp16 matrix instruction with fp32 accumulation and the
+ * inverse scales are applied to the fp32 sums: 2-3 x faster than the exact forms at 90 % sparsity.
+ * Scales (round 4, computed on the device: no synchronisation): 2^x that brings the largest |b| of a ~10^6-element strided
+ * sample of the dense operand into [2^12, 2^13) and 2^y that brings the largest |a| into [2^13, 2^14) -- so the error does not
+ * depend on the operands' magnitude (1e-6-sized activations or 1e+6-sized ones convert alike).
+ * Error: |C - exact| <= 2^-11 * |alpha| * sum|a||b|  (one fp16 rounding of b; 4.9e-4, inside the 1e-3 this build's fp32 products are
+ * held to) + fp32 accumulation + 2^-37 * max|b| * |alpha| * sum|a| (elements of the dense operand more than 2^26 below its
+ * largest one lose relative precision: they are rounded to a multiple of 2^-37 of the largest).
+ * Range flag: the first int of the workspace is set != 0 on the device when an element does NOT convert -- non-finite, or more
+ * than 8 x the sampled maximum (|x * scale| > 65504), or duplicates of A adding up beyond the range; the matrix kernel then
+ * returns without touching C, so that the caller can run an exact entry point on the untouched operands:
+ * sm_spmm_coo_fast_flag() copies the flag to the host (it synchronises the stream), which is what strided_coo does.
+ * Duplicates add (in an unspecified order).  Needs A_num_cols % 64 == 0 (> 0), A_num_rows % 4 == 0 (>= 8), 16-byte aligned B and
+ * C and sm_spmm_coo_fast_workspace_size bytes of workspace (SM_STATUS_NOT_SUPPORTED when the sizes overflow size_t);
+ * SM_STATUS_NOT_SUPPORTED otherwise (use the exact entry points). */
 int sm_spmm_coo_fast_workspace_size(size_t A_num_rows, size_t A_num_cols, size_t B_num_cols, size_t num_batches, size_t* bytes /*host*/);
+int sm_spmm_coo_fast_flag(const void* workspace, int* host_flag, sm_stream_t stream);
 int sm_spmm_coo_f32_fast(size_t A_num_rows, size_t A_num_cols, size_t A_nnz, size_t B_num_cols, size_t num_batches,
                          const int* rows, const int* cols, const float* vals, const float* B, float* C, float alpha,
                          float beta, void* workspace, size_t workspace_bytes, sm_stream_t stream);

@@ -79,6 +79,7 @@ _SIGS = {
     "sm_spmm_coo_f32_ws": [_c_size, _c_size, _c_size, _c_size, _c_size, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_f, _c_f,
                            _c_ptr, _c_ptr],
     "sm_spmm_coo_fast_workspace_size": [_c_size, _c_size, _c_size, _c_size, ctypes.POINTER(_c_size)],
+    "sm_spmm_coo_fast_flag": [_c_ptr, ctypes.POINTER(_c_i), _c_ptr],
     "sm_spmm_coo_f32_fast": [_c_size, _c_size, _c_size, _c_size, _c_size, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_f, _c_f,
                              _c_ptr, _c_size, _c_ptr],
     "sm_fill_uniform_f16": [_c_ptr, _c_size, ctypes.c_uint64, _c_f, _c_f, _c_ptr],

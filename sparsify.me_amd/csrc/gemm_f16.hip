@@ -33,6 +33,11 @@ struct GemmArgs {
   // k runs over [0, a_wrap_kt * 64) TWICE (stage kt >= a_wrap_kt re-reads stage kt - a_wrap_kt) against a B of 2 x that depth
   float* C32;
   int a_wrap_kt;
+  // (round 4) device-side scalars of the COO dense-MFMA form: the result is multiplied by alpha_dev[0] and alpha_dev[1] (the
+  // inverses of the operands' power-of-two scales, computed on the device), and a workgroup returns at once when *skip_flag != 0 (an operand left the
+  // fp16 range: C must stay untouched for the exact kernels that run instead)
+  const float* alpha_dev;
+  const int* skip_flag;
 };
 
 // 8 halves starting at p[col]; elements at or beyond `limit` columns read as zero.
@@ -262,6 +267,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_dma_kernel(const GemmAr
   static_assert(LPS >= 1, "every wave must issue at least one DMA per stage");
   constexpr int CPITCH = BN * 2 + 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  if constexpr (F32OUT) {  // (a scalar load: the same for every wave of the grid, before any DMA is issued)
+    if (p.skip_flag && *p.skip_flag != 0) return;
+  }
 
   const unsigned tid = threadIdx.x, lane = tid & 63u;
   const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -377,6 +385,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_dma_kernel(const GemmAr
     // fp32 output straight from the accumulators: a lane holds 4 consecutive columns of one row = one 16-byte store
     // (ldc % 4 == 0 and N % 4 == 0 are the launcher's conditions, so a 4-column piece is all in or all out)
     float* C32 = p.C32 + (size_t)b * p.sC;
+    // two exact power-of-two factors applied one after the other: their product alone need not be a normal float
+    const float alpha_ = p.alpha_dev ? p.alpha * p.alpha_dev[0] : p.alpha, post_ = p.alpha_dev ? p.alpha_dev[1] : 1.0f;
 #pragma unroll
     for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -391,7 +401,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f16_dma_kernel(const GemmAr
         }
         if (gc >= p.N) continue;
         float* dst = C32 + (size_t)gr * p.ldc + gc;
-        f4 v = {p.alpha * acc[i][j][0], p.alpha * acc[i][j][1], p.alpha * acc[i][j][2], p.alpha * acc[i][j][3]};
+        f4 v = {alpha_ * acc[i][j][0] * post_, alpha_ * acc[i][j][1] * post_, alpha_ * acc[i][j][2] * post_, alpha_ * acc[i][j][3] * post_};
         if (p.beta != 0.0f) {
           const f4 o = *reinterpret_cast<const f4*>(dst);
           v = {v[0] + p.beta * o[0], v[1] + p.beta * o[1], v[2] + p.beta * o[2], v[3] + p.beta * o[3]};
@@ -539,7 +549,7 @@ static int launch_gemm_f16(const GemmArgs& a, hipStream_t st, bool ta = false, b
 // (B[0 .. K) + B[K .. 2K)) (ldb, the two fp16 planes of one fp32 operand stacked along k) + beta * C32.  K % 64 == 0,
 // N % 4 == 0, N >= 8, leading dimensions multiples of 4, 8-byte aligned bases (the DMA kernel's conditions).
 int gemm_f16_f32out(const void* A, const void* B2, float* C, size_t M, size_t N, size_t K, size_t lda, size_t ldb, size_t ldc, float alpha,
-                    float beta, hipStream_t st) {
+                    float beta, hipStream_t st, const float* alpha_dev, const int* skip_flag) {
   if (K % 64 != 0 || N % 4 != 0 || N < 8 || lda % 4 != 0 || ldb % 4 != 0 || ldc % 4 != 0 || M > 0x7fffffffull || N > 0x7fffffffull ||
       2 * K > 0x7fffffffull || (reinterpret_cast<uintptr_t>(A) & 7u) || (reinterpret_cast<uintptr_t>(B2) & 7u) || (reinterpret_cast<uintptr_t>(C) & 15u)) {
     set_error("gemm_f16_f32out: shape / alignment not served");
@@ -551,6 +561,8 @@ int gemm_f16_f32out(const void* A, const void* B2, float* C, size_t M, size_t N,
   a.lda = (int)lda; a.ldb = (int)ldb; a.ldc = (int)ldc;
   a.batch = 1; a.alpha = alpha; a.beta = beta;
   a.a_wrap_kt = (int)(K / 64);
+  a.alpha_dev = alpha_dev;
+  a.skip_flag = skip_flag;
   if (N <= 64) return launch_dma<128, 64, 4, 1, 2, false, true>(a, st);
 #ifdef SM_TUNING
   switch (tuning_int("SM_COOFAST_TILE", 0)) {  // A/B of the tile shape of this compute-bound product

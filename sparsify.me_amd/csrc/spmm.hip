@@ -808,16 +808,72 @@ int sm_spmm_coo_packed_workspace_size(size_t A_num_rows, size_t A_nnz, size_t* b
 // ---------------------------------------------------------------------------------------------
 namespace sm {
 int gemm_f16_f32out(const void* A, const void* B2, float* C, size_t M, size_t N, size_t K, size_t lda, size_t ldb, size_t ldc, float alpha,
-                    float beta, hipStream_t st);  // gemm_f16.hip
+                    float beta, hipStream_t st, const float* alpha_dev, const int* skip_flag);  // gemm_f16.hip
 
-__global__ __launch_bounds__(256) void f32_to_f16_kernel(const float* __restrict__ in, _Float16* __restrict__ out, size_t n8) {
+// Header of the fast form's workspace (round 4: power-of-two operand scales, so that the 2^-11 bound does not depend on the
+// operands' magnitude, and a range flag, so that a caller can tell when it did not hold).  All written on the device.
+struct CooFastHdr {
+  int flag;            // != 0: an element left the fp16 range under the call's scales -> C was NOT written (the GEMM returns at once)
+  unsigned max_b;      // bit pattern of max |b| over a strided sample of the dense operand (the scale's ESTIMATE)
+  unsigned max_a;      // bit pattern of max |a| over all values of A (exact)
+  float scale_b, scale_a;              // 2^x, 2^y
+  float inv_scale[2];                  // 2^-y, 2^-x: applied to the fp32 sums one after the other (each a normal float)
+};
+constexpr size_t COO_FAST_HDR_BYTES = 256;
+
+__global__ __launch_bounds__(256) void coo_fast_scan_kernel(const float* __restrict__ vals, size_t nnz, const float* __restrict__ B, size_t nb, size_t bstride,
+                                                            CooFastHdr* hdr) {
+  unsigned ma = 0u, mb = 0u;
+  const size_t t0 = blockIdx.x * (size_t)256 + threadIdx.x, nt = (size_t)gridDim.x * 256;
+  for (size_t i = t0; i < nnz; i += nt) { const unsigned u = __builtin_bit_cast(unsigned, vals[i]) & 0x7fffffffu; ma = u > ma ? u : ma; }
+  for (size_t i = t0 * bstride; i < nb; i += nt * bstride) { const unsigned u = __builtin_bit_cast(unsigned, B[i]) & 0x7fffffffu; mb = u > mb ? u : mb; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned xa = (unsigned)__shfl_xor((int)ma, o), xb = (unsigned)__shfl_xor((int)mb, o);
+    ma = xa > ma ? xa : ma;
+    mb = xb > mb ? xb : mb;
+  }
+  if ((threadIdx.x & 63u) == 0) {
+    if (ma) atomicMax(&hdr->max_a, ma);
+    if (mb) atomicMax(&hdr->max_b, mb);
+  }
+}
+// scale = 2^(target - floor(log2(max))), kept a finite normal float; max = 0 / inf / NaN -> 1 (the conversion pass then flags inf / NaN)
+__device__ __forceinline__ int coo_fast_scale_exp(unsigned maxbits, int target) {
+  const int e = (int)(maxbits >> 23) - 127;
+  if (maxbits == 0u || maxbits >= 0x7f800000u) return 0;
+  int x = target - (e < -126 ? -126 : e);
+  x = x > 126 ? 126 : (x < -126 ? -126 : x);
+  return x;
+}
+__global__ void coo_fast_scale_kernel(CooFastHdr* hdr) {
+  // sampled max |b| -> [2^12, 2^13): elements up to 8 x the sample's maximum still convert; max |a| -> [2^13, 2^14): room for
+  // duplicates that add up
+  const int xb = coo_fast_scale_exp(hdr->max_b, 12), xa = coo_fast_scale_exp(hdr->max_a, 13);
+  hdr->scale_b = __builtin_bit_cast(float, (unsigned)(xb + 127) << 23);
+  hdr->scale_a = __builtin_bit_cast(float, (unsigned)(xa + 127) << 23);
+  hdr->inv_scale[0] = __builtin_bit_cast(float, (unsigned)(-xa + 127) << 23);
+  hdr->inv_scale[1] = __builtin_bit_cast(float, (unsigned)(-xb + 127) << 23);
+}
+// |x * scale| must not exceed fp16's largest finite value (and x must be finite): then fp16(x * scale) has relative error
+// <= 2^-11 in the normal range and ABSOLUTE error <= 2^-25 below it (|x * scale| < 2^-14: more than 2^26 below the operand's
+// largest element) -- the bound stated in include/sparsifyme.h.  Underflow is therefore not flagged: with ~10^8 elements of
+// ordinary data a few always fall that far below the maximum, and what they lose is 2^-37 of the maximum each.
+__device__ __forceinline__ bool coo_fast_out_of_range(float xs) { return !(__builtin_fabsf(xs) <= 65504.0f); }
+__global__ __launch_bounds__(256) void f32_to_f16_scaled_kernel(const float* __restrict__ in, _Float16* __restrict__ out, size_t n8, CooFastHdr* hdr) {
+  const float sc = hdr->scale_b;
+  bool bad = false;
   for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
     const f4 a = __builtin_nontemporal_load(reinterpret_cast<const f4*>(in) + 2 * i);
     const f4 c = __builtin_nontemporal_load(reinterpret_cast<const f4*>(in) + 2 * i + 1);
     typedef _Float16 hv8 __attribute__((ext_vector_type(8)));
-    const hv8 o = {(_Float16)a[0], (_Float16)a[1], (_Float16)a[2], (_Float16)a[3], (_Float16)c[0], (_Float16)c[1], (_Float16)c[2], (_Float16)c[3]};
+    const float x[8] = {a[0] * sc, a[1] * sc, a[2] * sc, a[3] * sc, c[0] * sc, c[1] * sc, c[2] * sc, c[3] * sc};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bad |= coo_fast_out_of_range(x[j]);
+    const hv8 o = {(_Float16)x[0], (_Float16)x[1], (_Float16)x[2], (_Float16)x[3], (_Float16)x[4], (_Float16)x[5], (_Float16)x[6], (_Float16)x[7]};
     *(reinterpret_cast<hv8*>(out) + i) = o;
   }
+  if (__any(bad) && (threadIdx.x & 63u) == 0) atomicOr(&hdr->flag, 1);
 }
 __global__ __launch_bounds__(256) void coo_scatter_dense_kernel(const int* __restrict__ rows, const int* __restrict__ cols, const float* __restrict__ vals,
                                                                 size_t nnz, size_t A_rows, size_t A_cols, float* __restrict__ AT /*[cols][rows]*/) {
@@ -826,21 +882,39 @@ __global__ __launch_bounds__(256) void coo_scatter_dense_kernel(const int* __res
     if (r < A_rows && c < A_cols) atomicAdd(AT + c * A_rows + r, vals[e]);  // an out-of-range coordinate is skipped, as in the other COO forms
   }
 }
-__global__ __launch_bounds__(256) void split_f16x2_kernel(const float* __restrict__ in, _Float16* __restrict__ hi, _Float16* __restrict__ lo, size_t n) {
+__global__ __launch_bounds__(256) void split_f16x2_scaled_kernel(const float* __restrict__ in, _Float16* __restrict__ hi, _Float16* __restrict__ lo, size_t n,
+                                                                 CooFastHdr* hdr) {
+  const float sc = hdr->scale_a;
+  bool bad = false;
   for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-    const float x = in[i];
+    const float x = in[i] * sc;
+    bad |= coo_fast_out_of_range(x);   // the hi plane carries the 2^-11 bound; lo only refines it (A exact to 2^-22 where lo is normal too)
     const _Float16 h = (_Float16)x;
     hi[i] = h;
     lo[i] = (_Float16)(x - (float)h);
   }
+  if (__any(bad) && (threadIdx.x & 63u) == 0) atomicOr(&hdr->flag, 1);
 }
 }  // namespace sm
 
+static bool coo_fast_sizes(size_t m, size_t k, size_t n, size_t b, size_t* b16, size_t* at32, size_t* aop) {
+  size_t nv, e;
+  if (__builtin_mul_overflow(n, b, &nv) || __builtin_mul_overflow(nv, k, &e) || __builtin_mul_overflow(e, (size_t)2, b16) ||
+      __builtin_mul_overflow(k, m, &e) || __builtin_mul_overflow(e, (size_t)4, at32) || __builtin_mul_overflow(e, (size_t)4, aop))
+    return false;
+  *b16 = sm::round_up(*b16, 256); *at32 = sm::round_up(*at32, 256); *aop = sm::round_up(*aop, 256);
+  return *b16 < ((size_t)1 << 62) && *at32 < ((size_t)1 << 62);
+}
+
 extern "C" int sm_spmm_coo_fast_workspace_size(size_t A_num_rows, size_t A_num_cols, size_t B_num_cols, size_t num_batches, size_t* bytes) {
   if (!bytes) return SM_STATUS_INVALID_VALUE;
-  const size_t b16 = sm::round_up(B_num_cols * num_batches * A_num_cols * 2, 256), at32 = sm::round_up(A_num_cols * A_num_rows * 4, 256),
-               aop = sm::round_up(2 * A_num_cols * A_num_rows * 2, 256);
-  *bytes = b16 + at32 + aop;
+  size_t b16, at32, aop;
+  if (!coo_fast_sizes(A_num_rows, A_num_cols, B_num_cols, num_batches, &b16, &at32, &aop)) {
+    sm::set_error("sm_spmm_coo_fast_workspace_size: the operand sizes overflow size_t");
+    *bytes = 0;
+    return SM_STATUS_NOT_SUPPORTED;
+  }
+  *bytes = sm::COO_FAST_HDR_BYTES + b16 + at32 + aop;
   return SM_STATUS_SUCCESS;
 }
 
@@ -855,24 +929,38 @@ extern "C" int sm_spmm_coo_f32_fast(size_t A_num_rows, size_t A_num_cols, size_t
     return SM_STATUS_INVALID_VALUE;
   }
   size_t need = 0;
-  (void)sm_spmm_coo_fast_workspace_size(m, k, B_num_cols, num_batches, &need);
-  if (k % 64 != 0 || m % 4 != 0 || m < 8 || !aligned16(B) || !aligned16(C) || workspace_bytes < need || nv > 0x7fffffffull) {
-    set_error("sm_spmm_coo_f32_fast: needs cols %% 64 == 0, rows %% 4 == 0, 16-byte aligned B and C and the workspace of sm_spmm_coo_fast_workspace_size "
+  const int rs = sm_spmm_coo_fast_workspace_size(m, k, B_num_cols, num_batches, &need);
+  if (rs != SM_STATUS_SUCCESS || k == 0 || k % 64 != 0 || m % 4 != 0 || m < 8 || !aligned16(B) || !aligned16(C) || workspace_bytes < need || nv > 0x7fffffffull) {
+    set_error("sm_spmm_coo_f32_fast: needs cols %% 64 == 0 (cols > 0), rows %% 4 == 0, 16-byte aligned B and C and the workspace of sm_spmm_coo_fast_workspace_size "
               "(use sm_spmm_coo_f32_packed)");
     return SM_STATUS_NOT_SUPPORTED;
   }
   hipStream_t st = (hipStream_t)stream;
   char* ws = (char*)workspace;
-  _Float16* B16 = (_Float16*)ws;
-  float* AT = (float*)(ws + round_up(nv * k * 2, 256));
+  CooFastHdr* hdr = (CooFastHdr*)ws;
+  _Float16* B16 = (_Float16*)(ws + COO_FAST_HDR_BYTES);
+  float* AT = (float*)((char*)B16 + round_up(nv * k * 2, 256));
   _Float16* Aop = (_Float16*)((char*)AT + round_up(k * m * 4, 256));
+  if (hipMemsetAsync(hdr, 0, COO_FAST_HDR_BYTES, st) != hipSuccess) return check_launch("hipMemsetAsync");
   if (hipMemsetAsync(AT, 0, k * m * 4, st) != hipSuccess) return check_launch("hipMemsetAsync");
-  const size_t n8 = nv * k / 8;  // k % 64 == 0
-  f32_to_f16_kernel<<<stream_grid(n8, 256), 256, 0, st>>>(B, B16, n8);
+  const size_t nB = nv * k;
+  const size_t bstride = nB > ((size_t)1 << 20) ? nB >> 20 : 1;  // ~ 1 M sampled elements of the dense operand
+  coo_fast_scan_kernel<<<256, 256, 0, st>>>(vals, A_nnz, B, nB, bstride | 1, hdr);
+  coo_fast_scale_kernel<<<1, 1, 0, st>>>(hdr);
+  const size_t n8 = nB / 8;  // k % 64 == 0
+  f32_to_f16_scaled_kernel<<<stream_grid(n8, 256), 256, 0, st>>>(B, B16, n8, hdr);
   if (A_nnz) coo_scatter_dense_kernel<<<stream_grid(A_nnz, 256), 256, 0, st>>>(rows, cols, vals, A_nnz, m, k, AT);
-  split_f16x2_kernel<<<stream_grid(k * m, 256), 256, 0, st>>>(AT, Aop, Aop + k * m, k * m);
+  split_f16x2_scaled_kernel<<<stream_grid(k * m, 256), 256, 0, st>>>(AT, Aop, Aop + k * m, k * m, hdr);
   if (const int rc = check_launch("sm_spmm_coo_f32_fast: operand preparation")) return rc;
-  return gemm_f16_f32out(B16, Aop, C, nv, m, k, k, m, m, alpha, beta, st);
+  return gemm_f16_f32out(B16, Aop, C, nv, m, k, k, m, m, alpha, beta, st, hdr->inv_scale, &hdr->flag);
+}
+
+extern "C" int sm_spmm_coo_fast_flag(const void* workspace, int* host_flag, sm_stream_t stream) {
+  if (!workspace || !host_flag) return SM_STATUS_INVALID_VALUE;
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemcpyAsync(host_flag, workspace, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+    return sm::check_launch("sm_spmm_coo_fast_flag");
+  return SM_STATUS_SUCCESS;
 }
 
 extern "C" {

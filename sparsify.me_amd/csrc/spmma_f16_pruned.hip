@@ -35,7 +35,7 @@ struct PrunedArgs {
 
 template <int BN, bool BF, bool TILE>
 __global__ __launch_bounds__(256) void spmma_f16_pruned_kernel(const PrunedArgs p) {
-  constexpr int BM = 128, NW = 4, NS = 2, TM = BM / NW, FM = TM / 16, FN = BN / 16;
+  constexpr int BM = 128, NW = 4, TM = BM / NW, FM = TM / 16, FN = BN / 16;  // ring of 2 stage buffers
   constexpr int SA = BM * 128, SB = 64 * BN * 2, STAGE = SA + SB;
   constexpr int A_N = BM / 8, B_N = BN / 8, W = A_N + B_N, SL = W / NW;
   static_assert(W % NW == 0 && A_N % NW == 0, "equal DMA share per wave; A / B split per instruction index");

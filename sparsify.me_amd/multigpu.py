@@ -11,18 +11,31 @@ import os
 
 MODES = ("weak", "strong", "lpt", "hybrid")
 
-# hybrid: a layer is split by batch index only while a rank's share still fills the chip with resident row tiles: 256 CUs x
-# the three 128-row workgroups a CU holds of the kernels that serve the tall layers.  Below that a tile's time is set by
-# its K stages, not by its rows (128 tiles of a 784 x 256 x 2304 layer take the time of 256), so a batch
-# slice of such a layer costs every rank most of the whole layer's time.  Whole layers balance well on their own: the
-# ResNet tables repeat each shape 1-6 times (bytes within 1.2 % at 8 ranks).
-HYBRID_FILL_ROWS = 768 * 128
+# hybrid (round 4 form): a layer is split by batch index when its SHAPE GROUP -- the same-shape layers a rank launches as one
+# grouped grid -- still fills the chip on a rank's batch share: count x m x (b / world) >= HYBRID_FILL_ROWS rows (512 resident
+# 128-row workgroups: the direct kernels hold two to three per CU).  On the ResNet-50 table that is every 12544-row layer at
+# up to 8 ranks.  The other layers stay WHOLE (a batch slice of a few-tile layer costs a rank most of the whole layer's time:
+# a tile's time is set by its K stages) and are placed longest-first by measured time, in chunks of the same
+# shape so that a rank still launches them grouped.
+HYBRID_FILL_ROWS = 512 * 128
+
+# Measured time of one layer INSIDE a grouped launch of its shape, us at b = 32 on one MI355X (profiles/sweep_r04_f16_resnet50.txt,
+# column `fused`); shapes that are not in the table fall back to bytes over the rate of their kernel family.
+MEASURED_US_B32 = {
+    (12544, 64, 147): 55.1, (12544, 64, 64): 21.2, (12544, 64, 576): 94.7, (12544, 256, 64): 55.1, (12544, 64, 256): 47.0,
+    (12544, 128, 256): 66.2, (3136, 128, 1152): 49.8, (3136, 512, 128): 32.2, (3136, 128, 512): 27.4, (3136, 256, 512): 45.0,
+    (784, 256, 2304): 32.6, (784, 1024, 256): 19.9, (784, 256, 1024): 16.3, (784, 512, 1024): 38.0, (196, 512, 4608): 42.8,
+    (196, 2048, 512): 24.9, (196, 512, 2048): 16.8,
+}
 
 
 def layer_cost(m, n, k, b):
-    """Modelled time of one layer (arbitrary unit): the elements it streams over the rate its kernel family reaches alone
-    (bench.py `families`: direct 4.9, wide 3.0, A-stationary 3.1, span 2.9 TB/s of algorithmic bytes, round 3)."""
-    by = b * (m * k + m * n) + k * n
+    """Modelled time of one layer in us: the measured per-instance time of its shape scaled by b / 32 when the shape is in
+    MEASURED_US_B32, else the elements it streams over the rate its kernel family reaches alone (TB/s of algorithmic bytes)."""
+    t = MEASURED_US_B32.get((m, n, k))
+    if t is not None:
+        return t * b / 32.0
+    by = 2.0 * (b * (m * k + m * n) + k * n)
     if k % 64:
         rate = 2.9
     elif n <= 128 or (n <= 256 and k <= 64):
@@ -31,7 +44,7 @@ def layer_cost(m, n, k, b):
         rate = 3.1
     else:
         rate = 3.0
-    return by / rate
+    return by / rate * 1e-6
 
 
 def env_world():
@@ -58,10 +71,10 @@ def plan_units(shapes, world, rank, mode="weak"):
     strong: all layers, [g*b/G, (g+1)*b/G) of each layer's batch (SURVEY.md 8(e) primary partitioning; B replicated)
     lpt   : whole layers, greedy longest-processing-time assignment by 2*m*n*k*b (SURVEY.md 8(e) alternative; the
             config-4 sweep over several tables), deterministic: ties by layer index, equal loads to the lower rank
-    hybrid: strong scaling (total work fixed) with the granularity chosen per layer: a layer whose per-rank batch share
-            still has >= HYBRID_FILL_ROWS rows is split by batch index as in `strong`; a smaller one stays whole and goes
-            to the least-loaded rank (LPT by the layer's modelled time, layer_cost(), on top of the split layers' equal shares).
-            What `bench.py --gpus N` uses by default on one table"""
+    hybrid: strong scaling (total work fixed) with the granularity chosen per SHAPE GROUP: the layers of a shape whose grouped
+            launch still fills the chip on a rank's batch share (count x m x b / world >= HYBRID_FILL_ROWS rows) are split by
+            batch index as in `strong`; the others stay whole and are placed in same-shape chunks, longest measured time first
+            (layer_cost()), on top of the split layers' equal shares.  What `bench.py --gpus N` uses by default on one table"""
     if mode not in MODES:
         raise ValueError(mode)
     if world < 1 or not (0 <= rank < world):
@@ -76,22 +89,40 @@ def plan_units(shapes, world, rank, mode="weak"):
                 out.append((l, lo, hi))
         return out
     if mode == "hybrid":
-        by = layer_cost  # modelled time: the layers are HBM-bound, at a rate that depends on the kernel family
-        out, whole, load = [], [], [0.0] * world
-        for l, (m, n, k, b) in enumerate(shapes):
-            if world > 1 and (b < world or m * (b // world) < HYBRID_FILL_ROWS):
-                whole.append(l)
-                continue
-            for r in range(world):
-                lo, hi = _split(b, world, r)
-                load[r] += by(m, n, k, hi - lo)
-                if r == rank and hi > lo:
-                    out.append((l, lo, hi))
-        for l in sorted(whole, key=lambda l: (-by(*shapes[l]), l)):
+        groups = {}
+        for l, sh in enumerate(shapes):
+            groups.setdefault(sh, []).append(l)
+        out, load, whole_groups = [], [0.0] * world, []
+        for (m, n, k, b), ls in groups.items():
+            if world == 1 or (b >= world and len(ls) * m * (b // world) >= HYBRID_FILL_ROWS):
+                for l in ls:  # split by batch index as in `strong`
+                    for r in range(world):
+                        lo, hi = _split(b, world, r)
+                        load[r] += layer_cost(m, n, k, hi - lo)
+                        if r == rank and hi > lo:
+                            out.append((l, lo, hi))
+            else:
+                whole_groups.append(((m, n, k, b), ls))
+        # whole layers: chunks of one shape (a rank launches a chunk as one grouped grid), no chunk above ~ 0.6 of a rank's
+        # fair share of the whole-layer time, placed longest-first on the least-loaded rank
+        total = sum(layer_cost(*sh) * len(ls) for sh, ls in whole_groups)
+        cap = 0.6 * total / world if world > 1 else float("inf")
+        chunks = []
+        for sh, ls in whole_groups:
+            c1 = layer_cost(*sh)
+            per = max(1, int(cap // c1)) if c1 > 0 else len(ls)
+            nch = -(-len(ls) // per)
+            base, extra = divmod(len(ls), nch)
+            i = 0
+            for j in range(nch):  # nch chunks of nearly equal size
+                sz = base + (1 if j < extra else 0)
+                chunks.append((c1 * sz, ls[i:i + sz]))
+                i += sz
+        for cost, ls in sorted(chunks, key=lambda c: (-c[0], c[1][0])):
             g = min(range(world), key=lambda r: (load[r], r))
-            load[g] += by(*shapes[l])
+            load[g] += cost
             if g == rank:
-                out.append((l, 0, shapes[l][3]))
+                out += [(l, 0, shapes[l][3]) for l in ls]
         return sorted(out)
     cost = [2.0 * m * n * k * b for (m, n, k, b) in shapes]
     order = sorted(range(len(shapes)), key=lambda l: (-cost[l], l))

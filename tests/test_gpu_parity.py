@@ -1237,6 +1237,81 @@ def test_spmm_coo_fast_small_vs_oracle(gpu, orc, shape, order):
     assert np.array_equal(host(dC), C0)
 
 
+@pytest.mark.parametrize("mag_b,mag_a", [(1e-6, 1.0), (3e5, 1.0), (1e-20, 1e-12), (1e12, 1e10), (1.0, 1e-30)], ids=lambda v: "%g" % v)
+def test_spmm_coo_fast_holds_its_bound_at_any_magnitude(gpu, orc, mag_b, mag_a):
+    """the fp16-split form cast its operands straight to fp16 -- uniformly small operands (activations
+    ~1e-6) fell below fp16's normal range and came back with percent-level error while the call returned SUCCESS, large ones
+    overflowed.  Round 4: power-of-two scales computed on the device (largest |b| of a strided sample -> [2^12, 2^13), largest |a|
+    -> [2^13, 2^14)) and folded back into the fp32 sums, so the 2^-11 bound holds whatever the magnitude, and the range flag stays 0."""
+    import ctypes
+    import torch
+    m, n, k, batches = 260, 72, 192, 3
+    rng = np.random.default_rng(77)
+    dens = rng.uniform(0, 1, (m, k)) < 0.1
+    r, c = np.nonzero(dens)
+    r, c = r.astype(np.int32), c.astype(np.int32)
+    v = (rng.uniform(-1, 1, r.size) * mag_a).astype(np.float32)
+    B = (rng.uniform(-1, 1, batches * k * n) * mag_b).astype(np.float32)
+    C0 = np.zeros(batches * m * n, dtype=np.float32)
+    dC = to_dev(C0.copy())
+    nb = ctypes.c_size_t(0)
+    assert gpu.lib().sm_spmm_coo_fast_workspace_size(m, k, n, batches, ctypes.byref(nb)) == 0
+    ws = torch.full((nb.value,), 0x5A, dtype=torch.uint8, device="cuda")
+    dr, dc_, dv, dB = to_dev(r), to_dev(c), to_dev(v), to_dev(B)
+    rc = gpu.lib().sm_spmm_coo_f32_fast(m, k, r.size, n, batches, dr.data_ptr(), dc_.data_ptr(), dv.data_ptr(), dB.data_ptr(), dC.data_ptr(),
+                                        1.0, 0.0, ws.data_ptr(), nb.value, None)
+    assert rc == 0, gpu.lib().sm_last_error()
+    flag = ctypes.c_int(-1)
+    assert gpu.lib().sm_spmm_coo_fast_flag(ws.data_ptr(), ctypes.byref(flag), None) == 0 and flag.value == 0
+    want = np.zeros(batches * m * n, dtype=np.float64)
+    A64 = np.zeros((m, k))
+    np.add.at(A64, (r, c), v.astype(np.float64))
+    absA = np.abs(A64)
+    for bb in range(batches):
+        Bb = B[bb * k * n:(bb + 1) * k * n].astype(np.float64).reshape(n, k)
+        want[bb * m * n:(bb + 1) * m * n] = (Bb @ A64.T).reshape(-1)
+    scale = np.concatenate([(np.abs(B[bb * k * n:(bb + 1) * k * n].astype(np.float64)).reshape(n, k) @ absA.T).reshape(-1) for bb in range(batches)])
+    err = np.abs(host(dC).astype(np.float64) - want)
+    # + the absolute term of the stated bound: 2^-37 max|b| sum|a| (elements far below the largest one)
+    extra = 2.0 ** -37 * float(np.abs(B).max()) * np.tile(absA.sum(axis=1), batches * n).reshape(batches, n, m).reshape(-1)
+    worst = float(np.max(err / np.maximum(COO_FAST_TOL * scale + extra, 1e-300)))
+    assert worst <= 1.0, f"scaled fast coo at |b| ~ {mag_b:g}, |a| ~ {mag_a:g}: worst error / bound = {worst:.3f}"
+
+
+def test_spmm_coo_fast_flags_what_does_not_convert_and_leaves_c_alone(gpu):
+    """An element the scales cannot bring into the fp16 range (inf, NaN, or far above the sampled maximum) raises the flag on the
+    device and the matrix kernel returns without writing C: the caller (sparsifyme::batched::strided_coo) then runs the exact form
+    on untouched operands."""
+    import ctypes
+    import torch
+    m, n, k, batches = 128, 64, 64, 2
+    rng = np.random.default_rng(5)
+    r = np.repeat(np.arange(m, dtype=np.int32), 4)
+    c = rng.integers(0, k, r.size).astype(np.int32)
+    v = rng.uniform(-1, 1, r.size).astype(np.float32)
+    nb = ctypes.c_size_t(0)
+    gpu.lib().sm_spmm_coo_fast_workspace_size(m, k, n, batches, ctypes.byref(nb))
+    for poison in (np.float32("inf"), np.float32("nan")):
+        B = rng.uniform(-1, 1, batches * k * n).astype(np.float32)
+        B[777] = poison
+        C0 = rng.uniform(-1, 1, batches * m * n).astype(np.float32)
+        dC = to_dev(C0.copy())
+        ws = torch.zeros(nb.value, dtype=torch.uint8, device="cuda")
+        dr, dc_, dv, dB = to_dev(r), to_dev(c), to_dev(v), to_dev(B)
+        rc = gpu.lib().sm_spmm_coo_f32_fast(m, k, r.size, n, batches, dr.data_ptr(), dc_.data_ptr(), dv.data_ptr(), dB.data_ptr(), dC.data_ptr(),
+                                            1.0, 0.5, ws.data_ptr(), nb.value, None)
+        assert rc == 0
+        flag = ctypes.c_int(0)
+        assert gpu.lib().sm_spmm_coo_fast_flag(ws.data_ptr(), ctypes.byref(flag), None) == 0 and flag.value != 0
+        assert np.array_equal(host(dC), C0), "C was written although the range flag is up"
+    # k == 0 and overflowing sizes are declined, not mis-sized (ADVICE round 3)
+    huge = ctypes.c_size_t(0)
+    assert gpu.lib().sm_spmm_coo_fast_workspace_size(1 << 40, 1 << 40, 1 << 20, 1 << 20, ctypes.byref(huge)) == gpu.STATUS_NOT_SUPPORTED
+    dC = to_dev(np.ones(8 * 8, dtype=np.float32))
+    z = torch.zeros(64, dtype=torch.uint8, device="cuda")
+    assert gpu.lib().sm_spmm_coo_f32_fast(8, 0, 0, 8, 1, None, None, None, z.data_ptr(), dC.data_ptr(), 1.0, 0.0, z.data_ptr(), 64, None) == gpu.STATUS_NOT_SUPPORTED
+
+
 @pytest.mark.parametrize("shape", [(150, 33, 90, 3), (64, 9, 48, 2), (300, 130, 260, 1), (17, 5, 129, 4), (129, 64, 128, 2), (50, 70, 1000, 3), (33, 300, 52, 1)],
                          ids=lambda s_: "x".join(map(str, s_)))
 @pytest.mark.parametrize("order", ["sorted", "cols_shuffled_within_rows", "shuffled", "duplicates"])
