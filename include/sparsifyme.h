@@ -251,8 +251,8 @@ int sm_spmm_coo_f32_packed(size_t A_num_rows, size_t A_num_cols, size_t A_nnz, s
  * form as its fallback): the batches' dense operand is scaled by a power of two and rounded once to fp16, A is scattered dense,
  * scaled and split exactly into two fp16 planes, the product runs on the fp16 matrix instruction with fp32 accumulation and the
  * inverse scales are applied to the fp32 sums: 2-3 x faster than the exact forms at 90 % sparsity.
- * Scales (round 4, computed on the device: no synchronisation): 2^x that brings the largest |b| of a ~10^6-element strided
- * sample of the dense operand into [2^12, 2^13) and 2^y that brings the largest |a| into [2^13, 2^14) -- so the error does not
+ * Scales (round 4, computed on the device: no synchronisation): 2^x that brings the largest |b| of a ~10^6-element sample of
+ * the dense operand (1024 evenly spread runs of 1024 contiguous elements) into [2^12, 2^13) and 2^y that brings the largest |a| into [2^13, 2^14) -- so the error does not
  * depend on the operands' magnitude (1e-6-sized activations or 1e+6-sized ones convert alike).
  * Error: |C - exact| <= 2^-11 * |alpha| * sum|a||b|  (one fp16 rounding of b; 4.9e-4, inside the 1e-3 this build's fp32 products are
  * held to) + fp32 accumulation + 2^-37 * max|b| * |alpha| * sum|a| (elements of the dense operand more than 2^26 below its

@@ -242,8 +242,14 @@ __device__ __forceinline__ unsigned b32_off(unsigned kr, unsigned col) {  // byt
 // P24 (sm_spmma_fused_f32): the 2:4 STRIP rule is applied to each stage's A image in LDS, in place, before the MFMA reads
 // it -- so C = prune24_strip(A) * B without a blob and without a compress pass.  fp32 has no sparse matrix instruction: the matrix work is the dense
 // kernel's, what is saved is the 2.06 ms compress pass and the blob round trip of the staged pair (ResNet-18 table).
-template <int BM, int BN, int WM, int WN, int NS, bool BKM, bool P24 = false>
+// P24 = 2 (round 4): the same rule in the REGISTERS of the lane that feeds the strip to the MFMA -- a lane's two ds_read_b128 of
+// a stage are two whole strips of its row -- for tilings with ONE wave column (WN == 1: a wave owns its rows across all columns
+// of the tile, so every strip is selected exactly once; with WN > 1 the selection would repeat per wave column, which is what
+// made round 2's register form lose).  No pass over the LDS image, no extra barrier; the ~50 VALU per stage sit in the shadow
+// of the stage's 64-128 MFMAs.  Same values reach the MFMA: bit-identical C.
+template <int BM, int BN, int WM, int WN, int NS, bool BKM, int P24 = 0>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_dma_kernel(const Gemm32Args p) {
+  static_assert(P24 != 2 || WN == 1, "register form of the 2:4 rule: one wave column");
   constexpr int NW = WM * WN, TM = BM / WM, TN = BN / WN, FM = TM / 16, FN = TN / 16;
   constexpr int SA = BM * 128, SB = BN * 128, STAGE = SA + SB;
   constexpr int A_N = BM / 8, B_N = BN / 8, W = A_N + B_N;  // 1 KiB DMA wave-instructions per stage
@@ -320,7 +326,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_dma_kernel(const Gemm32
     if (kt + NS - 1 < nkt) stage(kt + NS - 1, fill);
     const char* As = smem + cur * STAGE;
     const char* Bs = As + SA;
-    if constexpr (P24) {
+    if constexpr (P24 == 1) {
       // the stage's A image pruned in place, once, by all threads: every 16-byte chunk of the image is one strip (4
       // consecutive k of a row, wherever the swizzle put it).  In the MFMA-feeding lanes' registers the same selection
       // ran once per wave column and cost 40 % over the dense kernel (profiles/bench_f32_r02m_regmask.json).
@@ -341,6 +347,16 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_dma_kernel(const Gemm32
       const unsigned row = wm * TM + i * 16 + r;
       alo[i] = *reinterpret_cast<const f4*>(As + a_off(row, 2u * g));
       ahi[i] = *reinterpret_cast<const f4*>(As + a_off(row, 2u * g + 1u));
+      if constexpr (P24 == 2) {
+        const u4 kl = __builtin_bit_cast(u4, alo[i]), kh = __builtin_bit_cast(u4, ahi[i]);
+        const unsigned ml = strip_keepmask(key_of(kl[0]), key_of(kl[1]), key_of(kl[2]), key_of(kl[3]));
+        const unsigned mh = strip_keepmask(key_of(kh[0]), key_of(kh[1]), key_of(kh[2]), key_of(kh[3]));
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          alo[i][t] = (ml >> t) & 1u ? alo[i][t] : 0.0f;
+          ahi[i][t] = (mh >> t) & 1u ? ahi[i][t] : 0.0f;
+        }
+      }
     }
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
@@ -393,7 +409,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_dma_kernel(const Gemm32
     }
 }
 
-template <int BM, int BN, int WM, int WN, int NS, bool BKM, bool P24 = false>
+template <int BM, int BN, int WM, int WN, int NS, bool BKM, int P24 = 0>
 static int launch32_dma(const Gemm32Args& a0, hipStream_t st) {
   Gemm32Args a = a0;
   a.tiles_m = (a.M + BM - 1) / BM;
@@ -872,8 +888,17 @@ int sm_spmma_fused_f32(const float* A, const float* B, float* C, size_t m, size_
     a.batch = 1;
   }
   hipStream_t st = (hipStream_t)stream;
-  if (a.M <= 64) return a.N <= 64 ? launch32_dma<64, 64, 2, 2, 2, false, true>(a, st) : launch32_dma<64, 128, 1, 4, 2, false, true>(a, st);
-  return a.N <= 128 ? launch32_dma<128, 64, 4, 1, 2, false, true>(a, st) : launch32_dma<128, 128, 4, 4, 2, false, true>(a, st);
+  if (a.M <= 64) return a.N <= 64 ? launch32_dma<64, 64, 2, 2, 2, false, 1>(a, st) : launch32_dma<64, 128, 1, 4, 2, false, 1>(a, st);
+#ifdef SM_TUNING
+  switch (tuning_int("SM_F32_FUSED_MODE", 0)) {  // A/B of the register form (round 4)
+    case 1: return a.N <= 128 ? launch32_dma<128, 64, 4, 1, 2, false, 2>(a, st) : launch32_dma<128, 128, 4, 4, 2, false, 1>(a, st);
+    case 2: return a.N <= 128 ? launch32_dma<128, 64, 4, 1, 2, false, 2>(a, st) : launch32_dma<128, 128, 4, 1, 2, false, 2>(a, st);
+    case 3: return a.N <= 64 ? launch32_dma<128, 64, 4, 1, 2, false, 2>(a, st) : launch32_dma<128, 128, 4, 1, 2, false, 2>(a, st);
+    case 4: return a.N <= 128 ? launch32_dma<128, 64, 4, 1, 3, false, 2>(a, st) : launch32_dma<128, 128, 8, 1, 2, false, 2>(a, st);
+    default: break;
+  }
+#endif
+  return a.N <= 128 ? launch32_dma<128, 64, 4, 1, 2, false, 1>(a, st) : launch32_dma<128, 128, 4, 4, 2, false, 1>(a, st);
 }
 
 int sm_gemm_batched_f32(const float* const* A_ptrs, const float* const* B_ptrs, float* const* C_ptrs, size_t m, size_t n,

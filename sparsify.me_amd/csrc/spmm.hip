@@ -821,12 +821,22 @@ struct CooFastHdr {
 };
 constexpr size_t COO_FAST_HDR_BYTES = 256;
 
-__global__ __launch_bounds__(256) void coo_fast_scan_kernel(const float* __restrict__ vals, size_t nnz, const float* __restrict__ B, size_t nb, size_t bstride,
-                                                            CooFastHdr* hdr) {
+// max |a| over all values of A (exact) and max |b| over a SAMPLE of the dense operand: `nchunks` runs of 1024 contiguous floats
+// spread evenly over it (whole cache lines: a strided element sample costs a line per element -- 35 us for a 10^6-element sample,
+// measured in round 4's first form -- where these 4 MB cost 2-3)
+__global__ __launch_bounds__(256) void coo_fast_scan_kernel(const float* __restrict__ vals, size_t nnz, const float* __restrict__ B, size_t nb, size_t nchunks,
+                                                            size_t chunk_step, CooFastHdr* hdr) {
   unsigned ma = 0u, mb = 0u;
   const size_t t0 = blockIdx.x * (size_t)256 + threadIdx.x, nt = (size_t)gridDim.x * 256;
   for (size_t i = t0; i < nnz; i += nt) { const unsigned u = __builtin_bit_cast(unsigned, vals[i]) & 0x7fffffffu; ma = u > ma ? u : ma; }
-  for (size_t i = t0 * bstride; i < nb; i += nt * bstride) { const unsigned u = __builtin_bit_cast(unsigned, B[i]) & 0x7fffffffu; mb = u > mb ? u : mb; }
+  for (size_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+    const size_t i = c * chunk_step + 4u * threadIdx.x;  // chunk_step % 4 == 0, B 16-byte aligned
+    if (i + 4 <= nb) {
+      const f4 v = *reinterpret_cast<const f4*>(B + i);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const unsigned u = __builtin_bit_cast(unsigned, v[e]) & 0x7fffffffu; mb = u > mb ? u : mb; }
+    }
+  }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     const unsigned xa = (unsigned)__shfl_xor((int)ma, o), xb = (unsigned)__shfl_xor((int)mb, o);
@@ -944,8 +954,10 @@ extern "C" int sm_spmm_coo_f32_fast(size_t A_num_rows, size_t A_num_cols, size_t
   if (hipMemsetAsync(hdr, 0, COO_FAST_HDR_BYTES, st) != hipSuccess) return check_launch("hipMemsetAsync");
   if (hipMemsetAsync(AT, 0, k * m * 4, st) != hipSuccess) return check_launch("hipMemsetAsync");
   const size_t nB = nv * k;
-  const size_t bstride = nB > ((size_t)1 << 20) ? nB >> 20 : 1;  // ~ 1 M sampled elements of the dense operand
-  coo_fast_scan_kernel<<<256, 256, 0, st>>>(vals, A_nnz, B, nB, bstride | 1, hdr);
+  // <= 1024 chunks of 1024 floats, evenly spread (a dense operand of <= 1 M elements is scanned whole)
+  const size_t nchunks = nB / 1024 < 1024 ? (nB + 1023) / 1024 : 1024;
+  const size_t chunk_step = nchunks >= 1024 ? (nB / nchunks) & ~(size_t)3 : 1024;
+  coo_fast_scan_kernel<<<256, 256, 0, st>>>(vals, A_nnz, B, nB, nchunks, chunk_step, hdr);
   coo_fast_scale_kernel<<<1, 1, 0, st>>>(hdr);
   const size_t n8 = nB / 8;  // k % 64 == 0
   f32_to_f16_scaled_kernel<<<stream_grid(n8, 256), 256, 0, st>>>(B, B16, n8, hdr);
