@@ -40,11 +40,20 @@ struct ConvArgs {
 
 __device__ __attribute__((aligned(256))) const unsigned char sm_conv_zero_page[256] = {0};
 
-template <int BN, bool BF>
-__global__ __launch_bounds__(256) void conv_spmma_fused_kernel(const ConvArgs p) {
+// V16 (round 4): 16-byte patch DMAs where the input rows are whole 16-byte pieces (W % 8 == 0: the 112- and 56-wide layers) --
+// a lane moves 8 halves, the row pitch is padl + W with padl a multiple of 8, so one wave instruction brings 4 (W = 112) or 8
+// (W = 56) patch rows instead of 1 or 2 and a stage needs a quarter of the DMA instructions (and of the plan's registers).
+// SMALL: the stage's patch needs at most 16 DMA instructions (always with V16; with 4-byte pieces for W <= 30): the plan then
+// holds 4 slots per wave instead of 12 and the kernel is asked to fit four (64-column tiles) or three (128) waves per SIMD --
+// it does, without scratch (102 / 142 registers against 167 / 238), so that three to four workgroups share a CU as far as
+// the LDS allows: the "fourth wave per SIMD" lever of DESIGN.md 4.4.
+template <int BN, bool BF, bool V16 = false, bool SMALL = V16>
+__global__ __launch_bounds__(256, SMALL ? (BN == 64 ? 4 : 3) : 1) void conv_spmma_fused_kernel(const ConvArgs p) {
   constexpr int BM = 128, NW = 4, TM = 32, FM = 2, FN = BN / 16;
   constexpr int SB = 64 * BN * 2, B_N = BN / 8;
-  constexpr int MAXA = 12;  // patch DMA slots per wave (a_n <= 48)
+  constexpr int EPL = V16 ? 8 : 2;    // halves per lane of a patch DMA
+  static_assert(SMALL || !V16, "16-byte pieces imply the small plan");
+  constexpr int MAXA = SMALL ? 4 : 12;  // patch DMA slots per wave (a_n <= 16 / 48)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int STAGE = p.patch_bytes + SB;
   // layout: [stage 0: patch | B][stage 1: patch | B][k-offset table: khkw rows of 64 u16]
@@ -77,7 +86,7 @@ __global__ __launch_bounds__(256) void conv_spmma_fused_kernel(const ConvArgs p)
   }
 
   // ---- per-lane DMA plan (fixed over the stages except for the channel base)
-  const int pdw = p.pitch >> 1;
+  const int pdw = p.pitch / EPL;  // lanes per patch row
   const size_t chan_bytes = (size_t)p.H * p.W * 2;
   const char* Ximg = reinterpret_cast<const char*>(p.X) + (size_t)img * p.Cin * chan_bytes;
   long long a_src[MAXA];   // byte offset from Ximg + cbase * chan_bytes; < 0: this lane reads zeros
@@ -88,9 +97,9 @@ __global__ __launch_bounds__(256) void conv_spmma_fused_kernel(const ConvArgs p)
     const int t = (int)wave + NW * i;
     const int prow = t * p.rpi + (int)lane / pdw, d = (int)lane % pdw;
     const int ch = prow / p.RI, rr = prow - ch * p.RI, ih = ih_lo + rr;
-    a_on[i] = t < p.a_n && (int)lane < p.rpi * pdw && prow < p.nch * p.RI && d >= (p.padl >> 1) && d < (p.padl >> 1) + (p.W >> 1);
+    a_on[i] = t < p.a_n && (int)lane < p.rpi * pdw && prow < p.nch * p.RI && d >= p.padl / EPL && d < p.padl / EPL + p.W / EPL;
     a_ch[i] = ch;
-    a_src[i] = (ih >= 0 && ih < p.H) ? (long long)(((size_t)ch * p.H + ih) * p.W * 2 + (size_t)(d - (p.padl >> 1)) * 4) : -1;
+    a_src[i] = (ih >= 0 && ih < p.H) ? (long long)(((size_t)ch * p.H + ih) * p.W * 2 + (size_t)(d - p.padl / EPL) * (EPL * 2)) : -1;
   }
   // B slots: B_N instructions of 8 k-rows x 128 B, instruction j -> wave j % 4
   constexpr int SLB = (B_N + NW - 1) / NW;
@@ -115,8 +124,13 @@ __global__ __launch_bounds__(256) void conv_spmma_fused_kernel(const ConvArgs p)
       if (t >= p.a_n) break;
       if (a_on[i] && !(p.ablate & 1)) {
         const bool live = a_src[i] >= 0 && cbase + a_ch[i] < p.Cin;
-        gptr_t* g = live ? (gptr_t*)(Xc + a_src[i]) : (gptr_t*)(sm_conv_zero_page + 4u * lane);
-        __builtin_amdgcn_global_load_lds(g, (lptr_t*)(base + (size_t)t * p.rpi * pdw * 4), 4, 0, 0);
+        if constexpr (V16) {
+          gptr_t* g = live ? (gptr_t*)(Xc + a_src[i]) : (gptr_t*)(sm_conv_zero_page + 16u * (lane & 15u));
+          __builtin_amdgcn_global_load_lds(g, (lptr_t*)(base + (size_t)t * p.rpi * pdw * 16), 16, 0, 0);
+        } else {
+          gptr_t* g = live ? (gptr_t*)(Xc + a_src[i]) : (gptr_t*)(sm_conv_zero_page + 4u * lane);
+          __builtin_amdgcn_global_load_lds(g, (lptr_t*)(base + (size_t)t * p.rpi * pdw * 4), 4, 0, 0);
+        }
       }
     }
 #pragma unroll
@@ -216,7 +230,7 @@ __global__ __launch_bounds__(256) void conv_spmma_fused_kernel(const ConvArgs p)
   store_c_tile<BM, BN, FM, FN, 64 * NW, BF>(smem, C, acc, true, wave * TM, 0, m0, n0, p.L, p.Nout, p.alpha, p.beta, tid);
 }
 
-template <int BN, bool BF>
+template <int BN, bool BF, bool V16 = false, bool SMALL = V16>
 static int launch_conv(const ConvArgs& a0, hipStream_t st) {
   ConvArgs a = a0;
   a.tiles_m = (a.L + 127) / 128;
@@ -235,8 +249,8 @@ static int launch_conv(const ConvArgs& a0, hipStream_t st) {
     return SM_STATUS_NOT_SUPPORTED;
   }
   static LdsOptIn lds_optin;
-  if (const int rc = ensure_dyn_lds(lds_optin, reinterpret_cast<const void*>(&conv_spmma_fused_kernel<BN, BF>), 160 * 1024, "conv_spmma_fused_kernel")) return rc;
-  conv_spmma_fused_kernel<BN, BF><<<dim3((unsigned)nwg), dim3(256), lds, st>>>(a);
+  if (const int rc = ensure_dyn_lds(lds_optin, reinterpret_cast<const void*>(&conv_spmma_fused_kernel<BN, BF, V16, SMALL>), 160 * 1024, "conv_spmma_fused_kernel")) return rc;
+  conv_spmma_fused_kernel<BN, BF, V16, SMALL><<<dim3((unsigned)nwg), dim3(256), lds, st>>>(a);
   return check_launch("conv_spmma_fused_kernel");
 }
 
@@ -265,10 +279,14 @@ static int conv_spmma16(const void* X, const void* B, void* C, size_t N, size_t 
   // what the kernel takes: whole 64-deep stages, 16-byte aligned B rows, 4-byte aligned input rows that fit one DMA
   // instruction with their border; anything else: sm_im2col_compress24_* + sm_spmma_* (the same result)
   size_t padl = pad > (sw - 1 > pad ? sw - 1 - pad : 0) ? pad : (sw - 1 > pad ? sw - 1 - pad : 0);
-  padl = (padl + 1) / 2 * 2;
-  if (padl == 0) padl = 2;  // a row's right border is the next row's left border: at least one dword
+  // 16-byte patch DMAs (round 4) where rows are whole 16-byte pieces: W % 8 == 0, a 16-byte aligned X, the border rounded up to
+  // 8 halves and the stage's plan within 4 instructions per wave; SM_CONV_V16 = 0 (tuning) keeps the 4-byte form
+  bool v16 = W % 8 == 0 && aligned16(X) && tuning_int("SM_CONV_V16", 1) != 0;
+  const size_t epl = v16 ? 8 : 2;
+  padl = (padl + epl - 1) / epl * epl;
+  if (padl == 0) padl = epl;  // a row's right border is the next row's left border: at least one lane's piece
   const size_t pitch = padl + W;
-  if (K % 64 != 0 || n_out % 8 != 0 || W % 2 != 0 || pitch / 2 > 64 || !aligned16(B) || (reinterpret_cast<uintptr_t>(X) & 3u) != 0 ||
+  if (K % 64 != 0 || n_out % 8 != 0 || W % 2 != 0 || pitch / epl > 64 || !aligned16(B) || (reinterpret_cast<uintptr_t>(X) & 3u) != 0 ||
       kh * kw > 64 || H > 0x7fff || N * L > 0x7fffffffull || K > 0x7fffffffull || n_out > 0x7fffffffull) {
     set_error("%s: needs C*kh*kw %% 64 == 0, n %% 8 == 0, an even W <= %zu and kh*kw <= 64 (use sm_im2col_compress24 + sm_spmma)", name,
               (size_t)(128 - padl));
@@ -282,14 +300,14 @@ static int conv_spmma16(const void* X, const void* B, void* C, size_t N, size_t 
   const size_t span = L < 128 ? (L - 1) / OW : (127 + OW - 1) / OW;  // most output rows a 128-pixel tile straddles, minus one
   a.RI = (int)(span * stride + sh);
   a.pitch = (int)pitch; a.padl = (int)padl;
-  a.rpi = (int)(64 / (pitch / 2));
+  a.rpi = (int)(64 / (pitch / epl));
   a.nch = (int)((kh * kw - 1 + 63) / (kh * kw) + 1);
   a.a_n = (int)ceil_div((size_t)a.nch * a.RI, (size_t)a.rpi);
   a.patch_bytes = (int)round_up(((size_t)a.nch * a.RI * pitch + padl + 2 * (sw + pad)) * 2 + 256, 16);
   a.alpha = alpha; a.beta = beta;
   a.ablate = tuning_int("SM_CONV_ABLATE", 0);
-  if (a.a_n > 48) {
-    set_error("%s: a stage's activation patch needs %d DMA instructions (limit 48)", name, a.a_n);
+  if (a.a_n > (v16 ? 16 : 48)) {
+    set_error("%s: a stage's activation patch needs %d DMA instructions (limit %d)", name, a.a_n, v16 ? 16 : 48);
     return SM_STATUS_NOT_SUPPORTED;
   }
   // the gather's k-offset table holds 16-bit byte offsets into the patch: largest = last channel's last window element
@@ -298,6 +316,11 @@ static int conv_spmma16(const void* X, const void* B, void* C, size_t N, size_t 
     return SM_STATUS_NOT_SUPPORTED;
   }
   hipStream_t st = (hipStream_t)stream;
+  // (256-column tiles for n_out > 128 -- the patch gathered once per 256 output channels -- were built and measured in round 4:
+  //  n = 256 unchanged (73.8 vs 74.1 us), n = 512 slower (134 vs 103 us: 223 registers, two workgroups per CU, half the tiles);
+  //  profiles/conv_levers_r04k.txt.  Not kept.)
+  if (v16) return n_out <= 64 ? launch_conv<64, BF, true>(a, st) : launch_conv<128, BF, true>(a, st);
+  if (a.a_n <= 16 && tuning_int("SM_CONV_SMALL", 1) != 0) return n_out <= 64 ? launch_conv<64, BF, false, true>(a, st) : launch_conv<128, BF, false, true>(a, st);
   if (n_out <= 64) return launch_conv<64, BF>(a, st);
   return launch_conv<128, BF>(a, st);
 }

@@ -889,16 +889,11 @@ int sm_spmma_fused_f32(const float* A, const float* B, float* C, size_t m, size_
   }
   hipStream_t st = (hipStream_t)stream;
   if (a.M <= 64) return a.N <= 64 ? launch32_dma<64, 64, 2, 2, 2, false, 1>(a, st) : launch32_dma<64, 128, 1, 4, 2, false, 1>(a, st);
-#ifdef SM_TUNING
-  switch (tuning_int("SM_F32_FUSED_MODE", 0)) {  // A/B of the register form (round 4)
-    case 1: return a.N <= 128 ? launch32_dma<128, 64, 4, 1, 2, false, 2>(a, st) : launch32_dma<128, 128, 4, 4, 2, false, 1>(a, st);
-    case 2: return a.N <= 128 ? launch32_dma<128, 64, 4, 1, 2, false, 2>(a, st) : launch32_dma<128, 128, 4, 1, 2, false, 2>(a, st);
-    case 3: return a.N <= 64 ? launch32_dma<128, 64, 4, 1, 2, false, 2>(a, st) : launch32_dma<128, 128, 4, 1, 2, false, 2>(a, st);
-    case 4: return a.N <= 128 ? launch32_dma<128, 64, 4, 1, 3, false, 2>(a, st) : launch32_dma<128, 128, 8, 1, 2, false, 2>(a, st);
-    default: break;
-  }
-#endif
-  return a.N <= 128 ? launch32_dma<128, 64, 4, 1, 2, false, 1>(a, st) : launch32_dma<128, 128, 4, 4, 2, false, 1>(a, st);
+  // n <= 128: 128 x 64 tiles with one wave column -> the register form (P24 = 2: every strip selected once, by the lane that
+  // feeds it, no LDS pass, no extra barrier); wider: 16 waves in a 4 x 4 grid, where the register form would repeat the selection
+  // per wave column -> the in-LDS form.  Round 4, ResNet-18 table: 4.47 -> 4.37 ms (0.85 -> 0.87 x the dense fp32 GEMM);
+  // one-wave-column tilings for n > 128 (128 x 128 x 4 or 8 waves) measured no better (4.43-4.48 ms).
+  return a.N <= 128 ? launch32_dma<128, 64, 4, 1, 2, false, 2>(a, st) : launch32_dma<128, 128, 4, 4, 2, false, 1>(a, st);
 }
 
 int sm_gemm_batched_f32(const float* const* A_ptrs, const float* const* B_ptrs, float* const* C_ptrs, size_t m, size_t n,

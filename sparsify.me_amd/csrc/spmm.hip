@@ -816,8 +816,8 @@ struct CooFastHdr {
   int flag;            // != 0: an element left the fp16 range under the call's scales -> C was NOT written (the GEMM returns at once)
   unsigned max_b;      // bit pattern of max |b| over a strided sample of the dense operand (the scale's ESTIMATE)
   unsigned max_a;      // bit pattern of max |a| over all values of A (exact)
-  float scale_b, scale_a;              // 2^x, 2^y
-  float inv_scale[2];                  // 2^-y, 2^-x: applied to the fp32 sums one after the other (each a normal float)
+  float inv_scale[2];                  // 2^-y, 2^-x (the inverse scales of A and of the dense operand), written by the split kernel,
+                                       // applied to the fp32 sums one after the other (each a normal float)
 };
 constexpr size_t COO_FAST_HDR_BYTES = 256;
 
@@ -856,22 +856,16 @@ __device__ __forceinline__ int coo_fast_scale_exp(unsigned maxbits, int target) 
   x = x > 126 ? 126 : (x < -126 ? -126 : x);
   return x;
 }
-__global__ void coo_fast_scale_kernel(CooFastHdr* hdr) {
-  // sampled max |b| -> [2^12, 2^13): elements up to 8 x the sample's maximum still convert; max |a| -> [2^13, 2^14): room for
-  // duplicates that add up
-  const int xb = coo_fast_scale_exp(hdr->max_b, 12), xa = coo_fast_scale_exp(hdr->max_a, 13);
-  hdr->scale_b = __builtin_bit_cast(float, (unsigned)(xb + 127) << 23);
-  hdr->scale_a = __builtin_bit_cast(float, (unsigned)(xa + 127) << 23);
-  hdr->inv_scale[0] = __builtin_bit_cast(float, (unsigned)(-xa + 127) << 23);
-  hdr->inv_scale[1] = __builtin_bit_cast(float, (unsigned)(-xb + 127) << 23);
-}
+// sampled max |b| -> [2^12, 2^13): elements up to 8 x the sample's maximum still convert; max |a| -> [2^13, 2^14): room for
+// duplicates that add up.  Every kernel derives the scales from the two maxima itself (no separate launch).
+__device__ __forceinline__ float coo_fast_pow2(int x) { return __builtin_bit_cast(float, (unsigned)(x + 127) << 23); }
 // |x * scale| must not exceed fp16's largest finite value (and x must be finite): then fp16(x * scale) has relative error
 // <= 2^-11 in the normal range and ABSOLUTE error <= 2^-25 below it (|x * scale| < 2^-14: more than 2^26 below the operand's
 // largest element) -- the bound stated in include/sparsifyme.h.  Underflow is therefore not flagged: with ~10^8 elements of
 // ordinary data a few always fall that far below the maximum, and what they lose is 2^-37 of the maximum each.
 __device__ __forceinline__ bool coo_fast_out_of_range(float xs) { return !(__builtin_fabsf(xs) <= 65504.0f); }
 __global__ __launch_bounds__(256) void f32_to_f16_scaled_kernel(const float* __restrict__ in, _Float16* __restrict__ out, size_t n8, CooFastHdr* hdr) {
-  const float sc = hdr->scale_b;
+  const float sc = coo_fast_pow2(coo_fast_scale_exp(hdr->max_b, 12));
   bool bad = false;
   for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
     const f4 a = __builtin_nontemporal_load(reinterpret_cast<const f4*>(in) + 2 * i);
@@ -894,7 +888,12 @@ __global__ __launch_bounds__(256) void coo_scatter_dense_kernel(const int* __res
 }
 __global__ __launch_bounds__(256) void split_f16x2_scaled_kernel(const float* __restrict__ in, _Float16* __restrict__ hi, _Float16* __restrict__ lo, size_t n,
                                                                  CooFastHdr* hdr) {
-  const float sc = hdr->scale_a;
+  const int xa = coo_fast_scale_exp(hdr->max_a, 13);
+  const float sc = coo_fast_pow2(xa);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {  // the matrix kernel, launched after this one, reads them
+    hdr->inv_scale[0] = coo_fast_pow2(-xa);
+    hdr->inv_scale[1] = coo_fast_pow2(-coo_fast_scale_exp(hdr->max_b, 12));
+  }
   bool bad = false;
   for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
     const float x = in[i] * sc;
@@ -947,18 +946,16 @@ extern "C" int sm_spmm_coo_f32_fast(size_t A_num_rows, size_t A_num_cols, size_t
   }
   hipStream_t st = (hipStream_t)stream;
   char* ws = (char*)workspace;
-  CooFastHdr* hdr = (CooFastHdr*)ws;
-  _Float16* B16 = (_Float16*)(ws + COO_FAST_HDR_BYTES);
-  float* AT = (float*)((char*)B16 + round_up(nv * k * 2, 256));
-  _Float16* Aop = (_Float16*)((char*)AT + round_up(k * m * 4, 256));
-  if (hipMemsetAsync(hdr, 0, COO_FAST_HDR_BYTES, st) != hipSuccess) return check_launch("hipMemsetAsync");
-  if (hipMemsetAsync(AT, 0, k * m * 4, st) != hipSuccess) return check_launch("hipMemsetAsync");
+  CooFastHdr* hdr = (CooFastHdr*)ws;                       // [header | A^T fp32 | dense operand fp16 | A planes fp16]
+  float* AT = (float*)(ws + COO_FAST_HDR_BYTES);
+  _Float16* B16 = (_Float16*)((char*)AT + round_up(k * m * 4, 256));
+  _Float16* Aop = (_Float16*)((char*)B16 + round_up(nv * k * 2, 256));
+  if (hipMemsetAsync(ws, 0, COO_FAST_HDR_BYTES + k * m * 4, st) != hipSuccess) return check_launch("hipMemsetAsync");  // header and A^T in one node
   const size_t nB = nv * k;
   // <= 1024 chunks of 1024 floats, evenly spread (a dense operand of <= 1 M elements is scanned whole)
   const size_t nchunks = nB / 1024 < 1024 ? (nB + 1023) / 1024 : 1024;
   const size_t chunk_step = nchunks >= 1024 ? (nB / nchunks) & ~(size_t)3 : 1024;
   coo_fast_scan_kernel<<<256, 256, 0, st>>>(vals, A_nnz, B, nB, nchunks, chunk_step, hdr);
-  coo_fast_scale_kernel<<<1, 1, 0, st>>>(hdr);
   const size_t n8 = nB / 8;  // k % 64 == 0
   f32_to_f16_scaled_kernel<<<stream_grid(n8, 256), 256, 0, st>>>(B, B16, n8, hdr);
   if (A_nnz) coo_scatter_dense_kernel<<<stream_grid(A_nnz, 256), 256, 0, st>>>(rows, cols, vals, A_nnz, m, k, AT);

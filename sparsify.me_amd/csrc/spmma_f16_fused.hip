@@ -210,8 +210,15 @@ static int launch_fused_direct(const FusedArgs& a0, hipStream_t st) {
 // retires in order, so at iteration kt's wait everything up to B(kt) has landed once only the pieces issued after it
 // -- A(kt + 1) when NSA = 3 / NSB = 2 -- remain.  Same operands, same instruction sequence per output element as the
 // direct / wide kernels: bit-identical C.
+// Where a stage's ~3 900 cycles go (s_memtime stamps, profiles/stamp_r04b_big_wide_direct.txt; per wave): vmcnt wait 280, barrier
+// 745, DMA issue 800 (eight 1 KiB pieces), selection 990, B sweep 1 100 -- the sweep is the LDS array's rate (eight waves each
+// read the whole 32 KiB B stage = 1 024 LDS cycles), the A share of a stage (32 KiB) is 73 % of a CU's fair share of the HBM
+// rate.  Built, bit-identical and NOT adopted (git history, profiles/ab_pingpong_r04h.txt, ab_variants_r04c.txt): two B
+// fragments in flight instead of one (no change: the sweep is throughput-, not latency-bound), waves 4-7 issuing their A
+// pieces after their compute (-1 .. +5 %), and a ping-pong form in which waves 0-3 select one stage ahead so that one wave
+// of every SIMD is on the VALU while its partner is on the matrix pipe (+0 .. +4 % time).
 // ---------------------------------------------------------------------------------------------
-template <int BN, bool BF = false, int NSA = 3, int NSB = 2, bool ANT = true, int BPF = 1, bool STAG = false, bool PP = false>
+template <int BN, bool BF = false, int NSA = 3, int NSB = 2, bool ANT = true>
 __global__ __launch_bounds__(512) void spmma_f16_fused_big_kernel(const FusedArgs p) {
   constexpr int BM = 256, NW = 8, TM = BM / NW, FM = TM / 16, FN = BN / 16;
   constexpr int SA = BM * 128, SB = 64 * BN * 2;
@@ -242,8 +249,7 @@ __global__ __launch_bounds__(512) void spmma_f16_fused_big_kernel(const FusedArg
   unsigned aoff[SLA], boff[SLB];
 #pragma unroll
   for (int i = 0; i < SLA; ++i) {  // 8 rows x 128 B: lane -> row 8t + lane/8, LDS chunk lane%8 holds source chunk (lane%8) ^ (row&7)
-    // PP: a wave brings exactly the 32 rows it owns (pieces 4 w .. 4 w + 3), so its own counted vmcnt orders its reads of them
-    const unsigned t = PP ? wave * (unsigned)SLA + i : wave + (unsigned)NW * i;
+    const unsigned t = wave + (unsigned)NW * i;
     const unsigned row = 8u * t + (lane >> 3), cs = (lane & 7u) ^ (row & 7u);
     int gr = m0 + (int)row;
     gr = gr < mlast ? gr : mlast;
@@ -286,56 +292,6 @@ __global__ __launch_bounds__(512) void spmma_f16_fused_big_kernel(const FusedArg
     if (j + NSA - 1 < nkt) stage_a(j + NSA - 1, j + NSA - 1);
   }
   int ca = 0, cb = 0, fa = NSA - 1, fb = NSB - 1;  // current / next-to-fill slots of the two rings
-  if constexpr (PP) {
-    // PING-PONG (round 4): the two waves of a SIMD (w, w + 4) run the same program between the same barriers, so both are
-    // in the selection (VALU) at the same time and both in the B sweep (MFMA + LDS) at the same time -- each phase takes twice
-    // what it takes alone (stamps, profiles/stamp_r04b_big_wide_direct.txt: select 990, sweep 1104 cycles per stage).  Here
-    // waves 0-3 select stage kt + 1 AFTER sweeping stage kt (their selection runs one stage ahead, its result waits in
-    // registers across the barrier) while waves 4-7 select and then sweep stage kt: inside every barrier interval one
-    // partner is on the VALU while the other is on the matrix pipe.  A needs no workgroup synchronisation at all (a wave
-    // loads and reads only its own rows); the one barrier per stage orders the shared B ring exactly as before.
-    static_assert(NSA == 3 && NSB == 2 && !STAG, "ping-pong form: rings of 3 / 2");
-    const bool ahead = wave < 4u;  // selects one stage ahead
-    const unsigned g16 = lane >> 4, r16 = lane & 15u;
-    h8 af[FM];
-    int idx[FM];
-    auto select_from = [&](int slot) {
-      const char* Araw = smem + slot * SA;
-#pragma unroll
-      for (int i = 0; i < FM; ++i) {
-        const unsigned row = wave * TM + i * 16 + r16;
-        const u4 lo = *reinterpret_cast<const u4*>(Araw + a_off(row, 2u * g16));
-        const u4 hi = *reinterpret_cast<const u4*>(Araw + a_off(row, 2u * g16 + 1u));
-        dense16_to_operand(lo, hi, af[i], idx[i]);
-      }
-    };
-    if (ahead && nkt > 0) {  // stage 0's own rows: everything issued after A(0) may stay in flight
-      if (nkt > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SLB + SLA) : "memory");
-      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SLB) : "memory");
-      select_from(0);
-    }
-    for (int kt = 0; kt < nkt; ++kt) {
-      if (kt + 1 < nkt) wait_dma_and_barrier<AHEAD>();
-      else wait_dma_and_barrier<0>();
-      if (kt + NSB - 1 < nkt) stage_b(kt + NSB - 1, fb);
-      if (kt + NSA - 1 < nkt) stage_a(kt + NSA - 1, fa);
-      const char* Bs = smem + BRING + cb * SB;
-      if (!ahead) select_from(ca);  // landed before this barrier's wait (it is older than B(kt))
-      smfmac_b_sweep<FM, FN, BF, BPF>(af, idx, Bs, 0, lane, acc);
-      if (ahead && kt + 1 < nkt) {  // own rows of stage kt + 1 (issued one interval ago): B(kt + 1) and A(kt + 2), issued since, may stay in flight
-        if (kt + 2 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SLB + SLA) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SLB) : "memory");
-        select_from(ca + 1 == NSA ? 0 : ca + 1);
-      }
-      ca = ca + 1 == NSA ? 0 : ca + 1;
-      fa = fa + 1 == NSA ? 0 : fa + 1;
-      cb = cb + 1 == NSB ? 0 : cb + 1;
-      fb = fb + 1 == NSB ? 0 : fb + 1;
-    }
-    __syncthreads();
-    store_c_tile<BM, BN, FM, FN, 64 * NW, BF>(smem, C, acc, true, wave * TM, 0, m0, n0, p.Mrows, p.N, p.alpha, p.beta, tid);
-    return;
-  }
   SM_T(unsigned long long tv = 0, tb = 0, ti = 0, ts = 0, tc = 0; unsigned long long s0 = sm_stamp(); const unsigned long long sstart = s0;)
   for (int kt = 0; kt < nkt; ++kt) {
 #ifdef SM_STAMP
@@ -348,13 +304,8 @@ __global__ __launch_bounds__(512) void spmma_f16_fused_big_kernel(const FusedArg
     if (kt + 1 < nkt) wait_dma_and_barrier<AHEAD>();
     else wait_dma_and_barrier<0>();
 #endif
-    // STAG: the two waves of a SIMD (w, w + 4) run the same program in lockstep between barriers -- both in the DMA issue,
-    // both in the selection (VALU), both in the B sweep (MFMA) at the same time.  Waves 4-7 therefore issue their A pieces
-    // (two stages ahead: nothing waits for them soon) AFTER their compute: their selection runs beside the partner's DMA
-    // issue, their sweep beside its selection.  Same issue ORDER per wave (B then A), so the counted waits are unchanged.
-    const bool late_a = STAG && wave >= 4u;
     if (kt + NSB - 1 < nkt) stage_b(kt + NSB - 1, fb);  // the slots stage kt - 1 occupied: every wave left them before this barrier
-    if (!late_a && kt + NSA - 1 < nkt) stage_a(kt + NSA - 1, fa);
+    if (kt + NSA - 1 < nkt) stage_a(kt + NSA - 1, fa);
 #ifdef SM_STAMP
     __builtin_amdgcn_sched_barrier(0);
     const unsigned long long si = sm_stamp(); ti += si - sb;
@@ -374,14 +325,13 @@ __global__ __launch_bounds__(512) void spmma_f16_fused_big_kernel(const FusedArg
       for (int i = 0; i < FM; ++i) asm volatile("" : "+v"(af[i]), "+v"(idx[i]));
       __builtin_amdgcn_sched_barrier(0);
       const unsigned long long ss = sm_stamp(); ts += ss - si;
-      smfmac_b_sweep<FM, FN, BF, BPF>(af, idx, smem + BRING + cb * SB, 0, lane, acc);
+      smfmac_b_sweep<FM, FN, BF>(af, idx, smem + BRING + cb * SB, 0, lane, acc);
       __builtin_amdgcn_sched_barrier(0);
       s0 = sm_stamp(); tc += s0 - ss;
     }
 #else
-    smfmac_stage_dense_a<FM, FN, BF, BPF>(smem + ca * SA, smem + BRING + cb * SB, wave * TM, 0, lane, acc);
+    smfmac_stage_dense_a<FM, FN, BF>(smem + ca * SA, smem + BRING + cb * SB, wave * TM, 0, lane, acc);
 #endif
-    if (late_a && kt + NSA - 1 < nkt) stage_a(kt + NSA - 1, fa);
     ca = ca + 1 == NSA ? 0 : ca + 1;
     fa = fa + 1 == NSA ? 0 : fa + 1;
     cb = cb + 1 == NSB ? 0 : cb + 1;
@@ -394,7 +344,7 @@ __global__ __launch_bounds__(512) void spmma_f16_fused_big_kernel(const FusedArg
         d[0] = tv; d[1] = tb; d[2] = ti; d[3] = ts; d[4] = tc; d[5] = sloop - sstart; d[6] = se - sloop; })
 }
 
-template <int BN, bool BF = false, int NSA = 3, int NSB = 2, bool ANT = true, int BPF = 1, bool STAG = false, bool PP = false>
+template <int BN, bool BF = false, int NSA = 3, int NSB = 2, bool ANT = true>
 static int launch_fused_big(const FusedArgs& a0, hipStream_t st) {
   constexpr int BM = 256;
   FusedArgs a = a0;
@@ -411,7 +361,7 @@ static int launch_fused_big(const FusedArgs& a0, hipStream_t st) {
   constexpr size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
   static_assert(lds <= 160 * 1024, "LDS budget of the big direct kernel");
   static LdsOptIn lds_optin;
-  if (const int rc = ensure_dyn_lds(lds_optin, reinterpret_cast<const void*>(&spmma_f16_fused_big_kernel<BN, BF, NSA, NSB, ANT, BPF, STAG, PP>), lds, "spmma_f16_fused_big_kernel")) return rc;
+  if (const int rc = ensure_dyn_lds(lds_optin, reinterpret_cast<const void*>(&spmma_f16_fused_big_kernel<BN, BF, NSA, NSB, ANT>), lds, "spmma_f16_fused_big_kernel")) return rc;
 #ifdef SM_STAMP
   {
     static unsigned long long* dbg = nullptr;
@@ -420,7 +370,7 @@ static int launch_fused_big(const FusedArgs& a0, hipStream_t st) {
     if (cnt > cap) { if (dbg) (void)hipFree(dbg); (void)hipMalloc((void**)&dbg, cnt * 8); cap = cnt; }
     (void)hipMemset(dbg, 0, cnt * 8);
     a.dbg = dbg;
-    spmma_f16_fused_big_kernel<BN, BF, NSA, NSB, ANT, BPF, STAG, PP><<<dim3((unsigned)nwg), dim3(512), lds, st>>>(a);
+    spmma_f16_fused_big_kernel<BN, BF, NSA, NSB, ANT><<<dim3((unsigned)nwg), dim3(512), lds, st>>>(a);
     (void)hipDeviceSynchronize();
     std::vector<unsigned long long> h(cnt);
     (void)hipMemcpy(h.data(), dbg, cnt * 8, hipMemcpyDeviceToHost);
@@ -433,7 +383,7 @@ static int launch_fused_big(const FusedArgs& a0, hipStream_t st) {
     return check_launch("spmma_f16_fused_big_kernel");
   }
 #endif
-  spmma_f16_fused_big_kernel<BN, BF, NSA, NSB, ANT, BPF, STAG, PP><<<dim3((unsigned)nwg), dim3(512), lds, st>>>(a);
+  spmma_f16_fused_big_kernel<BN, BF, NSA, NSB, ANT><<<dim3((unsigned)nwg), dim3(512), lds, st>>>(a);
   return check_launch("spmma_f16_fused_big_kernel");
 }
 
@@ -595,7 +545,7 @@ struct BTileDma {
 // PF stages ahead in registers, only B through LDS -- was built in round 2: bit-identical, 1.3x slower on every n <= 128 layer
 // (profiles/tune_rega_r02q.txt; 164 VGPRs, half-line wave loads).  Removed again; DESIGN.md 4.5, git history.)
 
-template <int BN, int WM, int WN, int NLB, int PF, int NSB, bool BF = false, int APRIO = 0>
+template <int BN, int WM, int WN, int NLB, int PF, int NSB, bool BF = false>
 __global__ __launch_bounds__(64 * (WM * WN + 4 + NLB)) void spmma_f16_fused_wide_kernel(const FusedArgs p) {
   constexpr int BM = 128, NLA = 4, NC = WM * WN, NW = NC + NLA + NLB;
   static_assert(PF >= 1 && PF <= 3 && NSB >= 2 && NSB <= 4, "pipeline depths");
@@ -662,9 +612,8 @@ __global__ __launch_bounds__(64 * (WM * WN + 4 + NLB)) void spmma_f16_fused_wide
     SM_T(if (p.dbg && lane == 0) { unsigned long long* d = p.dbg + ((size_t)blockIdx.x * NW + wave) * 8; d[0] = tb; d[1] = ti; d[2] = tv; d[3] = 2; d[6] = nlong; })
   } else if (wave >= (unsigned)NC) {
     // ------------------------------------------------------------------ A loader wave: load, select, ds_write
-    // (its selection is the stage's critical path and shares a SIMD's vector issue with two consumers and a B loader:
-    //  APRIO > 0 raises its priority once -- the branch is wave-uniform, s_setprio ignores EXEC)
-    if (APRIO > 0) __builtin_amdgcn_s_setprio(APRIO);
+    // (round 4: raising these waves' priority -- their selection is the stage's critical path -- changed nothing: within 2 %
+    //  either way on every wide shape, profiles/ab_variants_r04c.txt; three A stages in flight lost 3-6 %)
     const unsigned lw = wave - NC;
     const half_t* A = p.A[grp] + (size_t)b * p.sA;
     const int mlast = p.Mrows - 1;
@@ -793,7 +742,7 @@ __global__ __launch_bounds__(64 * (WM * WN + 4 + NLB)) void spmma_f16_fused_wide
   store_c_tile<BM, BN, FM, FN, 64 * NW, BF>(smem, C, acc, wave < (unsigned)NC, wm * TM, wn * TN, m0, n0, p.Mrows, p.N, p.alpha, p.beta, tid);
 }
 
-template <int BN, int WM, int WN, int NLB, int PF, int NSB, bool BF = false, int APRIO = 0>
+template <int BN, int WM, int WN, int NLB, int PF, int NSB, bool BF = false>
 static int launch_fused_wide(const FusedArgs& a0, hipStream_t st) {
   FusedArgs a = a0;
   a.tiles_m = (a.Mrows + 127) / 128;
@@ -809,7 +758,7 @@ static int launch_fused_wide(const FusedArgs& a0, hipStream_t st) {
   constexpr size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
   static LdsOptIn lds_optin;
   if (lds > 64 * 1024) {
-    if (const int rc = ensure_dyn_lds(lds_optin, reinterpret_cast<const void*>(&spmma_f16_fused_wide_kernel<BN, WM, WN, NLB, PF, NSB, BF, APRIO>), lds, "spmma_f16_fused_wide_kernel")) return rc;
+    if (const int rc = ensure_dyn_lds(lds_optin, reinterpret_cast<const void*>(&spmma_f16_fused_wide_kernel<BN, WM, WN, NLB, PF, NSB, BF>), lds, "spmma_f16_fused_wide_kernel")) return rc;
   }
 #ifdef SM_STAMP
   {
@@ -820,7 +769,7 @@ static int launch_fused_wide(const FusedArgs& a0, hipStream_t st) {
     if (cnt > cap) { if (dbg) (void)hipFree(dbg); (void)hipMalloc((void**)&dbg, cnt * 8); cap = cnt; }
     (void)hipMemset(dbg, 0, cnt * 8);
     a.dbg = dbg;
-    spmma_f16_fused_wide_kernel<BN, WM, WN, NLB, PF, NSB, BF, APRIO><<<dim3((unsigned)nwg), dim3(64 * NWV), lds, st>>>(a);
+    spmma_f16_fused_wide_kernel<BN, WM, WN, NLB, PF, NSB, BF><<<dim3((unsigned)nwg), dim3(64 * NWV), lds, st>>>(a);
     (void)hipDeviceSynchronize();
     std::vector<unsigned long long> h(cnt);
     (void)hipMemcpy(h.data(), dbg, cnt * 8, hipMemcpyDeviceToHost);
@@ -839,7 +788,7 @@ static int launch_fused_wide(const FusedArgs& a0, hipStream_t st) {
     return check_launch("spmma_f16_fused_wide_kernel");
   }
 #endif
-  spmma_f16_fused_wide_kernel<BN, WM, WN, NLB, PF, NSB, BF, APRIO><<<dim3((unsigned)nwg), dim3(64 * (WM * WN + 4 + NLB)), lds, st>>>(a);
+  spmma_f16_fused_wide_kernel<BN, WM, WN, NLB, PF, NSB, BF><<<dim3((unsigned)nwg), dim3(64 * (WM * WN + 4 + NLB)), lds, st>>>(a);
   return check_launch("spmma_f16_fused_wide_kernel");
 }
 
@@ -1417,12 +1366,7 @@ static int spmma_fused16(size_t ngroup, const void* const* Ag, const void* const
   }
 #ifdef SM_TUNING
   {  // A/B of the 256-row big form: bit 0 = n >= 256 (k > 64), bit 1 = 64 < n <= 128, bit 2 = n <= 256 with k <= 64; SM_FUSED_BIG_NSB = 2 / 3
-    const int big_env = tuning_int("SM_FUSED_BIG", 0), nsb = tuning_int("SM_FUSED_BIG_NSB", 2), bpf = tuning_int("SM_FUSED_BIG_PF", 1);
-    if (big_env < 8 && (big_env & 1) && n > 128 && k > 64 && tuning_int("SM_FUSED_BIG_STAG", 0)) return n <= 256 ? launch_fused_big<256, BF, 3, 2, true, 1, true>(a, st) : launch_fused_big<256, BF, 3, 2, false, 1, true>(a, st);
-    if (big_env < 8 && (big_env & 2) && n > 64 && n <= 128 && tuning_int("SM_FUSED_BIG_STAG", 0)) return launch_fused_big<128, BF, 3, 2, true, 1, true>(a, st);
-    if (big_env < 8 && (big_env & 1) && n > 128 && k > 64 && tuning_int("SM_FUSED_BIG_PP", 0)) return n <= 256 ? launch_fused_big<256, BF, 3, 2, true, 1, false, true>(a, st) : launch_fused_big<256, BF, 3, 2, false, 1, false, true>(a, st);
-    if (big_env < 8 && (big_env & 2) && n > 64 && n <= 128 && tuning_int("SM_FUSED_BIG_PP", 0)) return launch_fused_big<128, BF, 3, 2, true, 1, false, true>(a, st);
-    if (big_env < 8 && (big_env & 1) && n > 128 && k > 64 && bpf == 2) return n <= 256 ? launch_fused_big<256, BF, 3, 2, true, 2>(a, st) : launch_fused_big<256, BF, 3, 2, false, 2>(a, st);
+    const int big_env = tuning_int("SM_FUSED_BIG", 0), nsb = tuning_int("SM_FUSED_BIG_NSB", 2);
     if (big_env < 8 && (big_env & 1) && n > 128 && k > 64) return n <= 256 ? launch_fused_big<256, BF, 3, 2, true>(a, st) : launch_fused_big<256, BF, 3, 2, false>(a, st);
     if (big_env < 8 && (big_env & 4) && n > 128 && n <= 256 && k <= 64) return launch_fused_big<256, BF, 3, 2, true>(a, st);
     if (big_env < 8 && (big_env & 2) && n > 64 && n <= 128) return nsb == 3 ? launch_fused_big<128, BF, 3, 3, true>(a, st) : launch_fused_big<128, BF, 3, 2, true>(a, st);
@@ -1464,10 +1408,6 @@ static int spmma_fused16(size_t ngroup, const void* const* Ag, const void* const
   // profiles/widep_r03g.txt), so those keep one workgroup per tile.  SM_FUSED_WIDEP (tuning aid): 0 = never, 2 = always.
   static const int widep_env = tuning_int("SM_FUSED_WIDEP", 1);
   if (widep_env == 2 || (widep_env == 1 && k <= 1024)) return launch_fused_widep<256, 4, 2, 4, 2, 3, BF>(a, st);
-#ifdef SM_TUNING
-  if (tuning_int("SM_FUSED_APRIO", 0) > 0) return launch_fused_wide<256, 4, 2, 4, 2, 3, BF, 2>(a, st);
-  if (tuning_int("SM_FUSED_WIDE_PF", 2) == 3) return launch_fused_wide<256, 4, 2, 4, 3, 3, BF>(a, st);
-#endif
   return launch_fused_wide<256, 4, 2, 4, 2, 3, BF>(a, st);
 }
 

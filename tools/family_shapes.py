@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """One representative layer per kernel family of the timed step, a few launches each, for rocprofv3 --pmc passes
-(tools/pmc_families.sh): direct<64>, direct<128>, wide, A-stationary (fused), the staged producer/consumer 2:4 matmul,
+(tools/pmc_families.sh): direct<64>, direct<128>, wide, big (256-row tiles), A-stationary, span (fused; grouped launches since round 4),
+the staged producer/consumer 2:4 matmul,
 the dense GEMM on the wide shape, and the plain copy kernel as the reference point."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -20,16 +21,18 @@ def ops(m, n, k):
     return A, B, C
 
 
-for (m, n, k) in [(12544, 64, 576), (3136, 128, 1152), (784, 256, 2304), (784, 1024, 256)]:
-    A, B, C = ops(m, n, k)
+# round 4: every family as the timed step launches it -- the grouped launch of the shape's instance count
+for (m, n, k, cnt) in [(12544, 64, 576, 3), (3136, 128, 1152, 4), (784, 256, 2304, 6), (784, 256, 1024, 5), (196, 512, 4608, 3), (784, 1024, 256, 6), (12544, 64, 147, 1)]:
+    ops_ = [ops(m, n, k) for _ in range(cnt)]
     for _ in range(reps):
-        sm.spmma_fused(A, B, C, m, n, k, batch=b)
+        sm.spmma_fused_grouped([o[0] for o in ops_], [o[1] for o in ops_], [o[2] for o in ops_], m, n, k, batch=b)
     torch.cuda.synchronize()
     if (m, n, k) == (784, 256, 2304):
+        A, B, C = ops_[0]
         for _ in range(reps):
             sm.gemm_rowmajor(A, B, C, m, n, k, batch=b)
         torch.cuda.synchronize()
-    del A, B, C
+    del ops_
 m, n, k = 196, 512, 4608
 A, B, C = ops(m, n, k)
 blob = torch.empty(sm.compress24_size(m, k, 2, b), dtype=torch.uint8, device=dev)

@@ -16,8 +16,9 @@ for d in sys.argv[1:]:
                 seen.add(k)
                 dur[n].append((float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) / 1e3)
 A = lambda n, c: (sum(acc[n][c]) / len(acc[n][c])) if acc[n].get(c) else None
-shape = {"spmma_f16_fused_direct_kernel<64": "12544x64x576", "spmma_f16_fused_direct_kernel<128": "3136x128x1152", "spmma_f16_fused_wide_kernel": "784x256x2304",
-         "spmma_f16_fused_astat_kernel": "784x1024x256", "spmma_f16_pc_kernel": "196x512x4608 (staged 2:4 matmul)", "gemm_f16_dma_kernel": "784x256x2304 (dense)",
+shape = {"spmma_f16_fused_direct_kernel<64": "12544x64x576 x3", "spmma_f16_fused_direct_kernel<128": "3136x128x1152 x4", "spmma_f16_fused_wide_kernel": "784x256x2304 x6",
+         "spmma_f16_fused_big_kernel<256, false, 3, 2, true": "784x256x1024 x5 (big)", "spmma_f16_fused_big_kernel<256, false, 3, 2, false": "196x512x4608 x3 (big)",
+         "spmma_f16_fused_span_kernel": "12544x64x147", "spmma_f16_fused_astat_kernel": "784x1024x256 x6", "spmma_f16_pc_kernel": "196x512x4608 (staged 2:4 matmul)", "gemm_f16_dma_kernel": "784x256x2304 (dense)",
          "copy_bytes_kernel": "1 GiB copy", "compress_flat_kernel": "196x4608 compress"}
 print("%-46s %-28s %8s %8s %9s %9s %9s %9s %9s %9s %9s" % ("kernel", "layer (b = 32)", "us", "CUs", "rd/clk/CU", "lat cyc", "lines/CU", "wait%", "istall%", "active%", "VALU%"))
 for n in acc:
