@@ -78,9 +78,12 @@ __global__ __launch_bounds__(256) void spmma_f16_pruned_kernel(const PrunedArgs 
   }
   auto stage = [&](int kt, int buf) {
     char* base = smem + buf * STAGE;
+    // A is read exactly once by the whole grid (one column tile per row panel): non-temporal, as in the direct fused kernel
 #pragma unroll
-    for (int i = 0; i < SL; ++i)
-      __builtin_amdgcn_global_load_lds((gptr_t*)(src[i] + (size_t)kt * step[i]), (lptr_t*)(base + loff[i]), 16, 0, 0);
+    for (int i = 0; i < SL; ++i) {
+      if (NW * i < A_N) __builtin_amdgcn_global_load_lds((gptr_t*)(src[i] + (size_t)kt * step[i]), (lptr_t*)(base + loff[i]), 16, 0, 2);
+      else __builtin_amdgcn_global_load_lds((gptr_t*)(src[i] + (size_t)kt * step[i]), (lptr_t*)(base + loff[i]), 16, 0, 0);
+    }
   };
 
   // prune phase geometry: rows 4 q + i (i < 4), chunk c of the stage
@@ -148,7 +151,7 @@ __global__ __launch_bounds__(256) void spmma_f16_pruned_kernel(const PrunedArgs 
       for (int i = 0; i < 4; ++i) {
         const u4 w = u4{o[i][0], o[i][1], o[i][2], o[i][3]};
         *reinterpret_cast<u4*>(As + poff[i]) = w;
-        if (gok[i]) *reinterpret_cast<u4*>(gdst[i] + (size_t)kt * 64) = w;
+        if (gok[i]) __builtin_nontemporal_store(w, reinterpret_cast<u4*>(gdst[i] + (size_t)kt * 64));  // written once, not read again here
         // the flag comes from what is stored: a strip (two dwords) with more than two halves != 0 (-0 counts as zero)
 #pragma unroll
         for (unsigned t = 0; t < 2; ++t) {

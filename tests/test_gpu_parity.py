@@ -1572,6 +1572,49 @@ def test_fused_equals_staged(gpu, orc, shape, shared_b):
     check_close(host(C2), Cref.view(np.float16), scale, FP16_TOL, f"fused {shape}", k)
 
 
+@pytest.mark.parametrize("shape", [(2045, 256, 128, 32), (2045, 264, 576, 32), (2048, 512, 576, 32), (128, 256, 128, 1), (100, 264, 576, 1)],
+                         ids=lambda s_: "x".join(map(str, s_)))
+@pytest.mark.parametrize("bf", [False, True], ids=["f16", "bf16"])
+def test_fused_big_form_equals_staged(gpu, shape, bf):
+    """The 256-row BIG form of the fused kernel (round 4; spmma_f16_fused.hip: spmma_f16_fused_big_kernel), which the dispatch
+    takes for n > 128 when its one-per-CU workgroups fill the chip's rounds at least as well as the 128-row kernels' -- here:
+    65 440 / 65 536 stacked rows = 256 big tiles against 512 (a ragged last tile, one and two column tiles, a column tail), and
+    single-tile problems -- against sm_compress24 + sm_spmma, bit for bit: shared and per-batch B, alpha / beta != (1, 0),
+    grouped launches of three."""
+    import torch
+    m, n, k, batch = shape
+    tdt = torch.bfloat16 if bf else torch.float16
+    dA = torch.empty(batch * m * k, dtype=tdt, device="cuda")
+    gpu.fill_uniform(dA, 0xB16 + m + n, -1.0, 1.0)
+    blob = torch.empty(gpu.compress24_size(m, k, 2, batch), dtype=torch.uint8, device="cuda")
+    gpu.compress24(dA, m, k, k, batch, m * k, blob)
+    for shared_b, (alpha, beta) in ((True, (1.0, 0.0)), (False, (1.0, 0.0)), (True, (0.5, -2.0))):
+        nb = 1 if shared_b else batch
+        dB = torch.empty(nb * k * n, dtype=tdt, device="cuda")
+        gpu.fill_uniform(dB, 0xB17 + k, -1.0, 1.0)
+        strideB = 0 if shared_b else k * n
+        C0 = torch.empty(batch * m * n, dtype=tdt, device="cuda")
+        gpu.fill_uniform(C0, 0xC17, -1.0, 1.0)
+        C1, C2 = C0.clone(), C0.clone()
+        gpu.spmma(blob, dB, C1, m, n, k, batch, strideB, alpha=alpha, beta=beta)
+        gpu.spmma_fused(dA, dB, C2, m, n, k, batch=batch, strideB=strideB, alpha=alpha, beta=beta)
+        assert torch.equal(C1.view(torch.int16), C2.view(torch.int16)), f"big form differs from compress + spmma (shared_b={shared_b}, alpha={alpha}, beta={beta})"
+    # grouped: three problems in one grid
+    As = [dA] + [torch.empty_like(dA) for _ in range(2)]
+    for i in (1, 2):
+        gpu.fill_uniform(As[i], 0xB20 + i, -1.0, 1.0)
+    Bs = [torch.empty(k * n, dtype=tdt, device="cuda") for _ in range(3)]
+    for i, B_ in enumerate(Bs):
+        gpu.fill_uniform(B_, 0xB30 + i, -1.0, 1.0)
+    Cs = [torch.full((batch * m * n,), float("nan"), dtype=tdt, device="cuda") for _ in range(3)]
+    gpu.spmma_fused_grouped(As, Bs, Cs, m, n, k, batch=batch)
+    Cref = torch.empty(batch * m * n, dtype=tdt, device="cuda")
+    for i in range(3):
+        gpu.compress24(As[i], m, k, k, batch, m * k, blob)
+        gpu.spmma(blob, Bs[i], Cref, m, n, k, batch)
+        assert torch.equal(Cs[i].view(torch.int16), Cref.view(torch.int16)), f"grouped big form, problem {i}"
+
+
 @pytest.mark.parametrize("shape", [(3136, 512, 128, 24), (2100, 264, 256, 32), (4096, 384, 64, 17), (2049, 520, 192, 32)])
 def test_fused_astat_many_panels_equals_staged(gpu, shape):
     """The A-stationary kernel at grouped-launch sizes (several rounds of row panels per CU; one- to four-stage panels, ragged
