@@ -22,10 +22,10 @@ HYBRID_FILL_ROWS = 512 * 128
 # Measured time of one layer INSIDE a grouped launch of its shape, us at b = 32 on one MI355X (profiles/sweep_r04_f16_resnet50.txt,
 # column `fused`); shapes that are not in the table fall back to bytes over the rate of their kernel family.
 MEASURED_US_B32 = {
-    (12544, 64, 147): 55.1, (12544, 64, 64): 21.2, (12544, 64, 576): 94.7, (12544, 256, 64): 55.1, (12544, 64, 256): 47.0,
-    (12544, 128, 256): 66.2, (3136, 128, 1152): 49.8, (3136, 512, 128): 32.2, (3136, 128, 512): 27.4, (3136, 256, 512): 45.0,
-    (784, 256, 2304): 32.6, (784, 1024, 256): 19.9, (784, 256, 1024): 16.3, (784, 512, 1024): 38.0, (196, 512, 4608): 42.8,
-    (196, 2048, 512): 24.9, (196, 512, 2048): 16.8,
+    (12544, 64, 147): 55.7, (12544, 64, 64): 21.3, (12544, 64, 576): 91.4, (12544, 256, 64): 53.6, (12544, 64, 256): 48.2,
+    (12544, 128, 256): 64.6, (3136, 128, 1152): 48.3, (3136, 512, 128): 31.8, (3136, 128, 512): 27.1, (3136, 256, 512): 43.4,
+    (784, 256, 2304): 31.1, (784, 1024, 256): 19.2, (784, 256, 1024): 15.2, (784, 512, 1024): 33.9, (196, 512, 4608): 39.1,
+    (196, 2048, 512): 21.1, (196, 512, 2048): 16.5,
 }
 
 

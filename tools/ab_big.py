@@ -16,12 +16,15 @@ SETS = {
     "n128": [(3136, 128, 1152, 4), (3136, 128, 512, 3), (12544, 128, 256, 1)],
     "k64": [(12544, 256, 64, 3)],
     "astat": [(3136, 512, 128, 4), (784, 1024, 256, 6), (196, 2048, 512, 3)],
+    "ilv": [(784, 256, 2304, 6), (784, 256, 1024, 5), (3136, 256, 512, 1), (196, 512, 4608, 3), (196, 512, 2048, 2), (784, 512, 1024, 1), (196, 2048, 512, 3)],
 }
 VARIANTS = {
     "wide": [("base", {}), ("big", {"SM_FUSED_BIG": "1"})],
     "n128": [("base", {}), ("big nsb2", {"SM_FUSED_BIG": "2", "SM_FUSED_BIG_NSB": "2"}), ("big nsb3", {"SM_FUSED_BIG": "2", "SM_FUSED_BIG_NSB": "3"})],
     "k64": [("base", {}), ("big", {"SM_FUSED_BIG": "4"})],
     "astat": [("base", {}), ("big", {"SM_FUSED_BIG": "1", "SM_FUSED_ASTAT": "0"})],
+    "ilv": [("rule", {}), ("big", {"SM_FUSED_BIG": "1", "SM_FUSED_ASTAT": "0"}), ("big ilv1", {"SM_FUSED_BIG": "1", "SM_FUSED_ASTAT": "0", "SM_FUSED_BIG_ILV": "1"}),
+            ("big ilv2", {"SM_FUSED_BIG": "1", "SM_FUSED_ASTAT": "0", "SM_FUSED_BIG_ILV": "2"})],
 }
 which = sys.argv[1].split(",") if len(sys.argv) > 1 else ["wide", "n128", "k64"]
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 3
