@@ -696,14 +696,54 @@ def extras(args, sm, torch, dev, layers, flops, t_full, Forked, make_runner, tim
         out["stages"]["api_spmma_sequence"] = sm.API_SPMMA_SEQUENCE
         if not f32 and hasattr(sm, "api_spmma_step_fused"):
             # round 4: the same sequence as ONE kernel (sm_prune24_spmma_*: TILE prune written to the second buffer, flag, multiply,
-            # no blob) on the layers it takes (n <= 128, k % 64 == 0, m % 4 == 0); the two-launch pair on the others
+            # no blob) on the layers it takes (n <= 256, k % 64 == 0, m % 4 == 0); the two-launch pair on the others
             t_api1 = sec_per_call(Forked(lambda L: sm.api_spmma_step_fused(L["A"], L["Aapi"], L["B"], L["C"], L["blob"], valid, L["m"], L["n"], L["k"], L["b"])))
-            n_one = sum(1 for L in layers if L["n"] <= 128 and L["n"] % 8 == 0 and L["k"] % 64 == 0 and L["m"] % 4 == 0)
+            n_one = sum(1 for L in layers if L["n"] <= 256 and L["n"] % 8 == 0 and L["k"] % 64 == 0 and L["m"] % 4 == 0)
             out["stages"]["api_spmma_one_kernel_ms"] = t_api1 * 1e3
             out["stages"]["api_spmma_one_kernel_gfs"] = gfs(t_api1)
             out["stages"]["api_spmma_one_kernel_layers"] = n_one
         for L in layers:
             del L["Aapi"]
+
+    if f32 and hasattr(sm, "spmma_fused_f32_split"):
+        # round 4: the fp32 2:4 product on the SPARSE matrix instruction through exact bfloat16 splits of both operands
+        # (sm_spmma_fused_f32_split; planes = 3: |error| <= 2^-21 sum|a||b|, planes = 2: 2^-13) where it applies (k % 64 == 0,
+        # n % 8 == 0), the exact fused kernel elsewhere.  Reported BESIDE the headline, which stays the exact fp32 form.
+        split = {"kernel": "spmma_f32_split_kernel (v_smfmac_f32_16x16x64_bf16 on three / two truncated bfloat16 pieces per fp32 value, fp32 "
+                           "accumulation; mask = the exact path's) + split_planes_kernel (B's pieces, once per call, into a workspace)"}
+        for L in layers:
+            L["ws"] = torch.empty(max(16, sm.spmma_fused_f32_split_workspace(L["n"], L["k"], planes=3)), dtype=torch.uint8, device=dev)
+        for planes in (3, 2):
+            def layer_split(L, planes=planes):
+                if L["k"] % 64 or L["n"] % 8 or sm.spmma_fused_f32_split(L["A"], L["B"], L["C"], L["m"], L["n"], L["k"], L["ws"], batch=L["b"],
+                                                                          planes=planes, check=False) != 0:
+                    (sm.spmma_fused(L["A"], L["B"], L["C"], L["m"], L["n"], L["k"], batch=L["b"]) if use_fused(L) else
+                     (sm.compress24(L["A"], L["m"], L["k"], L["k"], L["b"], L["m"] * L["k"], L["blob"]),
+                      sm.spmma(L["blob"], L["B"], L["C"], L["m"], L["n"], L["k"], L["b"], 0)))
+            t_sp = sec_per_call(Forked(layer_split))
+            key = "planes%d" % planes
+            split[key + "_ms"] = t_sp * 1e3
+            split[key + "_gfs"] = gfs(t_sp)
+            split[key + "_speedup_vs_dense_rowmajor"] = t_drm / t_sp
+            split[key + "_speedup_vs_exact_fused"] = t_full / t_sp
+            split[key + "_hbm_frac"] = sum(L["b"] * 4 * (L["m"] * L["k"] + L["m"] * L["n"]) + 4 * L["k"] * L["n"] for L in layers) / t_sp / (HBM_PEAK_GBS * 1e9)
+        split["layers_on_split_form"] = sum(1 for L in layers if L["k"] % 64 == 0 and L["n"] % 8 == 0)
+        # error of the split forms against the exact kernel on the first layer they take (max |diff| / max sum|a||b| bound proxy)
+        L = next((L for L in layers if L["k"] % 64 == 0 and L["n"] % 8 == 0), None)
+        if L is not None:
+            Ce = torch.empty_like(L["C"])
+            sm.spmma_fused(L["A"], L["B"], Ce, L["m"], L["n"], L["k"], batch=L["b"])
+            for planes in (3, 2):
+                sm.spmma_fused_f32_split(L["A"], L["B"], L["C"], L["m"], L["n"], L["k"], L["ws"], batch=L["b"], planes=planes)
+                torch.cuda.synchronize()
+                d = (L["C"].double() - Ce.double()).abs().max().item()
+                split["planes%d_max_abs_diff_vs_exact" % planes] = d
+                split["planes%d_max_rel_diff_vs_exact" % planes] = d / max(Ce.double().abs().max().item(), 1e-30)
+            split["diff_layer"] = [L["m"], L["n"], L["k"], L["b"]]
+            del Ce
+        for L in layers:
+            del L["ws"]
+        out["stages"]["f32_split"] = split
 
     if not f32 and os.path.basename(args.tables.split(",")[0] if args.tables else (args.table or "resnet50")).startswith("resnet50"):
         out["stages"]["conv_path"] = conv_path_stage(sm, torch, dev, args.dtype)

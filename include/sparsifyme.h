@@ -168,6 +168,22 @@ int sm_spmma_fused_bf16_grouped(size_t count, const void* const* A, const void* 
 int sm_spmma_fused_f32(const float* A, const float* B, float* C, size_t m, size_t n, size_t k, size_t lda, size_t batch,
                        size_t strideA, size_t strideB, size_t strideC, float alpha, float beta, sm_stream_t stream);
 
+/* fp32 operands on the SPARSE matrix instruction (extension, round 4; csrc/spmma_f32_split.hip): the same product -- the 2:4
+ * STRIP selection made on the fp32 values, mask identical to sm_prune24_f32's -- computed by v_smfmac_f32_16x16x64_bf16 on
+ * exact bfloat16 splits of both operands (x = x1 + x2 + x3, 8 + 8 + 8 significand bits) with fp32 accumulation:
+ *   planes = 3: a1 b1 + a1 b2 + a2 b1 + a2 b2 + a1 b3 + a3 b1     |error| <= 2^-22 * sum |a| |b|  (+ fp32 accumulation)
+ *   planes = 2: a1 b1 + a1 b2 + a2 b1                             |error| <= 2^-13 * sum |a| |b|
+ * (north_star asks 1e-3 relative for fp32 products; cuSPARSELt, what spmma.hxx:106-114 calls, computes fp32 operands in
+ * TF32 = 10 significand bits).  Not bit-identical to sm_spmma_fused_f32 -- which stays the exact form -- and several times
+ * faster: bound by the HBM stream of A instead of the fp32 matrix rate.  `workspace` receives B's bfloat16 planes
+ * (sm_spmma_fused_f32_split_workspace bytes, 16-byte aligned; a strided B must be packed, strideB == k * n).  Non-finite
+ * operand values are carried by the first piece alone.  Needs k % 64 == 0, n % 8 == 0, 16-byte aligned rows of A, B and C
+ * (ldc = n); everything else: SM_STATUS_NOT_SUPPORTED, use sm_spmma_fused_f32. */
+int sm_spmma_fused_f32_split_workspace(size_t n, size_t k, size_t batch, size_t strideB, int planes, size_t* bytes);
+int sm_spmma_fused_f32_split(const float* A, const float* B, float* C, size_t m, size_t n, size_t k, size_t lda, size_t batch,
+                             size_t strideA, size_t strideB, size_t strideC, int planes, void* workspace, size_t workspace_bytes,
+                             float alpha, float beta, sm_stream_t stream);
+
 /* ---- (a5) dense batched GEMM: replaces cublas{H,S,D}gemmBatched (gemm.hxx:80-81, 133-134,
  *      186-187).  COLUMN-major, lda = m, ldb = k, ldc = m as the reference passes them;
  *      A_ptrs/B_ptrs/C_ptrs are device arrays of `batch` device pointers (examples/gemm.cu:65-90).

@@ -610,7 +610,8 @@ def test_full_size_properties_resnet50(gpu, orc, shape):
     check_close(got, Cref.view(np.float16), scale, FP16_TOL, f"sampled batch {shape}", k)
 
 
-PRUNE_SPMMA_SHAPES = [(128, 64, 64, 1), (196, 128, 256, 2), (132, 72, 192, 3), (4, 8, 64, 1), (260, 128, 128, 2), (3136, 128, 512, 2), (12544, 64, 576, 1)]
+PRUNE_SPMMA_SHAPES = [(128, 64, 64, 1), (196, 128, 256, 2), (132, 72, 192, 3), (4, 8, 64, 1), (260, 128, 128, 2), (3136, 128, 512, 2), (12544, 64, 576, 1),
+                      (196, 256, 256, 2), (132, 200, 64, 1), (784, 256, 1024, 1)]
 
 
 @pytest.mark.parametrize("alg", [0, 1], ids=["tile", "strip"])
@@ -668,7 +669,7 @@ def test_prune_spmma_rejects_what_it_cannot_take(gpu):
     B = torch.zeros(256 * 256, dtype=torch.float16, device="cuda")
     C = torch.zeros(200 * 256, dtype=torch.float16, device="cuda")
     NS = gpu.STATUS_NOT_SUPPORTED
-    assert gpu.prune24_spmma(A, A, B, C, 196, 256, 256, check=False) == NS       # n > 128: two column tiles would both rewrite A
+    assert gpu.prune24_spmma(A, A, B, C, 196, 264, 128, check=False) == NS       # n > 256: two column tiles would both rewrite A
     assert gpu.prune24_spmma(A, A, B, C, 196, 64, 72, check=False) == NS         # k % 64 != 0
     assert gpu.prune24_spmma(A, A, B, C, 130, 64, 64, check=False) == NS         # m % 4 != 0: a 4 x 4 tile would straddle two batches
     with pytest.raises(gpu.SparsifymeError):
@@ -782,6 +783,78 @@ def test_spmma_fused_f32(gpu, orc, shape, ab):
         Pm = np.abs(host(P).astype(np.float64)).reshape(batch * m, k)
         scale = abs(alpha) * (Pm @ np.abs(B.astype(np.float64)).reshape(k, n)).reshape(-1) + abs(beta) * np.abs(C0.astype(np.float64))
         check_close(host(Cf), Cref, scale, FP32_TOL, f"spmma_fused_f32 {shape}", k, "f32")
+
+
+SPLIT_TOL = {3: 2.0 ** -21, 2: 2.0 ** -13}  # sm_spmma_fused_f32_split: |error| <= SPLIT_TOL * sum |a||b| on top of the fp32 accumulation bound
+
+
+@pytest.mark.parametrize("shape", [(128, 64, 64, 1), (196, 128, 256, 2), (132, 72, 192, 3), (260, 256, 128, 2), (100, 512, 320, 1), (3136, 128, 576, 2),
+                                   (12544, 64, 576, 1)], ids=lambda s_: "x".join(map(str, s_)))
+@pytest.mark.parametrize("planes", [3, 2])
+@pytest.mark.parametrize("ab", [(1.0, 0.0), (0.5, -2.0)])
+@pytest.mark.parametrize("kind", ["uniform", "ties"])
+def test_spmma_f32_split(gpu, shape, planes, ab, kind):
+    """sm_spmma_fused_f32_split -- the fp32 2:4 product on v_smfmac_f32_16x16x64_bf16 through exact bfloat16 splits.  On small-integer
+    data every piece product is exact, so C must EQUAL the exact fp32 kernel's bit for bit (same mask, ties included); on U(-1, 1)
+    data the error against the fp64 product of the STRIP-pruned operand stays inside SPLIT_TOL * sum|a||b| + the fp32 accumulation
+    bound -- three (planes = 2) to five (planes = 3) orders of magnitude inside north_star's 1e-3."""
+    import torch
+    m, n, k, batch = shape
+    alpha, beta = ab
+    rng = np.random.default_rng(m + 3 * n + 5 * k + planes)
+    A = rand(rng, batch * m * k, np.float32, kind)
+    B = rand(rng, k * n, np.float32, kind)
+    C0 = rand(rng, batch * m * n, np.float32, kind)
+    dA, dB = to_dev(A), to_dev(B)
+    ws = torch.empty(gpu.spmma_fused_f32_split_workspace(n, k, planes=planes), dtype=torch.uint8, device="cuda")
+    Cs, Ce = to_dev(C0.copy()), to_dev(C0.copy())
+    gpu.spmma_fused_f32_split(dA, dB, Cs, m, n, k, ws, batch=batch, planes=planes, alpha=alpha, beta=beta)
+    gpu.spmma_fused(dA, dB, Ce, m, n, k, batch=batch, alpha=alpha, beta=beta)
+    assert torch.equal(dA.view(torch.int32), to_dev(A).view(torch.int32)), "A was modified"
+    if kind == "ties" and beta == 0.0:
+        assert torch.equal(Cs.view(torch.int32), Ce.view(torch.int32)), "exact data: the split form must equal the fp32 kernel bit for bit"
+        return
+    P = dA.clone()
+    gpu.prune24(P, P, batch * m, k, k, gpu.PRUNE_STRIP)
+    P64 = host(P).astype(np.float64).reshape(batch * m, k)
+    B64 = B.astype(np.float64).reshape(k, n)
+    ref = alpha * (P64 @ B64).reshape(-1) + beta * C0.astype(np.float64)
+    scale = abs(alpha) * (np.abs(P64) @ np.abs(B64)).reshape(-1) + abs(beta) * np.abs(C0.astype(np.float64))
+    err = np.abs(host(Cs).astype(np.float64) - ref)
+    bound = (SPLIT_TOL[planes] + 2.0 * k * 2.0 ** -24) * scale + 2.0 ** -22 * np.abs(ref) + 1e-30
+    ratio = float((err / bound).max())
+    assert ratio <= 1.0, f"split planes={planes} {shape}: max err / bound = {ratio:.3f} (max err {err.max():.3e})"
+    assert not (err > FP32_TOL * np.maximum(scale, 1e-30)).any()
+
+
+def test_spmma_f32_split_edges(gpu):
+    """What the split form declines, and what a non-finite operand value does: it stays in the first piece, so the outputs it
+    reaches are non-finite (NaN where the exact form may say inf: inf meets a zero low piece) and every other output is untouched."""
+    import torch
+    m, n, k = 128, 64, 128
+    rng = np.random.default_rng(77)
+    A, B = rand(rng, m * k, np.float32), rand(rng, k * n, np.float32)
+    A[5 * k + 3] = np.inf
+    A[5 * k + 2] = 0.5   # so that the inf is kept whatever its neighbours are
+    A[9 * k + 64] = np.nan
+    dA, dB = to_dev(A), to_dev(B)
+    C = torch.zeros(m * n, dtype=torch.float32, device="cuda")
+    Ce = torch.zeros(m * n, dtype=torch.float32, device="cuda")
+    ws = torch.empty(gpu.spmma_fused_f32_split_workspace(n, k), dtype=torch.uint8, device="cuda")
+    gpu.spmma_fused_f32_split(dA, dB, C, m, n, k, ws)
+    gpu.spmma_fused(dA, dB, Ce, m, n, k)
+    c, ce = host(C).reshape(m, n), host(Ce).reshape(m, n)
+    assert not np.isfinite(c[5]).any() and not np.isfinite(c[9]).any()
+    rows = [r for r in range(m) if r not in (5, 9)]
+    assert np.isfinite(c[rows]).all() and np.allclose(c[rows], ce[rows], rtol=0, atol=1e-4)
+    NS, INV = gpu.STATUS_NOT_SUPPORTED, 1
+    assert gpu.spmma_fused_f32_split(dA, dB, C, 64, 64, 72, ws, check=False) == NS    # k % 64 != 0
+    assert gpu.spmma_fused_f32_split(dA, dB, C, 64, 12, 64, ws, check=False) == NS    # n % 8 != 0
+    small = torch.empty(64, dtype=torch.uint8, device="cuda")
+    with pytest.raises(gpu.SparsifymeError):
+        gpu.spmma_fused_f32_split(dA, dB, C, m, n, k, small)                          # workspace too small
+    with pytest.raises(gpu.SparsifymeError):
+        gpu.spmma_fused_f32_split(dA, dB, C, m, n, k, ws, planes=4)
 
 
 def test_spmma_fused_f32_rejects_what_it_cannot_take(gpu):
