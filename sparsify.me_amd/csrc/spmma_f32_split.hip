@@ -1,0 +1,386 @@
+// spmma_f32_split.hip -- the fp32 2:4 product on the SPARSE matrix instruction (round 4): C = prune24_strip(A) * B for fp32
+// operands, computed by v_smfmac_f32_16x16x64_bf16 on exact bfloat16 splits of both operands.
+//
+// gfx950 has no fp32 sparse matrix instruction: sm_spmma_fused_f32 (gemm_f32.hip) expands the 2:4 operand back to dense
+// v_mfma_f32_16x16x4_f32 work -- 157 TF/s peak, the dense fp32 GEMM's rate at best, never the 2 x a 2:4 operand promises.
+// Here every fp32 value x is split EXACTLY into three bfloat16 pieces x = x1 + x2 + x3 (the top 8, middle 8 and low 8 bits
+// of its 24-bit significand: three truncations, each residual computed exactly in fp32), and
+//   a * b  ~  a1 b1 + a1 b2 + a2 b1 + a2 b2 + a1 b3 + a3 b1        (planes = 3: dropped terms a2 b3 + a3 b2 + a3 b3 < 2^-22 |a b|)
+//   a * b  ~  a1 b1 + a1 b2 + a2 b1                                  (planes = 2: |error| < 2^-13 |a b|)
+// each product exact in the instruction's fp32 accumulator arithmetic.  Six (three) sparse instructions per 16 x 16 x 64
+// block at ~3.5 PF/s dense-equivalent are 0.6 (1.2) PF/s of fp32-equivalent work against 0.157: the path becomes what the
+// fp16 path is, bound by the HBM stream of A.  The 2:4 selection itself is made on the fp32 values (frozen STRIP rule,
+// select24.h / oracle strip_select), so the mask is the exact path's bit for bit; what differs from sm_spmma_fused_f32 is
+// the rounding of the products (stated bound, asserted in tests/test_gpu_parity.py::test_spmma_f32_split_*), inside
+// north_star's 1e-3 for fp32 by three (planes = 2) to six (planes = 3) orders of magnitude.  Reference: the matmul step of
+// sparsifyme::spmma<float>, include/sparsify.me/spmma.hxx:106-114 (cuSPARSELt computes fp32 operands in TF32: 10 bits).
+//
+// Structure = the fp16 direct fused kernel in fp32 bytes: 128-row tiles, four waves (wave w owns rows 32 w .. 32 w + 31
+// and all BN columns: every strip is selected once, by the lane that feeds it), the DENSE fp32 A stage (128 rows x 256 B)
+// and the bfloat16 planes of the B stage (planes x 64 x BN) by LDS-DMA into a ring of two, one counted wait + barrier per
+// stage.  B is split once per call by a streaming pre-pass into the caller's workspace (planes x k x n bfloat16).
+// Non-finite values stay in the first piece (x2 = x3 = 0), so inf / NaN propagate as in the exact path except where an
+// inf meets a cancelled piece (inf * 0 contributions do not arise: the lower pieces of a non-finite value are zero).
+#include <algorithm>
+
+#include "select24.h"
+#include "spmma_args.h"
+
+namespace sm {
+
+struct SplitArgs {
+  const float* A;
+  const unsigned short* Bp;  // [plane][batchB][k][n] bfloat16
+  float* C;
+  size_t sA, sBp, plane, sC;  // elements
+  int Mrows, N, K, lda;
+  int batch, tiles_m, tiles_n;
+  float alpha, beta;
+};
+
+__device__ __forceinline__ float as_f32(uint32_t x) { return __builtin_bit_cast(float, x); }
+__device__ __forceinline__ uint32_t as_u32(float x) { return __builtin_bit_cast(uint32_t, x); }
+
+// residual of a truncation to bfloat16, exact; 0 for a non-finite x (its whole value stays in the first piece)
+__device__ __forceinline__ float trunc_residual(uint32_t x) {
+  const float r = as_f32(x) - as_f32(x & 0xffff0000u);
+  return (x & 0x7f800000u) != 0x7f800000u ? r : 0.0f;
+}
+
+// {hi16(b) : hi16(a)}: two bfloat16 (truncated) in SMFMAC operand order
+__device__ __forceinline__ uint32_t pack_hi16(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
+
+// top-2 of a strip by magnitude, ties to the lower index (frozen rule), as a 4-bit keep mask: a 5-compare selection
+// network on the 31-bit magnitude keys (pair winners, then the runner-up among the three that are left) -- 20 VALU against
+// ~40 for the compare-and-count form (strip_keepmask), same mask for every input.
+__device__ __forceinline__ unsigned strip_keepmask_net(uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3) {
+  const bool c01 = k0 >= k1, c23 = k2 >= k3;
+  const uint32_t w01 = c01 ? k0 : k1, l01 = c01 ? k1 : k0, w23 = c23 ? k2 : k3, l23 = c23 ? k3 : k2;
+  const unsigned mw01 = c01 ? 1u : 2u, ml01 = 3u ^ mw01, mw23 = c23 ? 4u : 8u, ml23 = 12u ^ mw23;
+  const unsigned sa = l01 >= w23 ? ml01 : mw23;  // first came from {0, 1}: runner-up among its loser and the other pair's winner
+  const unsigned sb = w01 >= l23 ? mw01 : ml23;  // first came from {2, 3}
+  return w01 >= w23 ? (mw01 | sa) : (mw23 | sb);
+}
+
+// One lane's 16 dense fp32 of a row (k = 16 g .. 16 g + 15 of the stage) -> NP bfloat16 SMFMAC A operands + the index halfword
+template <int NP>
+__device__ __forceinline__ void dense16_f32_to_operands(const u4 (&v)[4], h8 (&af)[NP], int& idx) {
+  uint32_t pk[NP][4];
+  unsigned meta = 0;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const uint32_t x0 = v[s][0], x1 = v[s][1], x2 = v[s][2], x3 = v[s][3];
+    const unsigned mk = strip_keepmask_net(x0 & 0x7fffffffu, x1 & 0x7fffffffu, x2 & 0x7fffffffu, x3 & 0x7fffffffu);
+    const uint32_t lo = (mk & 1u) ? x0 : ((mk & 2u) ? x1 : x2);  // position p0 < p1
+    const uint32_t hi = (mk & 8u) ? x3 : ((mk & 4u) ? x2 : x1);
+    meta |= nibble_of(mk) << (4 * s);
+    pk[0][s] = pack_hi16(lo, hi);
+    if constexpr (NP >= 2) {
+      const float rl = trunc_residual(lo), rh = trunc_residual(hi);
+      pk[1][s] = pack_hi16(as_u32(rl), as_u32(rh));
+      if constexpr (NP >= 3) {
+        const float ql = rl - as_f32(as_u32(rl) & 0xffff0000u), qh = rh - as_f32(as_u32(rh) & 0xffff0000u);  // <= 8 significant bits: exact
+        pk[2][s] = pack_hi16(as_u32(ql), as_u32(qh));
+      }
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < NP; ++p) af[p] = __builtin_bit_cast(h8, u4{pk[p][0], pk[p][1], pk[p][2], pk[p][3]});
+  idx = (int)meta;
+}
+
+template <int BN, int NP, bool ANT>
+__global__ __launch_bounds__(256) void spmma_f32_split_kernel(const SplitArgs p) {
+  constexpr int BM = 128, NW = 4, TM = BM / NW, FM = TM / 16, FN = BN / 16;
+  constexpr int SA = BM * 256, SBP = 64 * BN * 2, STAGE = SA + NP * SBP;
+  constexpr int A_N = BM / 4, B_N = NP * (BN / 8);  // 1 KiB DMA wave-instructions per stage
+  static_assert(A_N % NW == 0 && B_N % NW == 0, "equal DMA share per wave");
+  constexpr int SLA = A_N / NW, SLB = B_N / NW;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const unsigned tid = threadIdx.x, lane = tid & 63u;
+  const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const unsigned tiles = (unsigned)p.tiles_m * (unsigned)p.tiles_n;
+  const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
+  const unsigned b = lid / tiles, trem = lid - b * tiles;
+  const unsigned tile_m = trem / (unsigned)p.tiles_n, tile_n = trem - tile_m * (unsigned)p.tiles_n;
+  const int m0 = (int)tile_m * BM, n0 = (int)tile_n * BN;
+  const int nkt = p.K / 64;
+  const float* A = p.A + (size_t)b * p.sA;
+  const unsigned short* Bp = p.Bp + (size_t)b * p.sBp;
+  float* C = p.C + (size_t)b * p.sC;
+  const int mlast = p.Mrows - 1;
+
+  const char* asrc[SLA];
+  unsigned aoff[SLA];
+  const char* bsrc[SLB];
+  unsigned boff[SLB];
+#pragma unroll
+  for (int i = 0; i < SLA; ++i) {  // 4 rows x 256 B: lane -> row 4 t + lane / 16, LDS chunk lane % 16 holds source chunk (lane % 16) ^ (row & 15)
+    const unsigned t = wave + (unsigned)NW * i;
+    const unsigned row = 4u * t + (lane >> 4), cs = (lane & 15u) ^ (row & 15u);
+    int gr = m0 + (int)row;
+    gr = gr < mlast ? gr : mlast;
+    asrc[i] = reinterpret_cast<const char*>(A + (size_t)gr * p.lda) + 16u * cs;
+    aoff[i] = t * 1024u;
+  }
+#pragma unroll
+  for (int i = 0; i < SLB; ++i) {  // plane pl, 8 k-rows x 128 B of one 64-column panel (the fp16 kernels' B image, per plane)
+    const unsigned t = wave + (unsigned)NW * i;
+    const unsigned pl = t / (unsigned)(BN / 8), j = t - pl * (unsigned)(BN / 8);
+    const unsigned panel = j >> 3, kr = 8u * (j & 7u) + (lane >> 3);
+    const unsigned cs = (lane & 7u) ^ b_swz(kr);
+    int gc = n0 + (int)(64u * panel + 8u * cs);
+    gc = gc <= p.N - 8 ? gc : p.N - 8;
+    bsrc[i] = reinterpret_cast<const char*>(Bp + (size_t)pl * p.plane + (size_t)kr * p.N + gc);
+    boff[i] = SA + pl * SBP + panel * 8192u + (j & 7u) * 1024u;
+  }
+  const size_t bstep = (size_t)64 * p.N * 2;
+  auto stage = [&](int kt, int buf) {
+    char* base = smem + buf * STAGE;
+#pragma unroll
+    for (int i = 0; i < SLB; ++i) __builtin_amdgcn_global_load_lds((gptr_t*)(bsrc[i] + (size_t)kt * bstep), (lptr_t*)(base + boff[i]), 16, 0, 0);
+    // A is read once by the whole grid when there is one column tile: non-temporal (ANT); otherwise its re-reads come from L2
+#pragma unroll
+    for (int i = 0; i < SLA; ++i) {
+      if (ANT) __builtin_amdgcn_global_load_lds((gptr_t*)(asrc[i] + (size_t)kt * 256), (lptr_t*)(base + aoff[i]), 16, 0, 2);
+      else __builtin_amdgcn_global_load_lds((gptr_t*)(asrc[i] + (size_t)kt * 256), (lptr_t*)(base + aoff[i]), 16, 0, 0);
+    }
+  };
+
+  f4 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+
+  const unsigned g = lane >> 4, r = lane & 15u;
+  if (nkt > 0) stage(0, 0);
+  int cur = 0;
+  for (int kt = 0; kt < nkt; ++kt) {
+    wait_dma_and_barrier<0>();  // stage kt has landed for every wave; every wave has left the buffer about to be refilled
+    if (kt + 1 < nkt) stage(kt + 1, cur ^ 1);
+    const char* As = smem + cur * STAGE;
+    h8 af[FM][NP];
+    int idx[FM];
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      const unsigned row = wave * TM + i * 16 + r;
+      u4 v[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) v[c] = *reinterpret_cast<const u4*>(As + row * 256u + 16u * ((4u * g + c) ^ (row & 15u)));
+      dense16_f32_to_operands<NP>(v, af[i], idx[i]);
+    }
+    // B sweep: fragment j + 1's reads (4 per plane) in flight while fragment j's products run
+    const unsigned bs_addr = (unsigned)(uintptr_t)(lds_char*)(As + SA);
+    s4 t[2][NP][4];
+    auto issue = [&](int j, int buf) {
+      const unsigned q = r >> 2, pp = r & 3u;
+      const unsigned a = bs_addr + b_off<64>(8u * g + q, (unsigned)j * 16u + 4u * pp);
+#pragma unroll
+      for (int pl = 0; pl < NP; ++pl)
+        asm volatile("ds_read_b64_tr_b16 %0, %4\n\tds_read_b64_tr_b16 %1, %4 offset:512\n\t"
+                     "ds_read_b64_tr_b16 %2, %4 offset:4096\n\tds_read_b64_tr_b16 %3, %4 offset:4608"
+                     : "=&v"(t[buf][pl][0]), "=&v"(t[buf][pl][1]), "=&v"(t[buf][pl][2]), "=&v"(t[buf][pl][3])
+                     : "v"(a + (unsigned)pl * (unsigned)SBP)
+                     : "memory");
+    };
+    issue(0, 0);
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      const int c = j & 1;
+      if (j + 1 < FN) {
+        issue(j + 1, c ^ 1);
+        if constexpr (NP == 3)
+          asm volatile("s_waitcnt lgkmcnt(12)"
+                       : "+v"(t[c][0][0]), "+v"(t[c][0][1]), "+v"(t[c][0][2]), "+v"(t[c][0][3]), "+v"(t[c][1][0]), "+v"(t[c][1][1]), "+v"(t[c][1][2]),
+                         "+v"(t[c][1][3]), "+v"(t[c][2][0]), "+v"(t[c][2][1]), "+v"(t[c][2][2]), "+v"(t[c][2][3])
+                       :: "memory");
+        else
+          asm volatile("s_waitcnt lgkmcnt(8)"
+                       : "+v"(t[c][0][0]), "+v"(t[c][0][1]), "+v"(t[c][0][2]), "+v"(t[c][0][3]), "+v"(t[c][1][0]), "+v"(t[c][1][1]), "+v"(t[c][1][2]),
+                         "+v"(t[c][1][3])
+                       :: "memory");
+      } else {
+        if constexpr (NP == 3)
+          asm volatile("s_waitcnt lgkmcnt(0)"
+                       : "+v"(t[c][0][0]), "+v"(t[c][0][1]), "+v"(t[c][0][2]), "+v"(t[c][0][3]), "+v"(t[c][1][0]), "+v"(t[c][1][1]), "+v"(t[c][1][2]),
+                         "+v"(t[c][1][3]), "+v"(t[c][2][0]), "+v"(t[c][2][1]), "+v"(t[c][2][2]), "+v"(t[c][2][3])
+                       :: "memory");
+        else
+          asm volatile("s_waitcnt lgkmcnt(0)"
+                       : "+v"(t[c][0][0]), "+v"(t[c][0][1]), "+v"(t[c][0][2]), "+v"(t[c][0][3]), "+v"(t[c][1][0]), "+v"(t[c][1][1]), "+v"(t[c][1][2]),
+                         "+v"(t[c][1][3])
+                       :: "memory");
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      typedef short s16 __attribute__((ext_vector_type(16)));
+      h16 bf[NP];
+#pragma unroll
+      for (int pl = 0; pl < NP; ++pl) {
+        const s16 all = {t[c][pl][0][0], t[c][pl][0][1], t[c][pl][0][2], t[c][pl][0][3], t[c][pl][1][0], t[c][pl][1][1], t[c][pl][1][2], t[c][pl][1][3],
+                         t[c][pl][2][0], t[c][pl][2][1], t[c][pl][2][2], t[c][pl][2][3], t[c][pl][3][0], t[c][pl][3][1], t[c][pl][3][2], t[c][pl][3][3]};
+        bf[pl] = __builtin_bit_cast(h16, all);
+      }
+      // smallest terms first; consecutive instructions alternate between the FM accumulators (no back-to-back dependence)
+      if constexpr (NP == 3) {
+#pragma unroll
+        for (int i = 0; i < FM; ++i) acc[i][j] = smfmac16<true>(af[i][2], bf[0], acc[i][j], idx[i]);
+#pragma unroll
+        for (int i = 0; i < FM; ++i) acc[i][j] = smfmac16<true>(af[i][0], bf[2], acc[i][j], idx[i]);
+#pragma unroll
+        for (int i = 0; i < FM; ++i) acc[i][j] = smfmac16<true>(af[i][1], bf[1], acc[i][j], idx[i]);
+      }
+#pragma unroll
+      for (int i = 0; i < FM; ++i) acc[i][j] = smfmac16<true>(af[i][1], bf[0], acc[i][j], idx[i]);
+#pragma unroll
+      for (int i = 0; i < FM; ++i) acc[i][j] = smfmac16<true>(af[i][0], bf[1], acc[i][j], idx[i]);
+#pragma unroll
+      for (int i = 0; i < FM; ++i) acc[i][j] = smfmac16<true>(af[i][0], bf[0], acc[i][j], idx[i]);
+    }
+    cur ^= 1;
+  }
+  __syncthreads();
+  // epilogue: the SMFMAC result map leaves 4 consecutive ROWS of one column per lane; the tile goes through LDS (pitch BN * 4 + 16
+  // bytes, aliasing the ring) and out as 16-byte row pieces, alpha * acc + beta * C rounded once.
+  constexpr unsigned CP = BN * 4 + 16;
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<float*>(smem + (wave * TM + i * 16 + 4u * g + q) * CP + (j * 16 + r) * 4u) = acc[i][j][q];
+  __syncthreads();
+  constexpr unsigned PPR = BN / 4;  // 16-byte pieces per row
+  for (unsigned it = tid; it < (unsigned)BM * PPR; it += 256u) {
+    const unsigned row = it / PPR, pc = it - row * PPR;
+    const int gr = m0 + (int)row, gc = n0 + (int)(4u * pc);
+    if (gr > mlast || gc + 4 > p.N) continue;
+    f4 v = *reinterpret_cast<const f4*>(smem + row * CP + pc * 16u);
+    float* dst = C + (size_t)gr * p.N + gc;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] *= p.alpha;
+    if (p.beta != 0.0f) {
+      const f4 old = *reinterpret_cast<const f4*>(dst);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] += p.beta * old[q];
+    }
+    __builtin_nontemporal_store(v, reinterpret_cast<f4*>(dst));
+  }
+}
+
+// B (fp32, [k][n] row-major per batch) -> planes of truncated bfloat16 pieces, 8 elements per thread
+template <int NP>
+__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ B, unsigned short* __restrict__ P, size_t items /* of 8 */, size_t plane) {
+  for (size_t it = (size_t)blockIdx.x * 256u + threadIdx.x; it < items; it += (size_t)gridDim.x * 256u) {
+    const u4 lo = *reinterpret_cast<const u4*>(B + it * 8), hi = *reinterpret_cast<const u4*>(B + it * 8 + 4);
+    const uint32_t x[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    uint32_t o[NP][4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const uint32_t a = x[2 * e], b = x[2 * e + 1];
+      o[0][e] = pack_hi16(a, b);
+      if constexpr (NP >= 2) {
+        const float ra = trunc_residual(a), rb = trunc_residual(b);
+        o[1][e] = pack_hi16(as_u32(ra), as_u32(rb));
+        if constexpr (NP >= 3) {
+          const float qa = ra - as_f32(as_u32(ra) & 0xffff0000u), qb = rb - as_f32(as_u32(rb) & 0xffff0000u);
+          o[2][e] = pack_hi16(as_u32(qa), as_u32(qb));
+        }
+      }
+    }
+#pragma unroll
+    for (int pl = 0; pl < NP; ++pl) *reinterpret_cast<u4*>(P + (size_t)pl * plane + it * 8) = u4{o[pl][0], o[pl][1], o[pl][2], o[pl][3]};
+  }
+}
+
+template <int BN, int NP>
+static int launch_split(const SplitArgs& a0, hipStream_t st) {
+  SplitArgs a = a0;
+  a.tiles_m = (a.Mrows + 127) / 128;
+  a.tiles_n = (a.N + BN - 1) / BN;
+  const size_t nwg = (size_t)a.tiles_m * a.tiles_n * a.batch;
+  if (nwg == 0) return SM_STATUS_SUCCESS;
+  if (nwg > 0x7fffffffu) {
+    set_error("sm_spmma_fused_f32_split: grid too large");
+    return SM_STATUS_NOT_SUPPORTED;
+  }
+  constexpr size_t stage_bytes = (size_t)128 * 256 + (size_t)NP * 64 * BN * 2;
+  constexpr size_t lds_epi = (size_t)128 * (BN * 4 + 16);
+  const size_t lds_main = (a.K / 64 < 2 ? 1 : 2) * stage_bytes;
+  const size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
+  constexpr size_t lds_max = 2 * stage_bytes > lds_epi ? 2 * stage_bytes : lds_epi;
+  static_assert(lds_max <= 160 * 1024, "LDS budget");
+  static LdsOptIn lds_optin;
+  static LdsOptIn lds_optin_nt;
+  if (a.tiles_n == 1) {
+    if (const int rc = ensure_dyn_lds(lds_optin_nt, reinterpret_cast<const void*>(&spmma_f32_split_kernel<BN, NP, true>), lds_max, "spmma_f32_split_kernel")) return rc;
+    spmma_f32_split_kernel<BN, NP, true><<<dim3((unsigned)nwg), dim3(256), lds, st>>>(a);
+  } else {
+    if (const int rc = ensure_dyn_lds(lds_optin, reinterpret_cast<const void*>(&spmma_f32_split_kernel<BN, NP, false>), lds_max, "spmma_f32_split_kernel")) return rc;
+    spmma_f32_split_kernel<BN, NP, false><<<dim3((unsigned)nwg), dim3(256), lds, st>>>(a);
+  }
+  return check_launch("spmma_f32_split_kernel");
+}
+
+}  // namespace sm
+
+extern "C" int sm_spmma_fused_f32_split_workspace(size_t n, size_t k, size_t batch, size_t strideB, int planes, size_t* bytes) {
+  if (!bytes || (planes != 2 && planes != 3)) {
+    sm::set_error("sm_spmma_fused_f32_split_workspace: invalid argument");
+    return SM_STATUS_INVALID_VALUE;
+  }
+  size_t e = 0, t = 0;
+  if (__builtin_mul_overflow(n, k, &e) || __builtin_mul_overflow(e, strideB ? batch : (size_t)1, &e) || __builtin_mul_overflow(e, (size_t)planes * 2, &t)) {
+    sm::set_error("sm_spmma_fused_f32_split_workspace: size overflows");
+    return SM_STATUS_NOT_SUPPORTED;
+  }
+  *bytes = t;
+  return SM_STATUS_SUCCESS;
+}
+
+extern "C" int sm_spmma_fused_f32_split(const float* A, const float* B, float* C, size_t m, size_t n, size_t k, size_t lda, size_t batch, size_t strideA,
+                                        size_t strideB, size_t strideC, int planes, void* workspace, size_t workspace_bytes, float alpha, float beta,
+                                        sm_stream_t stream) {
+  using namespace sm;
+  if (!A || !B || !C || lda < k || (planes != 2 && planes != 3)) {
+    set_error("sm_spmma_fused_f32_split: invalid argument");
+    return SM_STATUS_INVALID_VALUE;
+  }
+  if (m == 0 || n == 0 || batch == 0) return SM_STATUS_SUCCESS;
+  if (k == 0 || k % 64 != 0 || n % 8 != 0 || lda % 4 != 0 || strideA % 4 != 0 || strideB % 8 != 0 || strideC % 4 != 0 || !aligned16(A) || !aligned16(B) ||
+      !aligned16(C) || m * batch > 0x7fffffffull || n > 0x7fffffffull || k > 0x7fffffffull || lda > 0x7fffffffull) {
+    set_error("sm_spmma_fused_f32_split: needs k %% 64 == 0, n %% 8 == 0 and 16-byte aligned rows of A, B and C (use sm_spmma_fused_f32)");
+    return SM_STATUS_NOT_SUPPORTED;
+  }
+  size_t need = 0;
+  if (const int rc = sm_spmma_fused_f32_split_workspace(n, k, batch, strideB, planes, &need)) return rc;
+  if (!workspace || workspace_bytes < need || !aligned16(workspace)) {
+    set_error("sm_spmma_fused_f32_split: workspace of %zu bytes (16-byte aligned) required", need);
+    return SM_STATUS_INVALID_VALUE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const size_t nb = strideB ? batch : 1;
+  if (nb > 1 && strideB != k * n) {
+    set_error("sm_spmma_fused_f32_split: a strided B must be packed (strideB == k * n)");
+    return SM_STATUS_NOT_SUPPORTED;
+  }
+  const size_t plane = nb * k * n, items = plane / 8;
+  unsigned short* P = (unsigned short*)workspace;
+  const unsigned grid = (unsigned)std::min<size_t>((items + 255) / 256, 4096);
+  if (planes == 3) split_planes_kernel<3><<<dim3(grid), dim3(256), 0, st>>>(B, P, items, plane);
+  else split_planes_kernel<2><<<dim3(grid), dim3(256), 0, st>>>(B, P, items, plane);
+  if (const int rc = check_launch("split_planes_kernel")) return rc;
+  SplitArgs a = {};
+  a.A = A; a.Bp = P; a.C = C;
+  a.sA = strideA; a.sBp = strideB ? k * n : 0; a.plane = plane; a.sC = strideC;
+  a.Mrows = (int)m; a.N = (int)n; a.K = (int)k; a.lda = (int)lda; a.batch = (int)batch;
+  a.alpha = alpha; a.beta = beta;
+  if (batch > 1 && strideB == 0 && strideA == m * lda && strideC == m * n) {  // one tall matrix
+    a.Mrows = (int)(m * batch);
+    a.batch = 1;
+  }
+  if (planes == 3) return n <= 64 ? launch_split<64, 3>(a, st) : launch_split<128, 3>(a, st);
+  return n <= 64 ? launch_split<64, 2>(a, st) : launch_split<128, 2>(a, st);
+}
