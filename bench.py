@@ -696,9 +696,9 @@ def extras(args, sm, torch, dev, layers, flops, t_full, Forked, make_runner, tim
         out["stages"]["api_spmma_sequence"] = sm.API_SPMMA_SEQUENCE
         if not f32 and hasattr(sm, "api_spmma_step_fused"):
             # round 4: the same sequence as ONE kernel (sm_prune24_spmma_*: TILE prune written to the second buffer, flag, multiply,
-            # no blob) on the layers it takes (n <= 256, k % 64 == 0, m % 4 == 0); the two-launch pair on the others
+            # no blob) on the layers it takes (n <= 128, k % 64 == 0, m % 4 == 0); the two-launch pair on the others
             t_api1 = sec_per_call(Forked(lambda L: sm.api_spmma_step_fused(L["A"], L["Aapi"], L["B"], L["C"], L["blob"], valid, L["m"], L["n"], L["k"], L["b"])))
-            n_one = sum(1 for L in layers if L["n"] <= 256 and L["n"] % 8 == 0 and L["k"] % 64 == 0 and L["m"] % 4 == 0)
+            n_one = sum(1 for L in layers if L["n"] <= 128 and L["n"] % 8 == 0 and L["k"] % 64 == 0 and L["m"] % 4 == 0)
             out["stages"]["api_spmma_one_kernel_ms"] = t_api1 * 1e3
             out["stages"]["api_spmma_one_kernel_gfs"] = gfs(t_api1)
             out["stages"]["api_spmma_one_kernel_layers"] = n_one

@@ -42,6 +42,14 @@ struct spmma_fns<float> {
   static int prune_mul(float*, float*, float*, std::size_t, std::size_t, std::size_t, std::size_t, int*, float, float) {
     return SM_STATUS_NOT_SUPPORTED;  // no one-kernel form for fp32 (no fp32 sparse matrix instruction: the 2:4 kernels expand)
   }
+  // (round 4) the product on the sparse matrix instruction through exact bfloat16 splits (sm_spmma_fused_f32_split); ws: planes of B
+  static int fused_split(float* A, float* B, float* C, std::size_t m, std::size_t n, std::size_t k, std::size_t b, int planes, void* ws,
+                         std::size_t ws_bytes, float al, float be) {
+    return sm_spmma_fused_f32_split(A, B, C, m, n, k, k, b, m * k, k * n, m * n, planes, ws, ws_bytes, al, be, nullptr);
+  }
+  static int split_workspace(std::size_t n, std::size_t k, std::size_t b, int planes, std::size_t* bytes) {
+    return sm_spmma_fused_f32_split_workspace(n, k, b, k * n, planes, bytes);
+  }
   static int prune_check_compress(float* A, std::size_t m, std::size_t k, std::size_t b, void* blob, int* v) {
     return sm_prune24_compress24_f32(A, A, m, k, k, b, m * k, blob, v, SM_PRUNE_TILE, nullptr);
   }
@@ -62,6 +70,13 @@ struct spmma_fns<float> {
   }
 };
 struct spmma_fns_f16 {
+  static int fused_split(void*, void*, void*, std::size_t, std::size_t, std::size_t, std::size_t, int, void*, std::size_t, float, float) {
+    return SM_STATUS_NOT_SUPPORTED;  // fp32 operands only (the 16-bit types run on the sparse matrix instruction as they are)
+  }
+  static int split_workspace(std::size_t, std::size_t, std::size_t, int, std::size_t* bytes) {
+    *bytes = 0;
+    return SM_STATUS_NOT_SUPPORTED;
+  }
   static int prune_mul(void* A, void* B, void* C, std::size_t m, std::size_t n, std::size_t k, std::size_t b, int* v, float al, float be) {
     return sm_prune24_spmma_f16(A, A, B, C, m, n, k, k, b, m * k, k * n, m * n, SM_PRUNE_TILE, v, al, be, nullptr);
   }
@@ -88,6 +103,13 @@ struct spmma_fns_f16 {
   }
 };
 struct spmma_fns_bf16 {  // bfloat16 (extension): same blob and rules, v_smfmac_f32_16x16x64_bf16
+  static int fused_split(void*, void*, void*, std::size_t, std::size_t, std::size_t, std::size_t, int, void*, std::size_t, float, float) {
+    return SM_STATUS_NOT_SUPPORTED;
+  }
+  static int split_workspace(std::size_t, std::size_t, std::size_t, int, std::size_t* bytes) {
+    *bytes = 0;
+    return SM_STATUS_NOT_SUPPORTED;
+  }
   static int prune_mul(void* A, void* B, void* C, std::size_t m, std::size_t n, std::size_t k, std::size_t b, int* v, float al, float be) {
     return sm_prune24_spmma_bf16(A, A, B, C, m, n, k, k, b, m * k, k * n, m * n, SM_PRUNE_TILE, v, al, be, nullptr);
   }
@@ -126,11 +148,20 @@ struct spmma_fns<__half> : spmma_fns_f16 {};
 // one-pass prune + check + compress followed by the multiply.  staged = true: the reference's three stages as three
 // separately launched, separately timed steps (prune + check + readback | blob allocation + compress | multiply), for
 // stage-level comparisons.  dA and dC end bit-identical either way.
+// f32_planes (round 4; float operands only): 0 (default) = the exact fp32 forms (dense fp32 MFMA work on the selected operand);
+// 3 / 2 = the multiply on the sparse matrix instruction through exact bfloat16 splits of both operands (sm_spmma_fused_f32_split:
+// |error| <= 2^-21 / 2^-13 of sum |a||b| -- the reference's cuSPARSELt computes float operands in TF32 --, several times faster,
+// same 2:4 mask); shapes it does not take (k % 64 != 0, n % 8 != 0) run the exact form.
 struct spmma_options_t {
 #ifdef SPARSIFYME_SPMMA_STAGED
   bool staged = true;
 #else
   bool staged = false;
+#endif
+#ifdef SPARSIFYME_F32_PLANES
+  int f32_planes = SPARSIFYME_F32_PLANES;
+#else
+  int f32_planes = 0;
 #endif
 };
 inline spmma_options_t& spmma_options() {
@@ -188,6 +219,34 @@ std::vector<float> spmma(type_t* dA,
     }
     (void)one_timer.end();
     if (rc1 != SM_STATUS_NOT_SUPPORTED) keep_first(rc1);
+  }
+  // (round 4, float with spmma_options().f32_planes = 2 / 3) prune (TILE, in place) + check as one launch pair, then the multiply
+  // on the sparse matrix instruction straight from the pruned dense operand: no blob is built (the STRIP selection the kernel
+  // applies to a 2:4 operand keeps exactly its non-zeros).  Times: {prune + check + readback, B-plane workspace allocation, multiply}.
+  if (!staged && !ta && !tb && spmma_options().f32_planes != 0) {
+    std::size_t ws_bytes = 0;
+    if (fns::split_workspace(n, k, batch_size, spmma_options().f32_planes, &ws_bytes) == SM_STATUS_SUCCESS && k % 64 == 0 && n % 8 == 0) {
+      util::timer_t prune_timer;
+      prune_timer.begin();
+      for (std::size_t b = 0; b < batch_size; ++b) keep_first(fns::prune(dA + b * m * k, m, k));
+      keep_first(fns::check(dA, m * batch_size, k, valid.data().get()));
+      report_flag();
+      const float t_prune = prune_timer.end();
+      util::timer_t alloc_timer;
+      alloc_timer.begin();
+      device_vector<unsigned char> ws(ws_bytes ? ws_bytes : 16);
+      const float t_alloc = alloc_timer.end();
+      util::timer_t mul_timer;
+      mul_timer.begin();
+      const int rcs = fns::fused_split(dA, dB, dC, m, n, k, batch_size, spmma_options().f32_planes, ws.data().get(), ws_bytes, alpha, beta);
+      (void)hipStreamSynchronize(nullptr);  // the workspace is released when this scope ends
+      const float t_mul = mul_timer.end();
+      if (rcs == SM_STATUS_SUCCESS) {
+        if (rc != SM_STATUS_SUCCESS) std::cerr << "sparsifyme::spmma: " << sm_last_error() << std::endl;
+        return {t_prune, t_alloc, t_mul};
+      }
+      if (rcs != SM_STATUS_NOT_SUPPORTED) keep_first(rcs);  // (A is pruned already: the sequence below prunes a 2:4 operand again -- idempotent)
+    }
   }
   std::size_t compressed_size = 0;
   (void)sm_compress24_size(m, k, sizeof(type_t), batch_size, &compressed_size);
@@ -262,7 +321,15 @@ float spmma_fused(type_t* dA, type_t* dB, type_t* dC, std::size_t m, std::size_t
   if (batch_size == 0) batch_size = 1;
   util::timer_t timer;
   timer.begin();
-  int rc = fns::fused(dA, dB, dC, m, n, k, batch_size, alpha, beta);
+  int rc = SM_STATUS_NOT_SUPPORTED;
+  std::size_t ws_bytes = 0;
+  if (spmma_options().f32_planes != 0 && k % 64 == 0 && n % 8 == 0 &&
+      fns::split_workspace(n, k, batch_size, spmma_options().f32_planes, &ws_bytes) == SM_STATUS_SUCCESS) {  // float only: see spmma_options_t
+    device_vector<unsigned char> ws(ws_bytes ? ws_bytes : 16);
+    rc = fns::fused_split(dA, dB, dC, m, n, k, batch_size, spmma_options().f32_planes, ws.data().get(), ws_bytes, alpha, beta);
+    (void)hipStreamSynchronize(nullptr);  // the workspace is released when this scope ends
+  }
+  if (rc == SM_STATUS_NOT_SUPPORTED) rc = fns::fused(dA, dB, dC, m, n, k, batch_size, alpha, beta);
   if (rc == SM_STATUS_NOT_SUPPORTED) {
     std::size_t compressed_size = 0;
     (void)sm_compress24_size(m, k, sizeof(type_t), batch_size, &compressed_size);

@@ -125,14 +125,9 @@ __device__ __forceinline__ void smfmac_stage(const char* As, const char* Ms, con
 // B sweep of one 64-deep stage for one wave: B fragments from the row-major [64][BN] image `Bs` through
 // ds_read_b64_tr_b16 (issued by hand, counted lgkmcnt: fragment j+1's four reads in flight while fragment j's SMFMACs run),
 // FM x FN v_smfmac_f32_16x16x64 with the A operands / index halfwords the caller built.
-struct NoSweepHook {
-  __device__ __forceinline__ void operator()(int) const {}
-};
-// `hook(j)` runs after fragment j's SMFMACs have been issued (j a constant after unrolling): the big kernel spreads its LDS-DMA
-// pieces of the coming stages over the sweep with it instead of issuing all of them in one burst after the barrier.
-template <int FM, int FN, bool BF = false, int D = 1, class Hook = NoSweepHook>
+template <int FM, int FN, bool BF = false, int D = 1>
 __device__ __forceinline__ void smfmac_b_sweep(const h8 (&af)[FM], const int (&idx)[FM], const char* Bs, unsigned col0, unsigned lane,
-                                               f4 (&acc)[FM][FN], Hook hook = Hook()) {
+                                               f4 (&acc)[FM][FN]) {
   // D = B fragments requested ahead of the one being multiplied (1: the default; 2: two fragments = eight reads in flight,
   // for wave tiles with few SMFMACs per fragment, where one fragment's two SMFMACs do not cover the next one's LDS latency)
   static_assert(D == 1 || D == 2, "fragments in flight");
@@ -167,7 +162,6 @@ __device__ __forceinline__ void smfmac_b_sweep(const h8 (&af)[FM], const int (&i
     const h16 bf = __builtin_bit_cast(h16, all);
 #pragma unroll
     for (int i = 0; i < FM; ++i) acc[i][j] = smfmac16<BF>(af[i], bf, acc[i][j], idx[i]);
-    hook(j);
   }
 }
 
@@ -187,9 +181,9 @@ __device__ __forceinline__ void dense16_to_operand(const u4 lo, const u4 hi, h8&
 // at chunk c ^ (r & 7), a_off), and the lane that would read 8 compressed halves + 4 nibbles reads its 16 dense halves
 // (two ds_read_b128) and selects in registers: four strips -> the A operand and the index halfword of
 // v_smfmac_f32_16x16x64_f16.  No compressed image, no metadata, no selecting loader waves.
-template <int FM, int FN, bool BF = false, int D = 1, class Hook = NoSweepHook>
+template <int FM, int FN, bool BF = false, int D = 1>
 __device__ __forceinline__ void smfmac_stage_dense_a(const char* Araw, const char* Bs, unsigned row0, unsigned col0,
-                                                     unsigned lane, f4 (&acc)[FM][FN], Hook hook = Hook()) {
+                                                     unsigned lane, f4 (&acc)[FM][FN]) {
   const unsigned g = lane >> 4, r = lane & 15u;
   h8 af[FM];
   int idx[FM];
@@ -200,7 +194,7 @@ __device__ __forceinline__ void smfmac_stage_dense_a(const char* Araw, const cha
     const u4 hi = *reinterpret_cast<const u4*>(Araw + a_off(row, 2u * g + 1u));
     dense16_to_operand(lo, hi, af[i], idx[i]);
   }
-  smfmac_b_sweep<FM, FN, BF, D, Hook>(af, idx, Bs, col0, lane, acc, hook);
+  smfmac_b_sweep<FM, FN, BF, D>(af, idx, Bs, col0, lane, acc);
 }
 
 // Epilogue of the 2:4 matmul kernels, called by EVERY thread of the workgroup after its last barrier: the SMFMAC

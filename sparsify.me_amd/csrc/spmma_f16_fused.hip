@@ -215,10 +215,13 @@ static int launch_fused_direct(const FusedArgs& a0, hipStream_t st) {
 // read the whole 32 KiB B stage = 1 024 LDS cycles), the A share of a stage (32 KiB) is 73 % of a CU's fair share of the HBM
 // rate.  Built, bit-identical and NOT adopted (git history, profiles/ab_pingpong_r04h.txt, ab_variants_r04c.txt): two B
 // fragments in flight instead of one (no change: the sweep is throughput-, not latency-bound), waves 4-7 issuing their A
-// pieces after their compute (-1 .. +5 %), and a ping-pong form in which waves 0-3 select one stage ahead so that one wave
-// of every SIMD is on the VALU while its partner is on the matrix pipe (+0 .. +4 % time).
+// pieces after their compute (-1 .. +5 %), a ping-pong form in which waves 0-3 select one stage ahead so that one wave
+// of every SIMD is on the VALU while its partner is on the matrix pipe (+0 .. +4 % time), and the stage's eight DMA pieces
+// per wave spread over the B sweep -- one after every second fragment's SMFMACs -- instead of issued in one burst behind the
+// barrier (profiles/ab_ilv_r04n.txt: -3 .. +3 % over seven shapes, A pieces only: -3 .. 0 %: the 800 cycles the burst spends in
+// issue are not won back by hiding them, so they are not what bounds the stage).
 // ---------------------------------------------------------------------------------------------
-template <int BN, bool BF = false, int NSA = 3, int NSB = 2, bool ANT = true, int ILV = 0>
+template <int BN, bool BF = false, int NSA = 3, int NSB = 2, bool ANT = true>
 __global__ __launch_bounds__(512) void spmma_f16_fused_big_kernel(const FusedArgs p) {
   constexpr int BM = 256, NW = 8, TM = BM / NW, FM = TM / 16, FN = BN / 16;
   constexpr int SA = BM * 128, SB = 64 * BN * 2;
@@ -304,13 +307,8 @@ __global__ __launch_bounds__(512) void spmma_f16_fused_big_kernel(const FusedArg
     if (kt + 1 < nkt) wait_dma_and_barrier<AHEAD>();
     else wait_dma_and_barrier<0>();
 #endif
-    const bool spread = ILV != 0 && kt + NSA - 1 < nkt;  // both coming stages exist: their pieces go out DURING the sweep
-    if (!spread || ILV == 2) {
-      if (kt + NSB - 1 < nkt) stage_b(kt + NSB - 1, fb);  // the slots stage kt - 1 occupied: every wave left them before this barrier
-    }
-    if (!spread) {
-      if (kt + NSA - 1 < nkt) stage_a(kt + NSA - 1, fa);
-    }
+    if (kt + NSB - 1 < nkt) stage_b(kt + NSB - 1, fb);  // the slots stage kt - 1 occupied: every wave left them before this barrier
+    if (kt + NSA - 1 < nkt) stage_a(kt + NSA - 1, fa);
 #ifdef SM_STAMP
     __builtin_amdgcn_sched_barrier(0);
     const unsigned long long si = sm_stamp(); ti += si - sb;
@@ -335,34 +333,7 @@ __global__ __launch_bounds__(512) void spmma_f16_fused_big_kernel(const FusedArg
       s0 = sm_stamp(); tc += s0 - ss;
     }
 #else
-    if constexpr (ILV != 0) {
-      // same issue order as the burst (B pieces, then A pieces: the counted wait at the next iteration relies on it), one piece
-      // after every FN / NP-th fragment's SMFMACs: a wave that finds the vector-memory queue full blocks for one piece at a
-      // time while its SIMD partner's SMFMACs run, instead of all eight waves blocking together behind the barrier.  ONE call
-      // site of the sweep (a second copy of the unrolled body costs ~100 spilled registers).
-      constexpr int NPB = ILV == 2 ? 0 : SLB, NP = NPB + SLA;
-      const size_t ka = (size_t)(kt + NSA - 1) * 128, kb = (size_t)(kt + NSB - 1) * bstep;
-      char* const la = smem + fa * SA;
-      char* const lb = smem + fb * SB;
-      auto hook = [&](int j) {
-        const int lo = (j * NP + FN - 1) / FN, hi = ((j + 1) * NP + FN - 1) / FN;
-        if (lo < hi && spread) {
-#pragma unroll
-          for (int q = lo; q < hi; ++q) {
-            if (q < NPB) {
-              __builtin_amdgcn_global_load_lds((gptr_t*)(bsrc[q] + kb), (lptr_t*)(lb + boff[q]), 16, 0, 0);
-            } else {
-              const int i = q - NPB;
-              if (ANT) __builtin_amdgcn_global_load_lds((gptr_t*)(asrc[i] + ka), (lptr_t*)(la + aoff[i]), 16, 0, 2);
-              else __builtin_amdgcn_global_load_lds((gptr_t*)(asrc[i] + ka), (lptr_t*)(la + aoff[i]), 16, 0, 0);
-            }
-          }
-        }
-      };
-      smfmac_stage_dense_a<FM, FN, BF, 1>(smem + ca * SA, smem + BRING + cb * SB, wave * TM, 0, lane, acc, hook);
-    } else {
-      smfmac_stage_dense_a<FM, FN, BF>(smem + ca * SA, smem + BRING + cb * SB, wave * TM, 0, lane, acc);
-    }
+    smfmac_stage_dense_a<FM, FN, BF>(smem + ca * SA, smem + BRING + cb * SB, wave * TM, 0, lane, acc);
 #endif
     ca = ca + 1 == NSA ? 0 : ca + 1;
     fa = fa + 1 == NSA ? 0 : fa + 1;
@@ -376,7 +347,7 @@ __global__ __launch_bounds__(512) void spmma_f16_fused_big_kernel(const FusedArg
         d[0] = tv; d[1] = tb; d[2] = ti; d[3] = ts; d[4] = tc; d[5] = sloop - sstart; d[6] = se - sloop; })
 }
 
-template <int BN, bool BF = false, int NSA = 3, int NSB = 2, bool ANT = true, int ILV = 0>
+template <int BN, bool BF = false, int NSA = 3, int NSB = 2, bool ANT = true>
 static int launch_fused_big(const FusedArgs& a0, hipStream_t st) {
   constexpr int BM = 256;
   FusedArgs a = a0;
@@ -393,7 +364,7 @@ static int launch_fused_big(const FusedArgs& a0, hipStream_t st) {
   constexpr size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
   static_assert(lds <= 160 * 1024, "LDS budget of the big direct kernel");
   static LdsOptIn lds_optin;
-  if (const int rc = ensure_dyn_lds(lds_optin, reinterpret_cast<const void*>(&spmma_f16_fused_big_kernel<BN, BF, NSA, NSB, ANT, ILV>), lds, "spmma_f16_fused_big_kernel")) return rc;
+  if (const int rc = ensure_dyn_lds(lds_optin, reinterpret_cast<const void*>(&spmma_f16_fused_big_kernel<BN, BF, NSA, NSB, ANT>), lds, "spmma_f16_fused_big_kernel")) return rc;
 #ifdef SM_STAMP
   {
     static unsigned long long* dbg = nullptr;
@@ -402,7 +373,7 @@ static int launch_fused_big(const FusedArgs& a0, hipStream_t st) {
     if (cnt > cap) { if (dbg) (void)hipFree(dbg); (void)hipMalloc((void**)&dbg, cnt * 8); cap = cnt; }
     (void)hipMemset(dbg, 0, cnt * 8);
     a.dbg = dbg;
-    spmma_f16_fused_big_kernel<BN, BF, NSA, NSB, ANT, ILV><<<dim3((unsigned)nwg), dim3(512), lds, st>>>(a);
+    spmma_f16_fused_big_kernel<BN, BF, NSA, NSB, ANT><<<dim3((unsigned)nwg), dim3(512), lds, st>>>(a);
     (void)hipDeviceSynchronize();
     std::vector<unsigned long long> h(cnt);
     (void)hipMemcpy(h.data(), dbg, cnt * 8, hipMemcpyDeviceToHost);
@@ -415,7 +386,7 @@ static int launch_fused_big(const FusedArgs& a0, hipStream_t st) {
     return check_launch("spmma_f16_fused_big_kernel");
   }
 #endif
-  spmma_f16_fused_big_kernel<BN, BF, NSA, NSB, ANT, ILV><<<dim3((unsigned)nwg), dim3(512), lds, st>>>(a);
+  spmma_f16_fused_big_kernel<BN, BF, NSA, NSB, ANT><<<dim3((unsigned)nwg), dim3(512), lds, st>>>(a);
   return check_launch("spmma_f16_fused_big_kernel");
 }
 
@@ -1382,14 +1353,6 @@ static int spmma_fused16(size_t ngroup, const void* const* Ag, const void* const
   // rounds against 4.6, 196 x 512 x 2048 x 2 = 100 tiles against 196).  Against the A-stationary kernel (n > 256, k <= 512) it
   // needs a clear margin (196 x 2048 x 512 x 3: 59 vs 68 us; 784 x 1024 x 256 x 6: 126 vs 111).  SM_FUSED_BIG (tuning): 0 = never.
   const int big_rule = tuning_int("SM_FUSED_BIG", 8);
-  auto big256 = [&](bool ant) {  // A read once by the grid (one column tile): non-temporal
-#ifdef SM_TUNING
-    const int ilv = tuning_int("SM_FUSED_BIG_ILV", 0);  // A/B: DMA pieces spread over the sweep (1: B and A pieces, 2: A pieces only)
-    if (ilv == 1) return ant ? launch_fused_big<256, BF, 3, 2, true, 1>(a, st) : launch_fused_big<256, BF, 3, 2, false, 1>(a, st);
-    if (ilv == 2) return ant ? launch_fused_big<256, BF, 3, 2, true, 2>(a, st) : launch_fused_big<256, BF, 3, 2, false, 2>(a, st);
-#endif
-    return ant ? launch_fused_big<256, BF, 3, 2, true>(a, st) : launch_fused_big<256, BF, 3, 2, false>(a, st);
-  };
   auto round_eff = [](size_t tiles, size_t cus) { const size_t r = (tiles + cus - 1) / cus; return r ? (double)tiles / (double)(r * cus) : 1.0; };
   if (big_rule == 8 && !wide_env && n > 128 && k > 64) {
     const size_t cus = (size_t)device_cu_count(), nb = (size_t)a.batch * a.ngroup;
@@ -1402,12 +1365,12 @@ static int spmma_fused16(size_t ngroup, const void* const* Ag, const void* const
       while (panels * ns * 4 < 3 * cus && (tn + 2 * ns - 1) / (2 * ns) >= 2) ns *= 2;
       big = round_eff(t_big, cus) > round_eff(panels * ns, cus) + 0.1;
     }
-    if (big) return big256(n <= 256);
+    if (big) return n <= 256 ? launch_fused_big<256, BF, 3, 2, true>(a, st) : launch_fused_big<256, BF, 3, 2, false>(a, st);
   }
 #ifdef SM_TUNING
   {  // A/B of the 256-row big form: bit 0 = n >= 256 (k > 64), bit 1 = 64 < n <= 128, bit 2 = n <= 256 with k <= 64; SM_FUSED_BIG_NSB = 2 / 3
     const int big_env = tuning_int("SM_FUSED_BIG", 0), nsb = tuning_int("SM_FUSED_BIG_NSB", 2);
-    if (big_env < 8 && (big_env & 1) && n > 128 && k > 64) return big256(n <= 256);
+    if (big_env < 8 && (big_env & 1) && n > 128 && k > 64) return n <= 256 ? launch_fused_big<256, BF, 3, 2, true>(a, st) : launch_fused_big<256, BF, 3, 2, false>(a, st);
     if (big_env < 8 && (big_env & 4) && n > 128 && n <= 256 && k <= 64) return launch_fused_big<256, BF, 3, 2, true>(a, st);
     if (big_env < 8 && (big_env & 2) && n > 64 && n <= 128) return nsb == 3 ? launch_fused_big<128, BF, 3, 3, true>(a, st) : launch_fused_big<128, BF, 3, 2, true>(a, st);
   }

@@ -204,7 +204,7 @@ static int prune24_spmma16(const void* A_in, void* A, const void* B, void* C, si
     return SM_STATUS_INVALID_VALUE;
   }
   if (m == 0 || n == 0 || batch == 0) return SM_STATUS_SUCCESS;
-  if (n > 256 || n % 8 != 0 || k == 0 || k % 64 != 0 || m % 4 != 0 || lda % 8 != 0 || strideA % 8 != 0 || strideB % 8 != 0 || !aligned16(A) || !aligned16(A_in) || !aligned16(B) ||
+  if (n > 128 || n % 8 != 0 || k == 0 || k % 64 != 0 || m % 4 != 0 || lda % 8 != 0 || strideA % 8 != 0 || strideB % 8 != 0 || !aligned16(A) || !aligned16(A_in) || !aligned16(B) ||
       m * batch > 0x7fffffffull || k > 0x7fffffffull || lda > 0x7fffffffull) {
     set_error("sm_prune24_spmma_{f16,bf16}: needs n <= 128, n %% 8 == 0, k %% 64 == 0, m %% 4 == 0 and 16-byte aligned rows "
               "(use sm_prune24_compress24 + sm_spmma)");
@@ -221,8 +221,11 @@ static int prune24_spmma16(const void* A_in, void* A, const void* B, void* C, si
   }
   hipStream_t st = (hipStream_t)stream;
   if (d_valid && hipMemsetAsync(d_valid, 0, sizeof(int), st) != hipSuccess) return check_launch("hipMemsetAsync(d_valid)");
-  if (alg == 0) return n <= 64 ? launch_pruned<64, BF, true>(a, st) : n <= 128 ? launch_pruned<128, BF, true>(a, st) : launch_pruned<256, BF, true>(a, st);
-  return n <= 64 ? launch_pruned<64, BF, false>(a, st) : n <= 128 ? launch_pruned<128, BF, false>(a, st) : launch_pruned<256, BF, false>(a, st);
+  // (a 256-column instantiation -- one workgroup per CU, 128 accumulator registers per lane -- was measured for 128 < n <= 256 and
+  // is slower than the two-launch pair on every such ResNet-50 shape, profiles/api_path_r04o.txt: 784 x 256 x 2304 125 vs 109 us,
+  // 12544 x 256 x 64 112 vs 75 us; not instantiated)
+  if (alg == 0) return n <= 64 ? launch_pruned<64, BF, true>(a, st) : launch_pruned<128, BF, true>(a, st);
+  return n <= 64 ? launch_pruned<64, BF, false>(a, st) : launch_pruned<128, BF, false>(a, st);
 }
 
 }  // namespace sm

@@ -19,8 +19,8 @@
 // and all BN columns: every strip is selected once, by the lane that feeds it), the DENSE fp32 A stage (128 rows x 256 B)
 // and the bfloat16 planes of the B stage (planes x 64 x BN) by LDS-DMA into a ring of two, one counted wait + barrier per
 // stage.  B is split once per call by a streaming pre-pass into the caller's workspace (planes x k x n bfloat16).
-// Non-finite values stay in the first piece (x2 = x3 = 0), so inf / NaN propagate as in the exact path except where an
-// inf meets a cancelled piece (inf * 0 contributions do not arise: the lower pieces of a non-finite value are zero).
+// Non-finite operand values: the residual of an inf / NaN is NaN, so every output such a value reaches is NaN (the exact
+// path may say +-inf there); all other outputs are untouched (tests: test_spmma_f32_split_edges).
 #include <algorithm>
 
 #include "select24.h"
@@ -41,28 +41,20 @@ struct SplitArgs {
 __device__ __forceinline__ float as_f32(uint32_t x) { return __builtin_bit_cast(float, x); }
 __device__ __forceinline__ uint32_t as_u32(float x) { return __builtin_bit_cast(uint32_t, x); }
 
-// residual of a truncation to bfloat16, exact; 0 for a non-finite x (its whole value stays in the first piece)
-__device__ __forceinline__ float trunc_residual(uint32_t x) {
-  const float r = as_f32(x) - as_f32(x & 0xffff0000u);
-  return (x & 0x7f800000u) != 0x7f800000u ? r : 0.0f;
-}
+// residual of a truncation to bfloat16: exact (a non-finite x gives NaN: see the header)
+__device__ __forceinline__ float trunc_residual(uint32_t x) { return as_f32(x) - as_f32(x & 0xffff0000u); }
 
 // {hi16(b) : hi16(a)}: two bfloat16 (truncated) in SMFMAC operand order
 __device__ __forceinline__ uint32_t pack_hi16(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
 
-// top-2 of a strip by magnitude, ties to the lower index (frozen rule), as a 4-bit keep mask: a 5-compare selection
-// network on the 31-bit magnitude keys (pair winners, then the runner-up among the three that are left) -- 20 VALU against
-// ~40 for the compare-and-count form (strip_keepmask), same mask for every input.
-__device__ __forceinline__ unsigned strip_keepmask_net(uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3) {
-  const bool c01 = k0 >= k1, c23 = k2 >= k3;
-  const uint32_t w01 = c01 ? k0 : k1, l01 = c01 ? k1 : k0, w23 = c23 ? k2 : k3, l23 = c23 ? k3 : k2;
-  const unsigned mw01 = c01 ? 1u : 2u, ml01 = 3u ^ mw01, mw23 = c23 ? 4u : 8u, ml23 = 12u ^ mw23;
-  const unsigned sa = l01 >= w23 ? ml01 : mw23;  // first came from {0, 1}: runner-up among its loser and the other pair's winner
-  const unsigned sb = w01 >= l23 ? mw01 : ml23;  // first came from {2, 3}
-  return w01 >= w23 ? (mw01 | sa) : (mw23 | sb);
-}
-
-// One lane's 16 dense fp32 of a row (k = 16 g .. 16 g + 15 of the stage) -> NP bfloat16 SMFMAC A operands + the index halfword
+// One lane's 16 dense fp32 of a row (k = 16 g .. 16 g + 15 of the stage) -> NP bfloat16 SMFMAC A operands + the index halfword.
+// The frozen STRIP rule (top-2 magnitudes, ties to the lower index; oracle strip_select) as a 5-compare selection network on
+// the 31-bit magnitude keys: pair winners (c01, c23), winner of winners (cw), then the runner-up among the three left (ca:
+// loser of {0, 1} against the winner of {2, 3}; cb: winner of {0, 1} against the loser of {2, 3}).  Which positions are kept
+// is then pure boolean algebra on the five compare results -- lane masks in scalar registers, combined on the scalar unit --
+// and the kept values / their positions fall out of two conditional moves each: ~23 vector instructions per strip against
+// ~45 for the compare-and-count form with integer masks (strip_keepmask), same mask for every input
+// (tests: test_spmma_f32_split on tie-heavy integer data must equal the exact kernel bit for bit).
 template <int NP>
 __device__ __forceinline__ void dense16_f32_to_operands(const u4 (&v)[4], h8 (&af)[NP], int& idx) {
   uint32_t pk[NP][4];
@@ -70,18 +62,28 @@ __device__ __forceinline__ void dense16_f32_to_operands(const u4 (&v)[4], h8 (&a
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     const uint32_t x0 = v[s][0], x1 = v[s][1], x2 = v[s][2], x3 = v[s][3];
-    const unsigned mk = strip_keepmask_net(x0 & 0x7fffffffu, x1 & 0x7fffffffu, x2 & 0x7fffffffu, x3 & 0x7fffffffu);
-    const uint32_t lo = (mk & 1u) ? x0 : ((mk & 2u) ? x1 : x2);  // position p0 < p1
-    const uint32_t hi = (mk & 8u) ? x3 : ((mk & 4u) ? x2 : x1);
-    meta |= nibble_of(mk) << (4 * s);
+    const uint32_t k0 = x0 & 0x7fffffffu, k1 = x1 & 0x7fffffffu, k2 = x2 & 0x7fffffffu, k3 = x3 & 0x7fffffffu;
+    // five compares -> lane masks in scalar registers (ballot); the keep logic is scalar boolean algebra on them, and the
+    // masks return as conditions of the conditional moves (inverse ballot).  Written with the builtins on purpose: as plain
+    // bool expressions the compiler either branched around every strip (&&, ||, ?:) or materialised the bools in vector registers.
+    typedef unsigned long long lm_t;
+    const lm_t c01 = __builtin_amdgcn_ballot_w64(k0 >= k1), c23 = __builtin_amdgcn_ballot_w64(k2 >= k3);
+    const uint32_t w01 = k0 > k1 ? k0 : k1, l01 = k0 > k1 ? k1 : k0, w23 = k2 > k3 ? k2 : k3, l23 = k2 > k3 ? k3 : k2;  // v_max_u32 / v_min_u32
+    const lm_t cw = __builtin_amdgcn_ballot_w64(w01 >= w23), ca = __builtin_amdgcn_ballot_w64(l01 >= w23), cb = __builtin_amdgcn_ballot_w64(w01 >= l23);
+    const bool keep0 = __builtin_amdgcn_inverse_ballot_w64((cw & (c01 | ca)) | (~cw & cb & c01));
+    const bool keep1 = __builtin_amdgcn_inverse_ballot_w64((cw & (~c01 | ca)) | (~cw & cb & ~c01));
+    const bool keep2 = __builtin_amdgcn_inverse_ballot_w64((cw & ~ca & c23) | (~cw & (c23 | ~cb)));
+    const bool keep3 = __builtin_amdgcn_inverse_ballot_w64((cw & ~ca & ~c23) | (~cw & (~c23 | ~cb)));
+    const uint32_t lo = keep0 ? x0 : (keep1 ? x1 : x2);  // the kept value at the lower position p0 ...
+    const uint32_t hi = keep3 ? x3 : (keep2 ? x2 : x1);  // ... and at the higher position p1
+    const unsigned q0 = keep0 ? 0u : (keep1 ? (1u << (4 * s)) : (2u << (4 * s)));             // p0 << 4 s
+    const unsigned q1 = keep3 ? (12u << (4 * s)) : (keep2 ? (8u << (4 * s)) : (4u << (4 * s)));  // p1 << (4 s + 2)
+    meta |= q0 | q1;
     pk[0][s] = pack_hi16(lo, hi);
     if constexpr (NP >= 2) {
       const float rl = trunc_residual(lo), rh = trunc_residual(hi);
       pk[1][s] = pack_hi16(as_u32(rl), as_u32(rh));
-      if constexpr (NP >= 3) {
-        const float ql = rl - as_f32(as_u32(rl) & 0xffff0000u), qh = rh - as_f32(as_u32(rh) & 0xffff0000u);  // <= 8 significant bits: exact
-        pk[2][s] = pack_hi16(as_u32(ql), as_u32(qh));
-      }
+      if constexpr (NP >= 3) pk[2][s] = pack_hi16(as_u32(trunc_residual(as_u32(rl))), as_u32(trunc_residual(as_u32(rh))));  // <= 8 significant bits left: exact
     }
   }
 #pragma unroll
@@ -89,9 +91,9 @@ __device__ __forceinline__ void dense16_f32_to_operands(const u4 (&v)[4], h8 (&a
   idx = (int)meta;
 }
 
-template <int BN, int NP, bool ANT>
-__global__ __launch_bounds__(256) void spmma_f32_split_kernel(const SplitArgs p) {
-  constexpr int BM = 128, NW = 4, TM = BM / NW, FM = TM / 16, FN = BN / 16;
+template <int BN, int NP, bool ANT, int NW>
+__global__ __launch_bounds__(64 * NW) void spmma_f32_split_kernel(const SplitArgs p) {
+  constexpr int BM = 128, TM = BM / NW, FM = TM / 16, FN = BN / 16;
   constexpr int SA = BM * 256, SBP = 64 * BN * 2, STAGE = SA + NP * SBP;
   constexpr int A_N = BM / 4, B_N = NP * (BN / 8);  // 1 KiB DMA wave-instructions per stage
   static_assert(A_N % NW == 0 && B_N % NW == 0, "equal DMA share per wave");
@@ -253,7 +255,7 @@ __global__ __launch_bounds__(256) void spmma_f32_split_kernel(const SplitArgs p)
         *reinterpret_cast<float*>(smem + (wave * TM + i * 16 + 4u * g + q) * CP + (j * 16 + r) * 4u) = acc[i][j][q];
   __syncthreads();
   constexpr unsigned PPR = BN / 4;  // 16-byte pieces per row
-  for (unsigned it = tid; it < (unsigned)BM * PPR; it += 256u) {
+  for (unsigned it = tid; it < (unsigned)BM * PPR; it += 64u * NW) {
     const unsigned row = it / PPR, pc = it - row * PPR;
     const int gr = m0 + (int)row, gc = n0 + (int)(4u * pc);
     if (gr > mlast || gc + 4 > p.N) continue;
@@ -285,8 +287,7 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
         const float ra = trunc_residual(a), rb = trunc_residual(b);
         o[1][e] = pack_hi16(as_u32(ra), as_u32(rb));
         if constexpr (NP >= 3) {
-          const float qa = ra - as_f32(as_u32(ra) & 0xffff0000u), qb = rb - as_f32(as_u32(rb) & 0xffff0000u);
-          o[2][e] = pack_hi16(as_u32(qa), as_u32(qb));
+          o[2][e] = pack_hi16(as_u32(trunc_residual(as_u32(ra))), as_u32(trunc_residual(as_u32(rb))));
         }
       }
     }
@@ -295,7 +296,7 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
   }
 }
 
-template <int BN, int NP>
+template <int BN, int NP, int NW>
 static int launch_split(const SplitArgs& a0, hipStream_t st) {
   SplitArgs a = a0;
   a.tiles_m = (a.Mrows + 127) / 128;
@@ -312,14 +313,13 @@ static int launch_split(const SplitArgs& a0, hipStream_t st) {
   const size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
   constexpr size_t lds_max = 2 * stage_bytes > lds_epi ? 2 * stage_bytes : lds_epi;
   static_assert(lds_max <= 160 * 1024, "LDS budget");
-  static LdsOptIn lds_optin;
-  static LdsOptIn lds_optin_nt;
-  if (a.tiles_n == 1) {
-    if (const int rc = ensure_dyn_lds(lds_optin_nt, reinterpret_cast<const void*>(&spmma_f32_split_kernel<BN, NP, true>), lds_max, "spmma_f32_split_kernel")) return rc;
-    spmma_f32_split_kernel<BN, NP, true><<<dim3((unsigned)nwg), dim3(256), lds, st>>>(a);
+  static LdsOptIn lds_optin, lds_optin_nt;
+  if (a.tiles_n == 1) {  // A is read once by the whole grid: non-temporal
+    if (const int rc = ensure_dyn_lds(lds_optin_nt, reinterpret_cast<const void*>(&spmma_f32_split_kernel<BN, NP, true, NW>), lds_max, "spmma_f32_split_kernel")) return rc;
+    spmma_f32_split_kernel<BN, NP, true, NW><<<dim3((unsigned)nwg), dim3(64 * NW), lds, st>>>(a);
   } else {
-    if (const int rc = ensure_dyn_lds(lds_optin, reinterpret_cast<const void*>(&spmma_f32_split_kernel<BN, NP, false>), lds_max, "spmma_f32_split_kernel")) return rc;
-    spmma_f32_split_kernel<BN, NP, false><<<dim3((unsigned)nwg), dim3(256), lds, st>>>(a);
+    if (const int rc = ensure_dyn_lds(lds_optin, reinterpret_cast<const void*>(&spmma_f32_split_kernel<BN, NP, false, NW>), lds_max, "spmma_f32_split_kernel")) return rc;
+    spmma_f32_split_kernel<BN, NP, false, NW><<<dim3((unsigned)nwg), dim3(64 * NW), lds, st>>>(a);
   }
   return check_launch("spmma_f32_split_kernel");
 }
@@ -381,6 +381,12 @@ extern "C" int sm_spmma_fused_f32_split(const float* A, const float* B, float* C
     a.Mrows = (int)(m * batch);
     a.batch = 1;
   }
-  if (planes == 3) return n <= 64 ? launch_split<64, 3>(a, st) : launch_split<128, 3>(a, st);
-  return n <= 64 ? launch_split<64, 2>(a, st) : launch_split<128, 2>(a, st);
+#ifdef SM_TUNING
+  if (tuning_int("SM_F32_SPLIT_NW", 8) == 4) {  // A/B: four waves of 32 rows (one per SIMD) instead of eight of 16
+    if (planes == 3) return n <= 64 ? launch_split<64, 3, 4>(a, st) : launch_split<128, 3, 4>(a, st);
+    return n <= 64 ? launch_split<64, 2, 4>(a, st) : launch_split<128, 2, 4>(a, st);
+  }
+#endif
+  if (planes == 3) return n <= 64 ? launch_split<64, 3, 8>(a, st) : launch_split<128, 3, 8>(a, st);
+  return n <= 64 ? launch_split<64, 2, 8>(a, st) : launch_split<128, 2, 8>(a, st);
 }

@@ -249,9 +249,12 @@ static void check_coo(size_t m, size_t n, size_t k, size_t b) {
 
 // spmma<type_t>(): TILE prune in place + check + compress + multiply; (N, N) and (T, N): the in-place pruned A must be the
 // oracle's TILE-pruned A bit for bit (in its stored orientation), C the oracle's product of the compressed operand
+// planes = 3 / 2 (float only): spmma_options().f32_planes -- the multiply on the sparse matrix instruction through bfloat16 splits;
+// same pruned A bit for bit, C within 2^-21 / 2^-13 of sum|a||b| on top of the fp32 terms (include/sparsifyme.h)
 template <typename T>
-static void check_spmma(size_t m, size_t n, size_t k, size_t b, const char* tname) {
+static void check_spmma(size_t m, size_t n, size_t k, size_t b, const char* tname, int planes = 0) {
   constexpr bool F32 = sizeof(T) == 4;
+  spmma_options().f32_planes = planes;
   std::mt19937 gen(0xa24 + (unsigned)(m + n * 3 + k * 5));
   std::uniform_real_distribution<float> U(-1.f, 1.f);
   using bits_t = typename std::conditional<F32, float, uint16_t>::type;
@@ -308,11 +311,14 @@ static void check_spmma(size_t m, size_t n, size_t k, size_t b, const char* tnam
           for (size_t j = 0; j < n; ++j) scale[bi * m * n + r * n + j] += a * std::fabs((double)dec(hB[bi * k * n + l * n + j]));
         }
     std::string detail;
+    if (planes)
+      for (auto& x : scale) x *= 1.0 + std::ldexp(1.0, planes == 3 ? -21 : -13) / (2.0 * k * std::ldexp(1.0, -24));
     // the oracle's C is already rounded to the type: allow one more rounding of the output on top of the accumulation bound
     const bool ok = close_enough(got, ref, scale, F32 ? std::ldexp(1.0, -22) : std::ldexp(1.0, -9), k, detail);
     std::snprintf(what, sizeof(what), "spmma<%s> %zux%zux%zu b=%zu (%s,N): C vs oracle", tname, m, n, k, b, ta ? "T" : "N");
     verdict(what, ok, false, detail);
   }
+  spmma_options().f32_planes = 0;
 }
 
 int main(int argc, char** argv) {
@@ -341,6 +347,8 @@ int main(int argc, char** argv) {
     check_coo(m, n, k, b);
     check_spmma<_Float16>(m, n, k, b, "half");
     check_spmma<float>(m, n, k, b, "float");
+    check_spmma<float>(m, n, k, b, "float, f32_planes = 3", 3);
+    check_spmma<float>(m, n, k, b, "float, f32_planes = 2", 2);
   }
   std::printf("%d checks, %d failed%s\n", g_checks, g_fail, g_swap ? " (--swap: a check passes iff the rotated table was noticed)" : "");
   return g_fail == 0 && g_checks > 0 ? EXIT_SUCCESS : EXIT_FAILURE;

@@ -23,6 +23,7 @@ VARIANTS = {
     "n128": [("base", {}), ("big nsb2", {"SM_FUSED_BIG": "2", "SM_FUSED_BIG_NSB": "2"}), ("big nsb3", {"SM_FUSED_BIG": "2", "SM_FUSED_BIG_NSB": "3"})],
     "k64": [("base", {}), ("big", {"SM_FUSED_BIG": "4"})],
     "astat": [("base", {}), ("big", {"SM_FUSED_BIG": "1", "SM_FUSED_ASTAT": "0"})],
+    # (SM_FUSED_BIG_ILV: the interleaved-issue variant of session r04n; measured, not adopted, removed from the source: git history)
     "ilv": [("rule", {}), ("big", {"SM_FUSED_BIG": "1", "SM_FUSED_ASTAT": "0"}), ("big ilv1", {"SM_FUSED_BIG": "1", "SM_FUSED_ASTAT": "0", "SM_FUSED_BIG_ILV": "1"}),
             ("big ilv2", {"SM_FUSED_BIG": "1", "SM_FUSED_ASTAT": "0", "SM_FUSED_BIG_ILV": "2"})],
 }
