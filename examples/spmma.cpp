@@ -2,7 +2,8 @@
 // of the reference's examples/spmma.cu:64-66.  The reference refuses every GPU that is not compute
 // capability 8.0 (:35-41); this driver refuses every GPU that is not gfx950.  Element type: fp16,
 // the type the reference's spmma actually declares to its back end (spmma.hxx:40); build with
-// -DSM_TYPE=float for the fp32 kernels.
+// -DSM_TYPE=float for the fp32 kernels (bin/spmma_f32; there a fifth argument 3 / 2 sets spmma_options().f32_planes: the multiply
+// on the sparse matrix instruction through exact bfloat16 splits instead of dense fp32 matrix work, include/sparsifyme.h).
 #include <cstdlib>
 #include <iostream>
 #include <string>
@@ -18,9 +19,17 @@
 int main(int argc, char** argv) {
   using namespace sparsifyme;
   using type_t = SM_TYPE;
-  if (argc != 5) {
-    std::cout << "Invalid # of arguments. Usage: ./spmma m n k b" << std::endl;
+  if (argc != 5 && !(argc == 6 && sizeof(type_t) == 4)) {
+    std::cout << "Invalid # of arguments. Usage: ./spmma m n k b" << (sizeof(type_t) == 4 ? " [f32_planes: 0 | 2 | 3]" : "") << std::endl;
     return EXIT_FAILURE;
+  }
+  if (argc == 6) {
+    const int planes = std::stoi(argv[5]);
+    if (planes != 0 && planes != 2 && planes != 3) {
+      std::cout << "f32_planes must be 0, 2 or 3" << std::endl;
+      return EXIT_FAILURE;
+    }
+    spmma_options().f32_planes = planes;
   }
   if (sm_device_check() != SM_STATUS_SUCCESS) {
     std::cerr << "\nlibsparsifyme is supported only on gfx950 (MI355X) devices: " << sm_last_error() << std::endl;

@@ -1470,6 +1470,12 @@ def test_cpp_drivers_cli_contract(gpu):
     lines = out.stdout.strip().splitlines()
     assert out.returncode == 0 and [l.split(":")[0] for l in lines] == ["Pruning Time (ms)", "Compression Time (ms)", "SpMMA Time (ms)"]
     assert all(float(l.split(":")[1]) > 0.0 for l in lines) and "Incorrect pruning" not in out.stderr
+    # ... and with the multiply on the sparse matrix instruction (spmma_options().f32_planes = 3): same three labels
+    out = run("spmma_f32", 196, 64, 128, 4, 3)
+    lines = out.stdout.strip().splitlines()
+    assert out.returncode == 0 and [l.split(":")[0] for l in lines] == ["Pruning Time (ms)", "Compression Time (ms)", "SpMMA Time (ms)"]
+    assert float(lines[0].split(":")[1]) > 0.0 and float(lines[2].split(":")[1]) > 0.0 and "Incorrect pruning" not in out.stderr
+    assert run("spmma_f32", 196, 64, 128, 4, 5).returncode != 0
     bad = run("spmma", 1, 2)
     assert bad.returncode != 0 and "Usage: ./spmma m n k b" in bad.stdout
     # int8 driver: stage labels of the fp16 one; its fused kernel must return the staged pair's bytes
