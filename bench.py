@@ -646,6 +646,17 @@ def extras(args, sm, torch, dev, layers, flops, t_full, Forked, make_runner, tim
             sm.gemm_batched(L0["gBp"], L0["gAp"], L0["gCp"], L0["n"], L0["m"] * L0["b"], L0["k"], len(Ls), args.dtype)
         t_drm_grouped = sec_per_call(ForkedItems(spread(ditems), dense_group,
                                                  lambda L: sm.gemm_rowmajor(L["A"], L["B"], L["C"], L["m"], L["n"], L["k"], batch=L["b"])))
+    # the 2:4 matmul on prepared blobs given the same treatment (round 4: sm_spmma_*_grouped, one grid per <= 8 same-shape blobs)
+    t_mul_grouped = None
+    if grouping and not f32 and hasattr(sm, "spmma_grouped"):
+        fused_groups, _, spread, ForkedItems = grouping
+        mitems = [("group" if len(Ls) > 1 else "single", Ls) for _, Ls in fused_groups(layers)]
+
+        def mul_group(Ls):
+            L0 = Ls[0]
+            sm.spmma_grouped([x["blob"] for x in Ls], [x["B"] for x in Ls], [x["C"] for x in Ls], L0["m"], L0["n"], L0["k"], batch=L0["b"])
+        t_mul_grouped = sec_per_call(ForkedItems(spread(mitems), mul_group,
+                                                 lambda L: sm.spmma(L["blob"], L["B"], L["C"], L["m"], L["n"], L["k"], L["b"], 0)))
     t_dcm = sec_per_call(dense_batched) if has_batched else None
     t_staged = t_full if args.path == "staged" else sec_per_call(Forked(lambda L: (
         sm.compress24(L["A"], L["m"], L["k"], L["k"], L["b"], L["m"] * L["k"], L["blob"]),
@@ -660,6 +671,10 @@ def extras(args, sm, torch, dev, layers, flops, t_full, Forked, make_runner, tim
         "dense_gemm_rowmajor_grouped_gfs": gfs(t_drm_grouped) if t_drm_grouped else None,
         "speedup_full_vs_dense_rowmajor_grouped": t_drm_grouped / t_full if t_drm_grouped else None,
         "speedup_mul_vs_dense_rowmajor_grouped": t_drm_grouped / t_mul if t_drm_grouped else None,
+        "spmma_mul_grouped_ms": t_mul_grouped * 1e3 if t_mul_grouped else None,
+        "spmma_mul_grouped_gfs": gfs(t_mul_grouped) if t_mul_grouped else None,
+        "speedup_mul_grouped_vs_dense_rowmajor_grouped": t_drm_grouped / t_mul_grouped if t_drm_grouped and t_mul_grouped else None,
+        "speedup_mul_grouped_vs_dense_batched": t_dcm / t_mul_grouped if t_dcm and t_mul_grouped else None,
         "full_path_staged_gfs": gfs(t_staged), "full_path_staged_ms": t_staged * 1e3,
         "timed_path": args.path, "timed_path_ms": t_full * 1e3,
         # what 2:4 can buy on these shapes when both products are HBM-bound (fp16: they are): the ratio of

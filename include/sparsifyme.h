@@ -151,6 +151,15 @@ int sm_spmma_fused_f16(const void* A, const void* B, void* C, size_t m, size_t n
                        size_t batch, size_t strideA, size_t strideB, size_t strideC, float alpha,
                        float beta, sm_stream_t stream);
 
+/* The matmul step on `count` same-shape compressed operands as ONE grid per 8 (extension, round 4): host arrays of device
+ * pointers blobs[i], B[i], C[i]; the same kernels and the same C, bit for bit, as `count` calls of sm_spmma_f16.  What the
+ * grouped form buys is the same as for the fused kernels below: a few-tile layer shape's last partial round of workgroups is
+ * filled by the next instance of that shape. */
+int sm_spmma_f16_grouped(size_t count, const void* const* blobs, const void* const* B, void* const* C, size_t m, size_t n, size_t k,
+                         size_t batch, size_t strideB, size_t strideC, float alpha, float beta, sm_stream_t stream);
+int sm_spmma_bf16_grouped(size_t count, const void* const* blobs, const void* const* B, void* const* C, size_t m, size_t n, size_t k,
+                          size_t batch, size_t strideB, size_t strideC, float alpha, float beta, sm_stream_t stream);
+
 /* Grouped form (extension; round 3): `count` same-shape problems -- host arrays of device pointers A[i], B[i], C[i], the way
  * the reference's batched::spmm takes its As / Cs (spmm.hxx:30-33) -- in one grid per 8 problems instead of one per problem:
  * the 3-6 instances of one layer shape in a network then share the chip (the last partial round of one instance is filled by

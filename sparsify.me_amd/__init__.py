@@ -51,6 +51,8 @@ _SIGS = {
                            _c_f, _c_f, _c_ptr],
     "sm_spmma_fused_f32": [_c_ptr, _c_ptr, _c_ptr, _c_size, _c_size, _c_size, _c_size, _c_size, _c_size, _c_size, _c_size,
                            _c_f, _c_f, _c_ptr],
+    "sm_spmma_f16_grouped": [_c_size, _c_ptr, _c_ptr, _c_ptr, _c_size, _c_size, _c_size, _c_size, _c_size, _c_size, _c_f, _c_f, _c_ptr],
+    "sm_spmma_bf16_grouped": [_c_size, _c_ptr, _c_ptr, _c_ptr, _c_size, _c_size, _c_size, _c_size, _c_size, _c_size, _c_f, _c_f, _c_ptr],
     "sm_spmma_fused_f32_split_workspace": [_c_size, _c_size, _c_size, _c_size, _c_i, ctypes.POINTER(_c_size)],
     "sm_spmma_fused_f32_split": [_c_ptr, _c_ptr, _c_ptr, _c_size, _c_size, _c_size, _c_size, _c_size, _c_size, _c_size, _c_size, _c_i,
                                  _c_ptr, _c_size, _c_f, _c_f, _c_ptr],
@@ -340,6 +342,20 @@ def spmma_fused(A, B, C, m, n, k, lda=None, batch=1, strideA=None, strideB=0, st
     fn = getattr(lib(), "sm_spmma_fused_" + _sfx(A))
     _check(fn(_dev(A), _dev(B), _dev(C), m, n, k, lda, batch, strideA, strideB, strideC, float(alpha), float(beta), _stream()),
            "sm_spmma_fused")
+
+
+def spmma_grouped(blobs, Bs, Cs, m, n, k, batch=1, strideB=0, strideC=None, alpha=1.0, beta=0.0):
+    """The matmul step on len(blobs) same-shape compressed operands in one grid per 8 (sm_spmma_*_grouped): the same C as that many
+    spmma() calls."""
+    if not (len(blobs) == len(Bs) == len(Cs)):
+        raise SparsifymeError("spmma_grouped: operand lists differ in length")
+    if not blobs:
+        return
+    if strideC is None:
+        strideC = m * n
+    fn = getattr(lib(), "sm_spmma_%s_grouped" % _sfx(Bs[0]))
+    _check(fn(len(blobs), _ptr_table(blobs), _ptr_table(Bs), _ptr_table(Cs), m, n, k, batch, strideB, strideC, float(alpha), float(beta),
+              _stream()), "sm_spmma_grouped")
 
 
 def spmma_fused_f32_split_workspace(n, k, batch=1, strideB=0, planes=3):

@@ -14,6 +14,7 @@
 // (B fragment as srcA) so each lane ends up with four CONSECUTIVE n of one row; the epilogue packs
 // them to 8 bytes, stages the tile in LDS and writes C with 16-byte row-contiguous stores.
 #include "mma_tile.h"
+#include "spmma_args.h"
 
 namespace sm {
 
@@ -527,6 +528,16 @@ static int launch_gemm_f16(const GemmArgs& a, hipStream_t st, bool ta = false, b
     if (ta && tb) return launch_cfg<128, 128, 2, 2, true, true>(a, vec, st);
     if (ta) return launch_cfg<128, 128, 2, 2, true, false>(a, vec, st);
     if (tb) return launch_cfg<128, 128, 2, 2, false, true>(a, vec, st);
+  }
+  // (round 4) the dense twin: ragged k and n > 128 run through the fused 2:4 kernels' pipelines with dense MFMA (spmma_f16_fused.hip:
+  // gemm_dense_twin) where those are the better pipelines; SM_GEMM_TWIN (tuning): 0 = never, 2 = wherever supported
+  if (a.ldb == a.N && a.ldc == a.N && a.M > 0) {
+    const int twin_mode = tuning_int("SM_GEMM_TWIN", 1);
+    if (twin_mode > 0) {
+      DenseTwinCall c = {a.A, a.B, a.C, a.Ap, a.Bp, a.Cp, a.sA, a.sB, a.sC, a.M, a.N, a.K, a.lda, a.batch, a.alpha, a.beta, BF, twin_mode};
+      const int rc = gemm_dense_twin(c, st);
+      if (rc != SM_STATUS_NOT_SUPPORTED) return rc;
+    }
   }
   // pointer-array batches: per-batch base alignment is the caller's (hipMalloc gives 256 B);
   // DMA fast path: whole 64-deep K stages, N a multiple of 4 (a half-valid last chunk is served from columns

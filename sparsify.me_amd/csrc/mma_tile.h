@@ -197,6 +197,57 @@ __device__ __forceinline__ void smfmac_stage_dense_a(const char* Araw, const cha
   smfmac_b_sweep<FM, FN, BF, D>(af, idx, Bs, col0, lane, acc);
 }
 
+// ---- the DENSE twin of the two functions above (round 4): the same stage images, the same B reads, dense v_mfma_f32_16x16x32 on
+// ALL of A's elements instead of the 2:4 selection + v_smfmac -- so that the dense GEMM the 2:4 path is measured against runs
+// through the very pipelines (direct / big / span) the fused kernels use.  A B fragment's 16 halves are already two dense
+// operands (elements 0-7: k = 8 g + j of the stage's first 32-k block, 8-15: the second block's); the A lane takes the matching
+// 8 + 8 halves of its row: chunks g and 4 + g of the 128-byte row image.
+template <int FM, int FN, bool BF = false>
+__device__ __forceinline__ void mfma_b_sweep(const h8 (&a0)[FM], const h8 (&a1)[FM], const char* Bs, unsigned col0, unsigned lane, f4 (&acc)[FM][FN]) {
+  const unsigned g = lane >> 4, r = lane & 15u;
+  const unsigned bs_addr = (unsigned)(uintptr_t)(lds_char*)Bs;
+  s4 t0[2], t1[2], t2[2], t3[2];
+  auto issue = [&](int j, s4& v0, s4& v1, s4& v2, s4& v3) {
+    const unsigned c0 = col0 + j * 16, q = r >> 2, pp = r & 3u;
+    const unsigned a = bs_addr + b_off<64>(8u * g + q, c0 + 4u * pp);
+    asm volatile("ds_read_b64_tr_b16 %0, %4\n\tds_read_b64_tr_b16 %1, %4 offset:512\n\t"
+                 "ds_read_b64_tr_b16 %2, %4 offset:4096\n\tds_read_b64_tr_b16 %3, %4 offset:4608"
+                 : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3) : "v"(a) : "memory");
+  };
+  issue(0, t0[0], t1[0], t2[0], t3[0]);
+#pragma unroll
+  for (int j = 0; j < FN; ++j) {
+    const int c = j & 1, n = c ^ 1;
+    if (j + 1 < FN) {
+      issue(j + 1, t0[n], t1[n], t2[n], t3[n]);
+      asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(t0[c]), "+v"(t1[c]), "+v"(t2[c]), "+v"(t3[c]) :: "memory");
+    } else {
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t0[c]), "+v"(t1[c]), "+v"(t2[c]), "+v"(t3[c]) :: "memory");
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    typedef short s8v __attribute__((ext_vector_type(8)));
+    const s8v lo = {t0[c][0], t0[c][1], t0[c][2], t0[c][3], t1[c][0], t1[c][1], t1[c][2], t1[c][3]};
+    const s8v hi = {t2[c][0], t2[c][1], t2[c][2], t2[c][3], t3[c][0], t3[c][1], t3[c][2], t3[c][3]};
+    const h8 b0 = __builtin_bit_cast(h8, lo), b1 = __builtin_bit_cast(h8, hi);
+#pragma unroll
+    for (int i = 0; i < FM; ++i) acc[i][j] = mfma16<BF>(a0[i], b0, acc[i][j]);
+#pragma unroll
+    for (int i = 0; i < FM; ++i) acc[i][j] = mfma16<BF>(a1[i], b1, acc[i][j]);
+  }
+}
+template <int FM, int FN, bool BF = false>
+__device__ __forceinline__ void mfma_stage_dense_a(const char* Araw, const char* Bs, unsigned row0, unsigned col0, unsigned lane, f4 (&acc)[FM][FN]) {
+  const unsigned g = lane >> 4, r = lane & 15u;
+  h8 a0[FM], a1[FM];
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+    const unsigned row = row0 + i * 16 + r;
+    a0[i] = *reinterpret_cast<const h8*>(Araw + a_off(row, g));
+    a1[i] = *reinterpret_cast<const h8*>(Araw + a_off(row, 4u + g));
+  }
+  mfma_b_sweep<FM, FN, BF>(a0, a1, Bs, col0, lane, acc);
+}
+
 // Epilogue of the 2:4 matmul kernels, called by EVERY thread of the workgroup after its last barrier: the SMFMAC
 // result map leaves 4 consecutive ROWS of one column per lane, so with beta == 0 and a 16-byte aligned C the tile is
 // transposed through LDS (`smem`, BM x (2 BN + 16) bytes, aliasing the stage buffers) and written as 16-byte row

@@ -45,15 +45,16 @@ __global__ __launch_bounds__(256) void spmma_f16_kernel(const SpmmaArgs p) {
 
   const unsigned tiles = (unsigned)p.tiles_m * (unsigned)p.tiles_n;
   const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
-  const unsigned b = lid / tiles, trem = lid - b * tiles;
+  const unsigned gb = lid / tiles, trem = lid - gb * tiles;
+  const unsigned grp = gb / (unsigned)p.batch, b = gb - grp * (unsigned)p.batch;  // problem of the group, grid batch in it
   const unsigned tile_m = trem / (unsigned)p.tiles_n, tile_n = trem - tile_m * (unsigned)p.tiles_n;
   const int m0 = (int)tile_m * BM, n0 = (int)tile_n * BN;
 
   const size_t row_base = (size_t)b * p.m;  // first blob row of this grid batch
-  const char* vals = p.vals + row_base * 64;  // + stage * Mtot * 64 per 64-k stage (stage-major values)
-  const char* meta = p.meta + row_base * 8;   // + stage * Mtot * 8 per 64-k stage
-  const half_t* B = p.B + (size_t)b * p.sB;
-  half_t* C = p.C + (size_t)b * p.sC;
+  const char* vals = p.vals[grp] + row_base * 64;  // + stage * Mtot * 64 per 64-k stage (stage-major values)
+  const char* meta = p.meta[grp] + row_base * 8;   // + stage * Mtot * 8 per 64-k stage
+  const half_t* B = p.B[grp] + (size_t)b * p.sB;
+  half_t* C = p.C[grp] + (size_t)b * p.sC;
 
   f4 acc[FM][FN];
 #pragma unroll
@@ -251,15 +252,16 @@ __global__ __launch_bounds__(64 * WM * WN) void spmma_f16_dma_kernel(const Spmma
   const unsigned wm = wave / WN, wn = wave % WN;
   const unsigned tiles = (unsigned)p.tiles_m * (unsigned)p.tiles_n;
   const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
-  const unsigned b = lid / tiles, trem = lid - b * tiles;
+  const unsigned gb = lid / tiles, trem = lid - gb * tiles;
+  const unsigned grp = gb / (unsigned)p.batch, b = gb - grp * (unsigned)p.batch;  // problem of the group, grid batch in it
   const unsigned tile_m = trem / (unsigned)p.tiles_n, tile_n = trem - tile_m * (unsigned)p.tiles_n;
   const int m0 = (int)tile_m * BM, n0 = (int)tile_n * BN;
 
   const size_t row_base = (size_t)b * p.m;
-  const char* vals = p.vals + row_base * 64;  // plane of stage 0; + Mtot * 64 per stage (stage-major values)
-  const char* meta = p.meta + row_base * 8;  // plane of stage 0; + Mtot * 8 per stage
-  const half_t* B = p.B + (size_t)b * p.sB;
-  half_t* C = p.C + (size_t)b * p.sC;
+  const char* vals = p.vals[grp] + row_base * 64;  // plane of stage 0; + Mtot * 64 per stage (stage-major values)
+  const char* meta = p.meta[grp] + row_base * 8;  // plane of stage 0; + Mtot * 8 per stage
+  const half_t* B = p.B[grp] + (size_t)b * p.sB;
+  half_t* C = p.C[grp] + (size_t)b * p.sC;
   const int mlast = p.Mrows - 1;
 
   // per-slot source address of stage 0 (advanced by `step` bytes per stage) and LDS offset in a stage
@@ -396,11 +398,12 @@ __global__ __launch_bounds__(64 * (WM * WN + NL)) void spmma_f16_pc_kernel(const
   const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const unsigned tiles = (unsigned)p.tiles_m * (unsigned)p.tiles_n;
   const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
-  const unsigned b = lid / tiles, trem = lid - b * tiles;
+  const unsigned gb = lid / tiles, trem = lid - gb * tiles;
+  const unsigned grp = gb / (unsigned)p.batch, b = gb - grp * (unsigned)p.batch;  // problem of the group, grid batch in it
   const unsigned tile_m = trem / (unsigned)p.tiles_n, tile_n = trem - tile_m * (unsigned)p.tiles_n;
   const int m0 = (int)tile_m * BM, n0 = (int)tile_n * BN;
   const int nkt = p.kc / 64;
-  half_t* C = p.C + (size_t)b * p.sC;
+  half_t* C = p.C[grp] + (size_t)b * p.sC;
 
   f4 acc[FM][FN];
 #pragma unroll
@@ -413,9 +416,9 @@ __global__ __launch_bounds__(64 * (WM * WN + NL)) void spmma_f16_pc_kernel(const
     // ------------------------------------------------------------------ loader wave
     const unsigned lw = wave - NC;
     const size_t row_base = (size_t)b * p.m;
-    const char* vals = p.vals + row_base * 64;  // plane of stage 0; + Mtot * 64 per stage (stage-major values)
-    const char* meta = p.meta + row_base * 8;
-    const half_t* B = p.B + (size_t)b * p.sB;
+    const char* vals = p.vals[grp] + row_base * 64;  // plane of stage 0; + Mtot * 64 per stage (stage-major values)
+    const char* meta = p.meta[grp] + row_base * 8;
+    const half_t* B = p.B[grp] + (size_t)b * p.sB;
     const int mlast = p.Mrows - 1;
     const char* src[SL];
     size_t step[SL];
@@ -527,7 +530,7 @@ static int launch_pc(const SpmmaArgs& a0, hipStream_t st) {
   SpmmaArgs a = a0;
   a.tiles_m = (a.Mrows + BM - 1) / BM;
   a.tiles_n = (a.N + BN - 1) / BN;
-  const size_t nwg = (size_t)a.tiles_m * a.tiles_n * a.batch;
+  const size_t nwg = (size_t)a.tiles_m * a.tiles_n * a.batch * a.ngroup;
   if (nwg == 0) return SM_STATUS_SUCCESS;
   if (nwg > 0x7fffffffu) {
     set_error("spmma_f16: grid too large");
@@ -576,7 +579,7 @@ static int launch_dma(const SpmmaArgs& a0, hipStream_t st) {
   SpmmaArgs a = a0;
   a.tiles_m = (a.Mrows + BM - 1) / BM;
   a.tiles_n = (a.N + BN - 1) / BN;
-  const size_t nwg = (size_t)a.tiles_m * a.tiles_n * a.batch;
+  const size_t nwg = (size_t)a.tiles_m * a.tiles_n * a.batch * a.ngroup;
   if (nwg == 0) return SM_STATUS_SUCCESS;
   if (nwg > 0x7fffffffu) {
     set_error("spmma_f16: grid too large");
@@ -626,7 +629,7 @@ static int launch_cfg(const SpmmaArgs& a0, hipStream_t st) {
   SpmmaArgs a = a0;
   a.tiles_m = (a.Mrows + BM - 1) / BM;
   a.tiles_n = (a.N + BN - 1) / BN;
-  const size_t nwg = (size_t)a.tiles_m * a.tiles_n * a.batch;
+  const size_t nwg = (size_t)a.tiles_m * a.tiles_n * a.batch * a.ngroup;
   if (nwg == 0) return SM_STATUS_SUCCESS;
   if (nwg > 0x7fffffffu) {
     set_error("spmma_f16: grid too large");
@@ -643,13 +646,23 @@ static int launch_cfg(const SpmmaArgs& a0, hipStream_t st) {
 
 using namespace sm;
 
-// BF = false: fp16, true: bfloat16 -- same blob layout, same kernels, other matrix instruction and final rounding
+// BF = false: fp16, true: bfloat16 -- same blob layout, same kernels, other matrix instruction and final rounding.
+// ng <= SPMMA_MAXG same-shape problems (blob, B, C triples) as one grid; a plain call is a group of one.
 template <bool BF>
-static int spmma16(const void* blob, const void* B, void* C, size_t m, size_t n, size_t k, size_t batch,
+static int spmma16(size_t ng, const void* const* blobs, const void* const* Bs, void* const* Cs, size_t m, size_t n, size_t k, size_t batch,
                    size_t strideB, size_t strideC, float alpha, float beta, sm_stream_t stream) {
-  if (!blob || !B || !C || !aligned16(blob)) {
-    set_error("sm_spmma_{f16,bf16}: invalid argument (blob must be 16-byte aligned)");
+  if (ng == 0) return SM_STATUS_SUCCESS;
+  if (!blobs || !Bs || !Cs || ng > (size_t)SPMMA_MAXG) {
+    set_error("sm_spmma_{f16,bf16}: invalid argument");
     return SM_STATUS_INVALID_VALUE;
+  }
+  bool b_aligned = true;
+  for (size_t g = 0; g < ng; ++g) {
+    if (!blobs[g] || !Bs[g] || !Cs[g] || !aligned16(blobs[g])) {
+      set_error("sm_spmma_{f16,bf16}: invalid argument (blob must be 16-byte aligned)");
+      return SM_STATUS_INVALID_VALUE;
+    }
+    b_aligned = b_aligned && aligned16(Bs[g]);
   }
   if (m == 0 || n == 0 || batch == 0) return SM_STATUS_SUCCESS;
   if (m * batch > 0x7fffffffull || n > 0x7fffffffull || k > 0x7fffffffull) {
@@ -658,11 +671,15 @@ static int spmma16(const void* blob, const void* B, void* C, size_t m, size_t n,
   }
   const BlobLayout L = blob_layout(m, k, 2, batch);
   SpmmaArgs a = {};
-  a.vals = (const char*)blob;
-  a.meta = (const char*)blob + L.meta_off;
+  for (size_t g = 0; g < (size_t)SPMMA_MAXG; ++g) {  // unused slots repeat problem 0 (never indexed: grp < ngroup)
+    const size_t s_ = g < ng ? g : 0;
+    a.vals[g] = (const char*)blobs[s_];
+    a.meta[g] = (const char*)blobs[s_] + L.meta_off;
+    a.B[g] = (const half_t*)Bs[s_];
+    a.C[g] = (half_t*)Cs[s_];
+  }
+  a.ngroup = (int)ng;
   a.Mtot = L.M;
-  a.B = (const half_t*)B;
-  a.C = (half_t*)C;
   a.sB = strideB; a.sC = strideC;
   a.m = (int)m; a.Mrows = (int)m; a.N = (int)n; a.K = (int)k; a.kc = (int)L.kc;
   a.batch = (int)batch; a.alpha = alpha; a.beta = beta;
@@ -673,7 +690,7 @@ static int spmma16(const void* blob, const void* B, void* C, size_t m, size_t n,
   }
   hipStream_t st = (hipStream_t)stream;
   // the metadata DMA moves 16-byte row pairs: batches and planes must start on even rows
-  const bool fast = (n % 8 == 0) && n >= 8 && aligned16(B) && (strideB % 8 == 0) && (m % 2 == 0) && k >= 8;
+  const bool fast = (n % 8 == 0) && n >= 8 && b_aligned && (strideB % 8 == 0) && (m % 2 == 0) && k >= 8;
   if (fast) {
     // Workgroup shape by how many tiles exist: with thousands of tiles 4 waves per tile and several
     // tiles per CU overlap each other's latencies; with about one tile per CU the same tile is spread
@@ -682,7 +699,7 @@ static int spmma16(const void* blob, const void* B, void* C, size_t m, size_t n,
     // 256 x 128 tiles (B lines amortised over twice the rows) pay with a long K and enough rows for >= 64 such
     // tiles per n-tile (profiles/sweep_r01_*.txt: 784x256x{1024,2304}, 3136x128x1152 at b=32)
     if (!tuning_env("SM_SPMMA_PC") && !tuning_env("SM_SPMMA_CFG") && n >= 128 && n <= 256 && k >= 1024 &&
-        (size_t)a.Mrows >= 16384)
+        (size_t)a.Mrows * ng >= 16384)
       return launch_pc<256, 128, 4, 2, 4, 3, BF>(a, st);
     static const char* pc_env = tuning_env("SM_SPMMA_PC");  // tuning aid: "<loaders>x<ring>", "0" = previous kernel
     // default: long K -> producer/consumer kernel (4 loader waves, ring of 3); short K -> the kernel
@@ -717,14 +734,14 @@ static int spmma16(const void* blob, const void* B, void* C, size_t m, size_t n,
     const size_t Mr = (size_t)a.Mrows;
     int nw, ns;
     if (n <= 64) {
-      const size_t tiles = ceil_div(Mr, 128) * a.batch;
+      const size_t tiles = ceil_div(Mr, 128) * a.batch * ng;
       nw = tiles >= 1024 ? 4 : 8;
       ns = 2;
       if (cfg_env) sscanf(cfg_env, "%dx%d", &nw, &ns);
       if (nw >= 8) return ns >= 3 ? launch_dma<128, 64, 4, 2, 3, BF>(a, st) : launch_dma<128, 64, 4, 2, 2, BF>(a, st);
       return ns >= 3 ? launch_dma<128, 64, 4, 1, 3, BF>(a, st) : launch_dma<128, 64, 4, 1, 2, BF>(a, st);
     }
-    const size_t tiles = ceil_div(Mr, 128) * ceil_div(n, 128) * a.batch;
+    const size_t tiles = ceil_div(Mr, 128) * ceil_div(n, 128) * a.batch * ng;
     nw = tiles >= 1024 ? 4 : (tiles >= 512 ? 8 : 16);
     ns = (tiles < 512 && k >= 1024) ? 3 : 2;
     if (cfg_env) sscanf(cfg_env, "%dx%d", &nw, &ns);
@@ -738,9 +755,33 @@ static int spmma16(const void* blob, const void* B, void* C, size_t m, size_t n,
 
 extern "C" int sm_spmma_f16(const void* blob, const void* B, void* C, size_t m, size_t n, size_t k, size_t batch,
                             size_t strideB, size_t strideC, float alpha, float beta, sm_stream_t stream) {
-  return spmma16<false>(blob, B, C, m, n, k, batch, strideB, strideC, alpha, beta, stream);
+  return spmma16<false>(1, &blob, &B, &C, m, n, k, batch, strideB, strideC, alpha, beta, stream);
 }
 extern "C" int sm_spmma_bf16(const void* blob, const void* B, void* C, size_t m, size_t n, size_t k, size_t batch,
                              size_t strideB, size_t strideC, float alpha, float beta, sm_stream_t stream) {
-  return spmma16<true>(blob, B, C, m, n, k, batch, strideB, strideC, alpha, beta, stream);
+  return spmma16<true>(1, &blob, &B, &C, m, n, k, batch, strideB, strideC, alpha, beta, stream);
+}
+
+// `count` same-shape problems in as few grids as possible (SPMMA_MAXG per launch): same kernels, same C bit for bit
+template <bool BF>
+static int spmma16_grouped(size_t count, const void* const* blobs, const void* const* Bs, void* const* Cs, size_t m, size_t n, size_t k, size_t batch,
+                           size_t strideB, size_t strideC, float alpha, float beta, sm_stream_t stream) {
+  if (count == 0) return SM_STATUS_SUCCESS;
+  if (!blobs || !Bs || !Cs) {
+    set_error("sm_spmma_{f16,bf16}_grouped: null pointer table");
+    return SM_STATUS_INVALID_VALUE;
+  }
+  for (size_t i = 0; i < count; i += (size_t)SPMMA_MAXG) {
+    const size_t ng = count - i < (size_t)SPMMA_MAXG ? count - i : (size_t)SPMMA_MAXG;
+    if (const int rc = spmma16<BF>(ng, blobs + i, Bs + i, Cs + i, m, n, k, batch, strideB, strideC, alpha, beta, stream)) return rc;
+  }
+  return SM_STATUS_SUCCESS;
+}
+extern "C" int sm_spmma_f16_grouped(size_t count, const void* const* blobs, const void* const* B, void* const* C, size_t m, size_t n, size_t k,
+                                    size_t batch, size_t strideB, size_t strideC, float alpha, float beta, sm_stream_t stream) {
+  return spmma16_grouped<false>(count, blobs, B, C, m, n, k, batch, strideB, strideC, alpha, beta, stream);
+}
+extern "C" int sm_spmma_bf16_grouped(size_t count, const void* const* blobs, const void* const* B, void* const* C, size_t m, size_t n, size_t k,
+                                     size_t batch, size_t strideB, size_t strideC, float alpha, float beta, sm_stream_t stream) {
+  return spmma16_grouped<true>(count, blobs, B, C, m, n, k, batch, strideB, strideC, alpha, beta, stream);
 }

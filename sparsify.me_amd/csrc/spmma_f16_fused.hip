@@ -37,6 +37,10 @@ struct FusedArgs {
   int batch, tiles_m, tiles_n;
   int ngroup;
   float alpha, beta;
+  // dense twin through sm_gemm_batched_*: DEVICE arrays of per-batch pointers (null: the tables above + batch strides)
+  const half_t* const* dAp;
+  const half_t* const* dBp;
+  half_t* const* dCp;
 #ifdef SM_STAMP
   unsigned long long* dbg;  // diagnostic build only: per-wave cycle sums (never in the product library)
 #endif
@@ -49,7 +53,7 @@ struct FusedArgs {
 // so every row of A is selected exactly once -- by the lane that feeds it to the SMFMAC (smfmac_stage_dense_a).
 // The data in flight are LDS buffers, not registers: 2 x 24 KiB per workgroup, two workgroups per CU at n = 64.
 // ---------------------------------------------------------------------------------------------
-template <int BN, int NS, bool BF = false, int BM = 128, int NWV = 4, bool ANT = true>
+template <int BN, int NS, bool BF = false, int BM = 128, int NWV = 4, bool ANT = true, bool DENSE = false>
 __global__ __launch_bounds__(64 * NWV) void spmma_f16_fused_direct_kernel(const FusedArgs p) {
   static_assert(BM == 128 || BM == 64, "row tile");
   static_assert(NWV == 4 || (NWV == 8 && BM == 128), "waves per workgroup");
@@ -69,9 +73,9 @@ __global__ __launch_bounds__(64 * NWV) void spmma_f16_fused_direct_kernel(const 
   const unsigned tile_m = trem / (unsigned)p.tiles_n, tile_n = trem - tile_m * (unsigned)p.tiles_n;
   const int m0 = (int)tile_m * BM, n0 = (int)tile_n * BN;
   const int nkt = p.K / 64;
-  const half_t* A = p.A[grp] + (size_t)b * p.sA;
-  const half_t* B = p.B[grp] + (size_t)b * p.sB;
-  half_t* C = p.C[grp] + (size_t)b * p.sC;
+  const half_t* A = p.dAp ? p.dAp[gb] : p.A[grp] + (size_t)b * p.sA;  // (device pointer tables: the dense twin behind sm_gemm_batched_*)
+  const half_t* B = p.dBp ? p.dBp[gb] : p.B[grp] + (size_t)b * p.sB;
+  half_t* C = p.dCp ? p.dCp[gb] : p.C[grp] + (size_t)b * p.sC;
   const int mlast = p.Mrows - 1;
 
   const char* src[SL];
@@ -139,7 +143,8 @@ __global__ __launch_bounds__(64 * NWV) void spmma_f16_fused_direct_kernel(const 
     if (kt + NS - 1 < nkt) stage(kt + NS - 1, fill);
     SM_T(const unsigned long long si = sm_stamp(); ti += si - sb;)
     const char* As = smem + cur * STAGE;
-    smfmac_stage_dense_a<FM, FN, BF>(As, As + SA, wave * TM, 0, lane, acc);
+    if constexpr (DENSE) mfma_stage_dense_a<FM, FN, BF>(As, As + SA, wave * TM, 0, lane, acc);  // the dense twin: every element multiplied
+    else smfmac_stage_dense_a<FM, FN, BF>(As, As + SA, wave * TM, 0, lane, acc);
     cur = cur + 1 == NS ? 0 : cur + 1;
     fill = fill + 1 == NS ? 0 : fill + 1;
     SM_T(__builtin_amdgcn_sched_barrier(0); s0 = sm_stamp(); tc += s0 - si;)
@@ -151,7 +156,7 @@ __global__ __launch_bounds__(64 * NWV) void spmma_f16_fused_direct_kernel(const 
         d[0] = tv; d[1] = tb; d[2] = ti; d[3] = tc; d[4] = sloop - sstart; d[5] = se - sloop; })
 }
 
-template <int BN, int NS, bool BF = false, int BM = 128, int NWV = 4, bool ANT = true>
+template <int BN, int NS, bool BF = false, int BM = 128, int NWV = 4, bool ANT = true, bool DENSE = false>
 static int launch_fused_direct(const FusedArgs& a0, hipStream_t st) {
   FusedArgs a = a0;
   a.tiles_m = (a.Mrows + BM - 1) / BM;
@@ -171,7 +176,7 @@ static int launch_fused_direct(const FusedArgs& a0, hipStream_t st) {
   constexpr size_t lds_max = NS * stage_bytes > lds_epi ? NS * stage_bytes : lds_epi;
   static LdsOptIn lds_optin;
   if (lds_max > 64 * 1024) {
-    if (const int rc = ensure_dyn_lds(lds_optin, reinterpret_cast<const void*>(&spmma_f16_fused_direct_kernel<BN, NS, BF, BM, NWV, ANT>), lds_max, "spmma_f16_fused_direct_kernel")) return rc;
+    if (const int rc = ensure_dyn_lds(lds_optin, reinterpret_cast<const void*>(&spmma_f16_fused_direct_kernel<BN, NS, BF, BM, NWV, ANT, DENSE>), lds_max, "spmma_f16_fused_direct_kernel")) return rc;
   }
 #ifdef SM_STAMP
   {
@@ -181,7 +186,7 @@ static int launch_fused_direct(const FusedArgs& a0, hipStream_t st) {
     if (cnt > cap) { if (dbg) (void)hipFree(dbg); (void)hipMalloc((void**)&dbg, cnt * 8); cap = cnt; }
     (void)hipMemset(dbg, 0, cnt * 8);
     a.dbg = dbg;
-    spmma_f16_fused_direct_kernel<BN, NS, BF, BM, NWV, ANT><<<dim3((unsigned)nwg), dim3(64 * NWV), lds, st>>>(a);
+    spmma_f16_fused_direct_kernel<BN, NS, BF, BM, NWV, ANT, DENSE><<<dim3((unsigned)nwg), dim3(64 * NWV), lds, st>>>(a);
     (void)hipDeviceSynchronize();
     std::vector<unsigned long long> h(cnt);
     (void)hipMemcpy(h.data(), dbg, cnt * 8, hipMemcpyDeviceToHost);
@@ -194,7 +199,7 @@ static int launch_fused_direct(const FusedArgs& a0, hipStream_t st) {
     return check_launch("spmma_f16_fused_direct_kernel");
   }
 #endif
-  spmma_f16_fused_direct_kernel<BN, NS, BF, BM, NWV, ANT><<<dim3((unsigned)nwg), dim3(64 * NWV), lds, st>>>(a);
+  spmma_f16_fused_direct_kernel<BN, NS, BF, BM, NWV, ANT, DENSE><<<dim3((unsigned)nwg), dim3(64 * NWV), lds, st>>>(a);
   return check_launch("spmma_f16_fused_direct_kernel");
 }
 
@@ -221,7 +226,7 @@ static int launch_fused_direct(const FusedArgs& a0, hipStream_t st) {
 // barrier (profiles/ab_ilv_r04n.txt: -3 .. +3 % over seven shapes, A pieces only: -3 .. 0 %: the 800 cycles the burst spends in
 // issue are not won back by hiding them, so they are not what bounds the stage).
 // ---------------------------------------------------------------------------------------------
-template <int BN, bool BF = false, int NSA = 3, int NSB = 2, bool ANT = true>
+template <int BN, bool BF = false, int NSA = 3, int NSB = 2, bool ANT = true, bool DENSE = false>
 __global__ __launch_bounds__(512) void spmma_f16_fused_big_kernel(const FusedArgs p) {
   constexpr int BM = 256, NW = 8, TM = BM / NW, FM = TM / 16, FN = BN / 16;
   constexpr int SA = BM * 128, SB = 64 * BN * 2;
@@ -242,9 +247,9 @@ __global__ __launch_bounds__(512) void spmma_f16_fused_big_kernel(const FusedArg
   const unsigned tile_m = trem / (unsigned)p.tiles_n, tile_n = trem - tile_m * (unsigned)p.tiles_n;
   const int m0 = (int)tile_m * BM, n0 = (int)tile_n * BN;
   const int nkt = p.K / 64;
-  const half_t* A = p.A[grp] + (size_t)b * p.sA;
-  const half_t* B = p.B[grp] + (size_t)b * p.sB;
-  half_t* C = p.C[grp] + (size_t)b * p.sC;
+  const half_t* A = p.dAp ? p.dAp[gb] : p.A[grp] + (size_t)b * p.sA;  // (device pointer tables: the dense twin behind sm_gemm_batched_*)
+  const half_t* B = p.dBp ? p.dBp[gb] : p.B[grp] + (size_t)b * p.sB;
+  half_t* C = p.dCp ? p.dCp[gb] : p.C[grp] + (size_t)b * p.sC;
   const int mlast = p.Mrows - 1;
 
   const char* asrc[SLA];
@@ -333,7 +338,8 @@ __global__ __launch_bounds__(512) void spmma_f16_fused_big_kernel(const FusedArg
       s0 = sm_stamp(); tc += s0 - ss;
     }
 #else
-    smfmac_stage_dense_a<FM, FN, BF>(smem + ca * SA, smem + BRING + cb * SB, wave * TM, 0, lane, acc);
+    if constexpr (DENSE) mfma_stage_dense_a<FM, FN, BF>(smem + ca * SA, smem + BRING + cb * SB, wave * TM, 0, lane, acc);
+    else smfmac_stage_dense_a<FM, FN, BF>(smem + ca * SA, smem + BRING + cb * SB, wave * TM, 0, lane, acc);
 #endif
     ca = ca + 1 == NSA ? 0 : ca + 1;
     fa = fa + 1 == NSA ? 0 : fa + 1;
@@ -347,7 +353,7 @@ __global__ __launch_bounds__(512) void spmma_f16_fused_big_kernel(const FusedArg
         d[0] = tv; d[1] = tb; d[2] = ti; d[3] = ts; d[4] = tc; d[5] = sloop - sstart; d[6] = se - sloop; })
 }
 
-template <int BN, bool BF = false, int NSA = 3, int NSB = 2, bool ANT = true>
+template <int BN, bool BF = false, int NSA = 3, int NSB = 2, bool ANT = true, bool DENSE = false>
 static int launch_fused_big(const FusedArgs& a0, hipStream_t st) {
   constexpr int BM = 256;
   FusedArgs a = a0;
@@ -364,7 +370,7 @@ static int launch_fused_big(const FusedArgs& a0, hipStream_t st) {
   constexpr size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
   static_assert(lds <= 160 * 1024, "LDS budget of the big direct kernel");
   static LdsOptIn lds_optin;
-  if (const int rc = ensure_dyn_lds(lds_optin, reinterpret_cast<const void*>(&spmma_f16_fused_big_kernel<BN, BF, NSA, NSB, ANT>), lds, "spmma_f16_fused_big_kernel")) return rc;
+  if (const int rc = ensure_dyn_lds(lds_optin, reinterpret_cast<const void*>(&spmma_f16_fused_big_kernel<BN, BF, NSA, NSB, ANT, DENSE>), lds, "spmma_f16_fused_big_kernel")) return rc;
 #ifdef SM_STAMP
   {
     static unsigned long long* dbg = nullptr;
@@ -373,7 +379,7 @@ static int launch_fused_big(const FusedArgs& a0, hipStream_t st) {
     if (cnt > cap) { if (dbg) (void)hipFree(dbg); (void)hipMalloc((void**)&dbg, cnt * 8); cap = cnt; }
     (void)hipMemset(dbg, 0, cnt * 8);
     a.dbg = dbg;
-    spmma_f16_fused_big_kernel<BN, BF, NSA, NSB, ANT><<<dim3((unsigned)nwg), dim3(512), lds, st>>>(a);
+    spmma_f16_fused_big_kernel<BN, BF, NSA, NSB, ANT, DENSE><<<dim3((unsigned)nwg), dim3(512), lds, st>>>(a);
     (void)hipDeviceSynchronize();
     std::vector<unsigned long long> h(cnt);
     (void)hipMemcpy(h.data(), dbg, cnt * 8, hipMemcpyDeviceToHost);
@@ -386,7 +392,7 @@ static int launch_fused_big(const FusedArgs& a0, hipStream_t st) {
     return check_launch("spmma_f16_fused_big_kernel");
   }
 #endif
-  spmma_f16_fused_big_kernel<BN, BF, NSA, NSB, ANT><<<dim3((unsigned)nwg), dim3(512), lds, st>>>(a);
+  spmma_f16_fused_big_kernel<BN, BF, NSA, NSB, ANT, DENSE><<<dim3((unsigned)nwg), dim3(512), lds, st>>>(a);
   return check_launch("spmma_f16_fused_big_kernel");
 }
 
@@ -404,7 +410,7 @@ static int launch_fused_big(const FusedArgs& a0, hipStream_t st) {
 // ---------------------------------------------------------------------------------------------
 __device__ __attribute__((aligned(256))) const unsigned char sm_fused_zero_page[256] = {0};
 
-template <int BN, bool BF = false>
+template <int BN, bool BF = false, bool DENSE = false>
 __global__ __launch_bounds__(256) void spmma_f16_fused_span_kernel(const FusedArgs p, const unsigned span_lds /*bytes reserved for the A span*/,
                                                                    const size_t a_bytes /*bytes of one problem's A*/) {
   constexpr int BM = 128, NW = 4, TM = BM / NW, FM = TM / 16, FN = BN / 16;
@@ -418,9 +424,9 @@ __global__ __launch_bounds__(256) void spmma_f16_fused_span_kernel(const FusedAr
   const unsigned tile_m = trem / (unsigned)p.tiles_n, tile_n = trem - tile_m * (unsigned)p.tiles_n;
   const int m0 = (int)tile_m * BM, n0 = (int)tile_n * BN;
   const int nkt = (p.K + 63) / 64;
-  const char* A = reinterpret_cast<const char*>(p.A[grp]);
-  const half_t* B = p.B[grp];
-  half_t* C = p.C[grp];
+  const char* A = reinterpret_cast<const char*>(p.dAp ? p.dAp[grp] : p.A[grp]);  // (device pointer tables: the dense twin behind sm_gemm_batched_*)
+  const half_t* B = p.dBp ? p.dBp[grp] : p.B[grp];
+  half_t* C = p.dCp ? p.dCp[grp] : p.C[grp];
   const unsigned rowbytes = (unsigned)p.K * 2u;
   const int rows = p.Mrows - m0 < BM ? p.Mrows - m0 : BM;  // valid rows of this tile (>= 1)
 
@@ -469,6 +475,33 @@ __global__ __launch_bounds__(256) void spmma_f16_fused_span_kernel(const FusedAr
     rowoff[i] = (unsigned)row * rowbytes;
   }
   for (int kt = 0; kt < nkt; ++kt) {
+    if constexpr (DENSE) {
+      // the dense twin: the lane's 8 + 8 halves (k = 8 g .. + 7 of the stage's two 32-k blocks), those at or beyond k zeroed
+      h8 a0[FM], a1[FM];
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        uint32_t d[2][4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int k0 = kt * 64 + 32 * h + 8 * (int)g;
+          int nv = p.K - k0;
+          nv = nv < 0 ? 0 : (nv > 8 ? 8 : nv);
+          const char* src = smem + rowoff[i] + 2u * (unsigned)k0;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const uint32_t lo16 = *reinterpret_cast<const unsigned short*>(src + 4 * e);
+            const uint32_t hi16 = *reinterpret_cast<const unsigned short*>(src + 4 * e + 2);
+            uint32_t v = lo16 | (hi16 << 16);
+            v = 2 * e + 1 < nv ? v : (2 * e < nv ? (v & 0xffffu) : 0u);
+            d[h][e] = v;
+          }
+        }
+        a0[i] = __builtin_bit_cast(h8, u4{d[0][0], d[0][1], d[0][2], d[0][3]});
+        a1[i] = __builtin_bit_cast(h8, u4{d[1][0], d[1][1], d[1][2], d[1][3]});
+      }
+      mfma_b_sweep<FM, FN, BF>(a0, a1, Bimg + kt * SB, 0, lane, acc);
+      continue;
+    }
     h8 af[FM];
     int idx[FM];
     const int k0 = kt * 64 + 16 * (int)g;
@@ -495,7 +528,7 @@ __global__ __launch_bounds__(256) void spmma_f16_fused_span_kernel(const FusedAr
   store_c_tile<BM, BN, FM, FN, 64 * NW, BF>(smem, C, acc, true, wave * TM, 0, m0, n0, p.Mrows, p.N, p.alpha, p.beta, tid);
 }
 
-template <int BN, bool BF = false>
+template <int BN, bool BF = false, bool DENSE = false>
 static int launch_fused_span(const FusedArgs& a0, hipStream_t st) {
   FusedArgs a = a0;
   a.tiles_m = (a.Mrows + 127) / 128;
@@ -512,8 +545,8 @@ static int launch_fused_span(const FusedArgs& a0, hipStream_t st) {
     return SM_STATUS_NOT_SUPPORTED;
   }
   static LdsOptIn lds_optin;
-  if (const int rc = ensure_dyn_lds(lds_optin, reinterpret_cast<const void*>(&spmma_f16_fused_span_kernel<BN, BF>), 160 * 1024, "spmma_f16_fused_span_kernel")) return rc;
-  spmma_f16_fused_span_kernel<BN, BF><<<dim3((unsigned)nwg), dim3(256), lds, st>>>(a, (unsigned)span_lds, (size_t)a.Mrows * a.K * 2);
+  if (const int rc = ensure_dyn_lds(lds_optin, reinterpret_cast<const void*>(&spmma_f16_fused_span_kernel<BN, BF, DENSE>), 160 * 1024, "spmma_f16_fused_span_kernel")) return rc;
+  spmma_f16_fused_span_kernel<BN, BF, DENSE><<<dim3((unsigned)nwg), dim3(256), lds, st>>>(a, (unsigned)span_lds, (size_t)a.Mrows * a.K * 2);
   return check_launch("spmma_f16_fused_span_kernel");
 }
 
@@ -1427,6 +1460,47 @@ extern "C" int sm_spmma_fused_bf16(const void* A, const void* B, void* C, size_t
 
 // Grouped forms: `count` same-shape problems (host arrays of device pointers, as the reference's batched::spmm takes its
 // As / Cs, spmm.hxx:30-33) in as few grids as possible (MAXG problems per launch).  Same kernels, same C bit for bit.
+template <bool BF>
+static int dense_twin16(const DenseTwinCall& c, hipStream_t st) {
+  const size_t n = (size_t)c.N, k = (size_t)c.K;
+  const bool tables = c.Ap != nullptr;
+  if (tables != (c.Bp != nullptr) || tables != (c.Cp != nullptr)) return SM_STATUS_NOT_SUPPORTED;
+  if (c.N % 8 != 0 || c.N < 8 || (!tables && (!aligned16(c.A) || !aligned16(c.B) || !aligned16(c.C)))) return SM_STATUS_NOT_SUPPORTED;
+  FusedArgs a = {};
+  for (int g = 0; g < MAXG; ++g) { a.A[g] = c.A; a.B[g] = c.B; a.C[g] = c.C; }
+  a.dAp = c.Ap; a.dBp = c.Bp; a.dCp = c.Cp;
+  a.ngroup = 1;
+  a.sA = c.sA; a.sB = c.sB; a.sC = c.sC;
+  a.Mrows = c.M; a.N = c.N; a.K = c.K; a.lda = c.lda;
+  a.batch = c.batch; a.alpha = c.alpha; a.beta = c.beta;
+  // ragged k: the span form -- one tall contiguous A per problem (lda == k), n <= 128, span + whole B inside the LDS
+  if (k % 64 != 0 || c.lda % 8 != 0) {
+    if (c.lda != c.K || n > 128 || ((size_t)c.M * k * 2) % 16 != 0 || (c.batch > 1 && !tables)) return SM_STATUS_NOT_SUPPORTED;
+    if (((size_t)128 * k * 2 + 1152) + ((k + 63) / 64 * 64) * (n <= 64 ? 64 : 128) * 2 > 160 * 1024) return SM_STATUS_NOT_SUPPORTED;
+    a.ngroup = c.batch;  // the span kernel indexes problems, not grid batches: with tables every batch entry is a problem
+    a.batch = 1;
+    if (!tables) a.ngroup = 1;
+    return n <= 64 ? launch_fused_span<64, BF, true>(a, st) : launch_fused_span<128, BF, true>(a, st);
+  }
+  if (c.sA % 8 != 0 || c.sB % 8 != 0) return SM_STATUS_NOT_SUPPORTED;
+  if (n <= 128) {  // gemm_f16.hip's 128 x 64 / 128 x 128 tiles are the direct pipeline already (A/B in tuning builds only)
+#ifdef SM_TUNING
+    if (c.mode >= 2) return n <= 64 ? launch_fused_direct<64, 2, BF, 128, 4, true, true>(a, st) : launch_fused_direct<128, 2, BF, 128, 4, true, true>(a, st);
+#endif
+    return SM_STATUS_NOT_SUPPORTED;
+  }
+  if (k <= 64) return SM_STATUS_NOT_SUPPORTED;
+  if (c.mode < 2 && ((size_t)c.M + 255) / 256 * 256 * 100 > (size_t)c.M * 115) return SM_STATUS_NOT_SUPPORTED;  // > 15 % of the 256-row tiles would be padding
+  // n > 128: 256 x 256 tiles (A streamed once per 256 columns instead of once per 128).  Measured per ResNet-50 shape against
+  // gemm_f16.hip's 128 x 128 tiles, two workgroups per CU (profiles/ab_dense_r04r2.txt): they win only on the long-K 256-column
+  // shape (784 x 256 x 2304 x 6: 40.1 -> 35.6 us per instance) and lose 5-17 % on 3136 x 256 x 512, 3136 x 512 x 128,
+  // 196 x 2048 x 512, 196 x 512 x 4608 -- the rule is that one case.
+  if (c.mode < 2 && !(n <= 256 && k >= 2048)) return SM_STATUS_NOT_SUPPORTED;
+  return n <= 256 ? launch_fused_big<256, BF, 3, 2, true, true>(a, st) : launch_fused_big<256, BF, 3, 2, false, true>(a, st);
+}
+
+int sm::gemm_dense_twin(const DenseTwinCall& c, hipStream_t st) { return c.bf ? dense_twin16<true>(c, st) : dense_twin16<false>(c, st); }
+
 template <bool BF>
 static int spmma_fused16_grouped(size_t count, const void* const* A, const void* const* B, void* const* C, size_t m, size_t n, size_t k,
                                  size_t lda, size_t batch, size_t strideA, size_t strideB, size_t strideC, float alpha, float beta,

@@ -1806,6 +1806,58 @@ def test_fused_grouped_equals_individual_calls(gpu, shape, count):
             assert torch.equal(C.view(torch.int16), Cb[i].view(torch.int16))
 
 
+@pytest.mark.parametrize("shape", [(196, 64, 128, 2), (784, 256, 1024, 1), (300, 520, 128, 2), (196, 512, 1152, 4), (3136, 128, 512, 1), (130, 72, 192, 1),
+                                   (131, 70, 100, 2), (12544, 64, 64, 1)], ids=lambda s_: "x".join(map(str, s_)))
+@pytest.mark.parametrize("count", [1, 3, 8, 11])
+def test_spmma_grouped_equals_individual_calls(gpu, shape, count):
+    """sm_spmma_f16_grouped over `count` same-shape compressed operands (one grid per 8) writes, into every C[i], exactly the bits of
+    a plain sm_spmma_f16 call on (blob[i], B[i]) -- every staged kernel (DMA, producer / consumer, the 256-row tile, the predicated
+    fall-back for ragged shapes), alpha / beta, more problems than one launch holds; bf16 rides the same kernels (one case)."""
+    import torch
+    m, n, k, batch = shape
+    rng = np.random.default_rng(count * 77 + m + n + k)
+    blobs, Bs, want = [], [], []
+    for i in range(count):
+        A = to_dev(rand(rng, batch * m * k, np.float16, "ties" if i % 3 == 2 else "uniform"))
+        blob = torch.empty(gpu.compress24_size(m, k, 2, batch), dtype=torch.uint8, device="cuda")
+        gpu.compress24(A, m, k, k, batch, m * k, blob)
+        blobs.append(blob)
+        Bs.append(to_dev(rand(rng, k * n, np.float16)))
+    for (alpha, beta) in [(1.0, 0.0), (0.5, -2.0)]:
+        want = []
+        for i in range(count):
+            C = torch.full((batch * m * n,), 3.0, dtype=torch.float16, device="cuda")
+            gpu.spmma(blobs[i], Bs[i], C, m, n, k, batch, alpha=alpha, beta=beta)
+            want.append(bits(host(C)))
+        Cs = [torch.full((batch * m * n,), 3.0, dtype=torch.float16, device="cuda") for _ in range(count)]
+        gpu.spmma_grouped(blobs, Bs, Cs, m, n, k, batch=batch, alpha=alpha, beta=beta)
+        for i in range(count):
+            assert np.array_equal(bits(host(Cs[i])), want[i]), f"grouped problem {i} of {count} differs from its own call (alpha {alpha}, beta {beta})"
+    if count == 3:
+        Bb = [b.view(torch.int16).view(torch.bfloat16) for b in Bs]
+        Cb = [torch.zeros(batch * m * n, dtype=torch.bfloat16, device="cuda") for _ in range(count)]
+        gpu.spmma_grouped(blobs, Bb, Cb, m, n, k, batch=batch)
+        for i in range(count):
+            C = torch.zeros(batch * m * n, dtype=torch.bfloat16, device="cuda")
+            gpu.spmma(blobs[i], Bb[i], C, m, n, k, batch)
+            torch.cuda.synchronize()
+            assert torch.equal(C.view(torch.int16), Cb[i].view(torch.int16))
+
+
+def test_spmma_grouped_rejects_bad_arguments(gpu):
+    import ctypes
+    import torch
+    L = gpu.lib()
+    blob = torch.zeros(gpu.compress24_size(128, 64, 2, 1), dtype=torch.uint8, device="cuda")
+    B = torch.zeros(64 * 64, dtype=torch.float16, device="cuda")
+    C = torch.zeros(128 * 64, dtype=torch.float16, device="cuda")
+    tab = lambda *ts: (ctypes.c_void_p * len(ts))(*[t if isinstance(t, int) else t.data_ptr() for t in ts])
+    z = ctypes.c_void_p(0)
+    assert L.sm_spmma_f16_grouped(2, tab(blob, 0), tab(B, B), tab(C, C), 128, 64, 64, 1, 0, 128 * 64, 1.0, 0.0, z) != 0   # a null blob in the table
+    assert L.sm_spmma_f16_grouped(2, z, tab(B, B), tab(C, C), 128, 64, 64, 1, 0, 128 * 64, 1.0, 0.0, z) != 0               # no table
+    assert L.sm_spmma_f16_grouped(0, z, z, z, 128, 64, 64, 1, 0, 128 * 64, 1.0, 0.0, z) == 0                               # nothing to do
+
+
 def test_fused_grouped_rejects_bad_arguments(gpu):
     import ctypes
     import torch
