@@ -742,6 +742,15 @@ def extras(args, sm, torch, dev, layers, flops, t_full, Forked, make_runner, tim
             split[key + "_speedup_vs_dense_rowmajor"] = t_drm / t_sp
             split[key + "_speedup_vs_exact_fused"] = t_full / t_sp
             split[key + "_hbm_frac"] = sum(L["b"] * 4 * (L["m"] * L["k"] + L["m"] * L["n"]) + 4 * L["k"] * L["n"] for L in layers) / t_sp / (HBM_PEAK_GBS * 1e9)
+        # the dense product by the same pieces (sm_gemm_rowmajor_f32_split): what the 2:4 split form should be held against
+        for planes in (3, 2):
+            def layer_dense_split(L, planes=planes):
+                if L["k"] % 64 or L["n"] % 8 or sm.spmma_fused_f32_split(L["A"], L["B"], L["C"], L["m"], L["n"], L["k"], L["ws"], batch=L["b"],
+                                                                          planes=planes, check=False, dense=True) != 0:
+                    sm.gemm_rowmajor(L["A"], L["B"], L["C"], L["m"], L["n"], L["k"], batch=L["b"])
+            t_ds = sec_per_call(Forked(layer_dense_split))
+            split["dense_planes%d_ms" % planes] = t_ds * 1e3
+            split["planes%d_speedup_vs_dense_split" % planes] = t_ds / (split["planes%d_ms" % planes] * 1e-3)
         split["layers_on_split_form"] = sum(1 for L in layers if L["k"] % 64 == 0 and L["n"] % 8 == 0)
         # error of the split forms against the exact kernel on the first layer they take (max |diff| / max sum|a||b| bound proxy)
         L = next((L for L in layers if L["k"] % 64 == 0 and L["n"] % 8 == 0), None)

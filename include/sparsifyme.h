@@ -188,10 +188,16 @@ int sm_spmma_fused_f32(const float* A, const float* B, float* C, size_t m, size_
  * (sm_spmma_fused_f32_split_workspace bytes, 16-byte aligned; a strided B must be packed, strideB == k * n).  Non-finite
  * operand values are carried by the first piece alone.  Needs k % 64 == 0, n % 8 == 0, 16-byte aligned rows of A, B and C
  * (ldc = n); everything else: SM_STATUS_NOT_SUPPORTED, use sm_spmma_fused_f32. */
+/* sm_gemm_rowmajor_f32_split: the DENSE product C = alpha * A * B + beta * C by the same pieces (v_mfma_f32_16x16x32_bf16, same
+ * workspace, same bounds with all of A's elements in the sums) -- the dense comparator the 2:4 split form is held against, and
+ * 1.5-2 x faster than the fp32-MFMA sm_gemm_rowmajor_f32 in its own right. */
 int sm_spmma_fused_f32_split_workspace(size_t n, size_t k, size_t batch, size_t strideB, int planes, size_t* bytes);
 int sm_spmma_fused_f32_split(const float* A, const float* B, float* C, size_t m, size_t n, size_t k, size_t lda, size_t batch,
                              size_t strideA, size_t strideB, size_t strideC, int planes, void* workspace, size_t workspace_bytes,
                              float alpha, float beta, sm_stream_t stream);
+int sm_gemm_rowmajor_f32_split(const float* A, const float* B, float* C, size_t m, size_t n, size_t k, size_t lda, size_t batch,
+                               size_t strideA, size_t strideB, size_t strideC, int planes, void* workspace, size_t workspace_bytes,
+                               float alpha, float beta, sm_stream_t stream);
 
 /* ---- (a5) dense batched GEMM: replaces cublas{H,S,D}gemmBatched (gemm.hxx:80-81, 133-134,
  *      186-187).  COLUMN-major, lda = m, ldb = k, ldc = m as the reference passes them;

@@ -51,6 +51,8 @@ _SIGS = {
                            _c_f, _c_f, _c_ptr],
     "sm_spmma_fused_f32": [_c_ptr, _c_ptr, _c_ptr, _c_size, _c_size, _c_size, _c_size, _c_size, _c_size, _c_size, _c_size,
                            _c_f, _c_f, _c_ptr],
+    "sm_gemm_rowmajor_f32_split": [_c_ptr, _c_ptr, _c_ptr, _c_size, _c_size, _c_size, _c_size, _c_size, _c_size, _c_size, _c_size, _c_i,
+                                   _c_ptr, _c_size, _c_f, _c_f, _c_ptr],
     "sm_spmma_f16_grouped": [_c_size, _c_ptr, _c_ptr, _c_ptr, _c_size, _c_size, _c_size, _c_size, _c_size, _c_size, _c_f, _c_f, _c_ptr],
     "sm_spmma_bf16_grouped": [_c_size, _c_ptr, _c_ptr, _c_ptr, _c_size, _c_size, _c_size, _c_size, _c_size, _c_size, _c_f, _c_f, _c_ptr],
     "sm_spmma_fused_f32_split_workspace": [_c_size, _c_size, _c_size, _c_size, _c_i, ctypes.POINTER(_c_size)],
@@ -365,14 +367,15 @@ def spmma_fused_f32_split_workspace(n, k, batch=1, strideB=0, planes=3):
 
 
 def spmma_fused_f32_split(A, B, C, m, n, k, workspace, lda=None, batch=1, strideA=None, strideB=0, strideC=None, planes=3, alpha=1.0,
-                          beta=0.0, check=True):
+                          beta=0.0, check=True, dense=False):
     """fp32 2:4 product on the sparse matrix instruction through exact bfloat16 splits (sm_spmma_fused_f32_split); `workspace`:
     a uint8 tensor of spmma_fused_f32_split_workspace(...) bytes.  Returns the status (check=False: NOT_SUPPORTED is returned)."""
     lda = k if lda is None else lda
     strideA = m * lda if strideA is None else strideA
     strideC = m * n if strideC is None else strideC
-    rc = lib().sm_spmma_fused_f32_split(_dev(A), _dev(B), _dev(C), m, n, k, lda, batch, strideA, strideB, strideC, planes, _dev(workspace),
-                                        workspace.numel() * workspace.element_size(), float(alpha), float(beta), _stream())
+    fn = lib().sm_gemm_rowmajor_f32_split if dense else lib().sm_spmma_fused_f32_split  # dense: every element of A multiplied
+    rc = fn(_dev(A), _dev(B), _dev(C), m, n, k, lda, batch, strideA, strideB, strideC, planes, _dev(workspace),
+            workspace.numel() * workspace.element_size(), float(alpha), float(beta), _stream())
     if check or rc not in (0, STATUS_NOT_SUPPORTED):
         _check(rc, "sm_spmma_fused_f32_split")
     return rc

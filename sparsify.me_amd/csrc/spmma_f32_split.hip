@@ -91,7 +91,10 @@ __device__ __forceinline__ void dense16_f32_to_operands(const u4 (&v)[4], h8 (&a
   idx = (int)meta;
 }
 
-template <int BN, int NP, bool ANT, int NW>
+// DENSE (sm_gemm_rowmajor_f32_split): no selection -- every element of A is split and multiplied, by v_mfma_f32_16x16x32_bf16 (a B
+// fragment's 16 values are already two dense operands: the stage's k = 8 g + j and 32 + 8 g + j): the dense product by the same
+// pieces, the comparator the 2:4 form should be held against.
+template <int BN, int NP, bool ANT, int NW, bool DENSE = false>
 __global__ __launch_bounds__(64 * NW) void spmma_f32_split_kernel(const SplitArgs p) {
   constexpr int BM = 128, TM = BM / NW, FM = TM / 16, FN = BN / 16;
   constexpr int SA = BM * 256, SBP = 64 * BN * 2, STAGE = SA + NP * SBP;
@@ -163,15 +166,41 @@ __global__ __launch_bounds__(64 * NW) void spmma_f32_split_kernel(const SplitArg
     wait_dma_and_barrier<0>();  // stage kt has landed for every wave; every wave has left the buffer about to be refilled
     if (kt + 1 < nkt) stage(kt + 1, cur ^ 1);
     const char* As = smem + cur * STAGE;
-    h8 af[FM][NP];
+    h8 af[FM][NP];   // 2:4: the kept values' pieces;  DENSE: the pieces of k = 8 g .. 8 g + 7 of the first 32-k block ...
+    h8 ag[FM][NP];   // ... and of the second (DENSE only)
     int idx[FM];
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
       const unsigned row = wave * TM + i * 16 + r;
       u4 v[4];
+      if constexpr (DENSE) {
+        // chunks (of 4 floats) 2 g, 2 g + 1 and 8 + 2 g, 9 + 2 g of the row
 #pragma unroll
-      for (int c = 0; c < 4; ++c) v[c] = *reinterpret_cast<const u4*>(As + row * 256u + 16u * ((4u * g + c) ^ (row & 15u)));
-      dense16_f32_to_operands<NP>(v, af[i], idx[i]);
+        for (int c = 0; c < 4; ++c) v[c] = *reinterpret_cast<const u4*>(As + row * 256u + 16u * ((8u * (c >> 1) + 2u * g + (c & 1)) ^ (row & 15u)));
+        uint32_t pk[2][NP][4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const uint32_t xa = v[2 * h + (e >> 1)][2 * (e & 1)], xb = v[2 * h + (e >> 1)][2 * (e & 1) + 1];
+            pk[h][0][e] = pack_hi16(xa, xb);
+            if constexpr (NP >= 2) {
+              const float ra = trunc_residual(xa), rb = trunc_residual(xb);
+              pk[h][1][e] = pack_hi16(as_u32(ra), as_u32(rb));
+              if constexpr (NP >= 3) pk[h][2][e] = pack_hi16(as_u32(trunc_residual(as_u32(ra))), as_u32(trunc_residual(as_u32(rb))));
+            }
+          }
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) {
+          af[i][pl] = __builtin_bit_cast(h8, u4{pk[0][pl][0], pk[0][pl][1], pk[0][pl][2], pk[0][pl][3]});
+          ag[i][pl] = __builtin_bit_cast(h8, u4{pk[1][pl][0], pk[1][pl][1], pk[1][pl][2], pk[1][pl][3]});
+        }
+        idx[i] = 0;
+      } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = *reinterpret_cast<const u4*>(As + row * 256u + 16u * ((4u * g + c) ^ (row & 15u)));
+        dense16_f32_to_operands<NP>(v, af[i], idx[i]);
+      }
     }
     // B sweep: fragment j + 1's reads (4 per plane) in flight while fragment j's products run
     const unsigned bs_addr = (unsigned)(uintptr_t)(lds_char*)(As + SA);
@@ -225,20 +254,29 @@ __global__ __launch_bounds__(64 * NW) void spmma_f32_split_kernel(const SplitArg
         bf[pl] = __builtin_bit_cast(h16, all);
       }
       // smallest terms first; consecutive instructions alternate between the FM accumulators (no back-to-back dependence)
+      auto prod = [&](int pa, int pb) {
+        if constexpr (DENSE) {
+          typedef short s8v __attribute__((ext_vector_type(8)));
+          const s8v lo = {t[c][pb][0][0], t[c][pb][0][1], t[c][pb][0][2], t[c][pb][0][3], t[c][pb][1][0], t[c][pb][1][1], t[c][pb][1][2], t[c][pb][1][3]};
+          const s8v hi = {t[c][pb][2][0], t[c][pb][2][1], t[c][pb][2][2], t[c][pb][2][3], t[c][pb][3][0], t[c][pb][3][1], t[c][pb][3][2], t[c][pb][3][3]};
+          const h8 b0 = __builtin_bit_cast(h8, lo), b1 = __builtin_bit_cast(h8, hi);
+#pragma unroll
+          for (int i = 0; i < FM; ++i) acc[i][j] = mfma16<true>(af[i][pa], b0, acc[i][j]);
+#pragma unroll
+          for (int i = 0; i < FM; ++i) acc[i][j] = mfma16<true>(ag[i][pa], b1, acc[i][j]);
+        } else {
+#pragma unroll
+          for (int i = 0; i < FM; ++i) acc[i][j] = smfmac16<true>(af[i][pa], bf[pb], acc[i][j], idx[i]);
+        }
+      };
       if constexpr (NP == 3) {
-#pragma unroll
-        for (int i = 0; i < FM; ++i) acc[i][j] = smfmac16<true>(af[i][2], bf[0], acc[i][j], idx[i]);
-#pragma unroll
-        for (int i = 0; i < FM; ++i) acc[i][j] = smfmac16<true>(af[i][0], bf[2], acc[i][j], idx[i]);
-#pragma unroll
-        for (int i = 0; i < FM; ++i) acc[i][j] = smfmac16<true>(af[i][1], bf[1], acc[i][j], idx[i]);
+        prod(2, 0);
+        prod(0, 2);
+        prod(1, 1);
       }
-#pragma unroll
-      for (int i = 0; i < FM; ++i) acc[i][j] = smfmac16<true>(af[i][1], bf[0], acc[i][j], idx[i]);
-#pragma unroll
-      for (int i = 0; i < FM; ++i) acc[i][j] = smfmac16<true>(af[i][0], bf[1], acc[i][j], idx[i]);
-#pragma unroll
-      for (int i = 0; i < FM; ++i) acc[i][j] = smfmac16<true>(af[i][0], bf[0], acc[i][j], idx[i]);
+      prod(1, 0);
+      prod(0, 1);
+      prod(0, 0);
     }
     cur ^= 1;
   }
@@ -296,7 +334,7 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
   }
 }
 
-template <int BN, int NP, int NW>
+template <int BN, int NP, int NW, bool DENSE = false>
 static int launch_split(const SplitArgs& a0, hipStream_t st) {
   SplitArgs a = a0;
   a.tiles_m = (a.Mrows + 127) / 128;
@@ -315,11 +353,11 @@ static int launch_split(const SplitArgs& a0, hipStream_t st) {
   static_assert(lds_max <= 160 * 1024, "LDS budget");
   static LdsOptIn lds_optin, lds_optin_nt;
   if (a.tiles_n == 1) {  // A is read once by the whole grid: non-temporal
-    if (const int rc = ensure_dyn_lds(lds_optin_nt, reinterpret_cast<const void*>(&spmma_f32_split_kernel<BN, NP, true, NW>), lds_max, "spmma_f32_split_kernel")) return rc;
-    spmma_f32_split_kernel<BN, NP, true, NW><<<dim3((unsigned)nwg), dim3(64 * NW), lds, st>>>(a);
+    if (const int rc = ensure_dyn_lds(lds_optin_nt, reinterpret_cast<const void*>(&spmma_f32_split_kernel<BN, NP, true, NW, DENSE>), lds_max, "spmma_f32_split_kernel")) return rc;
+    spmma_f32_split_kernel<BN, NP, true, NW, DENSE><<<dim3((unsigned)nwg), dim3(64 * NW), lds, st>>>(a);
   } else {
-    if (const int rc = ensure_dyn_lds(lds_optin, reinterpret_cast<const void*>(&spmma_f32_split_kernel<BN, NP, false, NW>), lds_max, "spmma_f32_split_kernel")) return rc;
-    spmma_f32_split_kernel<BN, NP, false, NW><<<dim3((unsigned)nwg), dim3(64 * NW), lds, st>>>(a);
+    if (const int rc = ensure_dyn_lds(lds_optin, reinterpret_cast<const void*>(&spmma_f32_split_kernel<BN, NP, false, NW, DENSE>), lds_max, "spmma_f32_split_kernel")) return rc;
+    spmma_f32_split_kernel<BN, NP, false, NW, DENSE><<<dim3((unsigned)nwg), dim3(64 * NW), lds, st>>>(a);
   }
   return check_launch("spmma_f32_split_kernel");
 }
@@ -340,9 +378,9 @@ extern "C" int sm_spmma_fused_f32_split_workspace(size_t n, size_t k, size_t bat
   return SM_STATUS_SUCCESS;
 }
 
-extern "C" int sm_spmma_fused_f32_split(const float* A, const float* B, float* C, size_t m, size_t n, size_t k, size_t lda, size_t batch, size_t strideA,
-                                        size_t strideB, size_t strideC, int planes, void* workspace, size_t workspace_bytes, float alpha, float beta,
-                                        sm_stream_t stream) {
+static int f32_split_product(bool dense, const float* A, const float* B, float* C, size_t m, size_t n, size_t k, size_t lda, size_t batch, size_t strideA,
+                             size_t strideB, size_t strideC, int planes, void* workspace, size_t workspace_bytes, float alpha, float beta,
+                             sm_stream_t stream) {
   using namespace sm;
   if (!A || !B || !C || lda < k || (planes != 2 && planes != 3)) {
     set_error("sm_spmma_fused_f32_split: invalid argument");
@@ -381,6 +419,10 @@ extern "C" int sm_spmma_fused_f32_split(const float* A, const float* B, float* C
     a.Mrows = (int)(m * batch);
     a.batch = 1;
   }
+  if (dense) {  // every element multiplied: the dense comparator of the 2:4 form (sm_gemm_rowmajor_f32_split)
+    if (planes == 3) return n <= 64 ? launch_split<64, 3, 8, true>(a, st) : launch_split<128, 3, 8, true>(a, st);
+    return n <= 64 ? launch_split<64, 2, 8, true>(a, st) : launch_split<128, 2, 8, true>(a, st);
+  }
 #ifdef SM_TUNING
   if (tuning_int("SM_F32_SPLIT_NW", 8) == 4) {  // A/B: four waves of 32 rows (one per SIMD) instead of eight of 16
     if (planes == 3) return n <= 64 ? launch_split<64, 3, 4>(a, st) : launch_split<128, 3, 4>(a, st);
@@ -389,4 +431,15 @@ extern "C" int sm_spmma_fused_f32_split(const float* A, const float* B, float* C
 #endif
   if (planes == 3) return n <= 64 ? launch_split<64, 3, 8>(a, st) : launch_split<128, 3, 8>(a, st);
   return n <= 64 ? launch_split<64, 2, 8>(a, st) : launch_split<128, 2, 8>(a, st);
+}
+
+extern "C" int sm_spmma_fused_f32_split(const float* A, const float* B, float* C, size_t m, size_t n, size_t k, size_t lda, size_t batch, size_t strideA,
+                                        size_t strideB, size_t strideC, int planes, void* workspace, size_t workspace_bytes, float alpha, float beta,
+                                        sm_stream_t stream) {
+  return f32_split_product(false, A, B, C, m, n, k, lda, batch, strideA, strideB, strideC, planes, workspace, workspace_bytes, alpha, beta, stream);
+}
+extern "C" int sm_gemm_rowmajor_f32_split(const float* A, const float* B, float* C, size_t m, size_t n, size_t k, size_t lda, size_t batch, size_t strideA,
+                                          size_t strideB, size_t strideC, int planes, void* workspace, size_t workspace_bytes, float alpha, float beta,
+                                          sm_stream_t stream) {
+  return f32_split_product(true, A, B, C, m, n, k, lda, batch, strideA, strideB, strideC, planes, workspace, workspace_bytes, alpha, beta, stream);
 }

@@ -826,6 +826,32 @@ def test_spmma_f32_split(gpu, shape, planes, ab, kind):
     assert not (err > FP32_TOL * np.maximum(scale, 1e-30)).any()
 
 
+@pytest.mark.parametrize("shape", [(128, 64, 64, 1), (196, 128, 256, 2), (260, 256, 128, 2), (3136, 64, 576, 1)], ids=lambda s_: "x".join(map(str, s_)))
+@pytest.mark.parametrize("planes", [3, 2])
+@pytest.mark.parametrize("kind", ["uniform", "ties"])
+def test_gemm_f32_split_dense(gpu, shape, planes, kind):
+    """sm_gemm_rowmajor_f32_split: the dense product by the same bfloat16 pieces (v_mfma_f32_16x16x32_bf16).  Exact data: equal to
+    sm_gemm_rowmajor_f32 bit for bit; U(-1, 1): inside SPLIT_TOL * sum|a||b| + the fp32 accumulation bound of the fp64 product."""
+    import torch
+    m, n, k, batch = shape
+    rng = np.random.default_rng(m + n + k + planes)
+    A, B = rand(rng, batch * m * k, np.float32, kind), rand(rng, k * n, np.float32, kind)
+    dA, dB = to_dev(A), to_dev(B)
+    ws = torch.empty(gpu.spmma_fused_f32_split_workspace(n, k, planes=planes), dtype=torch.uint8, device="cuda")
+    Cs = torch.zeros(batch * m * n, dtype=torch.float32, device="cuda")
+    Ce = torch.zeros(batch * m * n, dtype=torch.float32, device="cuda")
+    gpu.spmma_fused_f32_split(dA, dB, Cs, m, n, k, ws, batch=batch, planes=planes, dense=True)
+    gpu.gemm_rowmajor(dA, dB, Ce, m, n, k, batch=batch)
+    if kind == "ties":
+        assert torch.equal(Cs.view(torch.int32), Ce.view(torch.int32))
+        return
+    A64, B64 = A.astype(np.float64).reshape(batch * m, k), B.astype(np.float64).reshape(k, n)
+    ref, scale = (A64 @ B64).reshape(-1), (np.abs(A64) @ np.abs(B64)).reshape(-1)
+    err = np.abs(host(Cs).astype(np.float64) - ref)
+    bound = (SPLIT_TOL[planes] + 2.0 * k * 2.0 ** -24) * scale + 2.0 ** -22 * np.abs(ref) + 1e-30
+    assert float((err / bound).max()) <= 1.0, f"dense split planes={planes} {shape}: max err {err.max():.3e}"
+
+
 def test_spmma_f32_split_edges(gpu):
     """What the split form declines, and what a non-finite operand value does: it stays in the first piece, so the outputs it
     reaches are non-finite (NaN where the exact form may say inf: inf meets a zero low piece) and every other output is untouched."""

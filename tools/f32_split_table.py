@@ -26,7 +26,7 @@ def main():
     cnt = collections.Counter(rows)
     print(f"# {a.table}.csv: {len(rows)} layers, {len(cnt)} unique shapes, fp32; library {sm.version()}; us per layer, one launch at a time" +
           (" [SM_F32_SPLIT_NW=%s]" % os.environ["SM_F32_SPLIT_NW"] if "SM_F32_SPLIT_NW" in os.environ else ""))
-    print("%6s %5s %5s %3s %3s | %8s %8s | %8s %6s %8s %6s | %7s" % ("m", "n", "k", "b", "cnt", "dense", "exact", "split3", "TB/s", "split2", "TB/s", "roof"))
+    print("%6s %5s %5s %3s %3s | %8s %8s | %8s %6s %8s %6s | %8s %8s | %7s" % ("m", "n", "k", "b", "cnt", "dense", "exact", "split3", "TB/s", "split2", "TB/s", "dense s3", "dense s2", "roof"))
     tot = collections.defaultdict(float)
     for (m, n, k, b), c in cnt.items():
         A = torch.empty(b * m * k, dtype=torch.float32, device=dev); sm.fill_uniform(A, 1 + m + k, -1.0, 1.0)
@@ -42,13 +42,15 @@ def main():
         ok = sm.spmma_fused_f32_split(A, B, C, m, n, k, ws, batch=b, check=False) == 0
         t3 = t(lambda: sm.spmma_fused_f32_split(A, B, C, m, n, k, ws, batch=b, planes=3)) if ok else float("nan")
         t2 = t(lambda: sm.spmma_fused_f32_split(A, B, C, m, n, k, ws, batch=b, planes=2)) if ok else float("nan")
+        d3 = t(lambda: sm.spmma_fused_f32_split(A, B, C, m, n, k, ws, batch=b, planes=3, dense=True)) if ok else float("nan")
+        d2 = t(lambda: sm.spmma_fused_f32_split(A, B, C, m, n, k, ws, batch=b, planes=2, dense=True)) if ok else float("nan")
         by = 4.0 * (b * (m * k + m * n) + k * n)
-        print("%6d %5d %5d %3d %3d | %8.1f %8.1f | %8.1f %6.2f %8.1f %6.2f | %7.1f" % (m, n, k, b, c, t_d, t_e, t3, by / t3 / 1e6, t2, by / t2 / 1e6, by / 8e6), flush=True)
-        for key, v in (("dense", t_d), ("exact", t_e if ok_e else t_d), ("split3", t3 if ok else (t_e if ok_e else t_d)), ("split2", t2 if ok else (t_e if ok_e else t_d)), ("roof", by / 8e6)):
+        print("%6d %5d %5d %3d %3d | %8.1f %8.1f | %8.1f %6.2f %8.1f %6.2f | %8.1f %8.1f | %7.1f" % (m, n, k, b, c, t_d, t_e, t3, by / t3 / 1e6, t2, by / t2 / 1e6, d3, d2, by / 8e6), flush=True)
+        for key, v in (("dense", t_d), ("dense_s3", d3 if ok else t_d), ("dense_s2", d2 if ok else t_d), ("exact", t_e if ok_e else t_d), ("split3", t3 if ok else (t_e if ok_e else t_d)), ("split2", t2 if ok else (t_e if ok_e else t_d)), ("roof", by / 8e6)):
             tot[key] += v * c
         del A, B, C, ws
     print("# serial sums over the table (us; a shape a form does not take counted at the next form's time): " +
-          "  ".join(f"{k_} {tot[k_]:.0f}" for k_ in ("dense", "exact", "split3", "split2", "roof")))
+          "  ".join(f"{k_} {tot[k_]:.0f}" for k_ in ("dense", "exact", "split3", "split2", "dense_s3", "dense_s2", "roof")))
 
 
 if __name__ == "__main__":
