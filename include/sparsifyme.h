@@ -180,7 +180,7 @@ int sm_spmma_fused_f32(const float* A, const float* B, float* C, size_t m, size_
 /* fp32 operands on the SPARSE matrix instruction (extension, round 4; csrc/spmma_f32_split.hip): the same product -- the 2:4
  * STRIP selection made on the fp32 values, mask identical to sm_prune24_f32's -- computed by v_smfmac_f32_16x16x64_bf16 on
  * exact bfloat16 splits of both operands (x = x1 + x2 + x3, 8 + 8 + 8 significand bits) with fp32 accumulation:
- *   planes = 3: a1 b1 + a1 b2 + a2 b1 + a2 b2 + a1 b3 + a3 b1     |error| <= 2^-22 * sum |a| |b|  (+ fp32 accumulation)
+ *   planes = 3: a1 b1 + a1 b2 + a2 b1 + a2 b2 + a1 b3 + a3 b1     |error| <= 2^-21 * sum |a| |b|  (+ fp32 accumulation)
  *   planes = 2: a1 b1 + a1 b2 + a2 b1                             |error| <= 2^-13 * sum |a| |b|
  * (north_star asks 1e-3 relative for fp32 products; cuSPARSELt, what spmma.hxx:106-114 calls, computes fp32 operands in
  * TF32 = 10 significand bits).  Not bit-identical to sm_spmma_fused_f32 -- which stays the exact form -- and several times

@@ -701,6 +701,12 @@ static int spmma16(size_t ng, const void* const* blobs, const void* const* Bs, v
     if (!tuning_env("SM_SPMMA_PC") && !tuning_env("SM_SPMMA_CFG") && n >= 128 && n <= 256 && k >= 1024 &&
         (size_t)a.Mrows * ng >= 16384)
       return launch_pc<256, 128, 4, 2, 4, 3, BF>(a, st);
+#ifdef SM_TUNING
+    {  // A/B: 256 x 256 tiles, eight waves of 32 rows x 256 columns, all waves issue the DMA (ring of 3 / 2): SM_SPMMA_BIG = 3 / 2
+      const int big = tuning_int("SM_SPMMA_BIG", 0);
+      if (big && n > 128 && k > 64) return big == 2 ? launch_dma<256, 256, 8, 1, 2, BF>(a, st) : launch_dma<256, 256, 8, 1, 3, BF>(a, st);
+    }
+#endif
     static const char* pc_env = tuning_env("SM_SPMMA_PC");  // tuning aid: "<loaders>x<ring>", "0" = previous kernel
     // default: long K -> producer/consumer kernel (4 loader waves, ring of 3); short K -> the kernel
     // above with more tiles per CU (measured per shape on the ResNet tables, profiles/sweep_r01_*.txt)

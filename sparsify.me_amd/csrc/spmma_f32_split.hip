@@ -5,7 +5,7 @@
 // v_mfma_f32_16x16x4_f32 work -- 157 TF/s peak, the dense fp32 GEMM's rate at best, never the 2 x a 2:4 operand promises.
 // Here every fp32 value x is split EXACTLY into three bfloat16 pieces x = x1 + x2 + x3 (the top 8, middle 8 and low 8 bits
 // of its 24-bit significand: three truncations, each residual computed exactly in fp32), and
-//   a * b  ~  a1 b1 + a1 b2 + a2 b1 + a2 b2 + a1 b3 + a3 b1        (planes = 3: dropped terms a2 b3 + a3 b2 + a3 b3 < 2^-22 |a b|)
+//   a * b  ~  a1 b1 + a1 b2 + a2 b1 + a2 b2 + a1 b3 + a3 b1        (planes = 3: dropped terms a2 b3 + a3 b2 + a3 b3 < 2^-21 |a b|)
 //   a * b  ~  a1 b1 + a1 b2 + a2 b1                                  (planes = 2: |error| < 2^-13 |a b|)
 // each product exact in the instruction's fp32 accumulator arithmetic.  Six (three) sparse instructions per 16 x 16 x 64
 // block at ~3.5 PF/s dense-equivalent are 0.6 (1.2) PF/s of fp32-equivalent work against 0.157: the path becomes what the
@@ -15,7 +15,7 @@
 // north_star's 1e-3 for fp32 by three (planes = 2) to six (planes = 3) orders of magnitude.  Reference: the matmul step of
 // sparsifyme::spmma<float>, include/sparsify.me/spmma.hxx:106-114 (cuSPARSELt computes fp32 operands in TF32: 10 bits).
 //
-// Structure = the fp16 direct fused kernel in fp32 bytes: 128-row tiles, four waves (wave w owns rows 32 w .. 32 w + 31
+// Structure = the fp16 direct fused kernel in fp32 bytes: 128-row tiles, eight waves (wave w owns rows 16 w .. 16 w + 15
 // and all BN columns: every strip is selected once, by the lane that feeds it), the DENSE fp32 A stage (128 rows x 256 B)
 // and the bfloat16 planes of the B stage (planes x 64 x BN) by LDS-DMA into a ring of two, one counted wait + barrier per
 // stage.  B is split once per call by a streaming pre-pass into the caller's workspace (planes x k x n bfloat16).
