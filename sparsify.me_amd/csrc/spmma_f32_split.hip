@@ -310,6 +310,252 @@ __global__ __launch_bounds__(64 * NW) void spmma_f32_split_kernel(const SplitArg
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// n > 128: the COLUMN-LOOP form.  One workgroup owns 128 rows and ALL CT * 128 columns: a 64-k stage of A is selected and split
+// ONCE (the operands stay in registers), then CT sub-stages follow, each with its own 128-column slice of B's planes -- instead of
+// CT workgroups that each re-read the stage (from L2), select it again and split it again.  Two rings: A (2 x 32 KiB, refilled
+// once per stage) and B (2 x planes x 16 KiB, refilled every sub-stage).  Issue order per sub-stage: B(s + 1), then -- at a stage's
+// first sub-stage -- A(kt + 1); vmcnt retires in order, so at the top of sub-stage s everything up to B(s) has landed once only the
+// A pieces issued after it remain (ct == 1), and a stage's first sub-stage waits for all (its A was issued CT sub-stages ago).
+// Eight waves x 16 rows (FM = 1), accumulators for all CT * 8 column fragments in registers.
+// ---------------------------------------------------------------------------------------------
+template <int CT, int NP, bool DENSE>
+__global__ __launch_bounds__(512) void spmma_f32_split_cols_kernel(const SplitArgs p) {
+  constexpr int BM = 128, BN = 128, NW = 8, TM = 16, FN = BN / 16;
+  constexpr int SA = BM * 256, SBP = 64 * BN * 2, SB = NP * SBP;
+  constexpr int BRING = 2 * SA;
+  constexpr int A_N = BM / 4, B_N = NP * (BN / 8);
+  static_assert(A_N % NW == 0 && B_N % NW == 0, "equal DMA share per wave");
+  constexpr int SLA = A_N / NW, SLB = B_N / NW;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const unsigned tid = threadIdx.x, lane = tid & 63u;
+  const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
+  const unsigned b = lid / (unsigned)p.tiles_m, tile_m = lid - b * (unsigned)p.tiles_m;
+  const int m0 = (int)tile_m * BM;
+  const int nkt = p.K / 64;
+  const float* A = p.A + (size_t)b * p.sA;
+  const unsigned short* Bp = p.Bp + (size_t)b * p.sBp;
+  float* C = p.C + (size_t)b * p.sC;
+  const int mlast = p.Mrows - 1;
+  const unsigned g = lane >> 4, r = lane & 15u;
+
+  // per-lane DMA addresses as 32-bit offsets from two uniform bases (address state is what the 128 accumulators leave little room for)
+  const char* const abase = reinterpret_cast<const char*>(A + (size_t)m0 * p.lda);
+  const char* const bbase = reinterpret_cast<const char*>(Bp);
+  unsigned asrc[SLA], bsrc[SLB], bpk[SLB];  // bpk: LDS offset in a B stage (bits 31:8, a multiple of 1 KiB) | first column of the lane's piece (bits 7:0)
+#pragma unroll
+  for (int i = 0; i < SLA; ++i) {
+    const unsigned t = wave + (unsigned)NW * i;
+    const unsigned row = 4u * t + (lane >> 4), cs = (lane & 15u) ^ (row & 15u);
+    int lr = (int)row;
+    lr = m0 + lr < mlast ? lr : mlast - m0;
+    asrc[i] = (unsigned)lr * (unsigned)p.lda * 4u + 16u * cs;
+  }
+#pragma unroll
+  for (int i = 0; i < SLB; ++i) {
+    const unsigned t = wave + (unsigned)NW * i;
+    const unsigned pl = t / (unsigned)(BN / 8), j = t - pl * (unsigned)(BN / 8);
+    const unsigned panel = j >> 3, kr = 8u * (j & 7u) + (lane >> 3);
+    const unsigned cs = (lane & 7u) ^ b_swz(kr);
+    bsrc[i] = (unsigned)(((size_t)pl * p.plane + (size_t)kr * p.N) * 2);
+    bpk[i] = (pl * SBP + panel * 8192u + (j & 7u) * 1024u) | (64u * panel + 8u * cs);
+  }
+  const size_t bstep = (size_t)64 * p.N * 2;
+  auto stage_a = [&](int kt, int buf) {  // read once by the whole grid: non-temporal
+#pragma unroll
+    for (int i = 0; i < SLA; ++i) {
+      const unsigned t = wave + (unsigned)NW * i;
+      __builtin_amdgcn_global_load_lds((gptr_t*)(abase + asrc[i] + (size_t)kt * 256), (lptr_t*)(smem + buf * SA + t * 1024u), 16, 0, 2);
+    }
+  };
+  auto stage_b = [&](int kt, int ct, int buf) {
+#pragma unroll
+    for (int i = 0; i < SLB; ++i) {
+      int gc = ct * BN + (int)(bpk[i] & 0xffu);
+      gc = gc <= p.N - 8 ? gc : p.N - 8;
+      __builtin_amdgcn_global_load_lds((gptr_t*)(bbase + bsrc[i] + (size_t)kt * bstep + (size_t)gc * 2), (lptr_t*)(smem + BRING + buf * SB + (bpk[i] & ~0xffu)), 16, 0, 0);
+    }
+  };
+
+  f4 acc[CT][FN];
+#pragma unroll
+  for (int c = 0; c < CT; ++c)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[c][j] = f4{0.f, 0.f, 0.f, 0.f};
+
+  if (nkt > 0) {  // sub-stage -1's issue: B(0, 0), then A(0)
+    stage_b(0, 0, 0);
+    stage_a(0, 0);
+  }
+  h8 af[NP], ag[NP];
+  int idx = 0;
+  int bbuf = 0;
+  for (int kt = 0; kt < nkt; ++kt) {
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      __builtin_amdgcn_sched_barrier(0);  // sub-stages stay apart (the unrolled loop otherwise overlaps them and spills)
+      if (ct == 1) wait_dma_and_barrier<SLA>();  // B(kt, 1) has landed; A(kt + 1), issued after it, may still be in flight
+      else wait_dma_and_barrier<0>();
+      // next sub-stage's B into the slot sub-stage s - 1 read (every wave has left it), then -- once per stage -- the next A
+      if (ct + 1 < CT) stage_b(kt, ct + 1, bbuf ^ 1);
+      else if (kt + 1 < nkt) stage_b(kt + 1, 0, bbuf ^ 1);
+      if (ct == 0) {
+        if (kt + 1 < nkt) stage_a(kt + 1, (kt + 1) & 1);
+        // ---- this stage's A operands, once: selection (2:4) or plain split (DENSE), kept in registers for the CT sub-stages
+        const char* As = smem + (kt & 1) * SA;
+        const unsigned row = wave * TM + r;
+        u4 v[4];
+        if constexpr (DENSE) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) v[c] = *reinterpret_cast<const u4*>(As + row * 256u + 16u * ((8u * (c >> 1) + 2u * g + (c & 1)) ^ (row & 15u)));
+          uint32_t pk[2][NP][4];
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const uint32_t xa = v[2 * h + (e >> 1)][2 * (e & 1)], xb = v[2 * h + (e >> 1)][2 * (e & 1) + 1];
+              pk[h][0][e] = pack_hi16(xa, xb);
+              if constexpr (NP >= 2) {
+                const float ra = trunc_residual(xa), rb = trunc_residual(xb);
+                pk[h][1][e] = pack_hi16(as_u32(ra), as_u32(rb));
+                if constexpr (NP >= 3) pk[h][2][e] = pack_hi16(as_u32(trunc_residual(as_u32(ra))), as_u32(trunc_residual(as_u32(rb))));
+              }
+            }
+#pragma unroll
+          for (int pl = 0; pl < NP; ++pl) {
+            af[pl] = __builtin_bit_cast(h8, u4{pk[0][pl][0], pk[0][pl][1], pk[0][pl][2], pk[0][pl][3]});
+            ag[pl] = __builtin_bit_cast(h8, u4{pk[1][pl][0], pk[1][pl][1], pk[1][pl][2], pk[1][pl][3]});
+          }
+        } else {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) v[c] = *reinterpret_cast<const u4*>(As + row * 256u + 16u * ((4u * g + c) ^ (row & 15u)));
+          dense16_f32_to_operands<NP>(v, af, idx);
+        }
+      }
+      // ---- B sweep of this sub-stage's 128 columns
+      const unsigned bs_addr = (unsigned)(uintptr_t)(lds_char*)(smem + BRING + bbuf * SB);
+      s4 t[(CT == 4 && NP == 3) ? 1 : 2][NP][4];
+      auto issue = [&](int j, int buf) {
+        const unsigned q = r >> 2, pp = r & 3u;
+        const unsigned a = bs_addr + b_off<64>(8u * g + q, (unsigned)j * 16u + 4u * pp);
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl)
+          asm volatile("ds_read_b64_tr_b16 %0, %4\n\tds_read_b64_tr_b16 %1, %4 offset:512\n\t"
+                       "ds_read_b64_tr_b16 %2, %4 offset:4096\n\tds_read_b64_tr_b16 %3, %4 offset:4608"
+                       : "=&v"(t[buf][pl][0]), "=&v"(t[buf][pl][1]), "=&v"(t[buf][pl][2]), "=&v"(t[buf][pl][3])
+                       : "v"(a + (unsigned)pl * (unsigned)SBP)
+                       : "memory");
+      };
+      constexpr bool PF = !(CT == 4 && NP == 3);
+      if constexpr (PF) issue(0, 0);
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const int c = PF ? (j & 1) : 0;
+        if constexpr (PF) {
+          if (j + 1 < FN) issue(j + 1, c ^ 1);
+        } else {
+          issue(j, 0);
+        }
+        const bool more = PF && j + 1 < FN;
+        if constexpr (NP == 3) {
+          if (more)
+            asm volatile("s_waitcnt lgkmcnt(12)"
+                         : "+v"(t[c][0][0]), "+v"(t[c][0][1]), "+v"(t[c][0][2]), "+v"(t[c][0][3]), "+v"(t[c][1][0]), "+v"(t[c][1][1]), "+v"(t[c][1][2]),
+                           "+v"(t[c][1][3]), "+v"(t[c][2][0]), "+v"(t[c][2][1]), "+v"(t[c][2][2]), "+v"(t[c][2][3])
+                         :: "memory");
+          else
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(t[c][0][0]), "+v"(t[c][0][1]), "+v"(t[c][0][2]), "+v"(t[c][0][3]), "+v"(t[c][1][0]), "+v"(t[c][1][1]), "+v"(t[c][1][2]),
+                           "+v"(t[c][1][3]), "+v"(t[c][2][0]), "+v"(t[c][2][1]), "+v"(t[c][2][2]), "+v"(t[c][2][3])
+                         :: "memory");
+        } else {
+          if (more)
+            asm volatile("s_waitcnt lgkmcnt(8)"
+                         : "+v"(t[c][0][0]), "+v"(t[c][0][1]), "+v"(t[c][0][2]), "+v"(t[c][0][3]), "+v"(t[c][1][0]), "+v"(t[c][1][1]), "+v"(t[c][1][2]),
+                           "+v"(t[c][1][3])
+                         :: "memory");
+          else
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(t[c][0][0]), "+v"(t[c][0][1]), "+v"(t[c][0][2]), "+v"(t[c][0][3]), "+v"(t[c][1][0]), "+v"(t[c][1][1]), "+v"(t[c][1][2]),
+                           "+v"(t[c][1][3])
+                         :: "memory");
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        auto prod = [&](int pa, int pb) {
+          typedef short s8v __attribute__((ext_vector_type(8)));
+          const s8v lo = {t[c][pb][0][0], t[c][pb][0][1], t[c][pb][0][2], t[c][pb][0][3], t[c][pb][1][0], t[c][pb][1][1], t[c][pb][1][2], t[c][pb][1][3]};
+          const s8v hi = {t[c][pb][2][0], t[c][pb][2][1], t[c][pb][2][2], t[c][pb][2][3], t[c][pb][3][0], t[c][pb][3][1], t[c][pb][3][2], t[c][pb][3][3]};
+          if constexpr (DENSE) {
+            acc[ct][j] = mfma16<true>(af[pa], __builtin_bit_cast(h8, lo), acc[ct][j]);
+            acc[ct][j] = mfma16<true>(ag[pa], __builtin_bit_cast(h8, hi), acc[ct][j]);
+          } else {
+            typedef short s16 __attribute__((ext_vector_type(16)));
+            const s16 all = {lo[0], lo[1], lo[2], lo[3], lo[4], lo[5], lo[6], lo[7], hi[0], hi[1], hi[2], hi[3], hi[4], hi[5], hi[6], hi[7]};
+            acc[ct][j] = smfmac16<true>(af[pa], __builtin_bit_cast(h16, all), acc[ct][j], idx);
+          }
+        };
+        if constexpr (NP == 3) {
+          prod(2, 0);
+          prod(0, 2);
+          prod(1, 1);
+        }
+        prod(1, 0);
+        prod(0, 1);
+        prod(0, 0);
+      }
+      bbuf ^= 1;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  // epilogue, one 128-column tile at a time through LDS (pitch 128 * 4 + 16 bytes, aliasing the rings)
+  constexpr unsigned CP = BN * 4 + 16, PPR = BN / 4;
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) *reinterpret_cast<float*>(smem + (wave * TM + 4u * g + q) * CP + (j * 16 + r) * 4u) = acc[ct][j][q];
+    __syncthreads();
+    for (unsigned it = tid; it < (unsigned)BM * PPR; it += 512u) {
+      const unsigned row = it / PPR, pc = it - row * PPR;
+      const int gr = m0 + (int)row, gc = ct * BN + (int)(4u * pc);
+      if (gr > mlast || gc + 4 > p.N) continue;
+      f4 v = *reinterpret_cast<const f4*>(smem + row * CP + pc * 16u);
+      float* dst = C + (size_t)gr * p.N + gc;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] *= p.alpha;
+      if (p.beta != 0.0f) {
+        const f4 old = *reinterpret_cast<const f4*>(dst);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] += p.beta * old[q];
+      }
+      __builtin_nontemporal_store(v, reinterpret_cast<f4*>(dst));
+    }
+  }
+}
+
+template <int CT, int NP, bool DENSE>
+static int launch_split_cols(const SplitArgs& a0, hipStream_t st) {
+  SplitArgs a = a0;
+  a.tiles_m = (a.Mrows + 127) / 128;
+  a.tiles_n = 1;
+  const size_t nwg = (size_t)a.tiles_m * a.batch;
+  if (nwg == 0) return SM_STATUS_SUCCESS;
+  if (nwg > 0x7fffffffu) {
+    set_error("sm_spmma_fused_f32_split: grid too large");
+    return SM_STATUS_NOT_SUPPORTED;
+  }
+  constexpr size_t lds = 2 * (size_t)128 * 256 + 2 * (size_t)NP * 64 * 128 * 2;
+  static_assert(lds <= 160 * 1024 && (size_t)128 * (128 * 4 + 16) <= lds, "LDS budget");
+  static LdsOptIn lds_optin;
+  if (const int rc = ensure_dyn_lds(lds_optin, reinterpret_cast<const void*>(&spmma_f32_split_cols_kernel<CT, NP, DENSE>), lds, "spmma_f32_split_cols_kernel")) return rc;
+  spmma_f32_split_cols_kernel<CT, NP, DENSE><<<dim3((unsigned)nwg), dim3(512), lds, st>>>(a);
+  return check_launch("spmma_f32_split_cols_kernel");
+}
+
 // B (fp32, [k][n] row-major per batch) -> planes of truncated bfloat16 pieces, 8 elements per thread
 template <int NP>
 __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ B, unsigned short* __restrict__ P, size_t items /* of 8 */, size_t plane) {
@@ -418,6 +664,13 @@ static int f32_split_product(bool dense, const float* A, const float* B, float* 
   if (batch > 1 && strideB == 0 && strideA == m * lda && strideC == m * n) {  // one tall matrix
     a.Mrows = (int)(m * batch);
     a.batch = 1;
+  }
+  // 128 < n <= 256: the column-loop form (A selected / split once per stage for both 128-column halves).  Not beyond: four column
+  // tiles need 128 accumulator registers per lane (the kernel spills) and leave one workgroup per 128 rows -- 49 workgroups for the
+  // 196 x 512 layers -- where four column-tile workgroups per 128 rows at least fill the chip.
+  if (n > 128 && n <= 256 && tuning_int("SM_F32_SPLIT_COLS", 1)) {
+    if (dense) return planes == 3 ? launch_split_cols<2, 3, true>(a, st) : launch_split_cols<2, 2, true>(a, st);
+    return planes == 3 ? launch_split_cols<2, 3, false>(a, st) : launch_split_cols<2, 2, false>(a, st);
   }
   if (dense) {  // every element multiplied: the dense comparator of the 2:4 form (sm_gemm_rowmajor_f32_split)
     if (planes == 3) return n <= 64 ? launch_split<64, 3, 8, true>(a, st) : launch_split<128, 3, 8, true>(a, st);

@@ -787,8 +787,8 @@ def test_spmma_fused_f32(gpu, orc, shape, ab):
 SPLIT_TOL = {3: 2.0 ** -21, 2: 2.0 ** -13}  # sm_spmma_fused_f32_split: |error| <= SPLIT_TOL * sum |a||b| on top of the fp32 accumulation bound
 
 
-@pytest.mark.parametrize("shape", [(128, 64, 64, 1), (196, 128, 256, 2), (132, 72, 192, 3), (260, 256, 128, 2), (100, 512, 320, 1), (3136, 128, 576, 2),
-                                   (12544, 64, 576, 1)], ids=lambda s_: "x".join(map(str, s_)))
+@pytest.mark.parametrize("shape", [(128, 64, 64, 1), (196, 128, 256, 2), (132, 72, 192, 3), (260, 256, 128, 2), (132, 200, 192, 3), (100, 512, 320, 1),
+                                   (3136, 128, 576, 2), (784, 256, 1152, 2), (12544, 64, 576, 1)], ids=lambda s_: "x".join(map(str, s_)))
 @pytest.mark.parametrize("planes", [3, 2])
 @pytest.mark.parametrize("ab", [(1.0, 0.0), (0.5, -2.0)])
 @pytest.mark.parametrize("kind", ["uniform", "ties"])
@@ -826,7 +826,8 @@ def test_spmma_f32_split(gpu, shape, planes, ab, kind):
     assert not (err > FP32_TOL * np.maximum(scale, 1e-30)).any()
 
 
-@pytest.mark.parametrize("shape", [(128, 64, 64, 1), (196, 128, 256, 2), (260, 256, 128, 2), (3136, 64, 576, 1)], ids=lambda s_: "x".join(map(str, s_)))
+@pytest.mark.parametrize("shape", [(128, 64, 64, 1), (196, 128, 256, 2), (260, 256, 128, 2), (132, 200, 192, 3), (100, 512, 320, 1), (3136, 64, 576, 1)],
+                         ids=lambda s_: "x".join(map(str, s_)))
 @pytest.mark.parametrize("planes", [3, 2])
 @pytest.mark.parametrize("kind", ["uniform", "ties"])
 def test_gemm_f32_split_dense(gpu, shape, planes, kind):
