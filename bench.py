@@ -730,8 +730,7 @@ def extras(args, sm, torch, dev, layers, flops, t_full, Forked, make_runner, tim
             L["ws"] = torch.empty(max(16, sm.spmma_fused_f32_split_workspace(L["n"], L["k"], planes=3)), dtype=torch.uint8, device=dev)
         for planes in (3, 2):
             def layer_split(L, planes=planes):
-                if L["k"] % 64 or L["n"] % 8 or sm.spmma_fused_f32_split(L["A"], L["B"], L["C"], L["m"], L["n"], L["k"], L["ws"], batch=L["b"],
-                                                                          planes=planes, check=False) != 0:
+                if sm.spmma_fused_f32_split(L["A"], L["B"], L["C"], L["m"], L["n"], L["k"], L["ws"], batch=L["b"], planes=planes, check=False) != 0:
                     (sm.spmma_fused(L["A"], L["B"], L["C"], L["m"], L["n"], L["k"], batch=L["b"]) if use_fused(L) else
                      (sm.compress24(L["A"], L["m"], L["k"], L["k"], L["b"], L["m"] * L["k"], L["blob"]),
                       sm.spmma(L["blob"], L["B"], L["C"], L["m"], L["n"], L["k"], L["b"], 0)))
@@ -745,13 +744,13 @@ def extras(args, sm, torch, dev, layers, flops, t_full, Forked, make_runner, tim
         # the dense product by the same pieces (sm_gemm_rowmajor_f32_split): what the 2:4 split form should be held against
         for planes in (3, 2):
             def layer_dense_split(L, planes=planes):
-                if L["k"] % 64 or L["n"] % 8 or sm.spmma_fused_f32_split(L["A"], L["B"], L["C"], L["m"], L["n"], L["k"], L["ws"], batch=L["b"],
-                                                                          planes=planes, check=False, dense=True) != 0:
+                if sm.spmma_fused_f32_split(L["A"], L["B"], L["C"], L["m"], L["n"], L["k"], L["ws"], batch=L["b"], planes=planes, check=False, dense=True) != 0:
                     sm.gemm_rowmajor(L["A"], L["B"], L["C"], L["m"], L["n"], L["k"], batch=L["b"])
             t_ds = sec_per_call(Forked(layer_dense_split))
             split["dense_planes%d_ms" % planes] = t_ds * 1e3
             split["planes%d_speedup_vs_dense_split" % planes] = t_ds / (split["planes%d_ms" % planes] * 1e-3)
-        split["layers_on_split_form"] = sum(1 for L in layers if L["k"] % 64 == 0 and L["n"] % 8 == 0)
+        split["layers_on_split_form"] = sum(1 for L in layers if sm.spmma_fused_f32_split(L["A"], L["B"], L["C"], L["m"], L["n"], L["k"], L["ws"], batch=L["b"],
+                                                                                      planes=3, check=False) == 0)
         # error of the split forms against the exact kernel on the first layer they take (max |diff| / max sum|a||b| bound proxy)
         L = next((L for L in layers if L["k"] % 64 == 0 and L["n"] % 8 == 0), None)
         if L is not None:

@@ -225,7 +225,7 @@ std::vector<float> spmma(type_t* dA,
   // applies to a 2:4 operand keeps exactly its non-zeros).  Times: {prune + check + readback, B-plane workspace allocation, multiply}.
   if (!staged && !ta && !tb && spmma_options().f32_planes != 0) {
     std::size_t ws_bytes = 0;
-    if (fns::split_workspace(n, k, batch_size, spmma_options().f32_planes, &ws_bytes) == SM_STATUS_SUCCESS && k % 64 == 0 && n % 8 == 0) {
+    if (fns::split_workspace(n, k, batch_size, spmma_options().f32_planes, &ws_bytes) == SM_STATUS_SUCCESS && (k % 64 == 0 || n <= 128) && n % 8 == 0) {
       util::timer_t prune_timer;
       prune_timer.begin();
       for (std::size_t b = 0; b < batch_size; ++b) keep_first(fns::prune(dA + b * m * k, m, k));
@@ -323,7 +323,7 @@ float spmma_fused(type_t* dA, type_t* dB, type_t* dC, std::size_t m, std::size_t
   timer.begin();
   int rc = SM_STATUS_NOT_SUPPORTED;
   std::size_t ws_bytes = 0;
-  if (spmma_options().f32_planes != 0 && k % 64 == 0 && n % 8 == 0 &&
+  if (spmma_options().f32_planes != 0 && (k % 64 == 0 || n <= 128) && n % 8 == 0 &&
       fns::split_workspace(n, k, batch_size, spmma_options().f32_planes, &ws_bytes) == SM_STATUS_SUCCESS) {  // float only: see spmma_options_t
     device_vector<unsigned char> ws(ws_bytes ? ws_bytes : 16);
     rc = fns::fused_split(dA, dB, dC, m, n, k, batch_size, spmma_options().f32_planes, ws.data().get(), ws_bytes, alpha, beta);

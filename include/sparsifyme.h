@@ -186,8 +186,9 @@ int sm_spmma_fused_f32(const float* A, const float* B, float* C, size_t m, size_
  * TF32 = 10 significand bits).  Not bit-identical to sm_spmma_fused_f32 -- which stays the exact form -- and several times
  * faster: bound by the HBM stream of A instead of the fp32 matrix rate.  `workspace` receives B's bfloat16 planes
  * (sm_spmma_fused_f32_split_workspace bytes, 16-byte aligned; a strided B must be packed, strideB == k * n).  Non-finite
- * operand values are carried by the first piece alone.  Needs k % 64 == 0, n % 8 == 0, 16-byte aligned rows of A, B and C
- * (ldc = n); everything else: SM_STATUS_NOT_SUPPORTED, use sm_spmma_fused_f32. */
+ * operand values give NaN in the outputs they reach.  Needs k % 64 == 0, n % 8 == 0, 16-byte aligned rows of A, B and C (ldc = n);
+ * a ragged k (the stem layer's 147) runs the span form when n <= 128, lda == k, B is shared and the batches are one tall contiguous
+ * A (span + B's planes inside the LDS); everything else: SM_STATUS_NOT_SUPPORTED, use sm_spmma_fused_f32. */
 /* sm_gemm_rowmajor_f32_split: the DENSE product C = alpha * A * B + beta * C by the same pieces (v_mfma_f32_16x16x32_bf16, same
  * workspace, same bounds with all of A's elements in the sums) -- the dense comparator the 2:4 split form is held against, and
  * 1.5-2 x faster than the fp32-MFMA sm_gemm_rowmajor_f32 in its own right. */

@@ -310,6 +310,135 @@ __global__ __launch_bounds__(64 * NW) void spmma_f32_split_kernel(const SplitArg
   }
 }
 
+// ---- pieces shared by the column-loop and span forms (one 16-row fragment per wave: FM = 1)
+// the lane's 16 fp32 of its row -> operands.  2:4: v = 16 consecutive k (selection + pieces of the kept values, af / idx);
+// DENSE: v[0..1] = k 8 g .. 8 g + 7 of the stage's first 32-k block, v[2..3] = of the second (pieces of all, af / ag).
+template <int NP, bool DENSE>
+__device__ __forceinline__ void split_a_operands(const u4 (&v)[4], h8 (&af)[NP], h8 (&ag)[NP], int& idx) {
+  if constexpr (DENSE) {
+    uint32_t pk[2][NP][4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const uint32_t xa = v[2 * h + (e >> 1)][2 * (e & 1)], xb = v[2 * h + (e >> 1)][2 * (e & 1) + 1];
+        pk[h][0][e] = pack_hi16(xa, xb);
+        if constexpr (NP >= 2) {
+          const float ra = trunc_residual(xa), rb = trunc_residual(xb);
+          pk[h][1][e] = pack_hi16(as_u32(ra), as_u32(rb));
+          if constexpr (NP >= 3) pk[h][2][e] = pack_hi16(as_u32(trunc_residual(as_u32(ra))), as_u32(trunc_residual(as_u32(rb))));
+        }
+      }
+#pragma unroll
+    for (int pl = 0; pl < NP; ++pl) {
+      af[pl] = __builtin_bit_cast(h8, u4{pk[0][pl][0], pk[0][pl][1], pk[0][pl][2], pk[0][pl][3]});
+      ag[pl] = __builtin_bit_cast(h8, u4{pk[1][pl][0], pk[1][pl][1], pk[1][pl][2], pk[1][pl][3]});
+    }
+    idx = 0;
+  } else {
+    dense16_f32_to_operands<NP>(v, af, idx);
+  }
+}
+
+// B sweep of one 64-k (sub-)stage over FN 16-column fragments: the planes' images start at LDS address bs_addr, `pstride` bytes
+// apart; fragment j + 1's reads (4 per plane) are in flight while fragment j's products run.
+template <int FN, int NP, bool DENSE>
+__device__ __forceinline__ void split_sweep1(unsigned bs_addr, unsigned pstride, unsigned lane, const h8 (&af)[NP], const h8 (&ag)[NP], int idx, f4 (&acc)[FN]) {
+  const unsigned g = lane >> 4, r = lane & 15u;
+  s4 t[2][NP][4];
+  auto issue = [&](int j, int buf) {
+    const unsigned q = r >> 2, pp = r & 3u;
+    const unsigned a = bs_addr + b_off<64>(8u * g + q, (unsigned)j * 16u + 4u * pp);
+#pragma unroll
+    for (int pl = 0; pl < NP; ++pl)
+      asm volatile("ds_read_b64_tr_b16 %0, %4\n\tds_read_b64_tr_b16 %1, %4 offset:512\n\t"
+                   "ds_read_b64_tr_b16 %2, %4 offset:4096\n\tds_read_b64_tr_b16 %3, %4 offset:4608"
+                   : "=&v"(t[buf][pl][0]), "=&v"(t[buf][pl][1]), "=&v"(t[buf][pl][2]), "=&v"(t[buf][pl][3])
+                   : "v"(a + (unsigned)pl * pstride)
+                   : "memory");
+  };
+  issue(0, 0);
+#pragma unroll
+  for (int j = 0; j < FN; ++j) {
+    const int c = j & 1;
+    if (j + 1 < FN) issue(j + 1, c ^ 1);
+    if constexpr (NP == 3) {
+      if (j + 1 < FN)
+        asm volatile("s_waitcnt lgkmcnt(12)"
+                     : "+v"(t[c][0][0]), "+v"(t[c][0][1]), "+v"(t[c][0][2]), "+v"(t[c][0][3]), "+v"(t[c][1][0]), "+v"(t[c][1][1]), "+v"(t[c][1][2]),
+                       "+v"(t[c][1][3]), "+v"(t[c][2][0]), "+v"(t[c][2][1]), "+v"(t[c][2][2]), "+v"(t[c][2][3])
+                     :: "memory");
+      else
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(t[c][0][0]), "+v"(t[c][0][1]), "+v"(t[c][0][2]), "+v"(t[c][0][3]), "+v"(t[c][1][0]), "+v"(t[c][1][1]), "+v"(t[c][1][2]),
+                       "+v"(t[c][1][3]), "+v"(t[c][2][0]), "+v"(t[c][2][1]), "+v"(t[c][2][2]), "+v"(t[c][2][3])
+                     :: "memory");
+    } else {
+      if (j + 1 < FN)
+        asm volatile("s_waitcnt lgkmcnt(8)"
+                     : "+v"(t[c][0][0]), "+v"(t[c][0][1]), "+v"(t[c][0][2]), "+v"(t[c][0][3]), "+v"(t[c][1][0]), "+v"(t[c][1][1]), "+v"(t[c][1][2]),
+                       "+v"(t[c][1][3])
+                     :: "memory");
+      else
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(t[c][0][0]), "+v"(t[c][0][1]), "+v"(t[c][0][2]), "+v"(t[c][0][3]), "+v"(t[c][1][0]), "+v"(t[c][1][1]), "+v"(t[c][1][2]),
+                       "+v"(t[c][1][3])
+                     :: "memory");
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    auto prod = [&](int pa, int pb) {
+      typedef short s8v __attribute__((ext_vector_type(8)));
+      const s8v lo = {t[c][pb][0][0], t[c][pb][0][1], t[c][pb][0][2], t[c][pb][0][3], t[c][pb][1][0], t[c][pb][1][1], t[c][pb][1][2], t[c][pb][1][3]};
+      const s8v hi = {t[c][pb][2][0], t[c][pb][2][1], t[c][pb][2][2], t[c][pb][2][3], t[c][pb][3][0], t[c][pb][3][1], t[c][pb][3][2], t[c][pb][3][3]};
+      if constexpr (DENSE) {
+        acc[j] = mfma16<true>(af[pa], __builtin_bit_cast(h8, lo), acc[j]);
+        acc[j] = mfma16<true>(ag[pa], __builtin_bit_cast(h8, hi), acc[j]);
+      } else {
+        typedef short s16 __attribute__((ext_vector_type(16)));
+        const s16 all = {lo[0], lo[1], lo[2], lo[3], lo[4], lo[5], lo[6], lo[7], hi[0], hi[1], hi[2], hi[3], hi[4], hi[5], hi[6], hi[7]};
+        acc[j] = smfmac16<true>(af[pa], __builtin_bit_cast(h16, all), acc[j], idx);
+      }
+    };
+    if constexpr (NP == 3) {
+      prod(2, 0);
+      prod(0, 2);
+      prod(1, 1);
+    }
+    prod(1, 0);
+    prod(0, 1);
+    prod(0, 0);
+  }
+}
+
+// the epilogue of a 128 x BN fp32 tile held as 16-row fragments by eight waves: through LDS (pitch BN * 4 + 16 bytes) and out as
+// 16-byte row pieces, alpha * acc + beta * C rounded once; columns n0 .. n0 + BN - 1, rows m0 .. (called between two barriers)
+template <int BN, int FN>
+__device__ __forceinline__ void split_store_tile(char* smem, float* C, const f4 (&acc)[FN], unsigned wave, unsigned lane, unsigned tid, int m0, int n0,
+                                                 int mlast, int N, float alpha, float beta) {
+  constexpr unsigned CP = BN * 4 + 16, PPR = BN / 4;
+  const unsigned g = lane >> 4, r = lane & 15u;
+#pragma unroll
+  for (int j = 0; j < FN; ++j)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) *reinterpret_cast<float*>(smem + (wave * 16u + 4u * g + q) * CP + (j * 16 + r) * 4u) = acc[j][q];
+  __syncthreads();
+  for (unsigned it = tid; it < 128u * PPR; it += 512u) {
+    const unsigned row = it / PPR, pc = it - row * PPR;
+    const int gr = m0 + (int)row, gc = n0 + (int)(4u * pc);
+    if (gr > mlast || gc + 4 > N) continue;
+    f4 v = *reinterpret_cast<const f4*>(smem + row * CP + pc * 16u);
+    float* dst = C + (size_t)gr * N + gc;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] *= alpha;
+    if (beta != 0.0f) {
+      const f4 old = *reinterpret_cast<const f4*>(dst);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] += beta * old[q];
+    }
+    __builtin_nontemporal_store(v, reinterpret_cast<f4*>(dst));
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // n > 128: the COLUMN-LOOP form.  One workgroup owns 128 rows and ALL CT * 128 columns: a 64-k stage of A is selected and split
 // ONCE (the operands stay in registers), then CT sub-stages follow, each with its own 128-column slice of B's planes -- instead of
@@ -407,133 +536,24 @@ __global__ __launch_bounds__(512) void spmma_f32_split_cols_kernel(const SplitAr
         const char* As = smem + (kt & 1) * SA;
         const unsigned row = wave * TM + r;
         u4 v[4];
-        if constexpr (DENSE) {
 #pragma unroll
-          for (int c = 0; c < 4; ++c) v[c] = *reinterpret_cast<const u4*>(As + row * 256u + 16u * ((8u * (c >> 1) + 2u * g + (c & 1)) ^ (row & 15u)));
-          uint32_t pk[2][NP][4];
-#pragma unroll
-          for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const uint32_t xa = v[2 * h + (e >> 1)][2 * (e & 1)], xb = v[2 * h + (e >> 1)][2 * (e & 1) + 1];
-              pk[h][0][e] = pack_hi16(xa, xb);
-              if constexpr (NP >= 2) {
-                const float ra = trunc_residual(xa), rb = trunc_residual(xb);
-                pk[h][1][e] = pack_hi16(as_u32(ra), as_u32(rb));
-                if constexpr (NP >= 3) pk[h][2][e] = pack_hi16(as_u32(trunc_residual(as_u32(ra))), as_u32(trunc_residual(as_u32(rb))));
-              }
-            }
-#pragma unroll
-          for (int pl = 0; pl < NP; ++pl) {
-            af[pl] = __builtin_bit_cast(h8, u4{pk[0][pl][0], pk[0][pl][1], pk[0][pl][2], pk[0][pl][3]});
-            ag[pl] = __builtin_bit_cast(h8, u4{pk[1][pl][0], pk[1][pl][1], pk[1][pl][2], pk[1][pl][3]});
-          }
-        } else {
-#pragma unroll
-          for (int c = 0; c < 4; ++c) v[c] = *reinterpret_cast<const u4*>(As + row * 256u + 16u * ((4u * g + c) ^ (row & 15u)));
-          dense16_f32_to_operands<NP>(v, af, idx);
+        for (int c = 0; c < 4; ++c) {
+          const unsigned chunk = DENSE ? 8u * (c >> 1) + 2u * g + (c & 1) : 4u * g + c;
+          v[c] = *reinterpret_cast<const u4*>(As + row * 256u + 16u * (chunk ^ (row & 15u)));
         }
+        split_a_operands<NP, DENSE>(v, af, ag, idx);
       }
       // ---- B sweep of this sub-stage's 128 columns
-      const unsigned bs_addr = (unsigned)(uintptr_t)(lds_char*)(smem + BRING + bbuf * SB);
-      s4 t[(CT == 4 && NP == 3) ? 1 : 2][NP][4];
-      auto issue = [&](int j, int buf) {
-        const unsigned q = r >> 2, pp = r & 3u;
-        const unsigned a = bs_addr + b_off<64>(8u * g + q, (unsigned)j * 16u + 4u * pp);
-#pragma unroll
-        for (int pl = 0; pl < NP; ++pl)
-          asm volatile("ds_read_b64_tr_b16 %0, %4\n\tds_read_b64_tr_b16 %1, %4 offset:512\n\t"
-                       "ds_read_b64_tr_b16 %2, %4 offset:4096\n\tds_read_b64_tr_b16 %3, %4 offset:4608"
-                       : "=&v"(t[buf][pl][0]), "=&v"(t[buf][pl][1]), "=&v"(t[buf][pl][2]), "=&v"(t[buf][pl][3])
-                       : "v"(a + (unsigned)pl * (unsigned)SBP)
-                       : "memory");
-      };
-      constexpr bool PF = !(CT == 4 && NP == 3);
-      if constexpr (PF) issue(0, 0);
-#pragma unroll
-      for (int j = 0; j < FN; ++j) {
-        const int c = PF ? (j & 1) : 0;
-        if constexpr (PF) {
-          if (j + 1 < FN) issue(j + 1, c ^ 1);
-        } else {
-          issue(j, 0);
-        }
-        const bool more = PF && j + 1 < FN;
-        if constexpr (NP == 3) {
-          if (more)
-            asm volatile("s_waitcnt lgkmcnt(12)"
-                         : "+v"(t[c][0][0]), "+v"(t[c][0][1]), "+v"(t[c][0][2]), "+v"(t[c][0][3]), "+v"(t[c][1][0]), "+v"(t[c][1][1]), "+v"(t[c][1][2]),
-                           "+v"(t[c][1][3]), "+v"(t[c][2][0]), "+v"(t[c][2][1]), "+v"(t[c][2][2]), "+v"(t[c][2][3])
-                         :: "memory");
-          else
-            asm volatile("s_waitcnt lgkmcnt(0)"
-                         : "+v"(t[c][0][0]), "+v"(t[c][0][1]), "+v"(t[c][0][2]), "+v"(t[c][0][3]), "+v"(t[c][1][0]), "+v"(t[c][1][1]), "+v"(t[c][1][2]),
-                           "+v"(t[c][1][3]), "+v"(t[c][2][0]), "+v"(t[c][2][1]), "+v"(t[c][2][2]), "+v"(t[c][2][3])
-                         :: "memory");
-        } else {
-          if (more)
-            asm volatile("s_waitcnt lgkmcnt(8)"
-                         : "+v"(t[c][0][0]), "+v"(t[c][0][1]), "+v"(t[c][0][2]), "+v"(t[c][0][3]), "+v"(t[c][1][0]), "+v"(t[c][1][1]), "+v"(t[c][1][2]),
-                           "+v"(t[c][1][3])
-                         :: "memory");
-          else
-            asm volatile("s_waitcnt lgkmcnt(0)"
-                         : "+v"(t[c][0][0]), "+v"(t[c][0][1]), "+v"(t[c][0][2]), "+v"(t[c][0][3]), "+v"(t[c][1][0]), "+v"(t[c][1][1]), "+v"(t[c][1][2]),
-                           "+v"(t[c][1][3])
-                         :: "memory");
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        auto prod = [&](int pa, int pb) {
-          typedef short s8v __attribute__((ext_vector_type(8)));
-          const s8v lo = {t[c][pb][0][0], t[c][pb][0][1], t[c][pb][0][2], t[c][pb][0][3], t[c][pb][1][0], t[c][pb][1][1], t[c][pb][1][2], t[c][pb][1][3]};
-          const s8v hi = {t[c][pb][2][0], t[c][pb][2][1], t[c][pb][2][2], t[c][pb][2][3], t[c][pb][3][0], t[c][pb][3][1], t[c][pb][3][2], t[c][pb][3][3]};
-          if constexpr (DENSE) {
-            acc[ct][j] = mfma16<true>(af[pa], __builtin_bit_cast(h8, lo), acc[ct][j]);
-            acc[ct][j] = mfma16<true>(ag[pa], __builtin_bit_cast(h8, hi), acc[ct][j]);
-          } else {
-            typedef short s16 __attribute__((ext_vector_type(16)));
-            const s16 all = {lo[0], lo[1], lo[2], lo[3], lo[4], lo[5], lo[6], lo[7], hi[0], hi[1], hi[2], hi[3], hi[4], hi[5], hi[6], hi[7]};
-            acc[ct][j] = smfmac16<true>(af[pa], __builtin_bit_cast(h16, all), acc[ct][j], idx);
-          }
-        };
-        if constexpr (NP == 3) {
-          prod(2, 0);
-          prod(0, 2);
-          prod(1, 1);
-        }
-        prod(1, 0);
-        prod(0, 1);
-        prod(0, 0);
-      }
+      split_sweep1<FN, NP, DENSE>((unsigned)(uintptr_t)(lds_char*)(smem + BRING + bbuf * SB), (unsigned)SBP, lane, af, ag, idx, acc[ct]);
       bbuf ^= 1;
       __builtin_amdgcn_sched_barrier(0);
     }
   }
-  // epilogue, one 128-column tile at a time through LDS (pitch 128 * 4 + 16 bytes, aliasing the rings)
-  constexpr unsigned CP = BN * 4 + 16, PPR = BN / 4;
+  // epilogue, one 128-column tile at a time through LDS (aliasing the rings)
 #pragma unroll
   for (int ct = 0; ct < CT; ++ct) {
     __syncthreads();
-#pragma unroll
-    for (int j = 0; j < FN; ++j)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) *reinterpret_cast<float*>(smem + (wave * TM + 4u * g + q) * CP + (j * 16 + r) * 4u) = acc[ct][j][q];
-    __syncthreads();
-    for (unsigned it = tid; it < (unsigned)BM * PPR; it += 512u) {
-      const unsigned row = it / PPR, pc = it - row * PPR;
-      const int gr = m0 + (int)row, gc = ct * BN + (int)(4u * pc);
-      if (gr > mlast || gc + 4 > p.N) continue;
-      f4 v = *reinterpret_cast<const f4*>(smem + row * CP + pc * 16u);
-      float* dst = C + (size_t)gr * p.N + gc;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) v[q] *= p.alpha;
-      if (p.beta != 0.0f) {
-        const f4 old = *reinterpret_cast<const f4*>(dst);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] += p.beta * old[q];
-      }
-      __builtin_nontemporal_store(v, reinterpret_cast<f4*>(dst));
-    }
+    split_store_tile<BN, FN>(smem, C, acc[ct], wave, lane, tid, m0, ct * BN, mlast, p.N, p.alpha, p.beta);
   }
 }
 
@@ -554,6 +574,112 @@ static int launch_split_cols(const SplitArgs& a0, hipStream_t st) {
   if (const int rc = ensure_dyn_lds(lds_optin, reinterpret_cast<const void*>(&spmma_f32_split_cols_kernel<CT, NP, DENSE>), lds, "spmma_f32_split_cols_kernel")) return rc;
   spmma_f32_split_cols_kernel<CT, NP, DENSE><<<dim3((unsigned)nwg), dim3(512), lds, st>>>(a);
   return check_launch("spmma_f32_split_cols_kernel");
+}
+
+// ---------------------------------------------------------------------------------------------
+// k % 64 != 0 (the 7 x 7 x 3 stem layer, k = 147: rows of 588 bytes): the SPAN form, as the fp16 fused kernels have it.  A is one
+// tall contiguous matrix (lda == k), so a tile's 128 rows are ONE contiguous span of 128 * k * 4 bytes that starts on a 512-byte
+// boundary and reaches LDS by plain 1 KiB LDS-DMA pieces whatever the row pitch; B's planes arrive whole with it (rows at or beyond
+// k from a zero page: a 0 x inf must not poison finite outputs); one wait, one barrier, then every stage is computed out of LDS:
+// the lane reads its 16 fp32 with 4-byte LDS reads at row * k * 4 + ..., zeroes what lies at or beyond k (the virtual zeros that
+// complete a ragged strip, oracle: strip_select) and goes on as the other forms do.  n <= 128; span + planes inside the LDS.
+// ---------------------------------------------------------------------------------------------
+__device__ __attribute__((aligned(256))) const unsigned char sm_split_zero_page[256] = {0};
+
+template <int BN, int NP, bool DENSE>
+__global__ __launch_bounds__(512) void spmma_f32_split_span_kernel(const SplitArgs p, const unsigned span_lds /*bytes reserved for the A span*/,
+                                                                   const size_t a_bytes /*bytes of A*/) {
+  constexpr int BM = 128, NW = 8, FN = BN / 16;
+  constexpr int SBP = 64 * BN * 2;  // one plane of one stage
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const unsigned tid = threadIdx.x, lane = tid & 63u;
+  const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
+  const unsigned tile_m = lid / (unsigned)p.tiles_n, tile_n = lid - tile_m * (unsigned)p.tiles_n;
+  const int m0 = (int)tile_m * BM, n0 = (int)tile_n * BN;
+  const int nkt = (p.K + 63) / 64;
+  const char* A = reinterpret_cast<const char*>(p.A);
+  const unsigned rowbytes = (unsigned)p.K * 4u;
+  const int rows = p.Mrows - m0 < BM ? p.Mrows - m0 : BM;
+  const int mlast = p.Mrows - 1;
+  const unsigned g = lane >> 4, r = lane & 15u;
+  {  // ---- A span
+    const size_t s0 = (size_t)m0 * rowbytes;
+    const unsigned len = (unsigned)rows * rowbytes;
+    const unsigned np = (len + 1023u) / 1024u;
+    const size_t last16 = a_bytes - 16;
+    for (unsigned pc = wave; pc < np; pc += NW) {
+      size_t off = s0 + (size_t)pc * 1024u + 16u * lane;
+      off = off < last16 ? off : last16;
+      __builtin_amdgcn_global_load_lds((gptr_t*)(A + off), (lptr_t*)(smem + pc * 1024u), 16, 0, 2);
+    }
+  }
+  char* const Bimg = smem + span_lds;  // [stage][plane][64 x BN image]
+  {  // ---- B planes, whole
+    constexpr int B_N = BN / 8;
+    const int npb = nkt * NP * B_N;
+    for (int t = (int)wave; t < npb; t += NW) {
+      const int kt = t / (NP * B_N), rem = t - kt * (NP * B_N), pl = rem / B_N, j = rem - pl * B_N;
+      const unsigned panel = (unsigned)j >> 3, kr = 8u * ((unsigned)j & 7u) + (lane >> 3);
+      const unsigned cs = (lane & 7u) ^ b_swz(kr);
+      int gc = n0 + (int)(64u * panel + 8u * cs);
+      gc = gc <= p.N - 8 ? gc : p.N - 8;
+      const int krow = kt * 64 + (int)kr;
+      const char* src = krow < p.K ? reinterpret_cast<const char*>(p.Bp + (size_t)pl * p.plane + (size_t)krow * p.N + gc)
+                                   : reinterpret_cast<const char*>(sm_split_zero_page) + 16u * (lane & 7u);
+      __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)(Bimg + (kt * NP + pl) * SBP + panel * 8192u + ((unsigned)j & 7u) * 1024u), 16, 0, 0);
+    }
+  }
+  wait_dma_and_barrier<0>();
+
+  f4 acc[FN];
+#pragma unroll
+  for (int j = 0; j < FN; ++j) acc[j] = f4{0.f, 0.f, 0.f, 0.f};
+  int row = (int)(wave * 16u + r);
+  row = row < rows ? row : rows - 1;  // rows past the edge re-read the last valid one (their outputs are never stored)
+  const char* const arow = smem + (unsigned)row * rowbytes;
+  for (int kt = 0; kt < nkt; ++kt) {
+    u4 v[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      // 2:4: k = 64 kt + 16 g + 4 c ..;  DENSE: c < 2: k = 64 kt + 8 g + 4 c ..,  c >= 2: k = 64 kt + 32 + 8 g + 4 (c - 2) ..
+      const int k0 = kt * 64 + (DENSE ? 32 * (c >> 1) + 8 * (int)g + 4 * (c & 1) : 16 * (int)g + 4 * c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        // (reads at or beyond k are masked; they stay inside the LDS allocation: span_lds covers 128 rows + 256 bytes)
+        const uint32_t x = *reinterpret_cast<const uint32_t*>(arow + 4u * (unsigned)(k0 + e));
+        v[c][e] = k0 + e < p.K ? x : 0u;
+      }
+    }
+    h8 af[NP], ag[NP];
+    int idx;
+    split_a_operands<NP, DENSE>(v, af, ag, idx);
+    split_sweep1<FN, NP, DENSE>((unsigned)(uintptr_t)(lds_char*)(Bimg + kt * NP * SBP), (unsigned)SBP, lane, af, ag, idx, acc);
+  }
+  __syncthreads();
+  split_store_tile<BN, FN>(smem, p.C, acc, wave, lane, tid, m0, n0, mlast, p.N, p.alpha, p.beta);
+}
+
+template <int BN, int NP, bool DENSE>
+static int launch_split_span(const SplitArgs& a0, hipStream_t st) {
+  SplitArgs a = a0;
+  a.tiles_m = (a.Mrows + 127) / 128;
+  a.tiles_n = (a.N + BN - 1) / BN;
+  const size_t nwg = (size_t)a.tiles_m * a.tiles_n;
+  if (nwg == 0) return SM_STATUS_SUCCESS;
+  const size_t kc = ((size_t)a.K + 63) / 64 * 64;
+  const size_t span_lds = ((size_t)128 * a.K * 4 + 256 + 1023) / 1024 * 1024;  // whole pieces; >= 256 bytes past the last row
+  const size_t lds_main = span_lds + (size_t)NP * kc * BN * 2;
+  constexpr size_t lds_epi = (size_t)128 * (BN * 4 + 16);
+  const size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
+  if (lds > 160 * 1024 || nwg > 0x7fffffffu) {
+    set_error("sm_spmma_fused_f32_split: k too long for the span form (use sm_spmma_fused_f32)");
+    return SM_STATUS_NOT_SUPPORTED;
+  }
+  static LdsOptIn lds_optin;
+  if (const int rc = ensure_dyn_lds(lds_optin, reinterpret_cast<const void*>(&spmma_f32_split_span_kernel<BN, NP, DENSE>), 160 * 1024, "spmma_f32_split_span_kernel")) return rc;
+  spmma_f32_split_span_kernel<BN, NP, DENSE><<<dim3((unsigned)nwg), dim3(512), lds, st>>>(a, (unsigned)span_lds, (size_t)a.Mrows * a.K * 4);
+  return check_launch("spmma_f32_split_span_kernel");
 }
 
 // B (fp32, [k][n] row-major per batch) -> planes of truncated bfloat16 pieces, 8 elements per thread
@@ -633,9 +759,14 @@ static int f32_split_product(bool dense, const float* A, const float* B, float* 
     return SM_STATUS_INVALID_VALUE;
   }
   if (m == 0 || n == 0 || batch == 0) return SM_STATUS_SUCCESS;
-  if (k == 0 || k % 64 != 0 || n % 8 != 0 || lda % 4 != 0 || strideA % 4 != 0 || strideB % 8 != 0 || strideC % 4 != 0 || !aligned16(A) || !aligned16(B) ||
+  // ragged k: the span form -- one tall contiguous A (lda == k, shared B, batches back to back), n <= 128, span + planes inside the LDS
+  const bool span = (k % 64 != 0 || lda % 4 != 0) && k != 0 && lda == k && n <= 128 && (batch == 1 || (strideB == 0 && strideA == m * lda && strideC == m * n)) &&
+                    (m * batch * k * 4) % 16 == 0 &&
+                    ((size_t)128 * k * 4 + 256 + 1023) / 1024 * 1024 + (size_t)planes * ((k + 63) / 64 * 64) * (n <= 64 ? 64 : 128) * 2 <= 160 * 1024;
+  if (k == 0 || (!span && (k % 64 != 0 || lda % 4 != 0)) || n % 8 != 0 || strideA % 4 != 0 || strideB % 8 != 0 || strideC % 4 != 0 || !aligned16(A) || !aligned16(B) ||
       !aligned16(C) || m * batch > 0x7fffffffull || n > 0x7fffffffull || k > 0x7fffffffull || lda > 0x7fffffffull) {
-    set_error("sm_spmma_fused_f32_split: needs k %% 64 == 0, n %% 8 == 0 and 16-byte aligned rows of A, B and C (use sm_spmma_fused_f32)");
+    set_error("sm_spmma_fused_f32_split: needs k %% 64 == 0 (or a ragged k with n <= 128, lda == k and one tall A that fits the span form), n %% 8 == 0 and "
+              "16-byte aligned A, B and C (use sm_spmma_fused_f32)");
     return SM_STATUS_NOT_SUPPORTED;
   }
   size_t need = 0;
@@ -664,6 +795,16 @@ static int f32_split_product(bool dense, const float* A, const float* B, float* 
   if (batch > 1 && strideB == 0 && strideA == m * lda && strideC == m * n) {  // one tall matrix
     a.Mrows = (int)(m * batch);
     a.batch = 1;
+  }
+  if (span) {
+    a.Mrows = (int)(m * batch);
+    a.batch = 1;
+    if (dense) {
+      if (planes == 3) return n <= 64 ? launch_split_span<64, 3, true>(a, st) : launch_split_span<128, 3, true>(a, st);
+      return n <= 64 ? launch_split_span<64, 2, true>(a, st) : launch_split_span<128, 2, true>(a, st);
+    }
+    if (planes == 3) return n <= 64 ? launch_split_span<64, 3, false>(a, st) : launch_split_span<128, 3, false>(a, st);
+    return n <= 64 ? launch_split_span<64, 2, false>(a, st) : launch_split_span<128, 2, false>(a, st);
   }
   // 128 < n <= 256: the column-loop form (A selected / split once per stage for both 128-column halves).  Not beyond: four column
   // tiles need 128 accumulator registers per lane (the kernel spills) and leave one workgroup per 128 rows -- 49 workgroups for the

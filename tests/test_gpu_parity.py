@@ -788,7 +788,8 @@ SPLIT_TOL = {3: 2.0 ** -21, 2: 2.0 ** -13}  # sm_spmma_fused_f32_split: |error| 
 
 
 @pytest.mark.parametrize("shape", [(128, 64, 64, 1), (196, 128, 256, 2), (132, 72, 192, 3), (260, 256, 128, 2), (132, 200, 192, 3), (100, 512, 320, 1),
-                                   (3136, 128, 576, 2), (784, 256, 1152, 2), (12544, 64, 576, 1)], ids=lambda s_: "x".join(map(str, s_)))
+                                   (3136, 128, 576, 2), (784, 256, 1152, 2), (12544, 64, 576, 1), (300, 64, 147, 2), (130, 72, 100, 1), (128, 64, 72, 1),
+                                   (3136, 64, 147, 4)], ids=lambda s_: "x".join(map(str, s_)))
 @pytest.mark.parametrize("planes", [3, 2])
 @pytest.mark.parametrize("ab", [(1.0, 0.0), (0.5, -2.0)])
 @pytest.mark.parametrize("kind", ["uniform", "ties"])
@@ -808,13 +809,16 @@ def test_spmma_f32_split(gpu, shape, planes, ab, kind):
     ws = torch.empty(gpu.spmma_fused_f32_split_workspace(n, k, planes=planes), dtype=torch.uint8, device="cuda")
     Cs, Ce = to_dev(C0.copy()), to_dev(C0.copy())
     gpu.spmma_fused_f32_split(dA, dB, Cs, m, n, k, ws, batch=batch, planes=planes, alpha=alpha, beta=beta)
-    gpu.spmma_fused(dA, dB, Ce, m, n, k, batch=batch, alpha=alpha, beta=beta)
     assert torch.equal(dA.view(torch.int32), to_dev(A).view(torch.int32)), "A was modified"
+    P = dA.clone()
+    gpu.prune24(P, P, batch * m, k, k, gpu.PRUNE_STRIP)
+    if k % 32 == 0:
+        gpu.spmma_fused(dA, dB, Ce, m, n, k, batch=batch, alpha=alpha, beta=beta)
+    else:   # ragged k (the span form): the exact fused kernel does not take it; the dense fp32 kernel on the pruned operand is the same product
+        gpu.gemm_rowmajor(P, dB, Ce, m, n, k, batch=batch, alpha=alpha, beta=beta)
     if kind == "ties" and beta == 0.0:
         assert torch.equal(Cs.view(torch.int32), Ce.view(torch.int32)), "exact data: the split form must equal the fp32 kernel bit for bit"
         return
-    P = dA.clone()
-    gpu.prune24(P, P, batch * m, k, k, gpu.PRUNE_STRIP)
     P64 = host(P).astype(np.float64).reshape(batch * m, k)
     B64 = B.astype(np.float64).reshape(k, n)
     ref = alpha * (P64 @ B64).reshape(-1) + beta * C0.astype(np.float64)
@@ -826,8 +830,8 @@ def test_spmma_f32_split(gpu, shape, planes, ab, kind):
     assert not (err > FP32_TOL * np.maximum(scale, 1e-30)).any()
 
 
-@pytest.mark.parametrize("shape", [(128, 64, 64, 1), (196, 128, 256, 2), (260, 256, 128, 2), (132, 200, 192, 3), (100, 512, 320, 1), (3136, 64, 576, 1)],
-                         ids=lambda s_: "x".join(map(str, s_)))
+@pytest.mark.parametrize("shape", [(128, 64, 64, 1), (196, 128, 256, 2), (260, 256, 128, 2), (132, 200, 192, 3), (100, 512, 320, 1), (3136, 64, 576, 1),
+                                   (300, 64, 147, 2), (130, 72, 100, 1)], ids=lambda s_: "x".join(map(str, s_)))
 @pytest.mark.parametrize("planes", [3, 2])
 @pytest.mark.parametrize("kind", ["uniform", "ties"])
 def test_gemm_f32_split_dense(gpu, shape, planes, kind):
@@ -874,7 +878,7 @@ def test_spmma_f32_split_edges(gpu):
     rows = [r for r in range(m) if r not in (5, 9)]
     assert np.isfinite(c[rows]).all() and np.allclose(c[rows], ce[rows], rtol=0, atol=1e-4)
     NS, INV = gpu.STATUS_NOT_SUPPORTED, 1
-    assert gpu.spmma_fused_f32_split(dA, dB, C, 64, 64, 72, ws, check=False) == NS    # k % 64 != 0
+    assert gpu.spmma_fused_f32_split(dA, dB, C, 16, 256, 72, ws, check=False) == NS   # k % 64 != 0 with n > 128: no span form
     assert gpu.spmma_fused_f32_split(dA, dB, C, 64, 12, 64, ws, check=False) == NS    # n % 8 != 0
     small = torch.empty(64, dtype=torch.uint8, device="cuda")
     with pytest.raises(gpu.SparsifymeError):
