@@ -126,6 +126,9 @@ def main():
     ap.add_argument("--fused-max-k-wide", type=int, default=512,
                     help="auto path: wider layers (n > --fused-max-n) are still fused when k <= this (the A-stationary "
                          "kernel keeps the 2:4 image of a row panel in LDS across its column tiles); 0 = never")
+    ap.add_argument("--batch-split", type=int, default=1,
+                    help="run every layer's batch as this many independent problems of b / S entries (more, smaller work items "
+                         "for the streams to interleave; same kernels, same results)")
     ap.add_argument("--dtype", choices=["f16", "bf16", "f32"], default="f16",
                     help="element type (BASELINE's metric is quoted on f16; bf16 runs the same kernels with the bfloat16 matrix "
                          "instructions; f32 is BASELINE config 2: sm_compress24_f32 + sm_spmma_f32 against the fp32 dense GEMMs, "
@@ -216,7 +219,17 @@ def main():
         sm.fill_uniform(B, mg.unit_seed(0xB0000000, li, -1), 0.0, 1.0)
         blob = torch.empty(sm.compress24_size(m, k, es, b), dtype=torch.uint8, device=dev)
         C = torch.empty(b * m * n, dtype=tdt, device=dev)
-        layers.append(dict(li=li, m=m, n=n, k=k, b=b, A=A, B=B, blob=blob, C=C))
+        S = args.batch_split if args.batch_split > 1 and b % args.batch_split == 0 else 1
+        if S == 1:
+            layers.append(dict(li=li, m=m, n=n, k=k, b=b, A=A, B=B, blob=blob, C=C))
+        else:
+            # --batch-split S: the layer's batch as S independent problems of b / S batch entries (views of the same operands; own
+            # blobs): more, smaller work items for the streams to interleave -- same kernels, same C
+            bs = b // S
+            for s_ in range(S):
+                layers.append(dict(li=li, m=m, n=n, k=k, b=bs, A=A[s_ * bs * m * k:(s_ + 1) * bs * m * k], B=B,
+                                   blob=torch.empty(sm.compress24_size(m, k, es, bs), dtype=torch.uint8, device=dev),
+                                   C=C[s_ * bs * m * n:(s_ + 1) * bs * m * n]))
     flops = mg.unit_flops(shapes, units)
 
     # The layers of a step are independent problems (the reference's sweep runs them as separate
