@@ -762,6 +762,20 @@ def extras(args, sm, torch, dev, layers, flops, t_full, Forked, make_runner, tim
             t_ds = sec_per_call(Forked(layer_dense_split))
             split["dense_planes%d_ms" % planes] = t_ds * 1e3
             split["planes%d_speedup_vs_dense_split" % planes] = t_ds / (split["planes%d_ms" % planes] * 1e-3)
+        # the API-faithful sequence of spmma<float> with spmma_options().f32_planes: TILE prune in place (here: into a second buffer, as
+        # stages.api_spmma_ms does) + check in one pass, no blob, then the split multiply straight from the pruned dense operand
+        for L in layers:
+            L["Aapi"] = torch.empty_like(L["A"])
+        vflag = torch.zeros(1, dtype=torch.int32, device=dev)
+        for planes in (3, 2):
+            def layer_api_split(L, planes=planes):
+                sm.prune24_compress24(L["A"], L["Aapi"], L["m"], L["k"], L["k"], L["b"], L["m"] * L["k"], None, vflag, sm.PRUNE_TILE)
+                if sm.spmma_fused_f32_split(L["Aapi"], L["B"], L["C"], L["m"], L["n"], L["k"], L["ws"], batch=L["b"], planes=planes, check=False) != 0:
+                    sm.compress24(L["Aapi"], L["m"], L["k"], L["k"], L["b"], L["m"] * L["k"], L["blob"])
+                    sm.spmma(L["blob"], L["B"], L["C"], L["m"], L["n"], L["k"], L["b"], 0)
+            split["api_spmma_planes%d_ms" % planes] = sec_per_call(Forked(layer_api_split)) * 1e3
+        for L in layers:
+            del L["Aapi"]
         split["layers_on_split_form"] = sum(1 for L in layers if sm.spmma_fused_f32_split(L["A"], L["B"], L["C"], L["m"], L["n"], L["k"], L["ws"], batch=L["b"],
                                                                                       planes=3, check=False) == 0)
         # error of the split forms against the exact kernel on the first layer they take (max |diff| / max sum|a||b| bound proxy)

@@ -220,7 +220,7 @@ std::vector<float> spmma(type_t* dA,
     (void)one_timer.end();
     if (rc1 != SM_STATUS_NOT_SUPPORTED) keep_first(rc1);
   }
-  // (round 4, float with spmma_options().f32_planes = 2 / 3) prune (TILE, in place) + check as one launch pair, then the multiply
+  // (round 4, float with spmma_options().f32_planes = 2 / 3) prune (TILE, in place) + check in one pass, then the multiply
   // on the sparse matrix instruction straight from the pruned dense operand: no blob is built (the STRIP selection the kernel
   // applies to a 2:4 operand keeps exactly its non-zeros).  Times: {prune + check + readback, B-plane workspace allocation, multiply}.
   if (!staged && !ta && !tb && spmma_options().f32_planes != 0) {
@@ -228,8 +228,8 @@ std::vector<float> spmma(type_t* dA,
     if (fns::split_workspace(n, k, batch_size, spmma_options().f32_planes, &ws_bytes) == SM_STATUS_SUCCESS && (k % 64 == 0 || n <= 128) && n % 8 == 0) {
       util::timer_t prune_timer;
       prune_timer.begin();
-      for (std::size_t b = 0; b < batch_size; ++b) keep_first(fns::prune(dA + b * m * k, m, k));
-      keep_first(fns::check(dA, m * batch_size, k, valid.data().get()));
+      // prune (TILE, in place) + check as ONE pass over A, no blob (sm_prune24_compress24_* with a null blob)
+      keep_first(fns::prune_check_compress(dA, m, k, batch_size, nullptr, valid.data().get()));
       report_flag();
       const float t_prune = prune_timer.end();
       util::timer_t alloc_timer;
