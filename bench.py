@@ -940,7 +940,7 @@ def conv_path_stage(sm, torch, dev, dtype):
     of `value`: the headline step is defined on the reference's (m, n, k) operands."""
     tdt = torch.float16 if dtype == "f16" else torch.bfloat16
     N = 32
-    rows, tot_ms, tot_fl, tot_by, tot_roof = [], 0.0, 0.0, 0.0, 0.0
+    rows, tot_ms, tot_fl, tot_by, tot_roof, tot_routed = [], 0.0, 0.0, 0.0, 0.0, 0.0
     for Cin, HW, n, cnt in [(64, 112, 64, 3), (128, 56, 128, 4), (256, 28, 256, 6), (512, 14, 512, 3)]:
         L, K = HW * HW, Cin * 9
         X = torch.empty(N * Cin * L, dtype=tdt, device=dev)
@@ -951,10 +951,21 @@ def conv_path_stage(sm, torch, dev, dtype):
         ms = sm.graph_time_ms(lambda: sm.conv_spmma_fused(X, B, C, N, Cin, HW, HW, 3, 3, 1, 1, 1, n), iters=10)
         fl, by = 2.0 * N * L * n * K, 2.0 * (N * Cin * L + K * n + N * L * n)
         roof = max(by / (HBM_PEAK_GBS * 1e9), fl / 5.0e15)
-        rows.append({"m": L, "n": n, "k": K, "count": cnt, "ms": ms, "GBs": by / ms / 1e6, "eff_TFs": fl / ms / 1e9, "frac": roof * 1e3 / ms})
-        tot_ms += ms * cnt; tot_fl += fl * cnt; tot_by += by * cnt; tot_roof += roof * cnt
+        row = {"m": L, "n": n, "k": K, "count": cnt, "ms": ms, "GBs": by / ms / 1e6, "eff_TFs": fl / ms / 1e9, "frac": roof * 1e3 / ms}
+        # round 4: sm_conv_spmma_* picks the faster route per layer (small-spatial long-K layers: im2col-to-blob + staged matmul)
+        ms_r = ms
+        if hasattr(sm, "conv_spmma"):
+            need = sm.conv_spmma_workspace(N, Cin, HW, HW, 3, 3, 1, 1, 1)
+            ws = torch.empty(max(need, 16), dtype=torch.uint8, device=dev)
+            ms_r = sm.graph_time_ms(lambda: sm.conv_spmma(X, B, C, N, Cin, HW, HW, 3, 3, 1, 1, 1, n, workspace=ws), iters=10)
+            row["ms_routed"] = ms_r
+            row["route"] = "im2col_compress24 + spmma" if need else "implicit GEMM"
+            del ws
+        rows.append(row)
+        tot_ms += ms * cnt; tot_fl += fl * cnt; tot_by += by * cnt; tot_roof += roof * cnt; tot_routed += ms_r * cnt
         del X, C
-    return {"kernel": "conv_spmma_fused_kernel", "layers": rows, "table_weighted_ms": tot_ms, "eff_TFs": tot_fl / tot_ms / 1e9,
+    return {"kernel": "conv_spmma_fused_kernel", "layers": rows, "table_weighted_ms": tot_ms, "table_weighted_routed_ms": tot_routed,
+            "eff_TFs": tot_fl / tot_ms / 1e9,
             "roofline": {"bound": "hbm", "achieved": tot_by / tot_ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": tot_by / tot_ms / 1e6 / HBM_PEAK_GBS, "frac_of_per_layer_roofline": tot_roof * 1e3 / tot_ms},
             "note": "bytes = activations + B + C (no A); DESIGN.md 4.4: bound by the selection / gather instruction stream, not by HBM"}

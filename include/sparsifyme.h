@@ -396,6 +396,18 @@ int sm_conv_spmma_fused_f16(const void* X, const void* B, void* C, size_t N, siz
                             size_t stride, size_t pad, size_t dilation, size_t n_out, float alpha, float beta, sm_stream_t stream);
 int sm_conv_spmma_fused_bf16(const void* X, const void* B, void* C, size_t N, size_t Cin, size_t H, size_t W, size_t kh, size_t kw,
                              size_t stride, size_t pad, size_t dilation, size_t n_out, float alpha, float beta, sm_stream_t stream);
+/* The same product by the faster of its two routes (round 4): the implicit-GEMM kernel, or -- small-spatial layers with a long K
+ * (out_h * out_w <= 256 and K >= 2048: the 14 x 14 x 512-channel layers of a ResNet) -- sm_im2col_compress24_* into `workspace`
+ * followed by sm_spmma_*.  Same C bit for bit either way.  sm_conv_spmma_workspace gives the bytes (0 where the implicit kernel is
+ * kept); with no workspace the implicit kernel runs wherever it can. */
+int sm_conv_spmma_workspace(size_t N, size_t Cin, size_t H, size_t W, size_t kh, size_t kw, size_t stride, size_t pad, size_t dilation,
+                            size_t* bytes);
+int sm_conv_spmma_f16(const void* X, const void* B, void* C, size_t N, size_t Cin, size_t H, size_t W, size_t kh, size_t kw, size_t stride,
+                      size_t pad, size_t dilation, size_t n_out, float alpha, float beta, void* workspace, size_t workspace_bytes,
+                      sm_stream_t stream);
+int sm_conv_spmma_bf16(const void* X, const void* B, void* C, size_t N, size_t Cin, size_t H, size_t W, size_t kh, size_t kw, size_t stride,
+                       size_t pad, size_t dilation, size_t n_out, float alpha, float beta, void* workspace, size_t workspace_bytes,
+                       sm_stream_t stream);
 
 #ifdef __cplusplus
 }

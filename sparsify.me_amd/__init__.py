@@ -51,6 +51,11 @@ _SIGS = {
                            _c_f, _c_f, _c_ptr],
     "sm_spmma_fused_f32": [_c_ptr, _c_ptr, _c_ptr, _c_size, _c_size, _c_size, _c_size, _c_size, _c_size, _c_size, _c_size,
                            _c_f, _c_f, _c_ptr],
+    "sm_conv_spmma_workspace": [_c_size, _c_size, _c_size, _c_size, _c_size, _c_size, _c_size, _c_size, _c_size, ctypes.POINTER(_c_size)],
+    "sm_conv_spmma_f16": [_c_ptr, _c_ptr, _c_ptr, _c_size, _c_size, _c_size, _c_size, _c_size, _c_size, _c_size, _c_size, _c_size, _c_size, _c_f, _c_f,
+                          _c_ptr, _c_size, _c_ptr],
+    "sm_conv_spmma_bf16": [_c_ptr, _c_ptr, _c_ptr, _c_size, _c_size, _c_size, _c_size, _c_size, _c_size, _c_size, _c_size, _c_size, _c_size, _c_f, _c_f,
+                           _c_ptr, _c_size, _c_ptr],
     "sm_gemm_rowmajor_f32_split": [_c_ptr, _c_ptr, _c_ptr, _c_size, _c_size, _c_size, _c_size, _c_size, _c_size, _c_size, _c_size, _c_i,
                                    _c_ptr, _c_size, _c_f, _c_f, _c_ptr],
     "sm_spmma_f16_grouped": [_c_size, _c_ptr, _c_ptr, _c_ptr, _c_size, _c_size, _c_size, _c_size, _c_size, _c_size, _c_f, _c_f, _c_ptr],
@@ -427,6 +432,20 @@ def conv_spmma_fused(X, B, C, N, Cin, H, W, kh, kw, stride, pad, dilation, n_out
     fn = getattr(lib(), "sm_conv_spmma_fused_" + _sfx(X))
     _check(fn(_dev(X), _dev(B), _dev(C), N, Cin, H, W, kh, kw, stride, pad, dilation, n_out, float(alpha), float(beta), _stream()),
            "sm_conv_spmma_fused")
+
+
+def conv_spmma_workspace(N, Cin, H, W, kh, kw, stride, pad, dilation):
+    out = _c_size(0)
+    _check(lib().sm_conv_spmma_workspace(N, Cin, H, W, kh, kw, stride, pad, dilation, ctypes.byref(out)), "sm_conv_spmma_workspace")
+    return out.value
+
+
+def conv_spmma(X, B, C, N, Cin, H, W, kh, kw, stride, pad, dilation, n_out, workspace=None, alpha=1.0, beta=0.0):
+    """The convolution-layer 2:4 product by the faster route (implicit GEMM, or im2col-to-blob + matmul for small-spatial long-K layers)."""
+    fn = getattr(lib(), "sm_conv_spmma_" + _sfx(X))
+    wb = workspace.numel() * workspace.element_size() if workspace is not None else 0
+    _check(fn(_dev(X), _dev(B), _dev(C), N, Cin, H, W, kh, kw, stride, pad, dilation, n_out, float(alpha), float(beta),
+              _dev(workspace) if workspace is not None else None, wb, _stream()), "sm_conv_spmma")
 
 
 def gemm_batched(A_ptrs, B_ptrs, C_ptrs, m, n, k, batch, dtype_suffix, alpha=1.0, beta=0.0, ta=0, tb=0):

@@ -339,3 +339,58 @@ extern "C" int sm_conv_spmma_fused_bf16(const void* X, const void* B, void* C, s
                                         sm_stream_t stream) {
   return conv_spmma16<true>(X, B, C, N, Cin, H, W, kh, kw, stride, pad, dilation, n_out, alpha, beta, stream);
 }
+
+// ---------------------------------------------------------------------------------------------
+// The convolution-layer product by the faster of its two routes (round 4): the implicit-GEMM kernel above, or -- for the small-
+// spatial, long-K layers, where that kernel's per-stage gather is spread over few tiles (14 x 14 x 512 channels: 102 us against
+// 45 + 37 us, profiles/conv_routes_r04ac.txt) -- sm_im2col_compress24 into the caller's workspace followed by the staged 2:4
+// matmul.  Both routes give the same C bit for bit.  workspace: sm_conv_spmma_workspace bytes (0 for layers the rule keeps on
+// the implicit kernel); without one the implicit kernel runs wherever it can.
+// ---------------------------------------------------------------------------------------------
+static bool conv_prefers_blob(size_t out_h, size_t out_w, size_t K) { return out_h * out_w <= 256 && K >= 2048; }
+
+extern "C" int sm_conv_spmma_workspace(size_t N, size_t Cin, size_t H, size_t W, size_t kh, size_t kw, size_t stride, size_t pad, size_t dilation,
+                                       size_t* bytes) {
+  size_t oh = 0, ow = 0;
+  if (!bytes || sm_conv_out_size(H, kh, stride, pad, dilation, &oh) != SM_STATUS_SUCCESS || sm_conv_out_size(W, kw, stride, pad, dilation, &ow) != SM_STATUS_SUCCESS) {
+    set_error("sm_conv_spmma_workspace: invalid argument");
+    return SM_STATUS_INVALID_VALUE;
+  }
+  *bytes = 0;
+  if (!conv_prefers_blob(oh, ow, Cin * kh * kw)) return SM_STATUS_SUCCESS;
+  return sm_compress24_size(oh * ow, Cin * kh * kw, 2, N, bytes);
+}
+
+template <bool BF>
+static int conv_spmma_routed(const void* X, const void* B, void* C, size_t N, size_t Cin, size_t H, size_t W, size_t kh, size_t kw, size_t stride, size_t pad,
+                             size_t dilation, size_t n_out, float alpha, float beta, void* workspace, size_t workspace_bytes, sm_stream_t stream) {
+  size_t oh = 0, ow = 0, need = 0;
+  if (sm_conv_out_size(H, kh, stride, pad, dilation, &oh) != SM_STATUS_SUCCESS || sm_conv_out_size(W, kw, stride, pad, dilation, &ow) != SM_STATUS_SUCCESS) {
+    set_error("sm_conv_spmma: invalid geometry");
+    return SM_STATUS_INVALID_VALUE;
+  }
+  const size_t L = oh * ow, K = Cin * kh * kw;
+  bool blob_route = conv_prefers_blob(oh, ow, K) && workspace && sm_compress24_size(L, K, 2, N, &need) == SM_STATUS_SUCCESS && workspace_bytes >= need &&
+                    aligned16(workspace);
+  if (!blob_route) {
+    const int rc = conv_spmma16<BF>(X, B, C, N, Cin, H, W, kh, kw, stride, pad, dilation, n_out, alpha, beta, stream);
+    if (rc != SM_STATUS_NOT_SUPPORTED) return rc;
+    // a geometry the implicit kernel does not take: the pair, if the caller gave room for the blob
+    if (!workspace || sm_compress24_size(L, K, 2, N, &need) != SM_STATUS_SUCCESS || workspace_bytes < need || !aligned16(workspace)) return rc;
+  }
+  int rc = BF ? sm_im2col_compress24_bf16(X, N, Cin, H, W, kh, kw, stride, pad, dilation, workspace, stream)
+              : sm_im2col_compress24_f16(X, N, Cin, H, W, kh, kw, stride, pad, dilation, workspace, stream);
+  if (rc != SM_STATUS_SUCCESS) return rc;
+  return BF ? sm_spmma_bf16(workspace, B, C, L, n_out, K, N, 0, L * n_out, alpha, beta, stream) : sm_spmma_f16(workspace, B, C, L, n_out, K, N, 0, L * n_out, alpha, beta, stream);
+}
+
+extern "C" int sm_conv_spmma_f16(const void* X, const void* B, void* C, size_t N, size_t Cin, size_t H, size_t W, size_t kh, size_t kw, size_t stride,
+                                 size_t pad, size_t dilation, size_t n_out, float alpha, float beta, void* workspace, size_t workspace_bytes,
+                                 sm_stream_t stream) {
+  return conv_spmma_routed<false>(X, B, C, N, Cin, H, W, kh, kw, stride, pad, dilation, n_out, alpha, beta, workspace, workspace_bytes, stream);
+}
+extern "C" int sm_conv_spmma_bf16(const void* X, const void* B, void* C, size_t N, size_t Cin, size_t H, size_t W, size_t kh, size_t kw, size_t stride,
+                                  size_t pad, size_t dilation, size_t n_out, float alpha, float beta, void* workspace, size_t workspace_bytes,
+                                  sm_stream_t stream) {
+  return conv_spmma_routed<true>(X, B, C, N, Cin, H, W, kh, kw, stride, pad, dilation, n_out, alpha, beta, workspace, workspace_bytes, stream);
+}

@@ -2245,6 +2245,40 @@ def test_conv_spmma_fused_equals_im2col_compress_spmma(gpu, orc, case, bf):
         check_close(host(C2[:L * n_out]), Cref.view(np.float16), scale, FP16_TOL, f"conv implicit {case}", K)
 
 
+@pytest.mark.parametrize("geom", [(2, 512, 14, 14, 512), (2, 256, 16, 16, 64), (2, 64, 28, 28, 64), (1, 3, 16, 16, 64, 7)], ids=lambda g_: "x".join(map(str, g_)))
+def test_conv_spmma_routes_agree(gpu, geom):
+    """sm_conv_spmma_f16: the faster route per layer -- the implicit-GEMM kernel, or (out_h * out_w <= 256 with K >= 2048)
+    sm_im2col_compress24 into the workspace + sm_spmma -- gives the C of the pair bit for bit whichever route runs, with and
+    without a workspace; a geometry the implicit kernel declines (7 x 7 window on 3 channels: K = 147) runs the pair when a
+    workspace is given and is declined without one."""
+    import torch
+    N, Cin, H, W, n_out = geom[:5]
+    kh = kw = geom[5] if len(geom) > 5 else 3
+    pad = kh // 2
+    OH, OW = gpu.conv_out_size(H, kh, 1, pad, 1), gpu.conv_out_size(W, kw, 1, pad, 1)
+    L, K = OH * OW, Cin * kh * kw
+    rng = np.random.default_rng(Cin + H)
+    dX = to_dev(rand(rng, N * Cin * H * W, np.float16))
+    dB = to_dev(rand(rng, K * n_out, np.float16))
+    blob = torch.empty(gpu.compress24_size(L, K, 2, N), dtype=torch.uint8, device="cuda")
+    gpu.im2col(dX, N, Cin, H, W, kh, kw, 1, pad, 1, blob, compress=True)
+    want = torch.zeros(N * L * n_out, dtype=torch.float16, device="cuda")
+    gpu.spmma(blob, dB, want, L, n_out, K, N, 0)
+    need = gpu.conv_spmma_workspace(N, Cin, H, W, kh, kw, 1, pad, 1)
+    assert (need > 0) == (L <= 256 and K >= 2048)
+    ws = torch.empty(max(need, gpu.compress24_size(L, K, 2, N)), dtype=torch.uint8, device="cuda")
+    got = torch.full_like(want, 3.0)
+    gpu.conv_spmma(dX, dB, got, N, Cin, H, W, kh, kw, 1, pad, 1, n_out, workspace=ws)
+    assert torch.equal(got.view(torch.int16), want.view(torch.int16))
+    got.fill_(5.0)
+    if K % 64 == 0:
+        gpu.conv_spmma(dX, dB, got, N, Cin, H, W, kh, kw, 1, pad, 1, n_out)          # no workspace: the implicit kernel
+        assert torch.equal(got.view(torch.int16), want.view(torch.int16))
+    else:
+        with pytest.raises(gpu.SparsifymeError, match="status 2"):
+            gpu.conv_spmma(dX, dB, got, N, Cin, H, W, kh, kw, 1, pad, 1, n_out)
+
+
 def test_conv_spmma_fused_rejects_what_it_cannot_take(gpu):
     import torch
     x = torch.zeros(4096, dtype=torch.float16, device="cuda")
