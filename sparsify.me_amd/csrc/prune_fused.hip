@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256) void prune_compress_kernel(const PruneFusedArg
     for (unsigned r = 0; r < 4; ++r) v[r] = vn[r];
   }
   if (p.d_valid && __any(bad)) {
-    if (lane == 0) atomicOr(p.d_valid, 1);
+    if (lane == 0) raise_flag(p.d_valid);
   }
 }
 
@@ -343,7 +343,7 @@ __global__ __launch_bounds__(256) void prune_compress_f32_kernel(const PruneFuse
     }
   }
   if (p.d_valid && __any(bad)) {
-    if (lane == 0) atomicOr(p.d_valid, 1);
+    if (lane == 0) raise_flag(p.d_valid);
   }
 }
 

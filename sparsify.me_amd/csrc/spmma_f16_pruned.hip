@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void spmma_f16_pruned_kernel(const PrunedArgs 
     cur ^= 1;
   }
   if (p.d_valid && __any(bad)) {
-    if (lane == 0) atomicOr(p.d_valid, 1);
+    if (lane == 0) raise_flag(p.d_valid);
   }
   __syncthreads();
   store_c_tile<BM, BN, FM, FN, 64 * NW, BF>(smem, C, acc, true, wave * TM, 0, m0, 0, p.Mrows, p.N, p.alpha, p.beta, tid);

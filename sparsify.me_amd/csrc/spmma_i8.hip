@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void prune_check_i8_kernel(const uint8_t* A, s
     }
   }
   if (__any(bad)) {
-    if ((threadIdx.x & 63) == 0) atomicOr(d_valid, 1);
+    if ((threadIdx.x & 63) == 0) raise_flag(d_valid);
   }
 }
 

@@ -1,0 +1,9 @@
+#!/bin/bash
+# round 4, session af: four loads in flight in the check and STRIP prune kernels: parity of the prune tests, rates
+set -o pipefail
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+mkdir -p gpurun_out
+guard() { rc=$1; what=$2; echo "$what rc=$rc"; if [ "$rc" = 124 ] || [ "$rc" = 137 ]; then echo "$what hit its limit; stopping"; exit 1; fi; }
+timeout -k 10 500 python -m pytest tests/test_gpu_parity.py -m gpu -q --timeout 300 -k "prune or goldens or check" > gpurun_out/r04af_pytest.txt 2>&1; guard $? "pytest"; tail -4 gpurun_out/r04af_pytest.txt
+timeout -k 10 300 python tools/prune_rates.py > gpurun_out/r04af_prune_rates.txt 2> gpurun_out/r04af_prune_rates.err; guard $? "rates"
+cat gpurun_out/r04af_prune_rates.txt
