@@ -170,32 +170,11 @@ __device__ __forceinline__ void store8(const Vec8<T>& v, T* p, size_t nvalid, bo
 // ---------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void prune_strip_kernel(const T* A_in, T* A_out, size_t m, size_t k,
-                                                          size_t ld, bool vec_ok, bool unroll = true) {
+                                                          size_t ld, bool vec_ok) {
   const size_t ipr = (k + 7) / 8;  // items per row
   const size_t total = m * ipr;
   const bool flat = ld == k && (k & 7) == 0;  // rows are back to back: no 64-bit division per item
-  size_t it = blockIdx.x * (size_t)256 + threadIdx.x;
-  if (flat && vec_ok && unroll) {
-    // one contiguous stream of whole items: four independent loads in flight per lane before the first store
-    const size_t stride = (size_t)gridDim.x * 256;
-    for (; it + 3 * stride < total; it += 4 * stride) {
-      Vec8<T> v[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) v[u].load_vec(A_in + (it + u * stride) * 8);
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-#pragma unroll
-        for (unsigned s = 0; s < 2; ++s) {
-          const unsigned keep = strip_keepmask(key_of(v[u].e[4 * s]), key_of(v[u].e[4 * s + 1]), key_of(v[u].e[4 * s + 2]), key_of(v[u].e[4 * s + 3]));
-#pragma unroll
-          for (unsigned t = 0; t < 4; ++t)
-            if (!((keep >> t) & 1u)) v[u].e[4 * s + t] = 0;
-        }
-        v[u].store_vec(A_out + (it + u * stride) * 8);
-      }
-    }
-  }
-  for (; it < total; it += (size_t)gridDim.x * 256) {
+  for (size_t it = blockIdx.x * (size_t)256 + threadIdx.x; it < total; it += (size_t)gridDim.x * 256) {
     const size_t row = flat ? 0 : it / ipr, c = (it - row * ipr) * 8;
     const size_t nvalid = flat ? 8 : (k - c < 8 ? k - c : 8);
     Vec8<T> v;
@@ -310,31 +289,13 @@ __global__ __launch_bounds__(256) void prune_tile2_kernel(const T* __restrict__ 
 // ---------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void prune_check_kernel(const T* A, size_t m, size_t k, size_t ld,
-                                                          bool vec_ok, int* d_valid, bool unroll = true) {
+                                                          bool vec_ok, int* d_valid) {
   const size_t ipr = (k + 7) / 8;
   const size_t total = m * ipr;
   const bool flat = ld == k && (k & 7) == 0;
   bool bad = false;
-  size_t it = blockIdx.x * (size_t)256 + threadIdx.x;
-  if (flat && vec_ok && unroll) {
-    // one contiguous stream of whole items: four independent loads in flight per lane (a read-only pass with one was at 4.6 TB/s)
-    const size_t stride = (size_t)gridDim.x * 256;
-    for (; it + 3 * stride < total; it += 4 * stride) {
-      Vec8<T> v[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) v[u].load_vec(A + (it + u * stride) * 8);
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (unsigned s = 0; s < 2; ++s) {
-          unsigned nnz = 0;
-#pragma unroll
-          for (unsigned t = 0; t < 4; ++t) nnz += key_of(v[u].e[4 * s + t]) != 0;
-          bad |= nnz > 2;
-        }
-    }
-  }
-  for (; it < total; it += (size_t)gridDim.x * 256) {
+  // (four independent loads in flight per lane were measured: 95 vs 79 us on a 462 MB operand, profiles/prune_rates_r04al.txt: slower)
+  for (size_t it = blockIdx.x * (size_t)256 + threadIdx.x; it < total; it += (size_t)gridDim.x * 256) {
     const size_t row = flat ? 0 : it / ipr, c = (it - row * ipr) * 8;
     const size_t nvalid = flat ? 8 : (k - c < 8 ? k - c : 8);
     Vec8<T> v;
@@ -607,7 +568,7 @@ static int launch_prune(const void* A_in, void* A_out, size_t m, size_t k, size_
   if (m == 0 || k == 0) return SM_STATUS_SUCCESS;
   if (alg == SM_PRUNE_STRIP) {
     const bool vec_ok = vec_ok_2d<T>(A_in, A_out, ld, 0);
-    prune_strip_kernel<T><<<stream_grid(m * ceil_div(k, 8), 256), 256, 0, st>>>((const T*)A_in, (T*)A_out, m, k, ld, vec_ok, tuning_int("SM_PRUNE_UNROLL", 1) != 0);
+    prune_strip_kernel<T><<<stream_grid(m * ceil_div(k, 8), 256), 256, 0, st>>>((const T*)A_in, (T*)A_out, m, k, ld, vec_ok);
     return check_launch("prune_strip_kernel");
   }
   // TILE moves 4 elements per row access: 8-byte (f16) / 16-byte (f32) alignment
@@ -633,7 +594,7 @@ static int launch_check(const void* A, size_t m, size_t k, size_t ld, int* d_val
   if (hipMemsetAsync(d_valid, 0, sizeof(int), st) != hipSuccess) return check_launch("hipMemsetAsync");
   if (m == 0 || k == 0) return SM_STATUS_SUCCESS;
   const bool vec_ok = vec_ok_2d<T>(A, A, ld, 0);
-  prune_check_kernel<T><<<stream_grid(m * ceil_div(k, 8), 256), 256, 0, st>>>((const T*)A, m, k, ld, vec_ok, d_valid, tuning_int("SM_PRUNE_UNROLL", 1) != 0);
+  prune_check_kernel<T><<<stream_grid(m * ceil_div(k, 8), 256), 256, 0, st>>>((const T*)A, m, k, ld, vec_ok, d_valid);
   return check_launch("prune_check_kernel");
 }
 
