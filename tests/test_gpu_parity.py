@@ -857,6 +857,38 @@ def test_gemm_f32_split_dense(gpu, shape, planes, kind):
     assert float((err / bound).max()) <= 1.0, f"dense split planes={planes} {shape}: max err {err.max():.3e}"
 
 
+@pytest.mark.parametrize("dense", [False, True], ids=["2to4", "dense"])
+@pytest.mark.parametrize("planes", [3, 2])
+def test_f32_split_per_batch_b_and_alpha_beta(gpu, dense, planes):
+    """The split forms with a B per batch entry (strideB = k * n: what spmma<float> passes, examples/spmma.cu:48-59) and alpha / beta:
+    every batch entry equals its own single-matrix call bit for bit, and stays inside the bound of the fp64 product."""
+    import torch
+    m, n, k, batch = 196, 128, 256, 3
+    alpha, beta = 0.5, -2.0
+    rng = np.random.default_rng(planes + 10 * dense)
+    A, B, C0 = rand(rng, batch * m * k, np.float32), rand(rng, batch * k * n, np.float32), rand(rng, batch * m * n, np.float32)
+    dA, dB = to_dev(A), to_dev(B)
+    ws = torch.empty(gpu.spmma_fused_f32_split_workspace(n, k, batch=batch, strideB=k * n, planes=planes), dtype=torch.uint8, device="cuda")
+    C = to_dev(C0.copy())
+    gpu.spmma_fused_f32_split(dA, dB, C, m, n, k, ws, batch=batch, strideB=k * n, planes=planes, alpha=alpha, beta=beta, dense=dense)
+    ws1 = torch.empty(gpu.spmma_fused_f32_split_workspace(n, k, planes=planes), dtype=torch.uint8, device="cuda")
+    for b in range(batch):
+        C1 = to_dev(C0[b * m * n:(b + 1) * m * n].copy())
+        gpu.spmma_fused_f32_split(dA[b * m * k:(b + 1) * m * k], dB[b * k * n:(b + 1) * k * n], C1, m, n, k, ws1, planes=planes, alpha=alpha, beta=beta,
+                                  dense=dense)
+        assert torch.equal(C[b * m * n:(b + 1) * m * n].view(torch.int32), C1.view(torch.int32)), f"batch entry {b} differs from its own call"
+    P = dA.clone()
+    if not dense:
+        gpu.prune24(P, P, batch * m, k, k, gpu.PRUNE_STRIP)
+    P64 = host(P).astype(np.float64).reshape(batch, m, k)
+    B64 = B.astype(np.float64).reshape(batch, k, n)
+    ref = alpha * np.einsum("bmk,bkn->bmn", P64, B64).reshape(-1) + beta * C0.astype(np.float64)
+    scale = abs(alpha) * np.einsum("bmk,bkn->bmn", np.abs(P64), np.abs(B64)).reshape(-1) + abs(beta) * np.abs(C0.astype(np.float64))
+    err = np.abs(host(C).astype(np.float64) - ref)
+    bound = (SPLIT_TOL[planes] + 2.0 * k * 2.0 ** -24) * scale + 2.0 ** -22 * np.abs(ref) + 1e-30
+    assert float((err / bound).max()) <= 1.0
+
+
 def test_spmma_f32_split_edges(gpu):
     """What the split form declines, and what a non-finite operand value does: it stays in the first piece, so the outputs it
     reaches are non-finite (NaN where the exact form may say inf: inf meets a zero low piece) and every other output is untouched."""
@@ -2243,6 +2275,24 @@ def test_conv_spmma_fused_equals_im2col_compress_spmma(gpu, orc, case, bf):
         P = np.abs(orc.decompress24(ob, L, K, K, np.uint16).view(np.float16).astype(np.float64)).reshape(L, K)
         scale = (P @ np.abs(Bw.view(np.float16).astype(np.float64)).reshape(K, n_out)).reshape(-1)
         check_close(host(C2[:L * n_out]), Cref.view(np.float16), scale, FP16_TOL, f"conv implicit {case}", K)
+
+
+def test_conv_spmma_routes_agree_bf16(gpu):
+    """the routed entry in bfloat16 on the geometry that takes the blob route: same bits as the pair"""
+    import torch
+    N, Cin, H, W, n_out = 2, 512, 14, 14, 256
+    L, K = H * W, Cin * 9
+    rng = np.random.default_rng(9)
+    dX, dB = bf16_dev(bf16_bits(rng, N * Cin * H * W)), bf16_dev(bf16_bits(rng, K * n_out))
+    blob = torch.empty(gpu.compress24_size(L, K, 2, N), dtype=torch.uint8, device="cuda")
+    gpu.im2col(dX, N, Cin, H, W, 3, 3, 1, 1, 1, blob, compress=True)
+    want = torch.zeros(N * L * n_out, dtype=torch.bfloat16, device="cuda")
+    gpu.spmma(blob, dB, want, L, n_out, K, N, 0)
+    ws = torch.empty(gpu.conv_spmma_workspace(N, Cin, H, W, 3, 3, 1, 1, 1), dtype=torch.uint8, device="cuda")
+    assert ws.numel() > 0
+    got = torch.full_like(want, 3.0)
+    gpu.conv_spmma(dX, dB, got, N, Cin, H, W, 3, 3, 1, 1, 1, n_out, workspace=ws)
+    assert torch.equal(got.view(torch.int16), want.view(torch.int16))
 
 
 @pytest.mark.parametrize("geom", [(2, 512, 14, 14, 512), (2, 256, 16, 16, 64), (2, 64, 28, 28, 64), (1, 3, 16, 16, 64, 7)], ids=lambda g_: "x".join(map(str, g_)))

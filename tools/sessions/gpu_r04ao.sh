@@ -1,0 +1,7 @@
+#!/bin/bash
+# round 4, session ao: added tests (split forms with a B per batch entry and alpha / beta; routed convolution in bfloat16)
+set -o pipefail
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+mkdir -p gpurun_out
+guard() { rc=$1; what=$2; echo "$what rc=$rc"; if [ "$rc" = 124 ] || [ "$rc" = 137 ]; then echo "$what hit its limit; stopping"; exit 1; fi; }
+timeout -k 10 500 python -m pytest tests/test_gpu_parity.py -m gpu -q --timeout 300 -k "f32_split or conv_spmma_routes" > gpurun_out/r04ao_pytest.txt 2>&1; guard $? "pytest"; tail -12 gpurun_out/r04ao_pytest.txt
