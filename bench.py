@@ -1027,12 +1027,12 @@ def config5_stage(sm, torch, dev):
             ms_fast = sm.graph_time_ms(call_fast, iters=5)
             flag = ctypes.c_int(-1)
             L_.sm_spmm_coo_fast_flag(ws3.data_ptr(), ctypes.byref(flag), None)
-            row.update({"ms": ms_fast, "GBs": by / ms_fast / 1e6, "frac": by / ms_fast / 1e6 / HBM_PEAK_GBS, "form": "dense-MFMA (strided_coo's default)", "range_flag": flag.value})
+            row.update({"ms": ms_fast, "GBs": by / ms_fast / 1e6, "frac": by / ms_fast / 1e6 / HBM_PEAK_GBS, "form": "dense-MFMA (opt-in: strided_coo_options().fast)", "range_flag": flag.value})
         else:  # the stem layer's k = 147: the dense-MFMA form takes whole 64-deep stages only; strided_coo runs the exact form
             row.update({"ms": ms, "GBs": by / ms / 1e6, "frac": by / ms / 1e6 / HBM_PEAK_GBS, "form": "exact (packed)", "range_flag": None})
         rows.append(row)
         del B, C, ws, ws2, ws3
-    return {"kernel": "what sparsifyme::batched::strided_coo runs since round 4: sm_spmm_coo_f32_fast (dense operand and A scaled by powers of two computed on the "
+    return {"kernel": "ms / GBs / frac = the OPT-IN fast form of sparsifyme::batched::strided_coo (strided_coo_options().fast; the default is the exact fp32 form, ms_exact): sm_spmm_coo_f32_fast (dense operand and A scaled by powers of two computed on the "
                       "device, rounded to fp16 / split hi + lo, fp16 MFMA with fp32 accumulation, inverse scales on the fp32 sums; result within 2^-11 of "
                       "sum|a||b| at any magnitude; a range flag + untouched C when an operand does not convert -> exact fallback; whole call incl. its scan / "
                       "conversion / scatter passes) = ms / GBs / frac; the exact forms beside it: ms_exact = sm_spmm_coo_f32_packed (re-ordering of A + product), "

@@ -82,9 +82,11 @@ float spmm(ell_t<type_t, memory_space_t::device>* As,
   return t.milliseconds();
 }
 
-// exact = true: strided_coo always runs the exact fp32 kernels (default false: the fp16-split dense-MFMA form first, see below)
+// strided_coo computes in full fp32 by default, as the reference's cusparseSpMM call does (CUDA_R_32F operands and compute type,
+// spmm.hxx:165-187).  fast = true opts in to the dense-MFMA form first (operands rounded once to fp16: result within 2^-11 of
+// sum|a||b| instead of fp32 arithmetic -- about 12 bits of operand precision traded for speed; see below)
 struct strided_coo_options_t {
-  bool exact = false;
+  bool fast = false;
 };
 inline strided_coo_options_t& strided_coo_options() {
   static strided_coo_options_t o;
@@ -111,13 +113,14 @@ float strided_coo(std::size_t A_num_rows,
   util::range_t range("strided-COO-SpMM");
   t.begin();  // the reference times its buffer allocation too (spmm.hxx:155-156,183)
   int rc = SM_STATUS_NOT_SUPPORTED;
-  // (round 4) First the dense-MFMA form (sm_spmm_coo_f32_fast: operands scaled by powers of two and rounded to fp16, fp32
+  // Opt-in only (strided_coo_options().fast = true; round 5, ADVICE round 4: an fp32 caller must not lose operand precision
+  // silently): first the dense-MFMA form (sm_spmm_coo_f32_fast: operands scaled by powers of two and rounded to fp16, fp32
   // accumulation; result within 2^-11 of sum|a||b|, include/sparsifyme.h) where it pays -- at least ~2 % of A's entries present:
   // below that the exact kernels' work, which follows nnz, is less than the dense product's -- and where the library takes the
   // shape.  It raises a flag on the device and leaves C untouched when an operand does not fit the fp16 range under its scales;
-  // the exact form below then runs on the untouched operands.  strided_coo_options().exact = true skips it.
+  // the exact form below then runs on the untouched operands.
   const bool dense_enough = A_nnz * 50 >= A_num_rows * A_num_cols;
-  if (!strided_coo_options().exact && dense_enough) {
+  if (strided_coo_options().fast && dense_enough) {
     std::size_t fast_bytes = 0;
     if (sm_spmm_coo_fast_workspace_size(A_num_rows, A_num_cols, B_num_cols, num_batches, &fast_bytes) == SM_STATUS_SUCCESS) {
       device_vector<unsigned char> fws(fast_bytes);

@@ -398,8 +398,12 @@ int sm_conv_spmma_fused_bf16(const void* X, const void* B, void* C, size_t N, si
                              size_t stride, size_t pad, size_t dilation, size_t n_out, float alpha, float beta, sm_stream_t stream);
 /* The same product by the faster of its two routes (round 4): the implicit-GEMM kernel, or -- small-spatial layers with a long K
  * (out_h * out_w <= 256 and K >= 2048: the 14 x 14 x 512-channel layers of a ResNet) -- sm_im2col_compress24_* into `workspace`
- * followed by sm_spmma_*.  Same C bit for bit either way.  sm_conv_spmma_workspace gives the bytes (0 where the implicit kernel is
- * kept); with no workspace the implicit kernel runs wherever it can. */
+ * followed by sm_spmma_*.  Same C bit for bit either way.  sm_conv_spmma_workspace gives the bytes: the blob's size
+ * (sm_compress24_size(out_h * out_w, Cin * kh * kw, 2, N)) for the layers the rule sends to the pair AND for every geometry the
+ * implicit kernel cannot run (K % 64 != 0 such as a 7 x 7 x 3 stem, an odd or too wide W, kh * kw > 64, a patch beyond its DMA /
+ * LDS limits), so that a caller who sizes the workspace with it never gets SM_STATUS_NOT_SUPPORTED for a geometry reason; 0 where
+ * the implicit kernel is kept.  The query sees neither n_out nor the pointers: for n_out % 8 != 0 or a B / X that is not 16- /
+ * 4-byte aligned size the workspace with sm_compress24_size.  With no workspace the implicit kernel runs wherever it can. */
 int sm_conv_spmma_workspace(size_t N, size_t Cin, size_t H, size_t W, size_t kh, size_t kw, size_t stride, size_t pad, size_t dilation,
                             size_t* bytes);
 int sm_conv_spmma_f16(const void* X, const void* B, void* C, size_t N, size_t Cin, size_t H, size_t W, size_t kh, size_t kw, size_t stride,

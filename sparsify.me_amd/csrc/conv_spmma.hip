@@ -254,6 +254,48 @@ static int launch_conv(const ConvArgs& a0, hipStream_t st) {
   return check_launch("conv_spmma_fused_kernel");
 }
 
+// The geometry-only part of what the implicit kernel takes (no pointers, no n_out), and the stage plan that follows from it, for
+// one DMA piece size: v16 = 16-byte pieces (8 halves per lane: W % 8 == 0; the border rounded up to 8 halves, at most 16 DMA
+// instructions per stage) or 4-byte pieces (2 halves per lane, at most 48).  Shared by the launcher -- which tries the 16-byte form
+// first and falls back to the 4-byte form when only the tighter limits fail -- and by sm_conv_spmma_workspace.
+// Returns nullptr when the geometry fits, else what does not.
+static const char* conv_geometry_plan(size_t N, size_t Cin, size_t H, size_t W, size_t kh, size_t kw, size_t stride, size_t pad, size_t dil, bool v16,
+                                      size_t bn /*column tile: 64 or 128*/, ConvArgs& a) {
+  constexpr size_t GEO_MAX = 1u << 20;
+  if (kh == 0 || kw == 0 || stride == 0 || dil == 0) return "invalid argument";
+  if (N > 0x7fffffffull || Cin > 0x7fffffffull || H > GEO_MAX || W > GEO_MAX || kh > GEO_MAX || kw > GEO_MAX || stride > GEO_MAX || pad > GEO_MAX ||
+      dil > GEO_MAX)
+    return "a geometry argument exceeds what the kernel's 32-bit indexing takes";
+  const size_t sh = dil * (kh - 1) + 1, sw = dil * (kw - 1) + 1;
+  if (H + 2 * pad < sh || W + 2 * pad < sw) return "window larger than the padded input";
+  const size_t OH = (H + 2 * pad - sh) / stride + 1, OW = (W + 2 * pad - sw) / stride + 1, L = OH * OW, K = Cin * kh * kw;
+  if (v16 && W % 8 != 0) return "16-byte patch pieces need W % 8 == 0";
+  size_t padl = pad > (sw - 1 > pad ? sw - 1 - pad : 0) ? pad : (sw - 1 > pad ? sw - 1 - pad : 0);
+  const size_t epl = v16 ? 8 : 2;
+  padl = (padl + epl - 1) / epl * epl;
+  if (padl == 0) padl = epl;  // a row's right border is the next row's left border: at least one lane's piece
+  const size_t pitch = padl + W;
+  // whole 64-deep stages, input rows that fit one DMA instruction with their border
+  if (K == 0 || K % 64 != 0 || W % 2 != 0 || pitch / epl > 64 || kh * kw > 64 || H > 0x7fff || N * L > 0x7fffffffull || K > 0x7fffffffull)
+    return "needs C*kh*kw % 64 == 0, an even W that fits one DMA instruction with its border, and kh*kw <= 64";
+  a.N = (int)N; a.Cin = (int)Cin; a.H = (int)H; a.W = (int)W; a.kh = (int)kh; a.kw = (int)kw;
+  a.stride = (int)stride; a.pad = (int)pad; a.dil = (int)dil; a.OH = (int)OH; a.OW = (int)OW; a.L = (int)L;
+  a.K = (int)K; a.khkw = (int)(kh * kw);
+  const size_t span = L < 128 ? (L - 1) / OW : (127 + OW - 1) / OW;  // most output rows a 128-pixel tile straddles, minus one
+  a.RI = (int)(span * stride + sh);
+  a.pitch = (int)pitch; a.padl = (int)padl;
+  a.rpi = (int)(64 / (pitch / epl));
+  a.nch = (int)((kh * kw - 1 + 63) / (kh * kw) + 1);
+  a.a_n = (int)ceil_div((size_t)a.nch * a.RI, (size_t)a.rpi);
+  a.patch_bytes = (int)round_up(((size_t)a.nch * a.RI * pitch + padl + 2 * (sw + pad)) * 2 + 256, 16);
+  if (a.a_n > (v16 ? 16 : 48)) return "a stage's activation patch needs too many DMA instructions";
+  // the gather's k-offset table holds 16-bit byte offsets into the patch: largest = last channel's last window element
+  if (((size_t)a.nch * a.RI * pitch + kw * dil) * 2 >= 65536) return "a stage's activation patch exceeds the 16-bit offset table";
+  // the kernel's LDS: two patch + B stages, the k-offset table
+  if (2 * ((size_t)a.patch_bytes + 64 * bn * 2) + kh * kw * 128 > 160 * 1024) return "a stage's activation patch does not fit LDS";
+  return nullptr;
+}
+
 template <bool BF>
 static int conv_spmma16(const void* X, const void* B, void* C, size_t N, size_t Cin, size_t H, size_t W, size_t kh, size_t kw,
                         size_t stride, size_t pad, size_t dil, size_t n_out, float alpha, float beta, sm_stream_t stream) {
@@ -262,59 +304,42 @@ static int conv_spmma16(const void* X, const void* B, void* C, size_t N, size_t 
     set_error("%s: invalid argument", name);
     return SM_STATUS_INVALID_VALUE;
   }
-  // every geometry argument is narrowed to int below: refuse what does not fit instead of truncating it silently
-  constexpr size_t GEO_MAX = 1u << 20;
-  if (N > 0x7fffffffull || Cin > 0x7fffffffull || H > GEO_MAX || W > GEO_MAX || kh > GEO_MAX || kw > GEO_MAX || stride > GEO_MAX ||
-      pad > GEO_MAX || dil > GEO_MAX) {
-    set_error("%s: a geometry argument exceeds what the kernel's 32-bit indexing takes (use sm_im2col_compress24 + sm_spmma)", name);
-    return SM_STATUS_NOT_SUPPORTED;
-  }
-  const size_t sh = dil * (kh - 1) + 1, sw = dil * (kw - 1) + 1;
-  if (H + 2 * pad < sh || W + 2 * pad < sw) {
-    set_error("%s: window larger than the padded input", name);
-    return SM_STATUS_INVALID_VALUE;
+  {
+    const size_t sh = dil * (kh - 1) + 1, sw = dil * (kw - 1) + 1;
+    if (H <= (1u << 20) && W <= (1u << 20) && pad <= (1u << 20) && kh <= (1u << 20) && kw <= (1u << 20) && dil <= (1u << 20) &&
+        (H + 2 * pad < sh || W + 2 * pad < sw)) {
+      set_error("%s: window larger than the padded input", name);
+      return SM_STATUS_INVALID_VALUE;
+    }
   }
   if (N == 0 || Cin == 0 || n_out == 0) return SM_STATUS_SUCCESS;
-  const size_t OH = (H + 2 * pad - sh) / stride + 1, OW = (W + 2 * pad - sw) / stride + 1, L = OH * OW, K = Cin * kh * kw;
-  // what the kernel takes: whole 64-deep stages, 16-byte aligned B rows, 4-byte aligned input rows that fit one DMA
-  // instruction with their border; anything else: sm_im2col_compress24_* + sm_spmma_* (the same result)
-  size_t padl = pad > (sw - 1 > pad ? sw - 1 - pad : 0) ? pad : (sw - 1 > pad ? sw - 1 - pad : 0);
-  // 16-byte patch DMAs (round 4) where rows are whole 16-byte pieces: W % 8 == 0, a 16-byte aligned X, the border rounded up to
-  // 8 halves and the stage's plan within 4 instructions per wave; SM_CONV_V16 = 0 (tuning) keeps the 4-byte form
-  bool v16 = W % 8 == 0 && aligned16(X) && tuning_int("SM_CONV_V16", 1) != 0;
-  const size_t epl = v16 ? 8 : 2;
-  padl = (padl + epl - 1) / epl * epl;
-  if (padl == 0) padl = epl;  // a row's right border is the next row's left border: at least one lane's piece
-  const size_t pitch = padl + W;
-  if (K % 64 != 0 || n_out % 8 != 0 || W % 2 != 0 || pitch / epl > 64 || !aligned16(B) || (reinterpret_cast<uintptr_t>(X) & 3u) != 0 ||
-      kh * kw > 64 || H > 0x7fff || N * L > 0x7fffffffull || K > 0x7fffffffull || n_out > 0x7fffffffull) {
-    set_error("%s: needs C*kh*kw %% 64 == 0, n %% 8 == 0, an even W <= %zu and kh*kw <= 64 (use sm_im2col_compress24 + sm_spmma)", name,
-              (size_t)(128 - padl));
+  // what the kernel takes beyond the geometry: n % 8 == 0, 16-byte aligned B rows, 4-byte aligned input rows; anything else:
+  // sm_im2col_compress24_* + sm_spmma_* (the same result)
+  if (n_out % 8 != 0 || n_out > 0x7fffffffull || !aligned16(B) || (reinterpret_cast<uintptr_t>(X) & 3u) != 0) {
+    set_error("%s: needs n %% 8 == 0, a 16-byte aligned B and a 4-byte aligned X (use sm_im2col_compress24 + sm_spmma)", name);
     return SM_STATUS_NOT_SUPPORTED;
   }
+  // 16-byte patch DMAs (round 4) where rows are whole 16-byte pieces: W % 8 == 0, a 16-byte aligned X, the border rounded up to
+  // 8 halves and the stage's plan within 16 instructions; when only those tighter limits fail (narrow images: W = 8 gains little
+  // per instruction and pays the wider border) the 4-byte form takes the layer as it did before round 4.  SM_CONV_V16 = 0 (tuning)
+  // keeps the 4-byte form everywhere.
   ConvArgs a = {};
+  bool v16 = W % 8 == 0 && aligned16(X) && tuning_int("SM_CONV_V16", 1) != 0;
+  const size_t bn = n_out <= 64 ? 64 : 128;
+  const char* why = v16 ? conv_geometry_plan(N, Cin, H, W, kh, kw, stride, pad, dil, true, bn, a) : "";
+  if (why) {
+    v16 = false;
+    a = ConvArgs{};
+    why = conv_geometry_plan(N, Cin, H, W, kh, kw, stride, pad, dil, false, bn, a);
+  }
+  if (why) {
+    set_error("%s: %s (use sm_im2col_compress24 + sm_spmma)", name, why);
+    return SM_STATUS_NOT_SUPPORTED;
+  }
   a.X = (const half_t*)X; a.B = (const half_t*)B; a.C = (half_t*)C;
-  a.N = (int)N; a.Cin = (int)Cin; a.H = (int)H; a.W = (int)W; a.kh = (int)kh; a.kw = (int)kw;
-  a.stride = (int)stride; a.pad = (int)pad; a.dil = (int)dil; a.OH = (int)OH; a.OW = (int)OW; a.L = (int)L;
-  a.Nout = (int)n_out; a.K = (int)K; a.khkw = (int)(kh * kw);
-  const size_t span = L < 128 ? (L - 1) / OW : (127 + OW - 1) / OW;  // most output rows a 128-pixel tile straddles, minus one
-  a.RI = (int)(span * stride + sh);
-  a.pitch = (int)pitch; a.padl = (int)padl;
-  a.rpi = (int)(64 / (pitch / epl));
-  a.nch = (int)((kh * kw - 1 + 63) / (kh * kw) + 1);
-  a.a_n = (int)ceil_div((size_t)a.nch * a.RI, (size_t)a.rpi);
-  a.patch_bytes = (int)round_up(((size_t)a.nch * a.RI * pitch + padl + 2 * (sw + pad)) * 2 + 256, 16);
+  a.Nout = (int)n_out;
   a.alpha = alpha; a.beta = beta;
   a.ablate = tuning_int("SM_CONV_ABLATE", 0);
-  if (a.a_n > (v16 ? 16 : 48)) {
-    set_error("%s: a stage's activation patch needs %d DMA instructions (limit %d)", name, a.a_n, v16 ? 16 : 48);
-    return SM_STATUS_NOT_SUPPORTED;
-  }
-  // the gather's k-offset table holds 16-bit byte offsets into the patch: largest = last channel's last window element
-  if (((size_t)a.nch * a.RI * pitch + kw * dil) * 2 >= 65536) {
-    set_error("%s: a stage's activation patch exceeds the 16-bit offset table (use sm_im2col_compress24 + sm_spmma)", name);
-    return SM_STATUS_NOT_SUPPORTED;
-  }
   hipStream_t st = (hipStream_t)stream;
   // (256-column tiles for n_out > 128 -- the patch gathered once per 256 output channels -- were built and measured in round 4:
   //  n = 256 unchanged (73.8 vs 74.1 us), n = 512 slower (134 vs 103 us: 223 registers, two workgroups per CU, half the tiles);
@@ -344,10 +369,18 @@ extern "C" int sm_conv_spmma_fused_bf16(const void* X, const void* B, void* C, s
 // The convolution-layer product by the faster of its two routes (round 4): the implicit-GEMM kernel above, or -- for the small-
 // spatial, long-K layers, where that kernel's per-stage gather is spread over few tiles (14 x 14 x 512 channels: 102 us against
 // 45 + 37 us, profiles/conv_routes_r04ac.txt) -- sm_im2col_compress24 into the caller's workspace followed by the staged 2:4
-// matmul.  Both routes give the same C bit for bit.  workspace: sm_conv_spmma_workspace bytes (0 for layers the rule keeps on
-// the implicit kernel); without one the implicit kernel runs wherever it can.
+// matmul.  Both routes give the same C bit for bit.  workspace: sm_conv_spmma_workspace bytes -- the blob's size for the layers the
+// rule sends to the pair AND for every geometry the implicit kernel cannot run (K % 64 != 0 such as the 7 x 7 x 3 stem, an odd or
+// too wide W, kh * kw > 64, ...: conv_geometry_plan), 0 for the layers that stay on the implicit kernel; without a workspace the
+// implicit kernel runs wherever it can.
 // ---------------------------------------------------------------------------------------------
 static bool conv_prefers_blob(size_t out_h, size_t out_w, size_t K) { return out_h * out_w <= 256 && K >= 2048; }
+static bool conv_implicit_takes_geometry(size_t N, size_t Cin, size_t H, size_t W, size_t kh, size_t kw, size_t stride, size_t pad, size_t dil) {
+  ConvArgs a = {};
+  // (the 128-column tile's LDS: n_out is not known to the query)
+  return (W % 8 == 0 && conv_geometry_plan(N, Cin, H, W, kh, kw, stride, pad, dil, true, 128, a) == nullptr) ||
+         conv_geometry_plan(N, Cin, H, W, kh, kw, stride, pad, dil, false, 128, a) == nullptr;
+}
 
 extern "C" int sm_conv_spmma_workspace(size_t N, size_t Cin, size_t H, size_t W, size_t kh, size_t kw, size_t stride, size_t pad, size_t dilation,
                                        size_t* bytes) {
@@ -357,7 +390,10 @@ extern "C" int sm_conv_spmma_workspace(size_t N, size_t Cin, size_t H, size_t W,
     return SM_STATUS_INVALID_VALUE;
   }
   *bytes = 0;
-  if (!conv_prefers_blob(oh, ow, Cin * kh * kw)) return SM_STATUS_SUCCESS;
+  if (N == 0 || Cin == 0) return SM_STATUS_SUCCESS;
+  // 0 only where the implicit kernel both is the preferred route and can run the geometry (n_out and the operands' alignment are
+  // not known here: n_out % 8 != 0 or a misaligned B / X also need the blob -- size it with sm_compress24_size then)
+  if (!conv_prefers_blob(oh, ow, Cin * kh * kw) && conv_implicit_takes_geometry(N, Cin, H, W, kh, kw, stride, pad, dilation)) return SM_STATUS_SUCCESS;
   return sm_compress24_size(oh * ow, Cin * kh * kw, 2, N, bytes);
 }
 

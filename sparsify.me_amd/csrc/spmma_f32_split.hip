@@ -525,7 +525,9 @@ __global__ __launch_bounds__(512) void spmma_f32_split_cols_kernel(const SplitAr
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
       __builtin_amdgcn_sched_barrier(0);  // sub-stages stay apart (the unrolled loop otherwise overlaps them and spills)
-      if (ct == 1) wait_dma_and_barrier<SLA>();  // B(kt, 1) has landed; A(kt + 1), issued after it, may still be in flight
+      // B(kt, 1) has landed once only the SLA pieces of A(kt + 1), issued after it, remain -- but the LAST stage issues no A(kt + 1):
+      // there the youngest pieces in flight are B(kt, 1)'s own and the wait must be for all of them
+      if (ct == 1 && kt + 1 < nkt) wait_dma_and_barrier<SLA>();
       else wait_dma_and_barrier<0>();
       // next sub-stage's B into the slot sub-stage s - 1 read (every wave has left it), then -- once per stage -- the next A
       if (ct + 1 < CT) stage_b(kt, ct + 1, bbuf ^ 1);
@@ -809,7 +811,10 @@ static int f32_split_product(bool dense, const float* A, const float* B, float* 
   // 128 < n <= 256: the column-loop form (A selected / split once per stage for both 128-column halves).  Not beyond: four column
   // tiles need 128 accumulator registers per lane (the kernel spills) and leave one workgroup per 128 rows -- 49 workgroups for the
   // 196 x 512 layers -- where four column-tile workgroups per 128 rows at least fill the chip.
-  if (n > 128 && n <= 256 && tuning_int("SM_F32_SPLIT_COLS", 1)) {
+  // (its per-lane DMA sources are 32-bit offsets from two uniform bases: the last plane's last stage row and a tile's last A row must
+  // stay below 4 GiB, or the call takes the 128-column tiles below, whose addresses are 64-bit)
+  const bool cols_offsets_fit = (size_t)(planes - 1) * plane * 2 + (size_t)64 * n * 2 < ((size_t)1 << 32) && (size_t)128 * lda * 4 < ((size_t)1 << 32);
+  if (n > 128 && n <= 256 && cols_offsets_fit && tuning_int("SM_F32_SPLIT_COLS", 1)) {
     if (dense) return planes == 3 ? launch_split_cols<2, 3, true>(a, st) : launch_split_cols<2, 2, true>(a, st);
     return planes == 3 ? launch_split_cols<2, 3, false>(a, st) : launch_split_cols<2, 2, false>(a, st);
   }

@@ -228,10 +228,10 @@ static void check_coo(size_t m, size_t n, size_t k, size_t b) {
     for (size_t e = 0; e < nnz; ++e)
       for (size_t j = 0; j < n; ++j)
         scale[bi * m * n + j * m + rows[e]] += std::fabs((double)vals[e]) * std::fabs((double)hB[bi * k * n + j * k + cols[e]]);
-  // exact = true: the fp32 kernels, held to fp32 arithmetic; default: the fp16-split dense-MFMA form first where the library takes
-  // the shape -- then the bound is one fp16 rounding of the dense operand, 2^-11 of sum|a||b| (include/sparsifyme.h)
+  // default: the fp32 kernels, held to fp32 arithmetic; strided_coo_options().fast = true: the fp16-split dense-MFMA form first where
+  // the library takes the shape -- then the bound is one fp16 rounding of the dense operand, 2^-11 of sum|a||b| (include/sparsifyme.h)
   for (int exact = 1; exact >= 0; --exact) {
-    batched::strided_coo_options().exact = exact != 0;
+    batched::strided_coo_options().fast = exact == 0;
     (void)hipMemset(dC.data().get(), 0xff, b * m * n * sizeof(float));
     batched::strided_coo<float>(m, k, nnz, k, n, b, dr.data().get(), dc.data().get(), dv.data().get(), dB.data().get(), dC.data().get());
     (void)hipDeviceSynchronize();
@@ -241,10 +241,10 @@ static void check_coo(size_t m, size_t n, size_t k, size_t b) {
       for (auto& x : sc) x *= 1.0 + 1.02 * std::ldexp(1.0, -11) / (2.0 * k * std::ldexp(1.0, -24));  // + 1.02 * 2^-11 * scale on top of the fp32 terms
     const bool ok = close_enough(to_host(dC), ref, sc, std::ldexp(1.0, -22), k, detail);
     char what[128];
-    std::snprintf(what, sizeof(what), "batched::strided_coo<float> (%s) %zux%zux%zu b=%zu nnz=%zu vs oracle", exact ? "exact" : "default", m, n, k, b, nnz);
+    std::snprintf(what, sizeof(what), "batched::strided_coo<float> (%s) %zux%zux%zu b=%zu nnz=%zu vs oracle", exact ? "default: exact fp32" : "opt-in fast form", m, n, k, b, nnz);
     verdict(what, ok, false, detail);
   }
-  batched::strided_coo_options().exact = false;
+  batched::strided_coo_options().fast = false;
 }
 
 // spmma<type_t>(): TILE prune in place + check + compress + multiply; (N, N) and (T, N): the in-place pruned A must be the

@@ -889,6 +889,36 @@ def test_f32_split_per_batch_b_and_alpha_beta(gpu, dense, planes):
     assert float((err / bound).max()) <= 1.0
 
 
+@pytest.mark.parametrize("dense", [False, True], ids=["2to4", "dense"])
+@pytest.mark.parametrize("planes", [3, 2])
+@pytest.mark.parametrize("k", [64, 192])
+def test_f32_split_cols_last_stage_waits_for_its_own_b(gpu, dense, planes, k):
+    """The column-loop form (128 < n <= 256) on its LAST K stage: no A(kt + 1) follows B(kt, 1), so the counted wait in front of
+    the second 128-column half must drain everything (with vmcnt(SLA) the sweep could read B's second half before
+    it landed).  One K stage / three, a B per batch entry large enough (48 - 144 MiB of planes) not to sit in L2, many workgroups,
+    small-integer data: C[:, 128:256] must equal the exact fp32 kernel's bit for bit, ten times over."""
+    import torch
+    m, n, batch = 256, 256, 512
+    rng = np.random.default_rng(k + planes + 7 * dense)
+    A = rand(rng, batch * m * k, np.float32, "ties")
+    B = rand(rng, batch * k * n, np.float32, "ties")
+    dA, dB = to_dev(A), to_dev(B)
+    P = dA
+    if not dense:
+        P = dA.clone()
+        gpu.prune24(P, P, batch * m, k, k, gpu.PRUNE_STRIP)
+    Ce = torch.zeros(batch * m * n, dtype=torch.float32, device="cuda")
+    for i in range(batch):   # the exact dense fp32 kernel, a B per batch entry
+        gpu.gemm_rowmajor(P[i * m * k:(i + 1) * m * k], dB[i * k * n:(i + 1) * k * n], Ce[i * m * n:(i + 1) * m * n], m, n, k)
+    ws = torch.empty(gpu.spmma_fused_f32_split_workspace(n, k, batch=batch, strideB=k * n, planes=planes), dtype=torch.uint8, device="cuda")
+    flush = torch.empty(512 << 20, dtype=torch.uint8, device="cuda")
+    for rep in range(10):
+        C = torch.full((batch * m * n,), float("nan"), dtype=torch.float32, device="cuda")
+        flush.fill_(rep)   # push B's planes of the previous repetition out of the caches
+        gpu.spmma_fused_f32_split(dA, dB, C, m, n, k, ws, batch=batch, strideB=k * n, planes=planes, dense=dense)
+        assert torch.equal(C.view(torch.int32), Ce.view(torch.int32)), f"repetition {rep}: the split form differs from the exact kernel"
+
+
 def test_spmma_f32_split_edges(gpu):
     """What the split form declines, and what a non-finite operand value does: it stays in the first piece, so the outputs it
     reaches are non-finite (NaN where the exact form may say inf: inf meets a zero low piece) and every other output is untouched."""
@@ -2221,6 +2251,7 @@ CONV_CASES = [  # N, Cin, H, W, kh, kw, stride, pad, dil, n_out
     (1, 64, 30, 30, 7, 7, 2, 3, 1, 64),      # 49 phases, stride 2
     (3, 64, 6, 6, 3, 3, 1, 1, 1, 64),        # L = 36 < 128
     (1, 64, 10, 12, 3, 3, 1, 0, 1, 64),      # no padding, H != W
+    (1, 64, 56, 8, 7, 1, 2, 0, 1, 64),       # a narrow image whose stage plan exceeds the 16-byte form's 16 DMA instructions (18): the 4-byte form runs it
 ]
 
 
@@ -2315,8 +2346,11 @@ def test_conv_spmma_routes_agree(gpu, geom):
     want = torch.zeros(N * L * n_out, dtype=torch.float16, device="cuda")
     gpu.spmma(blob, dB, want, L, n_out, K, N, 0)
     need = gpu.conv_spmma_workspace(N, Cin, H, W, kh, kw, 1, pad, 1)
-    assert (need > 0) == (L <= 256 and K >= 2048)
-    ws = torch.empty(max(need, gpu.compress24_size(L, K, 2, N)), dtype=torch.uint8, device="cuda")
+    # the blob's size where the rule prefers the pair AND where the implicit kernel cannot run the geometry, else 0
+    assert (need > 0) == ((L <= 256 and K >= 2048) or K % 64 != 0)
+    if need:
+        assert need == gpu.compress24_size(L, K, 2, N)
+    ws = torch.empty(need or gpu.compress24_size(L, K, 2, N), dtype=torch.uint8, device="cuda")
     got = torch.full_like(want, 3.0)
     gpu.conv_spmma(dX, dB, got, N, Cin, H, W, kh, kw, 1, pad, 1, n_out, workspace=ws)
     assert torch.equal(got.view(torch.int16), want.view(torch.int16))
