@@ -34,6 +34,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+GUIDE_COPY_GBS = 6290.0    # the same guide, line 36: a float4 device copy measured at 6.29 TB/s (79 % of the specification)
 F32_MATRIX_PEAK_TFS = 157.3  # same guide: v_mfma_f32_16x16x4_f32, 64 FLOP/clk/SIMD
 
 
@@ -52,11 +53,14 @@ def table_path(name):
     return p
 
 
-def file_tag(path):
-    """provenance of a replayed (not measured-in-this-run) profile file: relative path + content hash"""
+def file_tag(path, measured_on=None, loaded=None):
+    """provenance of a replayed (not measured-in-this-run) profile file: relative path + content hash, the library it was
+    measured on (tools/pmc_*.py record it) and whether that is the library THIS process loaded: `stale` = it is not (or the
+    file does not say), and the caller then drops the replayed numbers instead of reporting another build's counters"""
     with open(path, "rb") as fh:
         return {"file": os.path.relpath(path, ROOT), "sha256_12": hashlib.sha256(fh.read()).hexdigest()[:12],
-                "measured_in_this_run": False,
+                "measured_in_this_run": False, "measured_on_library_sha256_16": measured_on, "loaded_library_sha256_16": loaded,
+                "stale": (measured_on is None) or (measured_on != loaded),
                 "how": "rocprofv3 --pmc passes of an earlier run of the same step (tools/pmc_traffic.py, tools/pmc_mfma.py); "
                        "the committed file is replayed here, the counters are not collected by bench.py itself"}
 
@@ -99,6 +103,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--streamk", choices=["on", "off"], default="on",
+                    help="give the grouped fused launches a workspace (sm_spmma_fused_*_grouped_ws): the library then runs the stream-K form "
+                         "on the shapes its rule names (round 5); off = the round-4 launches")
     ap.add_argument("--settle-ms", type=float, default=300.0,
                     help="setup, before the W warm-up steps: untimed replays of the step for this long (clock ramp after an idle "
                          "GPU, first-use state of a fresh graph); 0 = none.  Stated in config.launch")
@@ -316,9 +323,23 @@ def main():
             g.setdefault((L["m"], L["n"], L["k"], L["b"]), []).append(L)
         return list(g.items())
 
+    sk_ws = {}   # shape -> the stream-K workspace of that shape's grouped launches (one per work item: items run concurrently)
+
+    def sk_takes(L0, cnt):
+        """does the library run the stream-K form on a grouped launch of `cnt` instances of L0's shape? (its own rule, asked through
+        sm_spmma_fused_streamk_plan -- nothing is mirrored here)"""
+        if f32 or args.streamk != "on" or L0["k"] % 64 != 0 or L0["n"] <= 128:
+            return False
+        return sm.spmma_fused_streamk_plan(L0["m"] * L0["b"], L0["n"], L0["k"], cnt)[0]
+
     def run_group(Ls):
         L0 = Ls[0]
-        sm.spmma_fused_grouped([L["A"] for L in Ls], [L["B"] for L in Ls], [L["C"] for L in Ls], L0["m"], L0["n"], L0["k"], batch=L0["b"])
+        key = (L0["m"], L0["n"], L0["k"], L0["b"])
+        if key not in sk_ws:   # decided once per shape, at the first (untimed) call
+            chunks = {min(8, len(Ls) - i) for i in range(0, len(Ls), 8)}
+            sk_ws[key] = sm.spmma_fused_workspace() if any(sk_takes(L0, c) for c in chunks) else None
+        sm.spmma_fused_grouped([L["A"] for L in Ls], [L["B"] for L in Ls], [L["C"] for L in Ls], L0["m"], L0["n"], L0["k"], batch=L0["b"],
+                               workspace=sk_ws[key])
 
     grouped = args.group == "on" and not f32
 
@@ -494,17 +515,36 @@ def main():
         for L in layers:
             if not use_fused(L):
                 continue
-            fam = fused_variant(L["n"], L["k"], L["m"], L["b"],
-                                min(8, sum(1 for X in layers if (X["m"], X["n"], X["k"], X["b"]) == (L["m"], L["n"], L["k"], L["b"]))) if args.group == "on" else 1)
+            cnt_ = min(8, sum(1 for X in layers if (X["m"], X["n"], X["k"], X["b"]) == (L["m"], L["n"], L["k"], L["b"]))) if args.group == "on" else 1
+            fam = fused_variant(L["n"], L["k"], L["m"], L["b"], cnt_)
+            if grouped and sk_ws.get((L["m"], L["n"], L["k"], L["b"])) is not None and sk_takes(L, cnt_):
+                fam = "sk"
             if fam in seen:
                 continue
             seen.add(fam)
             Cref = torch.empty_like(L["C"])
             sm.compress24(L["A"], L["m"], L["k"], L["k"], L["b"], L["m"] * L["k"], L["blob"])
             sm.spmma(L["blob"], L["B"], Cref, L["m"], L["n"], L["k"], L["b"], 0)
-            same = bool(torch.equal(Cref.view(torch.int16), L["C"].view(torch.int16)))
+            if fam == "sk":
+                # the stream-K form: the tiles its plan cuts are sums of fp32 partials in a fixed order -- equal to compress + spmma to
+                # one fp16 rounding of the result (+ the few fp32 re-associations); every row panel the plan leaves whole: bit for bit
+                _, plan = sm.spmma_fused_streamk_plan(L["m"] * L["b"], L["n"], L["k"], cnt_)
+                M_, nkt_ = L["m"] * L["b"], L["k"] // 64
+                tm_ = (M_ + 255) // 256
+                inst = [X for X in layers if (X["m"], X["n"], X["k"], X["b"]) == (L["m"], L["n"], L["k"], L["b"])].index(L) % 8
+                whole = [t - inst * tm_ for t in sm.streamk_whole_panels(plan, cnt_ * tm_, nkt_) if inst * tm_ <= t < (inst + 1) * tm_]
+                a_, b_ = Cref.view(M_, L["n"]), L["C"].view(M_, L["n"])
+                same_whole = all(bool(torch.equal(a_[t * 256:(t + 1) * 256].view(torch.int16), b_[t * 256:(t + 1) * 256].view(torch.int16))) for t in whole)
+                af, bf_ = a_.float(), b_.float()
+                rel = float(((af - bf_).abs() / torch.maximum(af.abs(), bf_.abs()).clamp_min(2.0 ** -14)).max().item())
+                same = same_whole and rel <= 2.0 ** -9   # two neighbouring fp16 values of the larger magnitude differ by at most 2^-10 of it
+                checked.append({"family": fam, "m": L["m"], "n": L["n"], "k": L["k"], "b": L["b"], "whole_row_panels": len(whole),
+                                "whole_panels_bit_identical_to_compress_plus_spmma": same_whole,
+                                "cut_tiles_max_relative_difference": rel, "within_one_fp16_rounding": rel <= 2.0 ** -9})
+            else:
+                same = bool(torch.equal(Cref.view(torch.int16), L["C"].view(torch.int16)))
+                checked.append({"family": fam, "m": L["m"], "n": L["n"], "k": L["k"], "b": L["b"], "bit_identical_to_compress_plus_spmma": same})
             ok = ok and same
-            checked.append({"family": fam, "m": L["m"], "n": L["n"], "k": L["k"], "b": L["b"], "bit_identical_to_compress_plus_spmma": same})
             del Cref
         out["verified"] = ok
         out["verified_layers"] = checked
@@ -515,7 +555,7 @@ def main():
         out["emulated"] = {"world": plan_world, "rank": plan_rank, "units": len(units), "dense_equiv_gflop_per_step": flops / 1e9}
     if rank == 0 and not args.no_extras:
         extras(args, sm, torch, dev, layers, flops, wall / args.steps, Forked, make_runner, timed, event_seconds, use_fused, out,
-               (fused_groups, run_group, spread, ForkedItems) if grouped else None, step_full)
+               (fused_groups, run_group, spread, ForkedItems, sk_takes) if grouped else None, step_full)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(ge, shapes)
@@ -642,8 +682,9 @@ def extras(args, sm, torch, dev, layers, flops, t_full, Forked, make_runner, tim
     # (C^T = B^T A^T: the same kernel, sm_gemm_batched_* maps it back), so a group is one call with `count` pointer triples.
     t_drm_grouped = None
     if grouping and has_batched:
-        fused_groups, _, spread, ForkedItems = grouping
+        fused_groups, _, spread, ForkedItems = grouping[:4]
         ditems = []
+        dense_ws = {}   # the dense twin gets the stream-K workspace too (sm_gemm_batched_f16_ws): the library's rule decides, as for the 2:4 launches
         for _, Ls in fused_groups(layers):
             if len(Ls) == 1:
                 ditems.append(("single", Ls))
@@ -656,13 +697,16 @@ def extras(args, sm, torch, dev, layers, flops, t_full, Forked, make_runner, tim
 
         def dense_group(Ls):
             L0 = Ls[0]
-            sm.gemm_batched(L0["gBp"], L0["gAp"], L0["gCp"], L0["n"], L0["m"] * L0["b"], L0["k"], len(Ls), args.dtype)
+            key = (L0["m"], L0["n"], L0["k"])
+            if key not in dense_ws:
+                dense_ws[key] = sm.spmma_fused_workspace() if (args.streamk == "on" and args.dtype == "f16" and 128 < L0["n"] <= 256 and L0["k"] >= 2048) else None
+            sm.gemm_batched(L0["gBp"], L0["gAp"], L0["gCp"], L0["n"], L0["m"] * L0["b"], L0["k"], len(Ls), args.dtype, workspace=dense_ws[key])
         t_drm_grouped = sec_per_call(ForkedItems(spread(ditems), dense_group,
                                                  lambda L: sm.gemm_rowmajor(L["A"], L["B"], L["C"], L["m"], L["n"], L["k"], batch=L["b"])))
     # the 2:4 matmul on prepared blobs given the same treatment (round 4: sm_spmma_*_grouped, one grid per <= 8 same-shape blobs)
     t_mul_grouped = None
     if grouping and not f32 and hasattr(sm, "spmma_grouped"):
-        fused_groups, _, spread, ForkedItems = grouping
+        fused_groups, _, spread, ForkedItems = grouping[:4]
         mitems = [("group" if len(Ls) > 1 else "single", Ls) for _, Ls in fused_groups(layers)]
 
         def mul_group(Ls):
@@ -813,8 +857,10 @@ def extras(args, sm, torch, dev, layers, flops, t_full, Forked, make_runner, tim
         mpath = os.path.join(ROOT, "profiles", "mfma_util_latest.json")  # tools/pmc_mfma.py, from a rocprofv3 --pmc pass
         if os.path.exists(mpath):
             try:
-                mfma["pmc_mfma_util_percent"] = {k: round(v["mfma_util_percent"], 2) for k, v in json.load(open(mpath)).items()}
-                mfma["pmc_source"] = file_tag(mpath)
+                mtab = json.load(open(mpath))
+                mfma["pmc_source"] = file_tag(mpath, (mtab.get("_library") or {}).get("sha256_16"), out["config"]["library"]["sha256_16"])
+                if not mfma["pmc_source"]["stale"]:   # counters of another build are not this build's utilisation
+                    mfma["pmc_mfma_util_percent"] = {k: round(v["mfma_util_percent"], 2) for k, v in mtab.items() if not k.startswith("_")}
             except Exception:
                 pass
         out["stages"]["matmul_mfma"] = mfma
@@ -848,8 +894,10 @@ def extras(args, sm, torch, dev, layers, flops, t_full, Forked, make_runner, tim
 
         def variant_of(L):  # the kernel the timed step's (grouped) launch of this layer's shape runs
             cnt = min(8, shape_count[(L["m"], L["n"], L["k"], L["b"])]) if grouping else 1
+            if grouping and grouping[4](L, cnt):   # the library's own rule (sm_spmma_fused_streamk_plan): the stream-K form
+                return "sk"
             return fused_variant(L["n"], L["k"], L["m"], L["b"], cnt)
-        for var in ("direct", "big", "wide", "astat", "span"):
+        for var in ("direct", "big", "wide", "astat", "span", "sk"):
             fam["spmma_f16_fused_" + var] = dict(names=["spmma_f16_fused_%s_kernel" % var] + (["spmma_f16_fused_widep_kernel"] if var == "wide" else []),
                                                  layers=[L for L in layers if use_fused(L) and variant_of(L) == var],
                                                  call=lambda L: sm.spmma_fused(L["A"], L["B"], L["C"], L["m"], L["n"], L["k"], batch=L["b"]),
@@ -859,7 +907,9 @@ def extras(args, sm, torch, dev, layers, flops, t_full, Forked, make_runner, tim
     if os.path.exists(tpath):
         try:
             traffic_tab = json.load(open(tpath))
-            tsrc = file_tag(tpath)
+            tsrc = file_tag(tpath, (traffic_tab.get("_library") or {}).get("sha256_16"), out["config"]["library"]["sha256_16"])
+            if tsrc["stale"]:   # measured on another build of the library: not replayed (roofline.traffic stays null, the tag says why)
+                traffic_tab = {}
         except Exception:
             traffic_tab = {}
     rows = {}
@@ -900,7 +950,7 @@ def extras(args, sm, torch, dev, layers, flops, t_full, Forked, make_runner, tim
         domf = max((n_ for n_ in rows if n_.startswith("spmma_f32")), key=lambda n_: rows[n_]["seconds"])
         r_ = rows[domf]
         out["roofline"] = {"bound": "mfma", "achieved": r_["TFs"], "peak": F32_MATRIX_PEAK_TFS, "unit": "TFLOP/s",
-                           "frac": r_["TFs"] / F32_MATRIX_PEAK_TFS, "traffic": r_["traffic"], "traffic_source": tsrc if r_["traffic"] is not None else None,
+                           "frac": r_["TFs"] / F32_MATRIX_PEAK_TFS, "traffic": r_["traffic"], "traffic_source": tsrc if (r_["traffic"] is not None or (tsrc and tsrc["stale"])) else None,
                            "kernel": domf,
                            "launches_per_step": r_["launches"], "avg_launch_us": r_["seconds"] / r_["launches"] * 1e6,
                            "algorithmic_flops_per_launch": r_["TFs"] * 1e12 * r_["seconds"] / r_["launches"],
@@ -919,17 +969,20 @@ def extras(args, sm, torch, dev, layers, flops, t_full, Forked, make_runner, tim
         copy_GBs = 2.0 * half / t_copy / 1e9
         del ysrc, ydst
         out["roofline"] = {"bound": "hbm", "achieved": GBs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": GBs / HBM_PEAK_GBS, "traffic": d["traffic"], "traffic_source": tsrc if d["traffic"] is not None else None,
+                           "frac": GBs / HBM_PEAK_GBS, "traffic": d["traffic"], "traffic_source": tsrc if (d["traffic"] is not None or (tsrc and tsrc["stale"])) else None,
                            "kernel": dom, "launches_per_step": d["launches"], "avg_launch_us": d["seconds"] / d["launches"] * 1e6,
                            "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],
                            "measured": "single stream, one kernel family at a time, HIP events on the launch stream, hipGraph replay",
                            "yardstick": {"device_copy_GBs": copy_GBs, "frac_of_device_copy": GBs / copy_GBs,
+                                         "guide_float4_copy_GBs": GUIDE_COPY_GBS, "frac_of_guide_copy": GBs / GUIDE_COPY_GBS,
+                                         "step_frac_of_guide_copy": step_bytes / t_full / 1e9 / GUIDE_COPY_GBS,
                                          "copy_bytes": 2 * half, "copy_ms": t_copy * 1e3,
                                          "step_algorithmic_bytes": step_bytes, "step_GBs": step_bytes / t_full / 1e9,
                                          "step_frac_of_device_copy": step_bytes / t_full / 1e9 / copy_GBs,
                                          "source": "measured in this run: sm_copy_bytes (16-byte streaming copy kernel of libsparsifyme.so) over the "
-                                                   "timed step's own algorithmic byte count, half read + half written; context only -- `frac` is "
-                                                   "against the 8 TB/s specification"},
+                                                   "timed step's own algorithmic byte count, half read + half written; guide_float4_copy_GBs = the float4 copy "
+                                                   "/opt/skills/guides/MI355X_MICROARCH.md:36 measures (6.29 TB/s), the stricter of the two yardsticks; context "
+                                                   "only -- `frac` is against the 8 TB/s specification"},
                            "families": fams_out}
 
 

@@ -171,6 +171,43 @@ int sm_spmma_fused_bf16_grouped(size_t count, const void* const* A, const void* 
                                 size_t k, size_t lda, size_t batch, size_t strideA, size_t strideB, size_t strideC,
                                 float alpha, float beta, sm_stream_t stream);
 
+/* The fused entry points with a WORKSPACE (extension, round 5): the library may then run the STREAM-K form of the fused kernel on
+ * the shapes whose rounds of whole 256 x 256 tiles leave compute units idle (few row tiles, long K: 196 x 512 x 4608, 784 x 512 x 1024
+ * at batch 32): the launch's 64-deep stage units are cut into one equal contiguous range per compute unit, a tile that lies inside one
+ * range is computed and stored exactly as without a workspace (bit-identical), a tile cut by range borders is the sum of fp32 partial
+ * sums added IN A FIXED ORDER (ascending k) by the workgroup that holds its first stages -- no atomics on data: repeated runs give
+ * the same bits, and the result differs from the no-workspace result only in the order of those few fp32 additions (both within the
+ * fp32-accumulation bound of the exact product).  Every other shape runs exactly as sm_spmma_fused_* does.
+ * workspace: sm_spmma_fused_workspace_size bytes (4 KiB of flags + one 256 KiB slot per compute unit), 16-byte aligned, its first 4 KiB
+ * ZERO before the first call; every call leaves them zero again (hipGraph replays need no memset; a non-zero word 1023 afterwards
+ * means a fix-up wait gave up after ~0.3 s and the result is invalid -- it cannot happen with a zeroed flag page and one call at a time per workspace).  Calls that may run concurrently
+ * (different streams) need a workspace each; the grouped form's launches share one.  Nothing is allocated or synchronised inside. */
+int sm_spmma_fused_workspace_size(size_t* bytes);
+/* What the workspace entry points do with `problems` same-shape problems of `rows` x n x k (rows = m * batch when the batches share B
+ * and are stacked): *takes = 1 when they run the stream-K form, and the decomposition in plan[0 .. 24]: tg, wg, groups_full, tgl,
+ * wgl, slots, longest slot range (stage units), cut[0 .. 8], cutl[0 .. 8] -- row panels (256 rows of a problem, in problem order) x
+ * k / 64 stage units, groups of tg panels cut into wg slot ranges at cut[] (the last group: tgl panels, wgl slots, cutl[]); a tile
+ * that lies inside one slot range is bit-identical to the no-workspace result.  For tests, bench.py and schedulers; no device work. */
+int sm_spmma_fused_streamk_plan(size_t rows, size_t n, size_t k, size_t problems, int* takes, unsigned* plan);
+/* The dense entry points with the same workspace: the dense twin of the stream-K form (the dense GEMM the 2:4 path is measured
+ * against gets the tile economy the 2:4 path gets); same workspace contract, same bit-identity statement for uncut tiles. */
+int sm_gemm_rowmajor_f16_ws(const void* A, const void* B, void* C, size_t m, size_t n, size_t k, size_t lda, size_t batch, size_t strideA,
+                            size_t strideB, size_t strideC, float alpha, float beta, void* workspace, size_t workspace_bytes, sm_stream_t stream);
+int sm_gemm_rowmajor_bf16_ws(const void* A, const void* B, void* C, size_t m, size_t n, size_t k, size_t lda, size_t batch, size_t strideA,
+                             size_t strideB, size_t strideC, float alpha, float beta, void* workspace, size_t workspace_bytes, sm_stream_t stream);
+int sm_gemm_batched_f16_ws(const void* const* A_ptrs, const void* const* B_ptrs, void* const* C_ptrs, size_t m, size_t n, size_t k, size_t batch,
+                           int transpose_a, int transpose_b, float alpha, float beta, void* workspace, size_t workspace_bytes, sm_stream_t stream);
+int sm_spmma_fused_f16_ws(const void* A, const void* B, void* C, size_t m, size_t n, size_t k, size_t lda, size_t batch, size_t strideA,
+                          size_t strideB, size_t strideC, float alpha, float beta, void* workspace, size_t workspace_bytes, sm_stream_t stream);
+int sm_spmma_fused_bf16_ws(const void* A, const void* B, void* C, size_t m, size_t n, size_t k, size_t lda, size_t batch, size_t strideA,
+                           size_t strideB, size_t strideC, float alpha, float beta, void* workspace, size_t workspace_bytes, sm_stream_t stream);
+int sm_spmma_fused_f16_grouped_ws(size_t count, const void* const* A, const void* const* B, void* const* C, size_t m, size_t n,
+                                  size_t k, size_t lda, size_t batch, size_t strideA, size_t strideB, size_t strideC,
+                                  float alpha, float beta, void* workspace, size_t workspace_bytes, sm_stream_t stream);
+int sm_spmma_fused_bf16_grouped_ws(size_t count, const void* const* A, const void* const* B, void* const* C, size_t m, size_t n,
+                                   size_t k, size_t lda, size_t batch, size_t strideA, size_t strideB, size_t strideC,
+                                   float alpha, float beta, void* workspace, size_t workspace_bytes, sm_stream_t stream);
+
 /* fp32 form: the STRIP rule applied to the A fragments in registers of the dense fp32 MFMA kernel (there is no fp32 sparse
  * matrix instruction).  Equals sm_gemm_rowmajor_f32 of the STRIP-pruned A bit for bit; agrees with sm_compress24_f32 +
  * sm_spmma_f32 to fp32 accumulation order.  Needs k % 32 == 0, n % 4 == 0, 16-byte aligned rows. */

@@ -120,6 +120,15 @@ _SIGS["sm_spmma_i8_q"] = [_c_ptr, _c_ptr, _c_ptr, _c_size, _c_size, _c_size, _c_
 for _name in ("sm_prune24", "sm_prune24_check", "sm_compress24", "sm_decompress24", "sm_spmma", "sm_spmma_fused",
               "sm_gemm_rowmajor", "sm_fill_uniform", "sm_im2col", "sm_im2col_compress24"):
     _SIGS[_name + "_bf16"] = _SIGS[_name + "_f16"]
+_SIGS["sm_spmma_fused_workspace_size"] = [ctypes.POINTER(_c_size)]
+_SIGS["sm_spmma_fused_streamk_plan"] = [_c_size, _c_size, _c_size, _c_size, ctypes.POINTER(_c_i), ctypes.POINTER(ctypes.c_uint)]
+_SIGS["sm_gemm_rowmajor_f16_ws"] = [_c_ptr, _c_ptr, _c_ptr] + [_c_size] * 8 + [_c_f, _c_f, _c_ptr, _c_size, _c_ptr]
+_SIGS["sm_gemm_rowmajor_bf16_ws"] = _SIGS["sm_gemm_rowmajor_f16_ws"]
+_SIGS["sm_gemm_batched_f16_ws"] = [_c_ptr, _c_ptr, _c_ptr, _c_size, _c_size, _c_size, _c_size, _c_i, _c_i, _c_f, _c_f, _c_ptr, _c_size, _c_ptr]
+_SIGS["sm_spmma_fused_f16_ws"] = [_c_ptr, _c_ptr, _c_ptr] + [_c_size] * 8 + [_c_f, _c_f, _c_ptr, _c_size, _c_ptr]
+_SIGS["sm_spmma_fused_bf16_ws"] = _SIGS["sm_spmma_fused_f16_ws"]
+_SIGS["sm_spmma_fused_f16_grouped_ws"] = [_c_size, _c_ptr, _c_ptr, _c_ptr] + [_c_size] * 8 + [_c_f, _c_f, _c_ptr, _c_size, _c_ptr]
+_SIGS["sm_spmma_fused_bf16_grouped_ws"] = _SIGS["sm_spmma_fused_f16_grouped_ws"]
 _RET = {"sm_version": ctypes.c_char_p, "sm_last_error": ctypes.c_char_p}
 
 # every symbol include/sparsifyme.h declares (checked by tests/test_abi.py without a GPU)
@@ -341,11 +350,48 @@ def spmma_i8_q(blob, B, C, m, n, k, scale, batch=1, strideB=0, strideC=None):
            "sm_spmma_i8_q")
 
 
-def spmma_fused(A, B, C, m, n, k, lda=None, batch=1, strideA=None, strideB=0, strideC=None, alpha=1.0, beta=0.0):
-    """Fused prune(STRIP) + compress + 2:4 matmul straight from the dense A (no blob)."""
+def spmma_fused_workspace_size():
+    out = _c_size(0)
+    _check(lib().sm_spmma_fused_workspace_size(ctypes.byref(out)), "sm_spmma_fused_workspace_size")
+    return out.value
+
+
+def spmma_fused_streamk_plan(rows, n, k, problems=1):
+    """(takes, plan): whether the workspace entry points run the stream-K form on `problems` problems of rows x n x k, and its
+    decomposition as a dict (tg, wg, groups_full, tgl, wgl, slots, units, cut, cutl) -- sm_spmma_fused_streamk_plan."""
+    takes = _c_i(0)
+    buf = (ctypes.c_uint * 32)()
+    _check(lib().sm_spmma_fused_streamk_plan(rows, n, k, problems, ctypes.byref(takes), buf), "sm_spmma_fused_streamk_plan")
+    v = list(buf)
+    return bool(takes.value), dict(tg=v[0], wg=v[1], groups_full=v[2], tgl=v[3], wgl=v[4], slots=v[5], units=v[6], cut=v[7:16], cutl=v[16:25])
+
+
+def streamk_whole_panels(plan, panels, nkt):
+    """The row panels (0 .. panels - 1) that lie inside ONE slot range of `plan` (their tiles equal the no-workspace result bit for bit)."""
+    cuts = set()
+    for g in range(plan["groups_full"]):
+        cuts.update(g * plan["tg"] * nkt + c for c in plan["cut"][:plan["wg"] + 1])
+    base = plan["groups_full"] * plan["tg"] * nkt
+    cuts.update(base + c for c in plan["cutl"][:plan["wgl"] + 1])
+    return [t for t in range(panels) if not any(t * nkt < u < (t + 1) * nkt for u in cuts)]
+
+
+def spmma_fused_workspace():
+    """A zeroed workspace for the `workspace=` argument of spmma_fused / spmma_fused_grouped (the stream-K form; one per concurrent call)."""
+    return _t().zeros(spmma_fused_workspace_size(), dtype=_t().uint8, device="cuda")
+
+
+def spmma_fused(A, B, C, m, n, k, lda=None, batch=1, strideA=None, strideB=0, strideC=None, alpha=1.0, beta=0.0, workspace=None):
+    """Fused prune(STRIP) + compress + 2:4 matmul straight from the dense A (no blob).  workspace (spmma_fused_workspace()): the
+    library may run the stream-K form where whole-tile rounds leave CUs idle."""
     lda = k if lda is None else lda
     strideA = m * lda if strideA is None else strideA
     strideC = m * n if strideC is None else strideC
+    if workspace is not None:
+        fn = getattr(lib(), "sm_spmma_fused_%s_ws" % _sfx(A))
+        _check(fn(_dev(A), _dev(B), _dev(C), m, n, k, lda, batch, strideA, strideB, strideC, float(alpha), float(beta), _dev(workspace),
+                  workspace.numel() * workspace.element_size(), _stream()), "sm_spmma_fused_ws")
+        return
     fn = getattr(lib(), "sm_spmma_fused_" + _sfx(A))
     _check(fn(_dev(A), _dev(B), _dev(C), m, n, k, lda, batch, strideA, strideB, strideC, float(alpha), float(beta), _stream()),
            "sm_spmma_fused")
@@ -391,7 +437,7 @@ def _ptr_table(tensors):
     return arr
 
 
-def spmma_fused_grouped(As, Bs, Cs, m, n, k, lda=None, batch=1, strideA=None, strideB=0, strideC=None, alpha=1.0, beta=0.0):
+def spmma_fused_grouped(As, Bs, Cs, m, n, k, lda=None, batch=1, strideA=None, strideB=0, strideC=None, alpha=1.0, beta=0.0, workspace=None):
     """len(As) same-shape problems in one grid per 8 (sm_spmma_fused_*_grouped): the same C as len(As) spmma_fused calls."""
     if not (len(As) == len(Bs) == len(Cs)):
         raise SparsifymeError("spmma_fused_grouped: operand lists differ in length")
@@ -400,6 +446,11 @@ def spmma_fused_grouped(As, Bs, Cs, m, n, k, lda=None, batch=1, strideA=None, st
     lda = k if lda is None else lda
     strideA = m * lda if strideA is None else strideA
     strideC = m * n if strideC is None else strideC
+    if workspace is not None:
+        fn = getattr(lib(), "sm_spmma_fused_%s_grouped_ws" % _sfx(As[0]))
+        _check(fn(len(As), _ptr_table(As), _ptr_table(Bs), _ptr_table(Cs), m, n, k, lda, batch, strideA, strideB, strideC,
+                  float(alpha), float(beta), _dev(workspace), workspace.numel() * workspace.element_size(), _stream()), "sm_spmma_fused_grouped_ws")
+        return
     fn = getattr(lib(), "sm_spmma_fused_%s_grouped" % _sfx(As[0]))
     _check(fn(len(As), _ptr_table(As), _ptr_table(Bs), _ptr_table(Cs), m, n, k, lda, batch, strideA, strideB, strideC,
               float(alpha), float(beta), _stream()), "sm_spmma_fused_grouped")
@@ -448,17 +499,26 @@ def conv_spmma(X, B, C, N, Cin, H, W, kh, kw, stride, pad, dilation, n_out, work
               _dev(workspace) if workspace is not None else None, wb, _stream()), "sm_conv_spmma")
 
 
-def gemm_batched(A_ptrs, B_ptrs, C_ptrs, m, n, k, batch, dtype_suffix, alpha=1.0, beta=0.0, ta=0, tb=0):
+def gemm_batched(A_ptrs, B_ptrs, C_ptrs, m, n, k, batch, dtype_suffix, alpha=1.0, beta=0.0, ta=0, tb=0, workspace=None):
     """sparsifyme::batched::gemm (gemm.hxx:25-36): column-major, device pointer arrays (int64 tensors)."""
+    if workspace is not None and dtype_suffix == "f16":
+        _check(lib().sm_gemm_batched_f16_ws(_dev(A_ptrs), _dev(B_ptrs), _dev(C_ptrs), m, n, k, batch, ta, tb, alpha, beta, _dev(workspace),
+                                            workspace.numel() * workspace.element_size(), _stream()), "sm_gemm_batched_ws")
+        return
     fn = getattr(lib(), "sm_gemm_batched_" + dtype_suffix)
     _check(fn(_dev(A_ptrs), _dev(B_ptrs), _dev(C_ptrs), m, n, k, batch, ta, tb, alpha, beta, _stream()),
            "sm_gemm_batched")
 
 
-def gemm_rowmajor(A, B, C, m, n, k, lda=None, batch=1, strideA=None, strideB=0, strideC=None, alpha=1.0, beta=0.0):
+def gemm_rowmajor(A, B, C, m, n, k, lda=None, batch=1, strideA=None, strideB=0, strideC=None, alpha=1.0, beta=0.0, workspace=None):
     lda = k if lda is None else lda
     strideA = m * lda if strideA is None else strideA
     strideC = m * n if strideC is None else strideC
+    if workspace is not None and _sfx(A) in ("f16", "bf16"):
+        fn = getattr(lib(), "sm_gemm_rowmajor_%s_ws" % _sfx(A))
+        _check(fn(_dev(A), _dev(B), _dev(C), m, n, k, lda, batch, strideA, strideB, strideC, float(alpha), float(beta), _dev(workspace),
+                  workspace.numel() * workspace.element_size(), _stream()), "sm_gemm_rowmajor_ws")
+        return
     fn = getattr(lib(), "sm_gemm_rowmajor_" + _sfx(A))
     _check(fn(_dev(A), _dev(B), _dev(C), m, n, k, lda, batch, strideA, strideB, strideC, float(alpha), float(beta),
               _stream()), "sm_gemm_rowmajor")

@@ -517,7 +517,7 @@ static int launch_cfg(const GemmArgs& a0, int vec, hipStream_t st) {
 // Tile choice: the streamed dimension gets the long tile edge; narrow problems get a tile as wide
 // as they are, so the big operand is read from HBM exactly once.
 template <bool BF = false>
-static int launch_gemm_f16(const GemmArgs& a, hipStream_t st, bool ta = false, bool tb = false) {
+static int launch_gemm_f16(const GemmArgs& a, hipStream_t st, bool ta = false, bool tb = false, void* workspace = nullptr, size_t workspace_bytes = 0) {
   auto aligned_to = [&](unsigned halves) {
     const uintptr_t mask = halves * 2u - 1u;
     return (a.lda % halves == 0) && (a.ldb % halves == 0) && (a.sA % halves == 0) && (a.sB % halves == 0) &&
@@ -534,7 +534,7 @@ static int launch_gemm_f16(const GemmArgs& a, hipStream_t st, bool ta = false, b
   if (a.ldb == a.N && a.ldc == a.N && a.M > 0) {
     const int twin_mode = tuning_int("SM_GEMM_TWIN", 1);
     if (twin_mode > 0) {
-      DenseTwinCall c = {a.A, a.B, a.C, a.Ap, a.Bp, a.Cp, a.sA, a.sB, a.sC, a.M, a.N, a.K, a.lda, a.batch, a.alpha, a.beta, BF, twin_mode};
+      DenseTwinCall c = {a.A, a.B, a.C, a.Ap, a.Bp, a.Cp, a.sA, a.sB, a.sC, a.M, a.N, a.K, a.lda, a.batch, a.alpha, a.beta, BF, twin_mode, workspace, workspace_bytes};
       const int rc = gemm_dense_twin(c, st);
       if (rc != SM_STATUS_NOT_SUPPORTED) return rc;
     }
@@ -616,7 +616,7 @@ extern "C" {
 template <bool BF>
 static int gemm_rowmajor16(const void* A, const void* B, void* C, size_t m, size_t n, size_t k, size_t lda,
                            size_t batch, size_t strideA, size_t strideB, size_t strideC, float alpha, float beta,
-                           sm_stream_t stream) {
+                           sm_stream_t stream, void* workspace = nullptr, size_t workspace_bytes = 0) {
   if (!A || !B || !C || lda < k) {
     set_error("sm_gemm_rowmajor_{f16,bf16}: invalid argument");
     return SM_STATUS_INVALID_VALUE;
@@ -637,7 +637,7 @@ static int gemm_rowmajor16(const void* A, const void* B, void* C, size_t m, size
     a.M = (int)(m * batch);
     a.batch = 1;
   }
-  return launch_gemm_f16<BF>(a, (hipStream_t)stream);
+  return launch_gemm_f16<BF>(a, (hipStream_t)stream, false, false, workspace, workspace_bytes);
 }
 
 extern "C" {
@@ -654,9 +654,9 @@ int sm_gemm_rowmajor_bf16(const void* A, const void* B, void* C, size_t m, size_
   return gemm_rowmajor16<true>(A, B, C, m, n, k, lda, batch, strideA, strideB, strideC, alpha, beta, stream);
 }
 
-int sm_gemm_batched_f16(const void* const* A_ptrs, const void* const* B_ptrs, void* const* C_ptrs, size_t m,
-                        size_t n, size_t k, size_t batch, int ta, int tb, float alpha, float beta,
-                        sm_stream_t stream) {
+static int gemm_batched16(const void* const* A_ptrs, const void* const* B_ptrs, void* const* C_ptrs, size_t m,
+                          size_t n, size_t k, size_t batch, int ta, int tb, float alpha, float beta,
+                          sm_stream_t stream, void* workspace, size_t workspace_bytes) {
   if (!A_ptrs || !B_ptrs || !C_ptrs) {
     set_error("sm_gemm_batched_f16: null pointer array");
     return SM_STATUS_INVALID_VALUE;
@@ -687,7 +687,28 @@ int sm_gemm_batched_f16(const void* const* A_ptrs, const void* const* B_ptrs, vo
   a.batch = (int)batch; a.alpha = alpha; a.beta = beta;
   // op(B) = T: the row-major view's A operand (n x k) arrives n-contiguous; op(A) = T: its B operand (k x m) arrives
   // k-contiguous.  The leading dimensions stay (ldb = k, lda = m), as the reference passes them.
-  return launch_gemm_f16(a, (hipStream_t)stream, tb == SM_OP_T, ta == SM_OP_T);
+  return launch_gemm_f16(a, (hipStream_t)stream, tb == SM_OP_T, ta == SM_OP_T, workspace, workspace_bytes);
+}
+int sm_gemm_batched_f16(const void* const* A_ptrs, const void* const* B_ptrs, void* const* C_ptrs, size_t m,
+                        size_t n, size_t k, size_t batch, int ta, int tb, float alpha, float beta,
+                        sm_stream_t stream) {
+  return gemm_batched16(A_ptrs, B_ptrs, C_ptrs, m, n, k, batch, ta, tb, alpha, beta, stream, nullptr, 0);
+}
+/* the dense entry points with the fused kernels' stream-K workspace (round 5): the dense twin of sm_spmma_fused_*_ws */
+int sm_gemm_batched_f16_ws(const void* const* A_ptrs, const void* const* B_ptrs, void* const* C_ptrs, size_t m,
+                           size_t n, size_t k, size_t batch, int ta, int tb, float alpha, float beta,
+                           void* workspace, size_t workspace_bytes, sm_stream_t stream) {
+  return gemm_batched16(A_ptrs, B_ptrs, C_ptrs, m, n, k, batch, ta, tb, alpha, beta, stream, workspace, workspace_bytes);
+}
+int sm_gemm_rowmajor_f16_ws(const void* A, const void* B, void* C, size_t m, size_t n, size_t k, size_t lda,
+                            size_t batch, size_t strideA, size_t strideB, size_t strideC, float alpha, float beta,
+                            void* workspace, size_t workspace_bytes, sm_stream_t stream) {
+  return gemm_rowmajor16<false>(A, B, C, m, n, k, lda, batch, strideA, strideB, strideC, alpha, beta, stream, workspace, workspace_bytes);
+}
+int sm_gemm_rowmajor_bf16_ws(const void* A, const void* B, void* C, size_t m, size_t n, size_t k, size_t lda,
+                             size_t batch, size_t strideA, size_t strideB, size_t strideC, float alpha, float beta,
+                             void* workspace, size_t workspace_bytes, sm_stream_t stream) {
+  return gemm_rowmajor16<true>(A, B, C, m, n, k, lda, batch, strideA, strideB, strideC, alpha, beta, stream, workspace, workspace_bytes);
 }
 
 }  // extern "C"

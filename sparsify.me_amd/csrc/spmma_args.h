@@ -40,6 +40,8 @@ struct DenseTwinCall {
   float alpha, beta;
   bool bf;
   int mode;  // 1: where the rule says the twin wins; 2: wherever it is supported (tuning)
+  void* workspace;         // sm_gemm_*_ws: the stream-K form may run (sm_spmma_fused_workspace_size bytes, zero flag page); else null
+  size_t workspace_bytes;
 };
 int gemm_dense_twin(const DenseTwinCall& c, hipStream_t st);
 

@@ -397,6 +397,415 @@ static int launch_fused_big(const FusedArgs& a0, hipStream_t st) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// STREAM-K form of the big kernel (round 5): the shapes with few row tiles and a long K (196 x 512 x 4608: 150 tiles of 72 stages on
+// 256 CUs; 784 x 512 x 1024: 196 tiles) leave the last -- often the only -- round of one-per-CU workgroups 23-43 % empty, and a tile's
+// time is its K stages.  Here the launch's work is the list of STAGE UNITS (row panel major, stage inside the panel), cut into
+// contiguous ranges ("slots", SkPlan below: groups of tg panels cut into wg equal ranges), one per workgroup and column tile, at most
+// one workgroup per CU: a workgroup walks its range segment by segment (a segment = a run of stages of one tile), each segment
+// through the big kernel's own pipeline.  A tile that lies whole inside one range is computed
+// and stored exactly as the big kernel does (bit-identical); a tile cut by range borders is summed from fp32 partials in a FIXED
+// order -- no atomics on data, repeated runs give the same bits:
+//   * the workgroup that holds the tile's FIRST stages (they are the LAST segment of its range) owns the tile: it finishes its
+//     segment, then adds the partials of the same column tile's workgroups of the slots after it (ascending k) to its
+//     accumulators and runs the ordinary epilogue (alpha / beta, one rounding);
+//   * the other holders meet the tile in the FIRST segment of their range: they store their accumulators to their slot of the
+//     workspace (256 x BN fp32, register-image order: 1 KiB per wave instruction, no transposition on either side) and raise
+//     their flag -- long before the owner, whose range ends where theirs begins, comes looking for it.
+// Hand-off (MI355X_MICROARCH.md, inter-workgroup visibility, third table row): partials leave by `global_store_dwordx4 sc1` (write-
+// through, whole 128-byte lines per wave instruction), every storing wave drains vmcnt, a workgroup barrier, ONE lane's agent-scope
+// atomic add on the slot's flag; the owner's lane 0 polls the flag with agent-scope relaxed loads, a workgroup barrier, then every
+// wave reads with `global_load_dwordx4 sc1`.  The owner zeroes the flag again once every wave has read (the next launch on the
+// stream finds the workspace as this one did: zero flags -- hipGraph replays need no memset node).
+// Progress: an owner only waits for workgroups of HIGHER logical id, which produce what it waits for first thing after they start,
+// and the grid never exceeds the CU count (one workgroup per CU: the whole LDS), so they are resident or next in the dispatch order.
+// ---------------------------------------------------------------------------------------------
+struct SkArgs {
+  float* part;             // one slot of 256 x BN fp32 partial sums per workgroup
+  unsigned* flags;         // one word per workgroup; zero before the launch, zero after it
+  // the decomposition: row panels (256 rows of one problem: tiles_m x batch x ngroup of them) x nkt stage units; `slots` workgroup
+  // slots, each a contiguous range of panel units, every slot run by tiles_n workgroups in lockstep (one per column tile);
+  // a GROUP = tg consecutive panels cut into wg slot ranges at cut[0 .. wg] (units from the group's first; cut[0] = 0, cut[wg] =
+  // tg * nkt); the last group: tgl panels, wgl slots, cutl[]
+  unsigned panels, slots, tg, wg, groups_full, tgl, wgl;
+  unsigned cut[9], cutl[9];
+#ifdef SM_TUNING
+  int ablate;              // tuning builds only: 1 = no partial stores, 2 = no fix-up loads / waits (results wrong; timing only)
+#endif
+};
+// entry r of a 9-entry table held in the kernel arguments, by compares (a runtime index into a by-value argument array would
+// send the whole block through scratch memory)
+__device__ __forceinline__ unsigned sk_pick(const unsigned (&tab)[9], unsigned r) {
+  unsigned v = tab[0];
+#pragma unroll
+  for (unsigned i = 1; i < 9; ++i) v = r == i ? tab[i] : v;
+  return v;
+}
+// first panel unit of slot w (w == slots: the end of the launch's units)
+__device__ __forceinline__ unsigned long long sk_slot_start(const SkArgs& s, unsigned w, unsigned nkt) {
+  const unsigned q = w / s.wg;
+  if (q < s.groups_full) return ((unsigned long long)q * s.tg) * nkt + sk_pick(s.cut, w - q * s.wg);
+  unsigned r = w - s.groups_full * s.wg;
+  r = r < s.wgl ? r : s.wgl;
+  return ((unsigned long long)s.groups_full * s.tg) * nkt + (s.wgl ? sk_pick(s.cutl, r) : 0u);
+}
+// a pointer the compiler cannot prove wave-uniform (an entry of the by-value pointer tables picked by a runtime index), made so
+template <class T>
+__device__ __forceinline__ T* sk_uniform(T* ptr) {
+  const unsigned long long v = reinterpret_cast<unsigned long long>(ptr);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return reinterpret_cast<T*>(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ void sk_store_sc1(float* dst, f4 v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(v) : "memory");
+}
+__device__ __forceinline__ f4 sk_load_sc1(const float* src) {
+  f4 v;
+  asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(src) : "memory");
+  return v;
+}
+
+template <int BN, bool BF = false, bool ANT = true, bool DENSE = false>
+__global__ __launch_bounds__(512) void spmma_f16_fused_sk_kernel(const FusedArgs p, const SkArgs s) {
+  constexpr int BM = 256, NW = 8, TM = BM / NW, FM = TM / 16, FN = BN / 16, NSA = 3, NSB = 2;
+  constexpr int SA = BM * 128, SB = 64 * BN * 2;
+  constexpr int A_N = BM / 8, B_N = BN / 8;  // 1 KiB DMA wave-instructions per stage
+  static_assert(A_N % NW == 0 && B_N % NW == 0, "equal DMA share per wave");
+  constexpr int SLA = A_N / NW, SLB = B_N / NW;
+  constexpr int AHEAD = SLA;  // pieces issued after B(kt) that may stay in flight at iteration kt: A(kt + 1)
+  constexpr int BRING = NSA * SA;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const unsigned tid = threadIdx.x, lane = tid & 63u;
+  const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
+  const unsigned tn = (unsigned)p.tiles_n;
+  const unsigned slot = lid / tn, tile_n = lid - slot * tn;  // the tiles_n workgroups of a slot are neighbours: one XCD, one A stream
+  const unsigned nkt = (unsigned)(p.K / 64);
+  const unsigned long long u0 = sk_slot_start(s, slot, nkt), u1 = sk_slot_start(s, slot + 1u, nkt);
+  const int mlast = p.Mrows - 1;
+  const size_t bstep = (size_t)64 * p.N * 2;
+  // this lane's piece of a partial slot: fragment (i, j) of wave w at ((w * FM * FN + i * FN + j) * 64 + lane) float4s
+  const size_t slot_floats = (size_t)BM * BN;
+
+  bool publish_pending = false;  // this workgroup's partial stores are issued, its flag not yet raised
+  for (unsigned long long u = u0; u < u1;) {
+    const unsigned t = (unsigned)(u / nkt);
+    const unsigned kb = (unsigned)(u - (unsigned long long)t * nkt);
+    unsigned len = nkt - kb;
+    if (u1 - u < (unsigned long long)len) len = (unsigned)(u1 - u);
+    const unsigned ke = kb + len;
+    const unsigned gb = t / (unsigned)p.tiles_m, tile_m = t - gb * (unsigned)p.tiles_m;  // t: the row panel
+    const unsigned grp = gb / (unsigned)p.batch, b = gb - grp * (unsigned)p.batch;
+    const int m0 = (int)tile_m * BM, n0 = (int)tile_n * BN;
+    const half_t* A = sk_uniform(p.dAp ? p.dAp[gb] : p.A[grp] + (size_t)b * p.sA);
+    const half_t* B = sk_uniform(p.dBp ? p.dBp[gb] : p.B[grp] + (size_t)b * p.sB);
+    half_t* C = sk_uniform(p.dCp ? p.dCp[gb] : p.C[grp] + (size_t)b * p.sC);
+
+    // (the segment loop's per-lane values that do not depend on the tile -- DMA chunk swizzles, epilogue addresses, slot offsets --
+    // are recomputed per segment from opaque copies of the lane / thread id: hoisted out of the loop they would live across the
+    // main loop, whose 128 accumulators leave them no registers, and spill)
+    unsigned lane_p = lane;
+    asm volatile("" : "+v"(lane_p));
+    // per-lane DMA sources as 32-bit offsets from two uniform bases (the launcher checks that a tile's rows and a stage of B stay
+    // below 4 GiB): the accumulators and the segment loop leave no room for 64-bit addresses
+    const char* const abase = reinterpret_cast<const char*>(A + (size_t)m0 * p.lda) + (size_t)kb * 128;
+    const char* const bbase = reinterpret_cast<const char*>(B) + (size_t)kb * bstep;
+    unsigned asrc[SLA], bsrc[SLB], aoff[SLA], boff[SLB];
+#pragma unroll
+    for (int i = 0; i < SLA; ++i) {  // 8 rows x 128 B: lane -> row 8t + lane/8, LDS chunk lane%8 holds source chunk (lane%8) ^ (row&7)
+      const unsigned tt = wave + (unsigned)NW * i;
+      const unsigned row = 8u * tt + (lane_p >> 3), cs = (lane_p & 7u) ^ (row & 7u);
+      int lr = (int)row;
+      lr = m0 + lr < mlast ? lr : mlast - m0;
+      asrc[i] = (unsigned)lr * (unsigned)p.lda * 2u + 16u * cs;
+      aoff[i] = tt * 1024u;
+    }
+#pragma unroll
+    for (int i = 0; i < SLB; ++i) {
+      const unsigned j = wave + (unsigned)NW * i, panel = j >> 3, kr = 8u * (j & 7u) + (lane_p >> 3);
+      const unsigned cs = (lane_p & 7u) ^ b_swz(kr);
+      int gc = n0 + (int)(64u * panel + 8u * cs);
+      gc = gc <= p.N - 8 ? gc : p.N - 8;
+      bsrc[i] = (kr * (unsigned)p.N + (unsigned)gc) * 2u;
+      boff[i] = BRING + panel * 8192u + (j & 7u) * 1024u;
+    }
+    // buffer-addressed LDS-DMA: 32-bit per-lane offsets + a scalar stage offset against a uniform resource (no 64-bit address
+    // arithmetic per piece, half the address registers of the global form)
+    const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(abase), 0, (int)0xffffffffu, 0x27000);
+    const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(bbase), 0, (int)0xffffffffu, 0x27000);
+    auto stage_a = [&](int kt, int buf) {  // kt counts from the segment's first stage
+#pragma unroll
+      for (int i = 0; i < SLA; ++i) {
+        if (ANT) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsa, (lptr_t*)(smem + buf * SA + aoff[i]), 16, (int)asrc[i], kt * 128, 0, 2);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsa, (lptr_t*)(smem + buf * SA + aoff[i]), 16, (int)asrc[i], kt * 128, 0, 0);
+      }
+    };
+    auto stage_b = [&](int kt, int buf) {
+#pragma unroll
+      for (int i = 0; i < SLB; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsb, (lptr_t*)(smem + buf * SB + boff[i]), 16, (int)bsrc[i], kt * (int)bstep, 0, 0);
+    };
+
+    f4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+
+    const int nst = (int)len;
+    // prologue = iterations -(NSA-1) .. -1 of the loop's issue pattern (the big kernel's)
+#pragma unroll
+    for (int j = -(NSA - 1); j < 0; ++j) {
+      if (j + NSB - 1 >= 0 && j + NSB - 1 < nst) stage_b(j + NSB - 1, j + NSB - 1);
+      if (j + NSA - 1 < nst) stage_a(j + NSA - 1, j + NSA - 1);
+    }
+    int ca = 0, cb = 0, fa = NSA - 1, fb = NSB - 1;
+    for (int kt = 0; kt < nst; ++kt) {
+      if (kt + 1 < nst) wait_dma_and_barrier<AHEAD>();
+      else wait_dma_and_barrier<0>();
+      if (publish_pending) {
+        // the previous segment's partial stores are older than everything this segment issued: the counted wait above covered them
+        // for this wave, the barrier for all eight -- their drain was hidden behind this segment's first loads
+        if (tid == 0) (void)__hip_atomic_fetch_add(s.flags + lid, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        publish_pending = false;
+      }
+      if (kt + NSB - 1 < nst) stage_b(kt + NSB - 1, fb);
+      if (kt + NSA - 1 < nst) stage_a(kt + NSA - 1, fa);
+      if constexpr (DENSE) mfma_stage_dense_a<FM, FN, BF>(smem + ca * SA, smem + BRING + cb * SB, wave * TM, 0, lane, acc);
+      else smfmac_stage_dense_a<FM, FN, BF>(smem + ca * SA, smem + BRING + cb * SB, wave * TM, 0, lane, acc);
+      ca = ca + 1 == NSA ? 0 : ca + 1;
+      fa = fa + 1 == NSA ? 0 : fa + 1;
+      cb = cb + 1 == NSB ? 0 : cb + 1;
+      fb = fb + 1 == NSB ? 0 : fb + 1;
+    }
+    __syncthreads();  // every wave has left the rings; nothing is in flight (the last iteration waited for vmcnt(0))
+    unsigned tid_e = tid;
+    asm volatile("" : "+v"(tid_e));
+    const size_t lane_off = ((size_t)wave * (FM * FN) * 64u + (tid_e & 63u)) * 4u;
+
+    if (kb != 0) {
+      // ---- a later part of a tile that another workgroup owns: publish the fp32 partial sums, raise the flag
+      float* dst = s.part + (size_t)lid * slot_floats + lane_off;
+      asm volatile("" : "+v"(dst));  // (keeps the 32 store addresses from being computed ahead of the segment loop and spilled)
+      bool publish = true;
+#ifdef SM_TUNING
+      publish = !(s.ablate & 1);
+#endif
+      if (publish) {
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int j = 0; j < FN; ++j) sk_store_sc1(dst + (size_t)(i * FN + j) * 256u, acc[i][j]);
+      }
+      if (u + len < u1) {
+        publish_pending = true;  // another segment follows: it raises the flag behind its first stage's wait (above)
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) (void)__hip_atomic_fetch_add(s.flags + lid, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    } else {
+      if (ke != nkt) {
+        // ---- the tile's first stages, and others hold the rest: add their partials in ascending k (= ascending logical id)
+        const unsigned long long tile_end = (unsigned long long)(t + 1u) * nkt;
+        unsigned c_end = s.slots;
+#ifdef SM_TUNING
+        if (s.ablate & 2) c_end = 0;
+#endif
+        for (unsigned cs = slot + 1u; cs < c_end && sk_slot_start(s, cs, nkt) < tile_end; ++cs) {
+          const unsigned c = cs * tn + tile_n;  // the workgroup of slot cs that holds this column tile
+          if (tid == 0) {
+            // (bounded: ~0.3 s of polling -- five orders of magnitude beyond any legitimate wait -- then word 1023 of the flag page is
+            //  raised and the tile is stored without the missing partial: a broken hand-off must show as a wrong result and a
+            //  non-zero flag page, never as a hung device)
+            unsigned spins = 0;
+            while (__hip_atomic_load(s.flags + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+              __builtin_amdgcn_s_sleep(2);
+              if (++spins > (1u << 22)) {
+                __hip_atomic_store(s.flags + 1023, 0xdeadu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+              }
+            }
+          }
+          __syncthreads();
+          // (buffer loads with the sc1 bit: the compiler counts their vmcnt itself, so the 32 fragments need no hand-made waits)
+          const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(s.part + (size_t)c * slot_floats, 0, (int)(slot_floats * 4u), 0x27000);
+          const unsigned voff = (unsigned)lane_off * 4u;
+#pragma unroll
+          for (int f0 = 0; f0 < FM * FN; f0 += 8) {
+            u4 v[8];
+#pragma unroll
+            for (int f = 0; f < 8; ++f) v[f] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + (unsigned)(f0 + f) * 1024u, 0, 16 /* sc1 */);
+#pragma unroll
+            for (int f = 0; f < 8; ++f) acc[(f0 + f) / FN][(f0 + f) % FN] += __builtin_bit_cast(f4, v[f]);
+          }
+          __syncthreads();  // every wave has read slot c: hand the flag back as it was found
+          if (tid == 0) __hip_atomic_store(s.flags + c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      store_c_tile<BM, BN, FM, FN, 64 * NW, BF>(smem, C, acc, true, wave * TM, 0, m0, n0, p.Mrows, p.N, p.alpha, p.beta, tid_e);
+      __syncthreads();  // the epilogue image aliases the rings the next segment's DMA fills
+    }
+    u += len;
+  }
+}
+
+// bytes of the stream-K workspace for a launch of `nwg` workgroups (flags first, then the slots)
+static size_t sk_workspace_bytes(size_t nwg, int bn) { return 4096 + nwg * 256 * (size_t)bn * 4; }
+
+// The decomposition of a launch (host side): `panels` row panels of nkt stage units, tn column tiles, at most cus / tn slots.
+// A group of tg consecutive panels is cut into wg equal slot ranges; all groups have the same cuts, so at any moment the chip's
+// workgroups stand at only wg different K positions (and the tn workgroups of a slot at the same one): the B stage a workgroup
+// brings in is the one its neighbours on the XCD's L2 want now, and the two column tiles of a row panel stream A once.  (The first
+// form of this kernel cut the tile-major unit list into one range per CU, 256 different K positions: bit-correct, but B and the
+// second column tile's A then missed L2 and the launch ran at the fabric's rate -- 196 x 512 x 4608 x 3: 106 us for the main loops
+// alone against 126 us for whole tiles on 150 CUs, profiles/sk_probe_r05b.txt.)  Chosen: the (tg, wg <= 8) with the fewest units
+// per slot, ties to the smaller wg.
+struct SkPlan {
+  unsigned tg, wg, groups_full, tgl, wgl, slots, units;  // units: the longest slot range
+  unsigned cut[9], cutl[9];
+};
+// Where the wg ranges of a group of `tiles` panels are cut.  Equal ranges would make every workgroup finish at the same moment -- but
+// a range that ENDS inside a tile it does not own (its last segment starts past the tile's first stage) ends with a publish, and
+// the owner of that tile, finishing its own range at that same moment, then waits for the publish and the hand-off before it can
+// read the partial (measured: ~14 us at the end of a 100 us launch).  Such ranges are made `lead` units shorter, the others take up
+// the difference: the partial is in memory when the owner comes for it.  Returns the longest range.
+static unsigned sk_cuts(unsigned tiles, unsigned wg, unsigned nkt, unsigned lead, unsigned (&cut)[9]) {
+  const double total = (double)tiles * nkt;
+  double x[8];
+  for (unsigned r = 0; r < wg; ++r) x[r] = total / wg;
+  for (int it = 0; it < 6; ++it) {
+    double acc = 0;
+    cut[0] = 0;
+    for (unsigned r = 0; r < wg; ++r) {
+      acc += x[r];
+      cut[r + 1] = r + 1 == wg ? (unsigned)total : (unsigned)(acc + 0.5);
+    }
+    unsigned nshort = 0;
+    bool shrt[8];
+    for (unsigned r = 0; r < wg; ++r) {
+      const unsigned last_tile = (cut[r + 1] - 1) / nkt;                      // the tile the range ends in
+      const unsigned seg0 = cut[r] > last_tile * nkt ? cut[r] : last_tile * nkt;  // where its last segment starts
+      shrt[r] = cut[r + 1] > cut[r] && seg0 != last_tile * nkt;               // not at the tile's first stage: ends as a contributor
+      nshort += shrt[r] ? 1u : 0u;
+    }
+    const double T = (total + (double)lead * nshort) / wg;
+    if (T - lead < 2.0) break;  // (ranges too short to take a lead from: equal cuts)
+    for (unsigned r = 0; r < wg; ++r) x[r] = shrt[r] ? T - lead : T;
+  }
+  unsigned longest = 0;
+  for (unsigned r = 0; r < wg; ++r) {
+    if (cut[r + 1] < cut[r]) cut[r + 1] = cut[r];
+    longest = cut[r + 1] - cut[r] > longest ? cut[r + 1] - cut[r] : longest;
+  }
+  for (unsigned r = wg + 1; r < 9; ++r) cut[r] = cut[wg];
+  return longest;
+}
+static SkPlan sk_plan_for(size_t panels, size_t nkt, unsigned tg, unsigned wg, unsigned lead) {
+  SkPlan pl = {};
+  pl.tg = tg; pl.wg = wg;
+  pl.groups_full = (unsigned)(panels / tg);
+  pl.tgl = (unsigned)(panels % tg);
+  pl.wgl = pl.tgl ? (pl.tgl * wg + tg - 1) / tg : 0;
+  pl.slots = pl.groups_full * wg + pl.wgl;
+  pl.units = pl.groups_full ? sk_cuts(tg, wg, (unsigned)nkt, lead, pl.cut) : 0;
+  if (pl.tgl) {
+    const unsigned ul = sk_cuts(pl.tgl, pl.wgl, (unsigned)nkt, lead, pl.cutl);
+    pl.units = ul > pl.units ? ul : pl.units;
+  }
+  return pl;
+}
+constexpr unsigned SK_LEAD = 3;  // stage units (~5 us) a publishing range ends ahead of the owner that reads it
+static SkPlan sk_plan(size_t panels, size_t nkt, size_t tn, size_t cus) {
+  SkPlan best = {};
+  const size_t max_slots = cus / tn;
+  if (max_slots == 0 || panels == 0 || nkt == 0 || nkt > 0xffffu) return best;
+  const unsigned lead = (unsigned)tuning_int("SM_SK_LEAD", (int)SK_LEAD);
+  for (unsigned wg = 1; wg <= 8; ++wg)
+    for (unsigned tg = 1; tg <= 16; ++tg) {
+      if (wg > 1 && (size_t)tg * nkt < 2 * (size_t)wg) continue;  // at least two stages per range
+      const size_t gf = panels / tg, tgl = panels % tg, wgl = tgl ? (tgl * wg + tg - 1) / tg : 0;
+      if (gf * wg + wgl == 0 || gf * wg + wgl > max_slots) continue;
+      const SkPlan pl = sk_plan_for(panels, nkt, tg, wg, lead);
+      if (best.slots == 0 || pl.units < best.units) best = pl;
+    }
+  return best;
+}
+
+template <int BN, bool BF = false, bool ANT = true, bool DENSE = false>
+static int launch_fused_sk(const FusedArgs& a0, void* workspace, size_t workspace_bytes, hipStream_t st) {
+  constexpr int BM = 256;
+  FusedArgs a = a0;
+  a.tiles_m = (a.Mrows + BM - 1) / BM;
+  a.tiles_n = (a.N + BN - 1) / BN;
+  const size_t panels = (size_t)a.tiles_m * a.batch * a.ngroup;
+  if (panels == 0) return SM_STATUS_SUCCESS;
+  const size_t nkt = (size_t)a.K / 64;
+  if (panels > 0x7fffffu || nkt == 0 || nkt > 0xffffu) {
+    set_error("sm_spmma_fused_f16: grid too large");
+    return SM_STATUS_NOT_SUPPORTED;
+  }
+  if ((size_t)256 * a.lda * 2 + (size_t)a.K * 2 >= ((size_t)1 << 32) || (size_t)(a.K + 64) * a.N * 2 >= ((size_t)1 << 31)) {
+    set_error("sm_spmma_fused_*_ws: leading dimension too large for the stream-K form's 32-bit tile offsets");
+    return SM_STATUS_NOT_SUPPORTED;
+  }
+  const int cus = device_cu_count();
+  SkPlan pl = sk_plan(panels, nkt, (size_t)a.tiles_n, (size_t)cus);
+#ifdef SM_TUNING
+  if (const int wg_env = tuning_int("SM_SK_WG", 0)) {  // tuning: force the group shape (SM_SK_TG panels cut into SM_SK_WG ranges)
+    const unsigned tg = (unsigned)tuning_int("SM_SK_TG", 1), wg = (unsigned)(wg_env > 8 ? 8 : wg_env);
+    pl = sk_plan_for(panels, nkt, tg ? tg : 1, wg, (unsigned)tuning_int("SM_SK_LEAD", (int)SK_LEAD));
+  }
+#endif
+  const size_t nwg = (size_t)pl.slots * a.tiles_n;
+  if (pl.slots == 0 || nwg > (size_t)cus || nwg > 1023) {
+    set_error("sm_spmma_fused_*_ws: the shape has more column tiles than the stream-K form has compute units for");
+    return SM_STATUS_NOT_SUPPORTED;
+  }
+  if (!workspace || !aligned16(workspace) || workspace_bytes < sk_workspace_bytes(nwg, BN)) {
+    set_error("sm_spmma_fused_*_ws: the stream-K form needs a 16-byte aligned workspace of sm_spmma_fused_workspace_size bytes");
+    return SM_STATUS_INVALID_VALUE;
+  }
+  SkArgs s = {};
+  s.flags = reinterpret_cast<unsigned*>(workspace);
+  s.part = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + 4096);
+  s.panels = (unsigned)panels; s.slots = pl.slots; s.tg = pl.tg; s.wg = pl.wg; s.groups_full = pl.groups_full; s.tgl = pl.tgl; s.wgl = pl.wgl;
+  for (int i = 0; i < 9; ++i) { s.cut[i] = pl.cut[i]; s.cutl[i] = pl.cutl[i]; }
+#ifdef SM_TUNING
+  s.ablate = tuning_int("SM_SK_ABLATE", 0);
+#endif
+  constexpr size_t lds_main = (size_t)3 * BM * 128 + (size_t)2 * 64 * BN * 2;
+  constexpr size_t lds_epi = (size_t)BM * (BN * 2 + 16);
+  constexpr size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
+  static_assert(lds <= 160 * 1024, "LDS budget of the stream-K kernel");
+  static LdsOptIn lds_optin;
+  if (const int rc = ensure_dyn_lds(lds_optin, reinterpret_cast<const void*>(&spmma_f16_fused_sk_kernel<BN, BF, ANT, DENSE>), lds, "spmma_f16_fused_sk_kernel")) return rc;
+  spmma_f16_fused_sk_kernel<BN, BF, ANT, DENSE><<<dim3((unsigned)nwg), dim3(512), lds, st>>>(a, s);
+  return check_launch("spmma_f16_fused_sk_kernel");
+}
+
+// The dispatch rule of the workspace entry points: the stream-K form where the rounds of whole tiles leave CUs idle.  Costs in
+// stages of a 256 x 256 tile: stream-K = its longest slot range + ~8 stages for the fix-up (measured: 12-16 us -- every owner reads
+// its one or two 256 KiB partial tiles at the end of the launch, 40-100 MB at the chip's memory rate all at once: profiles/
+// sk_probe_r05d.txt); the big form = rounds x stages; a 128 x 256 tile's stage (wide kernel) takes ~0.6 of a 256 x 256 one
+// (profiles/stamp_r04b_big_wide_direct.txt).  The A-stationary shapes (n > 256, k <= 512, plain store) keep their kernel: few
+// stages per tile, nothing for a K split to balance.  SM_FUSED_SK (tuning): 0 = never, 2 = wherever the kernel takes the shape.
+static bool sk_takes(size_t rows, size_t problems, size_t n, size_t k, bool astat_shape, SkPlan& pl) {
+  const int sk_rule = tuning_int("SM_FUSED_SK", 1);
+  if (!sk_rule || n <= 128 || k < 128 || k % 64 != 0) return false;
+  const size_t cus = (size_t)device_cu_count(), nkt = k / 64;
+  const size_t panels = (rows + 255) / 256 * problems, tn = (n + 255) / 256;
+  const size_t t_big = panels * tn, t_wide = (rows + 127) / 128 * tn * problems;
+  pl = sk_plan(panels, nkt, tn, cus);
+  if (!pl.slots) return false;
+  if (sk_rule == 2) return true;
+  const double c_sk = (double)pl.units + (pl.wg > 1 ? 8.0 : 0.0);
+  const double c_big = (double)((t_big + cus - 1) / cus * nkt), c_wide = 0.6 * (double)((t_wide + cus - 1) / cus * nkt);
+  const double c_now = c_big < c_wide ? c_big : c_wide;
+  return !astat_shape && pl.wg > 1 && c_sk < 0.85 * c_now;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Rows that are NOT whole 64-deep stages of 16-byte aligned pieces (k % 64 != 0 or k % 8 != 0: the 7 x 7 x 3 stem layer
 // of every ResNet, k = 147), n <= 128, one tall contiguous A (lda == k, batches back to back): SPAN form.  A tile's 128
 // rows are ONE contiguous span of 128 * k * 2 bytes that starts on a 256-byte boundary, so it reaches LDS by plain
@@ -1316,7 +1725,7 @@ using namespace sm;
 template <bool BF>
 static int spmma_fused16(size_t ngroup, const void* const* Ag, const void* const* Bg, void* const* Cg, size_t m, size_t n, size_t k, size_t lda,
                          size_t batch, size_t strideA, size_t strideB, size_t strideC, float alpha, float beta,
-                         sm_stream_t stream) {
+                         sm_stream_t stream, void* workspace = nullptr, size_t workspace_bytes = 0) {
   if (ngroup == 0) return SM_STATUS_SUCCESS;
   if (!Ag || !Bg || !Cg || lda < k || ngroup > (size_t)MAXG) {
     set_error("sm_spmma_fused_{f16,bf16}: invalid argument");
@@ -1387,6 +1796,18 @@ static int spmma_fused16(size_t ngroup, const void* const* Ag, const void* const
   // needs a clear margin (196 x 2048 x 512 x 3: 59 vs 68 us; 784 x 1024 x 256 x 6: 126 vs 111).  SM_FUSED_BIG (tuning): 0 = never.
   const int big_rule = tuning_int("SM_FUSED_BIG", 8);
   auto round_eff = [](size_t tiles, size_t cus) { const size_t r = (tiles + cus - 1) / cus; return r ? (double)tiles / (double)(r * cus) : 1.0; };
+  // (round 5) with a workspace: the STREAM-K form where the rounds of whole tiles leave CUs idle.  Costs in stages of a 256 x 256
+  // tile: stream-K = its share of the stage units + ~3 stages for the fix-up of the two tiles a range cuts; the big form = rounds x
+  // stages; a 128 x 256 tile's stage (wide kernel) takes ~0.6 of a 256 x 256 one (profiles/stamp_r04b_big_wide_direct.txt).  The
+  // A-stationary shapes (n > 256, k <= 512) keep their kernel: few stages per tile, nothing for a K split to balance.
+  // SM_FUSED_SK (tuning): 0 = never, 2 = wherever the kernel takes the shape.
+  if (workspace && !wide_env) {
+    const bool astat_shape = n > 256 && k <= 512 && beta == 0.0f && aligned16(C) && (strideC % 8 == 0);
+    SkPlan pl;
+    if (sk_takes((size_t)a.Mrows, (size_t)a.batch * a.ngroup, n, k, astat_shape, pl) &&
+        workspace_bytes >= sk_workspace_bytes((size_t)pl.slots * ((n + 255) / 256), 256) && aligned16(workspace))
+      return n <= 256 ? launch_fused_sk<256, BF, true>(a, workspace, workspace_bytes, st) : launch_fused_sk<256, BF, false>(a, workspace, workspace_bytes, st);
+  }
   if (big_rule == 8 && !wide_env && n > 128 && k > 64) {
     const size_t cus = (size_t)device_cu_count(), nb = (size_t)a.batch * a.ngroup;
     const size_t t_big = ((size_t)a.Mrows + 255) / 256 * ((n + 255) / 256) * nb, t_wide = ((size_t)a.Mrows + 127) / 128 * ((n + 255) / 256) * nb;
@@ -1458,6 +1879,38 @@ extern "C" int sm_spmma_fused_bf16(const void* A, const void* B, void* C, size_t
   return spmma_fused16<true>(1, &A, &B, &C, m, n, k, lda, batch, strideA, strideB, strideC, alpha, beta, stream);
 }
 
+// The same entry points with a workspace (round 5): the library may then run the stream-K form (spmma_f16_fused_sk_kernel) on the
+// shapes whose whole-tile rounds leave CUs idle; every other shape runs exactly as without one.
+extern "C" int sm_spmma_fused_workspace_size(size_t* bytes) {
+  if (!bytes) {
+    set_error("sm_spmma_fused_workspace_size: invalid argument");
+    return SM_STATUS_INVALID_VALUE;
+  }
+  *bytes = sk_workspace_bytes((size_t)device_cu_count(), 256);
+  return SM_STATUS_SUCCESS;
+}
+extern "C" int sm_spmma_fused_streamk_plan(size_t rows, size_t n, size_t k, size_t problems, int* takes, unsigned* plan) {
+  if (!takes || !plan) {
+    set_error("sm_spmma_fused_streamk_plan: invalid argument");
+    return SM_STATUS_INVALID_VALUE;
+  }
+  SkPlan pl = {};
+  *takes = sk_takes(rows, problems, n, k, n > 256 && k <= 512, pl) ? 1 : 0;
+  unsigned* o = plan;
+  *o++ = pl.tg; *o++ = pl.wg; *o++ = pl.groups_full; *o++ = pl.tgl; *o++ = pl.wgl; *o++ = pl.slots; *o++ = pl.units;
+  for (int i = 0; i < 9; ++i) *o++ = pl.cut[i];
+  for (int i = 0; i < 9; ++i) *o++ = pl.cutl[i];
+  return SM_STATUS_SUCCESS;
+}
+extern "C" int sm_spmma_fused_f16_ws(const void* A, const void* B, void* C, size_t m, size_t n, size_t k, size_t lda, size_t batch, size_t strideA,
+                                     size_t strideB, size_t strideC, float alpha, float beta, void* workspace, size_t workspace_bytes, sm_stream_t stream) {
+  return spmma_fused16<false>(1, &A, &B, &C, m, n, k, lda, batch, strideA, strideB, strideC, alpha, beta, stream, workspace, workspace_bytes);
+}
+extern "C" int sm_spmma_fused_bf16_ws(const void* A, const void* B, void* C, size_t m, size_t n, size_t k, size_t lda, size_t batch, size_t strideA,
+                                      size_t strideB, size_t strideC, float alpha, float beta, void* workspace, size_t workspace_bytes, sm_stream_t stream) {
+  return spmma_fused16<true>(1, &A, &B, &C, m, n, k, lda, batch, strideA, strideB, strideC, alpha, beta, stream, workspace, workspace_bytes);
+}
+
 // Grouped forms: `count` same-shape problems (host arrays of device pointers, as the reference's batched::spmm takes its
 // As / Cs, spmm.hxx:30-33) in as few grids as possible (MAXG problems per launch).  Same kernels, same C bit for bit.
 template <bool BF>
@@ -1483,6 +1936,15 @@ static int dense_twin16(const DenseTwinCall& c, hipStream_t st) {
     return n <= 64 ? launch_fused_span<64, BF, true>(a, st) : launch_fused_span<128, BF, true>(a, st);
   }
   if (c.sA % 8 != 0 || c.sB % 8 != 0) return SM_STATUS_NOT_SUPPORTED;
+  // (round 5) with a workspace: the stream-K form -- only on the shapes where this pipeline is the dense GEMM's better one at all
+  // (n <= 256 with k >= 2048, below): elsewhere gemm_f16.hip's 128 x 128 tiles at two workgroups per CU beat it by more than a K split
+  // returns (196 x 512 x 4608 x 3: 163 us against 110, profiles/ab_streamk_r05e.txt)
+  if (c.workspace && c.mode < 2 && n > 128 && n <= 256 && k >= 2048) {
+    SkPlan pl;
+    if (sk_takes((size_t)c.M, (size_t)c.batch, n, k, false, pl) && c.workspace_bytes >= sk_workspace_bytes((size_t)pl.slots * ((n + 255) / 256), 256) &&
+        aligned16(c.workspace))
+      return n <= 256 ? launch_fused_sk<256, BF, true, true>(a, c.workspace, c.workspace_bytes, st) : launch_fused_sk<256, BF, false, true>(a, c.workspace, c.workspace_bytes, st);
+  }
   if (n <= 128) {  // gemm_f16.hip's 128 x 64 / 128 x 128 tiles are the direct pipeline already (A/B in tuning builds only)
 #ifdef SM_TUNING
     if (c.mode >= 2) return n <= 64 ? launch_fused_direct<64, 2, BF, 128, 4, true, true>(a, st) : launch_fused_direct<128, 2, BF, 128, 4, true, true>(a, st);
@@ -1504,14 +1966,15 @@ int sm::gemm_dense_twin(const DenseTwinCall& c, hipStream_t st) { return c.bf ? 
 template <bool BF>
 static int spmma_fused16_grouped(size_t count, const void* const* A, const void* const* B, void* const* C, size_t m, size_t n, size_t k,
                                  size_t lda, size_t batch, size_t strideA, size_t strideB, size_t strideC, float alpha, float beta,
-                                 sm_stream_t stream) {
+                                 sm_stream_t stream, void* workspace = nullptr, size_t workspace_bytes = 0) {
   if (count && (!A || !B || !C)) {
     set_error("sm_spmma_fused_{f16,bf16}_grouped: invalid argument");
     return SM_STATUS_INVALID_VALUE;
   }
   for (size_t i = 0; i < count; i += (size_t)MAXG) {
     const size_t ng = count - i < (size_t)MAXG ? count - i : (size_t)MAXG;
-    if (const int rc = spmma_fused16<BF>(ng, A + i, B + i, C + i, m, n, k, lda, batch, strideA, strideB, strideC, alpha, beta, stream)) return rc;
+    // (the launches of one call follow one another on the stream: they can share the workspace)
+    if (const int rc = spmma_fused16<BF>(ng, A + i, B + i, C + i, m, n, k, lda, batch, strideA, strideB, strideC, alpha, beta, stream, workspace, workspace_bytes)) return rc;
   }
   return SM_STATUS_SUCCESS;
 }
@@ -1524,4 +1987,14 @@ extern "C" int sm_spmma_fused_bf16_grouped(size_t count, const void* const* A, c
                                            size_t k, size_t lda, size_t batch, size_t strideA, size_t strideB, size_t strideC,
                                            float alpha, float beta, sm_stream_t stream) {
   return spmma_fused16_grouped<true>(count, A, B, C, m, n, k, lda, batch, strideA, strideB, strideC, alpha, beta, stream);
+}
+extern "C" int sm_spmma_fused_f16_grouped_ws(size_t count, const void* const* A, const void* const* B, void* const* C, size_t m, size_t n,
+                                             size_t k, size_t lda, size_t batch, size_t strideA, size_t strideB, size_t strideC,
+                                             float alpha, float beta, void* workspace, size_t workspace_bytes, sm_stream_t stream) {
+  return spmma_fused16_grouped<false>(count, A, B, C, m, n, k, lda, batch, strideA, strideB, strideC, alpha, beta, stream, workspace, workspace_bytes);
+}
+extern "C" int sm_spmma_fused_bf16_grouped_ws(size_t count, const void* const* A, const void* const* B, void* const* C, size_t m, size_t n,
+                                              size_t k, size_t lda, size_t batch, size_t strideA, size_t strideB, size_t strideC,
+                                              float alpha, float beta, void* workspace, size_t workspace_bytes, sm_stream_t stream) {
+  return spmma_fused16_grouped<true>(count, A, B, C, m, n, k, lda, batch, strideA, strideB, strideC, alpha, beta, stream, workspace, workspace_bytes);
 }

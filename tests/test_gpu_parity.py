@@ -1786,6 +1786,112 @@ def test_fused_big_form_equals_staged(gpu, shape, bf):
         assert torch.equal(Cs[i].view(torch.int16), Cref.view(torch.int16)), f"grouped big form, problem {i}"
 
 
+def _sk_ws(gpu):
+    import torch
+    ws = gpu.spmma_fused_workspace()
+    ws[4096:].fill_(0xff)   # so that a written slot shows (the flags -- the first 4 KiB -- must be zero before a call)
+    return ws
+
+
+def _sk_ran(ws):
+    return bool((ws[4096:] != 0xff).any().item())
+
+
+@pytest.mark.parametrize("shape", [(196, 512, 2048, 4), (100, 264, 2304, 3), (300, 256, 2304, 2), (64, 136, 4608, 1), (600, 512, 3072, 5)], ids=lambda s_: "x".join(map(str, s_)))
+@pytest.mark.parametrize("bf", [False, True], ids=["f16", "bf16"])
+@pytest.mark.parametrize("ab", [(1.0, 0.0), (0.5, -2.0)])
+def test_fused_streamk_vs_oracle(gpu, orc, shape, bf, ab):
+    """The STREAM-K form of the fused kernel (round 5: sm_spmma_fused_*_ws -> spmma_f16_fused_sk_kernel): few 256 x 256 tiles with a
+    long K, so every tile is cut into several slot ranges (2-9 stages per workgroup: up to seven partial sums meet in one tile's fix-up;
+    groups of several panels with a partial last group: the full-size test below), ragged rows and columns, shared B, alpha / beta.  Held against the ORACLE's compress -> spmma inside the tight bound
+    (one rounding + k fp32 accumulation steps): the order of a cut tile's fp32 additions differs from the staged kernels', nothing
+    else does.  Twice: the second run must give the same bits (fixed-order fix-up, no atomics on data), and the flags are zero again."""
+    import torch
+    m, n, k, batch = shape
+    alpha, beta = ab
+    rng = np.random.default_rng(m + 2 * n + 3 * k + 7 * bf)
+    if bf:
+        A, Bm, C0 = bf16_bits(rng, batch * m * k), bf16_bits(rng, k * n), bf16_bits(rng, batch * m * n)
+        dA, dB = bf16_dev(A), bf16_dev(Bm)
+        mk = bf16_dev
+    else:
+        A, Bm, C0 = bits(rand(rng, batch * m * k, np.float16)), bits(rand(rng, k * n, np.float16)), bits(rand(rng, batch * m * n, np.float16))
+        mk = lambda x: torch.from_numpy(x.view(np.int16)).cuda().view(torch.float16)
+        dA, dB = mk(A), mk(Bm)
+    ws = _sk_ws(gpu)
+    C1 = mk(C0.copy())
+    gpu.spmma_fused(dA, dB, C1, m, n, k, batch=batch, alpha=alpha, beta=beta, workspace=ws)
+    torch.cuda.synchronize()
+    assert _sk_ran(ws), "the shape was meant to take the stream-K kernel"
+    assert bool((ws[:4096] == 0).all().item()), "flags not handed back as zero"
+    C2 = mk(C0.copy())
+    gpu.spmma_fused(dA, dB, C2, m, n, k, batch=batch, alpha=alpha, beta=beta, workspace=ws)
+    assert torch.equal(C1.view(torch.int16), C2.view(torch.int16)), "stream-K result differs between two runs"
+    ob = orc.compress24(A, m, k, k, batch)
+    Cref = C0.copy()
+    kw = dict(alpha=alpha, beta=beta)
+    if bf:
+        orc.spmma(ob, Bm, Cref, m, n, k, batch, 0, bf16=True, **kw)
+        pruned = orc.prune24(A, batch * m, k, k, orc.STRIP, bf16=True)
+        scale = abs(alpha) * (np.abs(bf16_f64(pruned)).reshape(batch * m, k) @ np.abs(bf16_f64(Bm)).reshape(k, n)).reshape(-1) + abs(beta) * np.abs(bf16_f64(C0))
+        check_close(bf16_f64(bf16_host(C1)), bf16_f64(Cref), scale, FP16_TOL, f"stream-K bf16 {shape}", k, "bf16")
+    else:
+        orc.spmma(ob, Bm, Cref, m, n, k, batch, 0, **kw)
+        P = np.abs(orc.decompress24(ob, m, k, k, np.uint16, batch=batch).view(np.float16).astype(np.float64)).reshape(batch * m, k)
+        scale = abs(alpha) * (P @ np.abs(Bm.view(np.float16).astype(np.float64)).reshape(k, n)).reshape(-1) + abs(beta) * np.abs(C0.view(np.float16).astype(np.float64))
+        check_close(host(C1), Cref.view(np.float16), scale, FP16_TOL, f"stream-K {shape}", k)
+
+
+@pytest.mark.parametrize("case", [(196, 512, 4608, 32, 3), (196, 512, 4608, 32, 1), (784, 256, 4608, 32, 3)], ids=lambda c: "x".join(map(str, c)))
+def test_fused_streamk_full_size_properties(gpu, case):
+    """The ResNet-50 shapes the stream-K form serves, as bench.py launches them (b = 32, the table's instance count, grouped, one
+    workspace): (i) every tile that lies whole inside one workgroup's range of stage units equals the no-workspace result BIT FOR
+    BIT (that result equals compress + spmma, which is held against the oracle); (ii) every other element is within one fp16
+    rounding + the fp32 accumulation bound of it (the fp64 product of the STRIP-pruned operand on the device gives the scale);
+    (iii) two runs give the same bits; (iv) the flags are zero again."""
+    import torch
+    m, n, k, batch, cnt = case
+    As, Bs, Cb, Cw = [], [], [], []
+    for i in range(cnt):
+        A = torch.empty(batch * m * k, dtype=torch.float16, device="cuda"); gpu.fill_uniform(A, 0x51 + i, -1.0, 1.0)
+        B_ = torch.empty(k * n, dtype=torch.float16, device="cuda"); gpu.fill_uniform(B_, 0x61 + i, -1.0, 1.0)
+        As.append(A); Bs.append(B_)
+        Cb.append(torch.full((batch * m * n,), float("nan"), dtype=torch.float16, device="cuda"))
+        Cw.append(torch.full((batch * m * n,), float("nan"), dtype=torch.float16, device="cuda"))
+    ws = _sk_ws(gpu)
+    gpu.spmma_fused_grouped(As, Bs, Cb, m, n, k, batch=batch)
+    gpu.spmma_fused_grouped(As, Bs, Cw, m, n, k, batch=batch, workspace=ws)
+    torch.cuda.synchronize()
+    assert _sk_ran(ws) and bool((ws[:4096] == 0).all().item())
+    Cw2 = [torch.full_like(c, float("nan")) for c in Cw]
+    gpu.spmma_fused_grouped(As, Bs, Cw2, m, n, k, batch=batch, workspace=ws)
+    for x, y in zip(Cw, Cw2):
+        assert torch.equal(x.view(torch.int16), y.view(torch.int16)), "two stream-K runs differ"
+    # the decomposition the kernel uses, from the library itself: row panels (256 rows of a problem, problem order) x nkt stage units
+    M = m * batch
+    tm, tn, nkt = (M + 255) // 256, (n + 255) // 256, k // 64
+    takes, plan = gpu.spmma_fused_streamk_plan(M, n, k, cnt)
+    assert takes and plan["wg"] > 1
+    whole = set(gpu.streamk_whole_panels(plan, cnt * tm, nkt))
+    assert len(whole) < cnt * tm, "the plan was meant to cut some tiles"
+    for i in range(cnt):
+        base, got = Cb[i].view(M, n), Cw[i].view(M, n)
+        for r in range(tm):
+            if i * tm + r in whole:
+                b_, g_ = base[r * 256:(r + 1) * 256], got[r * 256:(r + 1) * 256]
+                assert torch.equal(b_.view(torch.int16), g_.view(torch.int16)), f"whole row panel {i * tm + r} differs from the no-workspace result"
+        # (ii) all elements: |got - fp64 product| <= one fp16 rounding + k accumulation steps
+        P = As[i].clone()
+        gpu.prune24(P, P, M, k, k, gpu.PRUNE_STRIP)
+        P64, B64 = P.view(M, k).double(), Bs[i].view(k, n).double()
+        ref, scale = P64 @ B64, P64.abs() @ B64.abs()
+        bound = ROUND["f16"] * ref.abs() + 2.0 * k * ACC["f16"] * scale + TINY["f16"]
+        ratio = float(((got.double() - ref).abs() / bound).max().item())
+        MARGINS.append((f"stream-K full size {case} problem {i}", ratio))
+        assert ratio <= 1.0, f"stream-K {case} problem {i}: max err / bound = {ratio:.3f}"
+        del P, P64, B64, ref, scale, bound
+
+
 @pytest.mark.parametrize("shape", [(3136, 512, 128, 24), (2100, 264, 256, 32), (4096, 384, 64, 17), (2049, 520, 192, 32)])
 def test_fused_astat_many_panels_equals_staged(gpu, shape):
     """The A-stationary kernel at grouped-launch sizes (several rounds of row panels per CU; one- to four-stage panels, ragged

@@ -7,12 +7,26 @@ In the CSV both counters arrive summed over the 8 XCDs: SQ_VALU_MFMA_BUSY_CYCLES
 the 12544 x 256 x 64 layer at b = 32 -- and GRBM_GUI_ACTIVE is 8 x the kernel's duration in shader cycles, so the
 per-XCD duration (rocprofv3's reduce(...,max)) is the sum / 8.
 
-usage: pmc_mfma.py <pass_dir> <out.json>"""
+usage: pmc_mfma.py <pass_dir> <out.json> [library.so]
+(the library's sha256 goes into the output under "_library": bench.py replays the file only for the library it was measured on)"""
 import collections
 import csv
 import glob
+import hashlib
 import json
+import os
 import sys
+
+
+def library_tag(path=None):
+    """sha256 (first 16 hex digits) of the library the profiled process loaded: SPARSIFYME_LIB or the in-tree product library"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = path or os.environ.get("SPARSIFYME_LIB") or os.path.join(root, "sparsify.me_amd", "libsparsifyme.so")
+    try:
+        with open(path, "rb") as fh:
+            return {"sha256_16": hashlib.sha256(fh.read()).hexdigest()[:16], "lib_path": os.path.relpath(path, root)}
+    except OSError:
+        return {"sha256_16": None, "lib_path": path}
 
 SIMDS = 256 * 4
 XCDS = 8
@@ -39,7 +53,9 @@ def main():
             per[n][2] += 1
     res = {n: {"launches_profiled": c, "mfma_busy_cycles": b, "gui_active_cycles": a,
                "mfma_util_percent": 100.0 * b / (a / XCDS * SIMDS)} for n, (b, a, c) in sorted(per.items()) if b > 0}
-    json.dump(res, open(out, "w"), indent=1)
+    res_out = dict(res)
+    res_out["_library"] = library_tag(sys.argv[3] if len(sys.argv) > 3 else None)
+    json.dump(res_out, open(out, "w"), indent=1)
     for n, v in res.items():
         print(f"{n:32s} launches {v['launches_profiled']:5d}  MfmaUtil {v['mfma_util_percent']:6.2f} %")
 

@@ -6,12 +6,26 @@ Correction applied as the guide's HBM section prescribes for gfx950: FETCH_SIZE 
 bytes of a wide coalesced streaming read (16 B per lane, plain loads and LDS-DMA alike), so it is doubled;
 WRITE_SIZE is exact for 16-B-per-lane stores.  Both counters are in KiB.
 
-usage: pmc_traffic.py <fetch_pass_dir> <write_pass_dir> <out.json>"""
+usage: pmc_traffic.py <fetch_pass_dir> <write_pass_dir> <out.json> [library.so]
+(the library's sha256 goes into the output under "_library": bench.py replays the file only for the library it was measured on)"""
 import collections
 import csv
 import glob
+import hashlib
 import json
+import os
 import sys
+
+
+def library_tag(path=None):
+    """sha256 (first 16 hex digits) of the library the profiled process loaded: SPARSIFYME_LIB or the in-tree product library"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = path or os.environ.get("SPARSIFYME_LIB") or os.path.join(root, "sparsify.me_amd", "libsparsifyme.so")
+    try:
+        with open(path, "rb") as fh:
+            return {"sha256_16": hashlib.sha256(fh.read()).hexdigest()[:16], "lib_path": os.path.relpath(path, root)}
+    except OSError:
+        return {"sha256_16": None, "lib_path": path}
 
 
 def per_kernel(d, counter):
@@ -53,7 +67,9 @@ def main():
         if dur.get(k):
             res[k]["avg_duration_us_in_pmc_pass"] = dur[k] / 1e3
             res[k]["hbm_GBs"] = res[k]["hbm_bytes_per_launch"] / dur[k]
-    json.dump(res, open(out, "w"), indent=1)
+    res_out = dict(res)
+    res_out["_library"] = library_tag(sys.argv[4] if len(sys.argv) > 4 else None)
+    json.dump(res_out, open(out, "w"), indent=1)
     for k, v in res.items():
         print(f"{k:32s} launches {v['launches_profiled']:5d}  hbm {v['hbm_bytes_per_launch'] / 1e6:10.2f} MB/launch"
               + (f"  {v['hbm_GBs']:8.1f} GB/s" if "hbm_GBs" in v else ""))

@@ -5,7 +5,11 @@ count `cnt`, the time PER INSTANCE of
   dense   sm_gemm_batched_f16 on the cnt instances as ONE pointer-array call (row-major product of the stacked operand:
           the dense comparator grouped like the step), and each instance alone (dense1)
   staged  sm_compress24_f16 + sm_spmma_f16 per instance (compress / spmma columns)
-  fused   sm_spmma_fused_f16_grouped on the cnt instances (one grid per <= 8), and each instance alone (fused1)
+  fused   sm_spmma_fused_f16_grouped on the cnt instances (one grid per <= 8; with a stream-K workspace, as bench.py's step
+          launches since round 5), and each instance alone without one (fused1)
+  prune   the reference's `prune` column (examples/profiling.py:10-13, examples/compare.csv): sparsifyme::sparsify<2,2> on ONE m x k
+          fp32 matrix + its 8-byte mask (what `./bin/sparsify m k` times; a1 of SURVEY.md 8), cycling buffers; pruneB: the same
+          positional operator on the layer's whole fp16 operand (b * m x k + mask); each with its fraction of the 8 TB/s peak (fp32: 4 + 4 + 8 = 16 B / element, fp16: 2 + 2 + 8 = 12)
 hipGraph-timed on resident random operands; roofline = max(algorithmic bytes / 8 TB/s, dense-equivalent flops / 5 PF/s).
 usage: python tools/sweep_grouped.py [--table resnet50] [--reps 3] > profiles/sweep_rNN_f16_<table>.txt"""
 import argparse
@@ -37,8 +41,9 @@ def main():
     rows = [tuple(int(x) for x in r[:4]) for r in list(csv.reader(open(path)))[1:] if r]
     cnt = collections.Counter(rows)
     print(f"# {os.path.basename(path)}: {len(rows)} layers, {len(cnt)} unique shapes; library {sm.version()}; times in us PER INSTANCE")
-    print("%6s %5s %5s %3s %3s %-7s | %8s %8s | %8s %8s | %8s %8s | %7s %6s %6s %7s" %
-          ("m", "n", "k", "b", "cnt", "kernel", "dense", "dense1", "compress", "spmma", "fused", "fused1", "roof", "frac", "TB/s", "effTF/s"))
+    print("%6s %5s %5s %3s %3s %-7s | %8s %8s | %8s %8s | %8s %8s | %7s %6s %6s %7s | %7s %5s %7s %5s" %
+          ("m", "n", "k", "b", "cnt", "kernel", "dense", "dense1", "compress", "spmma", "fused", "fused1", "roof", "frac", "TB/s", "effTF/s", "prune", "frac", "pruneB", "frac"))
+    ws = sm.spmma_fused_workspace()
     tot = collections.defaultdict(float)
     for (m, n, k, b), c in cnt.items():
         As, Bs, Cs = [], [], []
@@ -65,22 +70,40 @@ def main():
         sm.compress24(As[0], m, k, k, b, m * k, blob)
         t_mul = t(lambda: (lambda i: sm.spmma(blob, Bs[i], Cs[i], m, n, k, b, 0))(nxt()), 1)
         if fused_ok:
-            t_fused = t(lambda: sm.spmma_fused_grouped(As, Bs, Cs, m, n, k, batch=b), c)
+            t_fused = t(lambda: sm.spmma_fused_grouped(As, Bs, Cs, m, n, k, batch=b, workspace=ws), c)
             t_fused1 = t(lambda: (lambda i: sm.spmma_fused(As[i], Bs[i], Cs[i], m, n, k, batch=b))(nxt()), 1)
         else:
             t_fused = t_fused1 = t_cmp + t_mul
+        # a1: the positional operator, as the reference's harness times it (one m x k fp32 matrix) and on the layer's whole operand
+        nb32 = max(2, min(64, (256 << 20) // (m * k * 12)))   # enough buffers that small matrices are not served by the Infinity Cache
+        W32 = [torch.empty(m * k, dtype=torch.float32, device=dev) for _ in range(nb32)]
+        M32 = [torch.empty(m * k, dtype=torch.int64, device=dev) for _ in range(nb32)]
+        for w_ in W32:
+            sm.fill_uniform(w_, 7, 0.0, 1.0)
+        sp = {"i": 0}
+
+        def prune_one():
+            sp["i"] = (sp["i"] + 1) % nb32
+            sm.sparsify(W32[sp["i"]], M32[sp["i"]], m, k)
+        t_prune = t(prune_one, 1)
+        del W32, M32
+        MB = torch.empty(b * m * k, dtype=torch.int64, device=dev)
+        WB = As[0].clone()
+        t_pruneB = t(lambda: sm.sparsify(WB, MB, b * m, k), 1)
+        del MB, WB
         by = b * 2 * (m * k + m * n) + 2 * k * n
         fl = 2.0 * m * n * k * b
         roof = max(by / 8e12, fl / 5e15) * 1e6
-        print("%6d %5d %5d %3d %3d %-7s | %8.1f %8.1f | %8.1f %8.1f | %8.1f %8.1f | %7.1f %6.3f %6.2f %7.0f" %
+        print("%6d %5d %5d %3d %3d %-7s | %8.1f %8.1f | %8.1f %8.1f | %8.1f %8.1f | %7.1f %6.3f %6.2f %7.0f | %7.1f %5.3f %7.1f %5.3f" %
               (m, n, k, b, c, fused_variant(n, k, m, b, c) if fused_ok else "staged", t_dense, t_dense1, t_cmp, t_mul, t_fused, t_fused1, roof, roof / t_fused,
-               by / t_fused / 1e6, fl / t_fused / 1e6), flush=True)
-        for key, v in (("dense", t_dense), ("dense1", t_dense1), ("compress", t_cmp), ("spmma", t_mul), ("fused", t_fused), ("fused1", t_fused1), ("roof", roof)):
+               by / t_fused / 1e6, fl / t_fused / 1e6, t_prune, m * k * 16.0 / t_prune / 8e6, t_pruneB, b * m * k * 12.0 / t_pruneB / 8e6), flush=True)
+        for key, v in (("dense", t_dense), ("dense1", t_dense1), ("compress", t_cmp), ("spmma", t_mul), ("fused", t_fused), ("fused1", t_fused1), ("roof", roof),
+                       ("prune", t_prune), ("pruneB", t_pruneB)):
             tot[key] += v * c
         tot["bytes"] += by * c
         tot["flops"] += fl * c
         del As, Bs, Cs, blob
-    print("# table totals, serial sum over the %d layers (us): " % len(rows) + "  ".join(f"{k_} {tot[k_]:.0f}" for k_ in ("dense", "dense1", "compress", "spmma", "fused", "fused1", "roof")))
+    print("# table totals, serial sum over the %d layers (us): " % len(rows) + "  ".join(f"{k_} {tot[k_]:.0f}" for k_ in ("dense", "dense1", "compress", "spmma", "fused", "fused1", "roof", "prune", "pruneB")))
     print("# fused (grouped): %.2f TB/s of algorithmic bytes = %.3f of the 8 TB/s peak, %.0f effective TF/s; dense (grouped) / fused = %.3f; dense / (2:4 matmul alone) = %.3f" %
           (tot["bytes"] / tot["fused"] / 1e6, tot["bytes"] / tot["fused"] / 8e6, tot["flops"] / tot["fused"] / 1e6, tot["dense"] / tot["fused"], tot["dense"] / tot["spmma"]))
 
