@@ -145,8 +145,12 @@ int sm_spmma_f32(const void* blob, const float* B, float* C, size_t m, size_t n,
  *      reference rebuilds on every call (spmma.hxx:100-113).  Bit-identical to
  *      sm_compress24_f16 + sm_spmma_f16.  Takes k % 64 == 0, n % 8 == 0 and 16-byte aligned rows; or (round 3, the span
  *      form) any k with n % 8 == 0, n <= 128, lda == k, the batches one contiguous tall matrix that ends on a 16-byte
- *      boundary and whose 128-row span + B fit the LDS (k = 147, the ResNets' stem layer).  Returns SM_STATUS_NOT_SUPPORTED
- *      otherwise (use the staged pair). */
+ *      boundary and whose 128-row span + B fit the LDS (k = 147, the ResNets' stem layer); or (round 5, the THIN form) n < 8 with
+ *      k <= 64, lda == k, the batches one contiguous tall matrix of a multiple of 16 bytes with a shared B -- the depthwise
+ *      convolutions of MobileNet-type networks as im2col products (n = 1, k = 9 / 25) -- computed on the vector ALUs: that form is
+ *      inside the tight bound of the exact product (one rounding + k fp32 accumulation steps) but NOT bit-identical to the staged
+ *      pair, whose matrix instruction adds the same products in another order.  Returns SM_STATUS_NOT_SUPPORTED otherwise (use
+ *      the staged pair). */
 int sm_spmma_fused_f16(const void* A, const void* B, void* C, size_t m, size_t n, size_t k, size_t lda,
                        size_t batch, size_t strideA, size_t strideB, size_t strideC, float alpha,
                        float beta, sm_stream_t stream);

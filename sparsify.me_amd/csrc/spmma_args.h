@@ -45,6 +45,11 @@ struct DenseTwinCall {
 };
 int gemm_dense_twin(const DenseTwinCall& c, hipStream_t st);
 
+// spmma_f16_thin.hip: the fused 2:4 product for n < 8, k <= 64 (depthwise convolutions as im2col products) on the vector ALUs;
+// SM_STATUS_NOT_SUPPORTED for anything else
+int spmma_fused_thin(bool bf, int ngroup, const void* const* A, const void* const* B, void* const* C, size_t rows, size_t n, size_t k,
+                     float alpha, float beta, hipStream_t st);
+
 #ifdef SM_STAMP
 __device__ __forceinline__ unsigned long long sm_stamp() {
   unsigned long long t;

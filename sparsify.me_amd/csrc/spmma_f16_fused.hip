@@ -1741,6 +1741,12 @@ static int spmma_fused16(size_t ngroup, const void* const* Ag, const void* const
     c_aligned = c_aligned && aligned16(Cg[g]);
   }
   if (m == 0 || n == 0 || batch == 0) return SM_STATUS_SUCCESS;
+  // (round 5) thin problems -- n < 8, k <= 64, one tall contiguous A, shared B: the depthwise layers of the model zoo -- on the
+  // vector ALUs (spmma_f16_thin.hip); result inside the tight bound of the exact product, not bit-identical to the staged pair
+  if (n < 8 && k <= 64 && lda == k && (batch == 1 || (strideB == 0 && strideA == m * lda && strideC == m * n))) {
+    const int rc = spmma_fused_thin(BF, (int)ngroup, Ag, Bg, Cg, m * batch, n, k, alpha, beta, (hipStream_t)stream);
+    if (rc != SM_STATUS_NOT_SUPPORTED) return rc;
+  }
   // rows that are not whole 64-deep stages of 16-byte pieces: the span form, when A is one tall contiguous matrix, n <= 128
   // and a 128-row span + the whole B fit the LDS (k = 147: the stem layer of every ResNet)
   if ((k % 64 != 0 || lda % 8 != 0) && lda == k && n % 8 == 0 && n <= 128 && all_aligned && c_aligned && (batch == 1 || (strideB == 0 && strideA == m * lda && strideC == m * n)) &&

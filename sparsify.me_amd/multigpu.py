@@ -19,8 +19,53 @@ MODES = ("weak", "strong", "lpt", "hybrid")
 # shape so that a rank still launches them grouped.
 HYBRID_FILL_ROWS = 512 * 128
 
-# Measured time of one layer INSIDE a grouped launch of its shape, us at b = 32 on one MI355X (profiles/sweep_r04_f16_resnet50.txt,
-# column `fused`); shapes that are not in the table fall back to bytes over the rate of their kernel family.
+# Per-shape costs.  Since round 5 bench.py MEASURES them in its setup on the box it runs on (measure_costs(): one grouped launch per
+# unique shape, outside the timed region; rank 0's figures are broadcast so that every rank plans with the same numbers) and installs
+# them with set_measured_costs().  The table below is only the FALLBACK for planning without a GPU (the CPU tests, `--emulate-world`
+# children that are handed no cost file): one MI355X's round-4 figures, us per instance at b = 32 inside a grouped launch of the
+# shape (profiles/sweep_r04_f16_resnet50.txt, column `fused`); shapes in neither fall back to bytes over their kernel family's rate.
+_measured_us = {}   # (m, n, k) -> (us per instance, b it was measured at)
+
+
+def set_measured_costs(costs):
+    """costs: {(m, n, k): (us_per_instance, b)} as measure_costs() returns them (or None / {} to forget them)."""
+    _measured_us.clear()
+    for key, v in (costs or {}).items():
+        _measured_us[tuple(int(x) for x in key)] = (float(v[0]), int(v[1]))
+
+
+def measure_costs(sm, torch, shapes, dtype, reps=3):
+    """Time ONE grouped launch of every unique (m, n, k, b) of `shapes` with its instance count (capped at 8) on the current device:
+    the fused 2:4 path where it takes the shape, compress + spmma elsewhere.  The instances share one operand set (timing only: the
+    launch geometry is what costs; C is overwritten by every instance).  Returns {(m, n, k): (us per instance, b)}."""
+    import collections
+    cnt = collections.Counter(shapes)
+    out = {}
+    for (m, n, k, b), c in cnt.items():
+        c = min(8, c)
+        A = torch.empty(b * m * k, dtype=dtype, device="cuda"); sm.fill_uniform(A, 17, 0.0, 1.0)
+        B = torch.empty(k * n, dtype=dtype, device="cuda"); sm.fill_uniform(B, 18, 0.0, 1.0)
+        C = torch.empty(b * m * n, dtype=dtype, device="cuda")
+        fused = ((n % 8 == 0 and (k % 64 == 0 or (n <= 128 and (b * m * k * A.element_size()) % 16 == 0))) or (n < 8 and k <= 64)) and dtype != torch.float32
+        if fused:
+            try:
+                sm.spmma_fused_grouped([A] * c, [B] * c, [C] * c, m, n, k, batch=b)
+                call = lambda: sm.spmma_fused_grouped([A] * c, [B] * c, [C] * c, m, n, k, batch=b)
+            except sm.SparsifymeError:
+                fused = False
+        if not fused:
+            blob = torch.empty(sm.compress24_size(m, k, A.element_size(), b), dtype=torch.uint8, device="cuda")
+
+            def call():
+                for _ in range(c):
+                    sm.compress24(A, m, k, k, b, m * k, blob)
+                    sm.spmma(blob, B, C, m, n, k, b, 0)
+        t = min(sm.graph_time_ms(call, iters=2, replays=3) for _ in range(reps)) * 1e3 / c
+        out[(m, n, k)] = (t, b)
+        del A, B, C
+    return out
+
+
 MEASURED_US_B32 = {
     (12544, 64, 147): 55.7, (12544, 64, 64): 21.3, (12544, 64, 576): 91.4, (12544, 256, 64): 53.6, (12544, 64, 256): 48.2,
     (12544, 128, 256): 64.6, (3136, 128, 1152): 48.3, (3136, 512, 128): 31.8, (3136, 128, 512): 27.1, (3136, 256, 512): 43.4,
@@ -30,8 +75,12 @@ MEASURED_US_B32 = {
 
 
 def layer_cost(m, n, k, b):
-    """Modelled time of one layer in us: the measured per-instance time of its shape scaled by b / 32 when the shape is in
-    MEASURED_US_B32, else the elements it streams over the rate its kernel family reaches alone (TB/s of algorithmic bytes)."""
+    """Modelled time of one layer in us: the per-instance time of its shape measured on this box (set_measured_costs), else the
+    fallback table's, scaled by the batch share; else the elements it streams over the rate its kernel family reaches alone
+    (TB/s of algorithmic bytes)."""
+    if (m, n, k) in _measured_us:
+        t0, b0 = _measured_us[(m, n, k)]
+        return t0 * b / float(b0)
     t = MEASURED_US_B32.get((m, n, k))
     if t is not None:
         return t * b / 32.0

@@ -610,6 +610,133 @@ def test_full_size_properties_resnet50(gpu, orc, shape):
     check_close(got, Cref.view(np.float16), scale, FP16_TOL, f"sampled batch {shape}", k)
 
 
+@pytest.mark.parametrize("shape", [(196, 1, 9, 64), (49, 1, 25, 96), (784, 1, 9, 33), (100, 3, 18, 8), (64, 7, 64, 4), (3136, 1, 9, 512), (8, 1, 8, 1)],
+                         ids=lambda s_: "x".join(map(str, s_)))
+@pytest.mark.parametrize("bf", [False, True], ids=["f16", "bf16"])
+@pytest.mark.parametrize("ab", [(1.0, 0.0), (0.5, -2.0)])
+def test_fused_thin_vs_oracle(gpu, orc, shape, bf, ab):
+    """The THIN form of the fused kernel (round 5, spmma_f16_thin.hip): n < 8 output columns, k <= 64 -- the depthwise convolutions of
+    the model zoo as im2col products (n = 1, k = 9 / 25, thousands of batch entries) -- on the vector ALUs.  Against the ORACLE's
+    compress -> spmma inside the tight bound (one rounding + k fp32 accumulation steps), ties and ragged last strips included; and
+    against the staged pair on the GPU, which adds the same products in the matrix instruction's order: within one rounding of it."""
+    import torch
+    m, n, k, batch = shape
+    alpha, beta = ab
+    rng = np.random.default_rng(m + 5 * n + 7 * k + batch + 3 * bf)
+    kind = "ties" if k == 25 else "uniform"
+    if bf:
+        A, Bm, C0 = bf16_bits(rng, batch * m * k, kind), bf16_bits(rng, k * n), bf16_bits(rng, batch * m * n)
+        dA, dB, mk = bf16_dev(A), bf16_dev(Bm), bf16_dev
+    else:
+        A, Bm, C0 = bits(rand(rng, batch * m * k, np.float16, kind)), bits(rand(rng, k * n, np.float16)), bits(rand(rng, batch * m * n, np.float16))
+        mk = lambda x: torch.from_numpy(x.view(np.int16)).cuda().view(torch.float16)
+        dA, dB = mk(A), mk(Bm)
+    C1 = mk(C0.copy())
+    gpu.spmma_fused(dA, dB, C1, m, n, k, batch=batch, alpha=alpha, beta=beta)
+    assert torch.equal(dA.view(torch.int16), mk(A).view(torch.int16)), "A was modified"
+    ob = orc.compress24(A, m, k, k, batch)
+    Cref = C0.copy()
+    if bf:
+        orc.spmma(ob, Bm, Cref, m, n, k, batch, 0, alpha=alpha, beta=beta, bf16=True)
+        pruned = orc.prune24(A, batch * m, k, k, orc.STRIP, bf16=True)
+        scale = abs(alpha) * (np.abs(bf16_f64(pruned)).reshape(batch * m, k) @ np.abs(bf16_f64(Bm)).reshape(k, n)).reshape(-1) + abs(beta) * np.abs(bf16_f64(C0))
+        check_close(bf16_f64(bf16_host(C1)), bf16_f64(Cref), scale, FP16_TOL, f"thin bf16 {shape}", k, "bf16")
+    else:
+        orc.spmma(ob, Bm, Cref, m, n, k, batch, 0, alpha=alpha, beta=beta)
+        P = np.abs(orc.decompress24(ob, m, k, k, np.uint16, batch=batch).view(np.float16).astype(np.float64)).reshape(batch * m, k)
+        scale = abs(alpha) * (P @ np.abs(Bm.view(np.float16).astype(np.float64)).reshape(k, n)).reshape(-1) + abs(beta) * np.abs(C0.view(np.float16).astype(np.float64))
+        check_close(host(C1), Cref.view(np.float16), scale, FP16_TOL, f"thin {shape}", k)
+    # the staged pair on the GPU: the same products, another order of fp32 additions
+    blob = torch.empty(gpu.compress24_size(m, k, 2, batch), dtype=torch.uint8, device="cuda")
+    gpu.compress24(dA, m, k, k, batch, m * k, blob)
+    C2 = mk(C0.copy())
+    gpu.spmma(blob, dB, C2, m, n, k, batch, 0, alpha=alpha, beta=beta)
+    d = (C1.double() - C2.double()).abs()
+    lim = (2.0 ** -7 if bf else 2.0 ** -10) * torch.maximum(C1.double().abs(), C2.double().abs()) + 2.0 * k * 2.0 ** -24 * torch.from_numpy(scale).cuda() + 1e-7
+    assert bool((d <= lim).all().item()), "thin form and staged pair differ by more than a rounding"
+
+
+ZOO_TABLES = ["mobilenetv2", "mobilenetv3_small", "mobilenetv3_large", "densenet161", "densenet201"]
+
+
+@pytest.mark.parametrize("table", ZOO_TABLES)
+def test_model_zoo_tables_full_size(gpu, orc, table):
+    """The rest of the reference's model zoo (datasets/get_shapes.py:87-98; tables written by datasets/gen_shapes.py): EVERY unique
+    (m, n, k, b) of the table at its full size -- depthwise layers as b x groups products with n = 1 and k = 9 / 25, ragged k (16, 24,
+    27, 40, 72, 147, ...), b up to 30 720 -- through prune (STRIP: idempotent, passes the check), compress / decompress (== prune,
+    bit for bit), the staged 2:4 matmul (linear in B, one sampled batch entry against the ORACLE inside the tight bound) and, where
+    the fused kernels take the shape (n % 8 == 0 and whole 64-deep stages, or the span form), the fused kernel: same bits as the
+    staged pair.  Which shapes leave the fused kernels is written to gpurun_out/zoo_<table>_kernels.txt (profiles/ keeps a copy)."""
+    import csv
+    import os
+    import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rows = [tuple(int(x) for x in r[:4]) for r in list(csv.reader(open(os.path.join(root, "datasets", table + ".csv"))))[1:] if r]
+    uniq = list(dict.fromkeys(rows))
+    report = []
+    for (m, n, k, batch) in uniq:
+        dA = torch.empty(batch * m * k, dtype=torch.float16, device="cuda")
+        gpu.fill_uniform(dA, 0x200 + m + 3 * k, 0.0, 1.0)     # (positive data, as the ResNet-50 test: 2 x C is then exact in fp16 -- no
+        dB = torch.empty(k * n, dtype=torch.float16, device="cuda")   #  cancellation into the subnormal range)
+        gpu.fill_uniform(dB, 0x300 + n, 0.0, 1.0)
+        blob = torch.empty(gpu.compress24_size(m, k, 2, batch), dtype=torch.uint8, device="cuda")
+        gpu.compress24(dA, m, k, k, batch, m * k, blob)
+        P = dA.clone()
+        gpu.prune24(P, P, batch * m, k, k, gpu.PRUNE_STRIP)
+        valid = torch.ones(1, dtype=torch.int32, device="cuda")
+        gpu.prune24_check(P, batch * m, k, k, valid)
+        assert int(valid.item()) == 0, f"{table} {(m, n, k, batch)}: pruned operand fails the check"
+        D = torch.full_like(P, 7.0)
+        gpu.decompress24(blob, m, k, k, batch, m * k, D)
+        assert torch.equal(D.view(torch.int16), P.view(torch.int16)), f"{table} {(m, n, k, batch)}: decompress(compress(A)) != prune(A)"
+        del D
+        C = torch.empty(batch * m * n, dtype=torch.float16, device="cuda")
+        gpu.spmma(blob, dB, C, m, n, k, batch)
+        C2 = torch.empty_like(C)
+        gpu.spmma(blob, dB * 2, C2, m, n, k, batch)
+        assert torch.equal((C * 2).view(torch.int16), C2.view(torch.int16)), f"{table} {(m, n, k, batch)}: spmma not linear in B"
+        del C2
+        C3 = torch.full_like(C, 3.0)
+        fused = "fused"
+        try:
+            gpu.spmma_fused(dA, dB, C3, m, n, k, batch=batch)
+        except gpu.SparsifymeError as e:
+            assert "status 2" in str(e), str(e)     # NOT_SUPPORTED: the shape stays on the staged pair
+            fused = "staged only (n %% 8 = %d, k %% 64 = %d)" % (n % 8, k % 64)
+        if fused == "fused" and n < 8 and k <= 64:
+            fused = "fused (thin form)"   # vector-ALU kernel: the staged pair's products in another order of fp32 additions
+            lim = 2.0 ** -10 * torch.maximum(C3.float().abs(), C.float().abs()) + 2.0 ** -20 * k
+            assert bool(((C3.float() - C.float()).abs() <= lim).all().item()), f"{table} {(m, n, k, batch)}: thin form differs from compress + spmma by more than a rounding"
+        elif fused == "fused":
+            assert torch.equal(C3.view(torch.int16), C.view(torch.int16)), f"{table} {(m, n, k, batch)}: fused != compress + spmma"
+        else:
+            assert n % 8 != 0 or (k % 64 != 0 and (n > 128 or (batch * m * k * 2) % 16 != 0 or 128 * k * 2 + 1152 + (k + 63) // 64 * 64 * (64 if n <= 64 else 128) * 2 > 160 * 1024)), \
+                f"{table} {(m, n, k, batch)}: a shape the fused kernels document as theirs was declined"
+        del C3
+        report.append("%6d %5d %5d %6d  %s" % (m, n, k, batch, fused))
+        # one sampled batch entry against the oracle
+        b = batch - 1
+        nr = min(m, 64)
+        Ah = host(dA[b * m * k: b * m * k + nr * k])
+        ob = orc.compress24(bits(Ah), nr, k, k)
+        Cref = np.zeros(nr * n, dtype=np.uint16)
+        orc.spmma(ob, bits(host(dB)), Cref, nr, n, k)
+        got = host(C[b * m * n: b * m * n + nr * n])
+        Pm = np.abs(orc.decompress24(ob, nr, k, k, np.uint16).view(np.float16).astype(np.float64)).reshape(nr, k)
+        scale = (Pm @ np.abs(host(dB).astype(np.float64)).reshape(k, n)).reshape(-1)
+        check_close(got, Cref.view(np.float16), scale, FP16_TOL, f"{table} sampled batch {(m, n, k, batch)}", k)
+        del dA, dB, blob, P, C
+    try:
+        d = os.path.join(root, "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "zoo_%s_kernels.txt" % table), "w") as fh:
+            fh.write("# %s: %d layers, %d unique shapes; which 2:4 path each takes (tests/test_gpu_parity.py::test_model_zoo_tables_full_size)\n" % (table, len(rows), len(uniq)))
+            fh.write("#    m     n     k      b  path\n" + "\n".join(report) + "\n")
+            fh.write("# %d of %d unique shapes run the fused kernels\n" % (sum(1 for r in report if "  fused" in r), len(uniq)))
+    except OSError:
+        pass
+
+
 PRUNE_SPMMA_SHAPES = [(128, 64, 64, 1), (196, 128, 256, 2), (132, 72, 192, 3), (4, 8, 64, 1), (260, 128, 128, 2), (3136, 128, 512, 2), (12544, 64, 576, 1)]
 
 

@@ -60,7 +60,7 @@ def main():
         def nxt():
             st["i"] += 1
             return st["i"] % c
-        fused_ok = n % 8 == 0 and (k % 64 == 0 or (n <= 128 and (b * m * k * 2) % 16 == 0))
+        fused_ok = (n % 8 == 0 and (k % 64 == 0 or (n <= 128 and (b * m * k * 2) % 16 == 0))) or (n < 8 and k <= 64 and (b * m * k * 2) % 16 == 0)
 
         def t(fn, per):
             return min(sm.graph_time_ms(fn, iters=max(2, 8 // per), replays=3) for _ in range(a.reps)) * 1e3 / per
@@ -69,6 +69,11 @@ def main():
         t_cmp = t(lambda: sm.compress24(As[nxt()], m, k, k, b, m * k, blob), 1)
         sm.compress24(As[0], m, k, k, b, m * k, blob)
         t_mul = t(lambda: (lambda i: sm.spmma(blob, Bs[i], Cs[i], m, n, k, b, 0))(nxt()), 1)
+        if fused_ok:   # (the library has the last word: e.g. a ragged k whose 128-row span + B do not fit the LDS stays on the staged pair)
+            try:
+                sm.spmma_fused(As[0], Bs[0], Cs[0], m, n, k, batch=b)
+            except sm.SparsifymeError:
+                fused_ok = False
         if fused_ok:
             t_fused = t(lambda: sm.spmma_fused_grouped(As, Bs, Cs, m, n, k, batch=b, workspace=ws), c)
             t_fused1 = t(lambda: (lambda i: sm.spmma_fused(As[i], Bs[i], Cs[i], m, n, k, batch=b))(nxt()), 1)
