@@ -396,6 +396,28 @@ static int launch_fused_big(const FusedArgs& a0, hipStream_t st) {
   return check_launch("spmma_f16_fused_big_kernel");
 }
 
+// a pointer the compiler cannot prove wave-uniform (an entry of the by-value pointer tables picked by a runtime index), made so
+template <class T>
+__device__ __forceinline__ T* sk_uniform(T* ptr) {
+  const unsigned long long v = reinterpret_cast<unsigned long long>(ptr);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return reinterpret_cast<T*>(((unsigned long long)hi << 32) | lo);
+}
+// (Round 5: a SOFTWARE-PIPELINED form of the big kernel -- the selection of stage kt + 1 interleaved, one strip behind every second B
+//  fragment's SMFMACs, into the B sweep of stage kt; every wave loading exactly the rows it owns, so that A needed no barrier -- was
+//  built, bit-identical, and measured 3-6 % SLOWER than the big kernel on all eight n > 128 shapes of the table
+//  (profiles/ab_big2_r05k.txt): during the sweep the two waves of a SIMD already keep its matrix pipe issuing back to back, and vector
+//  instructions slipped in between only delay the SMFMACs behind them.  Removed again: git history)
+
+// (Round 5, second experiment: a SPLIT-ROLE form with a variable tile height -- the first NA waves issue only A pieces, the others only B,
+//  so that an A wave's in-order vmcnt holds nothing but A and NSA - 2 whole stages stay in flight behind the one it waits for; tile
+//  heights 256 / 224 / 192 / 160 / 128 rows (8 .. 4 waves of 32 rows, A rings of 3 .. 5 stages), so that 196 x 512 x 4608 x 3 has 150 /
+//  168 / 198 / 240 / 294 tiles for the 256 CUs -- bit-identical, and within 0-5 % of the big kernel where it is dispatched
+//  (196 x 512 x 4608 x 3: 114.0 / 110.1 / 109.1 / 110.7 / 163.8 us against 114.5; profiles/ab_big3_r05l.txt).  What that says: a tile's
+//  stage takes the same ~3 700 cycles at 160 rows as at 256 -- every wave owns 32 rows and ALL 256 columns whatever the tile's
+//  height, so the stage is one wave's own serial chain (its 8-11 DMA pieces, its 128 selection instructions at half a SIMD's issue
+//  rate, its 32 SMFMACs), not the A stream's latency and not the tile's bytes.  Removed again: git history)
+
 // ---------------------------------------------------------------------------------------------
 // STREAM-K form of the big kernel (round 5): the shapes with few row tiles and a long K (196 x 512 x 4608: 150 tiles of 72 stages on
 // 256 CUs; 784 x 512 x 1024: 196 tiles) leave the last -- often the only -- round of one-per-CU workgroups 23-43 % empty, and a tile's
@@ -447,13 +469,6 @@ __device__ __forceinline__ unsigned long long sk_slot_start(const SkArgs& s, uns
   unsigned r = w - s.groups_full * s.wg;
   r = r < s.wgl ? r : s.wgl;
   return ((unsigned long long)s.groups_full * s.tg) * nkt + (s.wgl ? sk_pick(s.cutl, r) : 0u);
-}
-// a pointer the compiler cannot prove wave-uniform (an entry of the by-value pointer tables picked by a runtime index), made so
-template <class T>
-__device__ __forceinline__ T* sk_uniform(T* ptr) {
-  const unsigned long long v = reinterpret_cast<unsigned long long>(ptr);
-  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-  return reinterpret_cast<T*>(((unsigned long long)hi << 32) | lo);
 }
 __device__ __forceinline__ void sk_store_sc1(float* dst, f4 v) {
   asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(v) : "memory");

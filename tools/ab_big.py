@@ -16,6 +16,7 @@ SETS = {
     "n128": [(3136, 128, 1152, 4), (3136, 128, 512, 3), (12544, 128, 256, 1)],
     "k64": [(12544, 256, 64, 3)],
     "astat": [(3136, 512, 128, 4), (784, 1024, 256, 6), (196, 2048, 512, 3)],
+    "big2": [(784, 256, 1024, 5), (3136, 256, 512, 1), (196, 512, 4608, 3), (784, 512, 1024, 1), (196, 2048, 512, 3), (784, 256, 2304, 6), (196, 512, 2048, 2), (784, 1024, 256, 6)],
     "ilv": [(784, 256, 2304, 6), (784, 256, 1024, 5), (3136, 256, 512, 1), (196, 512, 4608, 3), (196, 512, 2048, 2), (784, 512, 1024, 1), (196, 2048, 512, 3)],
 }
 VARIANTS = {
@@ -23,9 +24,13 @@ VARIANTS = {
     "n128": [("base", {}), ("big nsb2", {"SM_FUSED_BIG": "2", "SM_FUSED_BIG_NSB": "2"}), ("big nsb3", {"SM_FUSED_BIG": "2", "SM_FUSED_BIG_NSB": "3"})],
     "k64": [("base", {}), ("big", {"SM_FUSED_BIG": "4"})],
     "astat": [("base", {}), ("big", {"SM_FUSED_BIG": "1", "SM_FUSED_ASTAT": "0"})],
-    # (SM_FUSED_BIG_ILV: the interleaved-issue variant of session r04n; measured, not adopted, removed from the source: git history)
-    "ilv": [("rule", {}), ("big", {"SM_FUSED_BIG": "1", "SM_FUSED_ASTAT": "0"}), ("big ilv1", {"SM_FUSED_BIG": "1", "SM_FUSED_ASTAT": "0", "SM_FUSED_BIG_ILV": "1"}),
-            ("big ilv2", {"SM_FUSED_BIG": "1", "SM_FUSED_ASTAT": "0", "SM_FUSED_BIG_ILV": "2"})],
+    # round 5: the software-pipelined big form (selection of stage kt + 1 interleaved into the B sweep of stage kt) against the round-4 big form,
+    # under the dispatch rule and forced on every n > 128 shape
+    # (big2, the software-pipelined form, measured 3-6 % slower and was removed: profiles/ab_big2_r05k.txt)
+    # round 5: the split-role big form at every tile height (SM_FUSED_BIG3 = BM) against the dispatch rule
+    # (round 5: big2 = the software-pipelined big form, big3 = the split-role form at five tile heights: measured, not adopted, removed from the
+    #  source -- profiles/ab_big2_r05k.txt, ab_big3_r05l.txt; the shape set "big2" stays for re-use)
+    "big2": [("rule", {})],
 }
 which = sys.argv[1].split(",") if len(sys.argv) > 1 else ["wide", "n128", "k64"]
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 3
