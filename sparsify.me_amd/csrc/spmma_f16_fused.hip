@@ -44,6 +44,9 @@ struct FusedArgs {
 #ifdef SM_STAMP
   unsigned long long* dbg;  // diagnostic build only: per-wave cycle sums (never in the product library)
 #endif
+#ifdef SM_TUNING
+  int ablate;  // tuning builds only (direct kernel): 1 = no C store, 2 = no stage compute, 4 = no A / B loads (timing only: C is wrong)
+#endif
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -53,8 +56,11 @@ struct FusedArgs {
 // so every row of A is selected exactly once -- by the lane that feeds it to the SMFMAC (smfmac_stage_dense_a).
 // The data in flight are LDS buffers, not registers: 2 x 24 KiB per workgroup, two workgroups per CU at n = 64.
 // ---------------------------------------------------------------------------------------------
+// (round 5) the 128-column form is asked to fit four waves per SIMD (<= 128 registers; left alone it takes 129 = three): a single-stage
+// problem (k = 64) allocates 34 KiB of LDS, so a fourth workgroup then shares the CU -- with no K loop to pipeline, the workgroups
+// per CU are all that overlaps one tile's load latency with another's stores (12544 x 256 x 64)
 template <int BN, int NS, bool BF = false, int BM = 128, int NWV = 4, bool ANT = true, bool DENSE = false>
-__global__ __launch_bounds__(64 * NWV) void spmma_f16_fused_direct_kernel(const FusedArgs p) {
+__global__ __launch_bounds__(64 * NWV, (BN == 128 && NWV == 4 && BM == 128) ? 4 : 1) void spmma_f16_fused_direct_kernel(const FusedArgs p) {
   static_assert(BM == 128 || BM == 64, "row tile");
   static_assert(NWV == 4 || (NWV == 8 && BM == 128), "waves per workgroup");
   constexpr int NW = NWV, TM = BM / NW, FM = TM / 16, FN = BN / 16;
@@ -77,6 +83,10 @@ __global__ __launch_bounds__(64 * NWV) void spmma_f16_fused_direct_kernel(const 
   const half_t* B = p.dBp ? p.dBp[gb] : p.B[grp] + (size_t)b * p.sB;
   half_t* C = p.dCp ? p.dCp[gb] : p.C[grp] + (size_t)b * p.sC;
   const int mlast = p.Mrows - 1;
+  // (Round 5: the ablation of this kernel -- tools/direct_ablate.py, profiles/direct_ablate_r05n.txt -- reads "whole launch = launch without
+  //  the C store + the C store alone" on every shape (12544 x 256 x 64 x 3: 220 = 105 + 113 us): loads and stores do not overlap.  Starting the
+  //  workgroups that share a CU a third of a tile's lifetime apart, so that one stores while the others load, changed nothing
+  //  (profiles/direct_stagger_r05o.txt): it is not a phase alignment of the resident workgroups.  Removed again.)
 
   const char* src[SL];
   size_t step[SL];
@@ -103,6 +113,9 @@ __global__ __launch_bounds__(64 * NWV) void spmma_f16_fused_direct_kernel(const 
   }
   auto stage = [&](int kt, int buf) {
     char* base = smem + buf * STAGE;
+#ifdef SM_TUNING
+    if (p.ablate & 4) return;
+#endif
     // A is read exactly once by the whole grid: its DMA carries the non-temporal hint (aux = 2, `nt`); B is re-read by
     // every row tile and keeps the default policy.  Instruction i of a wave is an A piece iff NW * i < A_N (A_N % NW == 0).
     static_assert(A_N % NW == 0, "A / B split of the DMA instructions is per instruction index");
@@ -143,14 +156,26 @@ __global__ __launch_bounds__(64 * NWV) void spmma_f16_fused_direct_kernel(const 
     if (kt + NS - 1 < nkt) stage(kt + NS - 1, fill);
     SM_T(const unsigned long long si = sm_stamp(); ti += si - sb;)
     const char* As = smem + cur * STAGE;
+#ifdef SM_TUNING
+    if (!(p.ablate & 2)) {
+#endif
     if constexpr (DENSE) mfma_stage_dense_a<FM, FN, BF>(As, As + SA, wave * TM, 0, lane, acc);  // the dense twin: every element multiplied
     else smfmac_stage_dense_a<FM, FN, BF>(As, As + SA, wave * TM, 0, lane, acc);
+#ifdef SM_TUNING
+    }
+#endif
     cur = cur + 1 == NS ? 0 : cur + 1;
     fill = fill + 1 == NS ? 0 : fill + 1;
     SM_T(__builtin_amdgcn_sched_barrier(0); s0 = sm_stamp(); tc += s0 - si;)
   }
   __syncthreads();
   SM_T(const unsigned long long sloop = sm_stamp();)
+#ifdef SM_TUNING
+  if (p.ablate & 1) {  // no C store: one element per workgroup keeps the accumulators alive
+    if (tid == 0) C[(size_t)m0 * p.N + n0] = to_elt<BF>(acc[0][0][0] + acc[FM - 1][FN - 1][3]);
+    return;
+  }
+#endif
   store_c_tile<BM, BN, FM, FN, 64 * NW, BF>(smem, C, acc, true, wave * TM, 0, m0, n0, p.Mrows, p.N, p.alpha, p.beta, tid);
   SM_T(if (p.dbg && lane == 0) { unsigned long long* d = p.dbg + ((size_t)blockIdx.x * NW + wave) * 8; const unsigned long long se = sm_stamp();
         d[0] = tv; d[1] = tb; d[2] = ti; d[3] = tc; d[4] = sloop - sstart; d[5] = se - sloop; })
@@ -159,6 +184,9 @@ __global__ __launch_bounds__(64 * NWV) void spmma_f16_fused_direct_kernel(const 
 template <int BN, int NS, bool BF = false, int BM = 128, int NWV = 4, bool ANT = true, bool DENSE = false>
 static int launch_fused_direct(const FusedArgs& a0, hipStream_t st) {
   FusedArgs a = a0;
+#ifdef SM_TUNING
+  a.ablate = tuning_int("SM_DIRECT_ABLATE", 0);
+#endif
   a.tiles_m = (a.Mrows + BM - 1) / BM;
   a.tiles_n = (a.N + BN - 1) / BN;
   const size_t nwg = (size_t)a.tiles_m * a.tiles_n * a.batch * a.ngroup;
