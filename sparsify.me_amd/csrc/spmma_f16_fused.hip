@@ -1033,7 +1033,7 @@ struct BTileDma {
 // PF stages ahead in registers, only B through LDS -- was built in round 2: bit-identical, 1.3x slower on every n <= 128 layer
 // (profiles/tune_rega_r02q.txt; 164 VGPRs, half-line wave loads).  Removed again; DESIGN.md 4.5, git history.)
 
-template <int BN, int WM, int WN, int NLB, int PF, int NSB, bool BF = false>
+template <int BN, int WM, int WN, int NLB, int PF, int NSB, bool BF = false, bool ANT = true>
 __global__ __launch_bounds__(64 * (WM * WN + 4 + NLB)) void spmma_f16_fused_wide_kernel(const FusedArgs p) {
   constexpr int BM = 128, NLA = 4, NC = WM * WN, NW = NC + NLA + NLB;
   static_assert(PF >= 1 && PF <= 3 && NSB >= 2 && NSB <= 4, "pipeline depths");
@@ -1124,7 +1124,12 @@ __global__ __launch_bounds__(64 * (WM * WN + 4 + NLB)) void spmma_f16_fused_wide
     u4 ra[PF][4];
     auto load_a = [&](int kt, u4 (&dst)[4]) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) dst[i] = __builtin_nontemporal_load(reinterpret_cast<const u4*>(a_src[i] + (size_t)kt * 64));
+      for (int i = 0; i < 4; ++i) {
+        // non-temporal only when A is read once by the whole grid (one column tile): with several, the later tiles' reads of the same
+        // rows should find them in L2 (round 5, as for the direct kernel: profiles/nt_ab_r05q.txt)
+        if constexpr (ANT) dst[i] = __builtin_nontemporal_load(reinterpret_cast<const u4*>(a_src[i] + (size_t)kt * 64));
+        else dst[i] = *reinterpret_cast<const u4*>(a_src[i] + (size_t)kt * 64);
+      }
       __builtin_amdgcn_sched_barrier(0);  // stages are issued in stage order on every path (the counted waits rely on it)
     };
     auto write_stage = [&](int kt, const u4 (&src)[4]) {
@@ -1230,7 +1235,7 @@ __global__ __launch_bounds__(64 * (WM * WN + 4 + NLB)) void spmma_f16_fused_wide
   store_c_tile<BM, BN, FM, FN, 64 * NW, BF>(smem, C, acc, wave < (unsigned)NC, wm * TM, wn * TN, m0, n0, p.Mrows, p.N, p.alpha, p.beta, tid);
 }
 
-template <int BN, int WM, int WN, int NLB, int PF, int NSB, bool BF = false>
+template <int BN, int WM, int WN, int NLB, int PF, int NSB, bool BF = false, bool ANT = true>
 static int launch_fused_wide(const FusedArgs& a0, hipStream_t st) {
   FusedArgs a = a0;
   a.tiles_m = (a.Mrows + 127) / 128;
@@ -1246,7 +1251,7 @@ static int launch_fused_wide(const FusedArgs& a0, hipStream_t st) {
   constexpr size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
   static LdsOptIn lds_optin;
   if (lds > 64 * 1024) {
-    if (const int rc = ensure_dyn_lds(lds_optin, reinterpret_cast<const void*>(&spmma_f16_fused_wide_kernel<BN, WM, WN, NLB, PF, NSB, BF>), lds, "spmma_f16_fused_wide_kernel")) return rc;
+    if (const int rc = ensure_dyn_lds(lds_optin, reinterpret_cast<const void*>(&spmma_f16_fused_wide_kernel<BN, WM, WN, NLB, PF, NSB, BF, ANT>), lds, "spmma_f16_fused_wide_kernel")) return rc;
   }
 #ifdef SM_STAMP
   {
@@ -1257,7 +1262,7 @@ static int launch_fused_wide(const FusedArgs& a0, hipStream_t st) {
     if (cnt > cap) { if (dbg) (void)hipFree(dbg); (void)hipMalloc((void**)&dbg, cnt * 8); cap = cnt; }
     (void)hipMemset(dbg, 0, cnt * 8);
     a.dbg = dbg;
-    spmma_f16_fused_wide_kernel<BN, WM, WN, NLB, PF, NSB, BF><<<dim3((unsigned)nwg), dim3(64 * NWV), lds, st>>>(a);
+    spmma_f16_fused_wide_kernel<BN, WM, WN, NLB, PF, NSB, BF, ANT><<<dim3((unsigned)nwg), dim3(64 * NWV), lds, st>>>(a);
     (void)hipDeviceSynchronize();
     std::vector<unsigned long long> h(cnt);
     (void)hipMemcpy(h.data(), dbg, cnt * 8, hipMemcpyDeviceToHost);
@@ -1276,7 +1281,7 @@ static int launch_fused_wide(const FusedArgs& a0, hipStream_t st) {
     return check_launch("spmma_f16_fused_wide_kernel");
   }
 #endif
-  spmma_f16_fused_wide_kernel<BN, WM, WN, NLB, PF, NSB, BF><<<dim3((unsigned)nwg), dim3(64 * (WM * WN + 4 + NLB)), lds, st>>>(a);
+  spmma_f16_fused_wide_kernel<BN, WM, WN, NLB, PF, NSB, BF, ANT><<<dim3((unsigned)nwg), dim3(64 * (WM * WN + 4 + NLB)), lds, st>>>(a);
   return check_launch("spmma_f16_fused_wide_kernel");
 }
 
@@ -1868,6 +1873,7 @@ static int spmma_fused16(size_t ngroup, const void* const* Ag, const void* const
       while (panels * ns * 4 < 3 * cus && (tn + 2 * ns - 1) / (2 * ns) >= 2) ns *= 2;
       big = round_eff(t_big, cus) > round_eff(panels * ns, cus) + 0.1;
     }
+    // (the hint on the big form's A loads, n <= 256: measured indifferent, profiles/nt_ab_r05q.txt)
     if (big) return n <= 256 ? launch_fused_big<256, BF, 3, 2, true>(a, st) : launch_fused_big<256, BF, 3, 2, false>(a, st);
   }
 #ifdef SM_TUNING
@@ -1896,6 +1902,11 @@ static int spmma_fused16(size_t ngroup, const void* const* Ag, const void* const
     }
 #endif
     if (n <= 64) return direct_env >= 3 ? launch_fused_direct<64, 3, BF>(a, st) : launch_fused_direct<64, 2, BF>(a, st);
+    // (round 5) the non-temporal hint on the A loads only where A really is read once and streams long: with two column tiles (n = 256,
+    // k = 64) the second tile's read of the same rows then misses L2 -- 12544 x 256 x 64 x 3: 200 -> 166 us without the hint -- and the
+    // short-K 128-column layer is 5 % faster without it too (12544 x 128 x 256: 68.7 -> 64.8 us); 3136 x 128 x 512 / 1152 and every
+    // 64-column shape keep it (1-6 % faster with it; profiles/nt_ab_r05q.txt).  Same C either way.
+    if (direct_env < 3 && (n > 128 || k < 512)) return launch_fused_direct<128, 2, BF, 128, 4, false>(a, st);
     return direct_env >= 3 ? launch_fused_direct<128, 3, BF>(a, st) : launch_fused_direct<128, 2, BF>(a, st);
   }
   // n > 256, short K, plain store: A-stationary (the 2:4 image of a row panel stays in LDS across column tiles)
@@ -1914,6 +1925,7 @@ static int spmma_fused16(size_t ngroup, const void* const* Ag, const void* const
   // profiles/widep_r03g.txt), so those keep one workgroup per tile.  SM_FUSED_WIDEP (tuning aid): 0 = never, 2 = always.
   static const int widep_env = tuning_int("SM_FUSED_WIDEP", 1);
   if (widep_env == 2 || (widep_env == 1 && k <= 1024)) return launch_fused_widep<256, 4, 2, 4, 2, 3, BF>(a, st);
+  if (n > 256) return launch_fused_wide<256, 4, 2, 4, 2, 3, BF, false>(a, st);  // several column tiles read the same A rows: no non-temporal hint
   return launch_fused_wide<256, 4, 2, 4, 2, 3, BF>(a, st);
 }
 
