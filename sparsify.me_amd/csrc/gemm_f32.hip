@@ -594,7 +594,7 @@ static int launch_spmma32_dma(const Gemm32Args& a0, hipStream_t st) {
 // Tile shape: the kernel is bound by the fp32 matrix pipe, not by operand traffic, so small tiles cost nothing per
 // flop (4096^3: 104.7 / 111.1 / 101.7 / 105.3 TF/s for 128x128 / 128x64 / 64x128 / 64x64) and win whenever the
 // tile count is not a large multiple of the CU count: 64 x 64 is the best shape on every ResNet-18 layer at
-// b = 32 (5.34 ms for the table against 8.25 / 6.01 / 7.18 ms, tools/f32_probe.py and tools/sweep.py
+// b = 32 (5.34 ms for the table against 8.25 / 6.01 / 7.18 ms, tools/archive/f32_probe.py and tools/sweep.py
 // --dtype f32).  128 x 64 takes over once a CU gets >= 32 of the small tiles.
 template <int MODE>
 static int dispatch32(const Gemm32Args& a, hipStream_t st) {
@@ -624,7 +624,7 @@ static int dispatch32(const Gemm32Args& a, hipStream_t st) {
       if (cfg == 9) return launch32_dma<128, 128, 4, 4, 2, BKM>(a, st);
       // short operands get tiles as short as they are; narrow outputs 128 x 64 tiles (more of them); otherwise
       // 128 x 128 over 16 waves (measured on the ResNet
-      // shapes and on 4096^3 / 8192^2 x 2048: tools/f32_probe.py under SM_GEMM32_DMA=2..9)
+      // shapes and on 4096^3 / 8192^2 x 2048: tools/archive/f32_probe.py under SM_GEMM32_DMA=2..9)
       if (cfg == 10) return launch32_dma<64, 128, 1, 4, 2, BKM>(a, st);
       if (a.M <= 64) return a.N <= 64 ? launch32_dma<64, 64, 2, 2, 2, BKM>(a, st) : launch32_dma<64, 128, 1, 4, 2, BKM>(a, st);
       return a.N <= 128 ? launch32_dma<128, 64, 4, 1, 2, BKM>(a, st) : launch32_dma<128, 128, 4, 4, 2, BKM>(a, st);
@@ -999,7 +999,7 @@ int sm_gemm_batched_f64(const double* const* A_ptrs, const double* const* B_ptrs
       ceil_div((size_t)a.M, (size_t)64) <= 65535) {
     if (dma_env == 2) return launch64_dma<64, 64, 2, 2>(a, batch, (hipStream_t)stream);
     if (dma_env == 5) return launch64_dma<128, 128, 4, 4>(a, batch, (hipStream_t)stream);
-    // 128 x 128 tiles over 16 waves once they fill 3/4 of the CUs, 64 x 64 otherwise (tools/f64_probe.py under SM_GEMM64_DMA=2..5)
+    // 128 x 128 tiles over 16 waves once they fill 3/4 of the CUs, 64 x 64 otherwise (tools/archive/f64_probe.py under SM_GEMM64_DMA=2..5)
     const size_t big_tiles = ceil_div((size_t)a.M, (size_t)128) * ceil_div((size_t)a.N, (size_t)128) * batch;
     if (a.M > 64 && a.N > 64 && 4 * big_tiles >= 3 * (size_t)device_cu_count())
       return launch64_dma<128, 128, 4, 4>(a, batch, (hipStream_t)stream);

@@ -6,7 +6,7 @@
 //   sm_spmma_i8: C (int32) = A_2:4 . B (+ C), exact integer arithmetic on v_smfmac_i32_16x16x128_i8.  B is given
 //     K-CONTIGUOUS per output column ([n][k], "TN", the layout int8 matrix cores are fed in): a column's 128-k stage
 //     piece is one 128-byte row of the LDS image and a lane's operand is two 16-byte chunks of it.
-// Operand maps of the instruction, determined on hardware (tools/probe_i8.hip -> profiles/probe_i8_r01.txt):
+// Operand maps of the instruction, determined on hardware (tools/archive/probe_i8.hip -> profiles/probe_i8_r01.txt):
 //   A lane l: row l & 15, g = l >> 4: 16 kept bytes = strips 8 g .. 8 g + 7 of the 128-k stage (dense k 32 g .. + 31),
 //     2-bit position code of kept byte e in bits [2 e, 2 e + 1] of the index operand -- i.e. the blob's nibbles of
 //     those 8 strips, 4 consecutive metadata bytes, as they are;
@@ -618,7 +618,7 @@ static int spmma_i8_entry(const void* blob, const void* B, int32_t* C, int8_t* C
   if (cfg == 2) return launch_spmma_i8<128, 2, 2>(a, st);
   if (cfg == 3) return launch_spmma_i8<128, 2, 4>(a, st);
   if (cfg == 4) return launch_spmma_i8<128, 4, 4>(a, st);
-  // narrow outputs: 128 x 64 tiles over 4 waves (more tiles); otherwise 128 x 128 over 8 (tools/i8_probe.py)
+  // narrow outputs: 128 x 64 tiles over 4 waves (more tiles); otherwise 128 x 128 over 8 (tools/archive/i8_probe.py)
   return n <= 128 ? launch_spmma_i8<64, 4, 1>(a, st) : launch_spmma_i8<128, 2, 4>(a, st);
 }
 
