@@ -59,8 +59,15 @@ struct FusedArgs {
 // (round 5) the 128-column form is asked to fit four waves per SIMD (<= 128 registers; left alone it takes 129 = three): a single-stage
 // problem (k = 64) allocates 34 KiB of LDS, so a fourth workgroup then shares the CU -- with no K loop to pipeline, the workgroups
 // per CU are all that overlaps one tile's load latency with another's stores (12544 x 256 x 64)
+// (measured indifferent: profiles/direct_ablate_occ4_r05p.txt -- kept, it costs nothing.  Tuning builds, whose ablation switches push the kernel past 128 registers,
+// keep the default bound: with the hint they spill 204 bytes per lane and run 3 x slower, profiles/ab_bm192_r05s.txt)
+#ifdef SM_TUNING
+#define SM_DIRECT_MIN_WAVES(BN, NWV, BM) 1
+#else
+#define SM_DIRECT_MIN_WAVES(BN, NWV, BM) (((BN) == 128 && (NWV) == 4 && (BM) == 128) ? 4 : 1)
+#endif
 template <int BN, int NS, bool BF = false, int BM = 128, int NWV = 4, bool ANT = true, bool DENSE = false>
-__global__ __launch_bounds__(64 * NWV, (BN == 128 && NWV == 4 && BM == 128) ? 4 : 1) void spmma_f16_fused_direct_kernel(const FusedArgs p) {
+__global__ __launch_bounds__(64 * NWV, SM_DIRECT_MIN_WAVES(BN, NWV, BM)) void spmma_f16_fused_direct_kernel(const FusedArgs p) {
   static_assert(BM == 128 || BM == 64, "row tile");
   static_assert(NWV == 4 || (NWV == 8 && BM == 128), "waves per workgroup");
   constexpr int NW = NWV, TM = BM / NW, FM = TM / 16, FN = BN / 16;
@@ -1894,6 +1901,10 @@ static int spmma_fused16(size_t ngroup, const void* const* Ag, const void* const
       if (n <= 64) return launch_fused_direct<64, 2, BF, 64>(a, st);
       return launch_fused_direct<128, 2, BF, 64>(a, st);
     }
+    // (round 5: 192-row tiles at 128 columns -- four waves of 48 rows, a third less B re-read per A byte, 80 KiB: still two workgroups per CU -- bit-identical and
+    //  no faster than the 128-row tiles on any n = 128 shape: 3136 x 128 x 1152 x 4 193.5 us against 194, 3136 x 128 x 512 x 3 83.7 against 80, 12544 x 128 x 256 61 against 60
+    //  (profiles/ab_bm192_r05s.txt: its "bm128" column is the spilling tuning build, compare with profiles/sweep_r05y_f16_resnet50.txt).  So the B tile re-read through
+    //  the CU's L2 port is NOT what holds the 128-column shapes at 4.5 TB/s.  Removed.)
 #endif
 #ifdef SM_TUNING
     if (tuning_int("SM_DIRECT_NT", 1) == 0) {  // A/B of the non-temporal hint on the A DMA
