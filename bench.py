@@ -873,6 +873,24 @@ def extras(args, sm, torch, dev, layers, flops, t_full, Forked, make_runner, tim
             split[key + "_speedup_vs_dense_rowmajor"] = t_drm / t_sp
             split[key + "_speedup_vs_exact_fused"] = t_full / t_sp
             split[key + "_hbm_frac"] = sum(L["b"] * 4 * (L["m"] * L["k"] + L["m"] * L["n"]) + 4 * L["k"] * L["n"] for L in layers) / t_sp / (HBM_PEAK_GBS * 1e9)
+        # B's planes kept across calls (round 5: sm_spmma_fused_f32_split_prepare once, untimed -- B is the layer's weights in the reference's
+        # use -- then sm_spmma_fused_f32_split_prepared per step): the same C bit for bit, without the per-call pass over B
+        if hasattr(sm, "spmma_fused_f32_split_prepared"):
+            for planes in (3, 2):
+                for L in layers:
+                    L["prep"] = sm.spmma_fused_f32_split(L["A"], L["B"], L["C"], L["m"], L["n"], L["k"], L["ws"], batch=L["b"], planes=planes, check=False) == 0
+                    if L["prep"]:
+                        sm.spmma_fused_f32_split_prepare(L["B"], L["n"], L["k"], L["ws"], planes=planes)
+                def layer_prepared(L, planes=planes):
+                    if L["prep"]:
+                        sm.spmma_fused_f32_split_prepared(L["A"], L["ws"], L["C"], L["m"], L["n"], L["k"], batch=L["b"], planes=planes)
+                    else:
+                        (sm.spmma_fused(L["A"], L["B"], L["C"], L["m"], L["n"], L["k"], batch=L["b"]) if use_fused(L) else
+                         (sm.compress24(L["A"], L["m"], L["k"], L["k"], L["b"], L["m"] * L["k"], L["blob"]),
+                          sm.spmma(L["blob"], L["B"], L["C"], L["m"], L["n"], L["k"], L["b"], 0)))
+                t_pp = sec_per_call(Forked(layer_prepared))
+                split["planes%d_prepared_ms" % planes] = t_pp * 1e3
+                split["planes%d_prepared_speedup_vs_dense_rowmajor" % planes] = t_drm / t_pp
         # the dense product by the same pieces (sm_gemm_rowmajor_f32_split): what the 2:4 split form should be held against
         for planes in (3, 2):
             def layer_dense_split(L, planes=planes):
@@ -1220,16 +1238,20 @@ def config5_stage(sm, torch, dev):
         by = nnz * 8.0 + (m + 1) * 4.0 + 4.0 * b * (k * n + m * n)
         row = {"m": m, "n": n, "k": k, "b": b, "nnz": nnz, "ms_exact": ms, "GBs_exact": by / ms / 1e6, "frac_exact": by / ms / 1e6 / HBM_PEAK_GBS,
                "TFs_exact": 2.0 * nnz * n * b / ms / 1e9, "ms_exact_rowptr_form": ms_rowptr}
-        if k % 64 == 0:
+        form = L_.sm_spmm_coo_fast_form(m, k, nnz, n, b, 0.0) if hasattr(L_, "sm_spmm_coo_fast_form") else (1 if k % 64 == 0 else 0)
+        if form:
             ms_fast = sm.graph_time_ms(call_fast, iters=5)
             flag = ctypes.c_int(-1)
             L_.sm_spmm_coo_fast_flag(ws3.data_ptr(), ctypes.byref(flag), None)
-            row.update({"ms": ms_fast, "GBs": by / ms_fast / 1e6, "frac": by / ms_fast / 1e6 / HBM_PEAK_GBS, "form": "dense-MFMA (opt-in: strided_coo_options().fast)", "range_flag": flag.value})
+            row.update({"ms": ms_fast, "GBs": by / ms_fast / 1e6, "frac": by / ms_fast / 1e6 / HBM_PEAK_GBS, "range_flag": flag.value,
+                        "form": ("sparse matrix instruction" if form == 2 else "dense-MFMA") + " (opt-in: strided_coo_options().fast)"})
         else:  # the stem layer's k = 147: the dense-MFMA form takes whole 64-deep stages only; strided_coo runs the exact form
             row.update({"ms": ms, "GBs": by / ms / 1e6, "frac": by / ms / 1e6 / HBM_PEAK_GBS, "form": "exact (packed)", "range_flag": None})
         rows.append(row)
         del B, C, ws, ws2, ws3
-    return {"kernel": "ms / GBs / frac = the OPT-IN fast form of sparsifyme::batched::strided_coo (strided_coo_options().fast; the default is the exact fp32 form, ms_exact): sm_spmm_coo_f32_fast (dense operand and A scaled by powers of two computed on the "
+    return {"kernel": "ms / GBs / frac = the OPT-IN fast form of sparsifyme::batched::strided_coo (strided_coo_options().fast; the default is the exact fp32 form, ms_exact): sm_spmm_coo_f32_fast -- round 5, `form` = sparse matrix instruction: "
+                      "spmm_coo_smfmac_kernel (a 2:4 image of A, hi + lo fp16 planes, + its few third / fourth non-zeros per strip as fp32 entries; B converted in the loader; v_smfmac_f32_16x16x64_f16) after scan / scatter / image kernels, "
+                      "whole call timed; `form` = dense-MFMA: the round-4 pipeline (dense operand and A scaled by powers of two computed on the "
                       "device, rounded to fp16 / split hi + lo, fp16 MFMA with fp32 accumulation, inverse scales on the fp32 sums; result within 2^-11 of "
                       "sum|a||b| at any magnitude; a range flag + untouched C when an operand does not convert -> exact fallback; whole call incl. its scan / "
                       "conversion / scatter passes) = ms / GBs / frac; the exact forms beside it: ms_exact = sm_spmm_coo_f32_packed (re-ordering of A + product), "

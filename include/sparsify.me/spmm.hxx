@@ -114,8 +114,9 @@ float strided_coo(std::size_t A_num_rows,
   t.begin();  // the reference times its buffer allocation too (spmm.hxx:155-156,183)
   int rc = SM_STATUS_NOT_SUPPORTED;
   // Opt-in only (strided_coo_options().fast = true; round 5, ADVICE round 4: an fp32 caller must not lose operand precision
-  // silently): first the dense-MFMA form (sm_spmm_coo_f32_fast: operands scaled by powers of two and rounded to fp16, fp32
-  // accumulation; result within 2^-11 of sum|a||b|, include/sparsifyme.h) where it pays -- at least ~2 % of A's entries present:
+  // silently): first the matrix-core form (sm_spmm_coo_f32_fast: operands scaled by powers of two and rounded to fp16, fp32
+  // accumulation; result within 2^-11 of sum|a||b|, include/sparsifyme.h; round 5: for beta == 0 and at most 20 % of A present the
+  // product runs on the sparse matrix instruction from a 2:4 image of A, any A_num_cols) where it pays -- at least ~2 % of A's entries present:
   // below that the exact kernels' work, which follows nnz, is less than the dense product's -- and where the library takes the
   // shape.  It raises a flag on the device and leaves C untouched when an operand does not fit the fp16 range under its scales;
   // the exact form below then runs on the untouched operands.

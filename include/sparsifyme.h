@@ -234,6 +234,14 @@ int sm_spmma_fused_f32(const float* A, const float* B, float* C, size_t m, size_
  * workspace, same bounds with all of A's elements in the sums) -- the dense comparator the 2:4 split form is held against, and
  * 1.5-2 x faster than the fp32-MFMA sm_gemm_rowmajor_f32 in its own right. */
 int sm_spmma_fused_f32_split_workspace(size_t n, size_t k, size_t batch, size_t strideB, int planes, size_t* bytes);
+/* B's planes once (round 5): for a B that stays the same across calls (weights), sm_spmma_fused_f32_split_prepare splits it into `workspace`
+ * (the same sm_spmma_fused_f32_split_workspace bytes) and sm_spmma_fused_f32_split_prepared multiplies from those planes: the same kernels and the
+ * same C bit for bit as sm_spmma_fused_f32_split, without its per-call streaming pass over B. */
+int sm_spmma_fused_f32_split_prepare(const float* B, size_t n, size_t k, size_t batch, size_t strideB, int planes, void* workspace, size_t workspace_bytes,
+                                     sm_stream_t stream);
+int sm_spmma_fused_f32_split_prepared(const float* A, const void* planes_workspace, float* C, size_t m, size_t n, size_t k, size_t lda, size_t batch,
+                                      size_t strideA, size_t strideB, size_t strideC, int planes, size_t workspace_bytes, float alpha, float beta,
+                                      sm_stream_t stream);
 int sm_spmma_fused_f32_split(const float* A, const float* B, float* C, size_t m, size_t n, size_t k, size_t lda, size_t batch,
                              size_t strideA, size_t strideB, size_t strideC, int planes, void* workspace, size_t workspace_bytes,
                              float alpha, float beta, sm_stream_t stream);
@@ -336,7 +344,15 @@ int sm_spmm_coo_f32_packed(size_t A_num_rows, size_t A_num_cols, size_t A_nnz, s
  * sm_spmm_coo_fast_flag() copies the flag to the host (it synchronises the stream), which is what strided_coo does.
  * Duplicates add (in an unspecified order).  Needs A_num_cols % 64 == 0 (> 0), A_num_rows % 4 == 0 (>= 8), 16-byte aligned B and
  * C and sm_spmm_coo_fast_workspace_size bytes of workspace (SM_STATUS_NOT_SUPPORTED when the sizes overflow size_t);
- * SM_STATUS_NOT_SUPPORTED otherwise (use the exact entry points). */
+ * SM_STATUS_NOT_SUPPORTED otherwise (use the exact entry points).
+ * Round 5 -- the SPARSE matrix instruction for the same call: with beta == 0, A_num_rows % 4 == 0 and at most 20 % of A's entries present
+ * (sm_spmm_coo_fast_form says which form a call gets: where both apply, this one for A_num_cols <= 128 and for few-row matrices with A_num_cols <= 512), A becomes a 2:4 image (per 1 x 4 strip its first two non-zeros, scaled and split hi + lo
+ * as above; a random 10 %-dense A has a third non-zero in 0.4 % of its strips -- those entries are kept as fp32 values beside the image) and
+ * the product runs on v_smfmac_f32_16x16x64_f16 with the dense operand converted inside the kernel's loader: no fp16 copy of B, any
+ * A_num_cols (k % 64 != 0, k % 4 != 0 included).  Same error bound.  Flag, this form: A out of range, or a 32 x 64 block of A with more than
+ * 64 third / fourth non-zeros -> nothing is written; an element of B out of range -> the 128 x 128 tiles of C that read it are not written, the
+ * others are (beta == 0: the exact form overwrites all of C anyway). */
+int sm_spmm_coo_fast_form(size_t A_num_rows, size_t A_num_cols, size_t A_nnz, size_t B_num_cols, size_t num_batches, float beta); /* 2: sparse matrix instruction, 1: dense-MFMA pipeline, 0: not taken */
 int sm_spmm_coo_fast_workspace_size(size_t A_num_rows, size_t A_num_cols, size_t B_num_cols, size_t num_batches, size_t* bytes /*host*/);
 int sm_spmm_coo_fast_flag(const void* workspace, int* host_flag, sm_stream_t stream);
 int sm_spmm_coo_f32_fast(size_t A_num_rows, size_t A_num_cols, size_t A_nnz, size_t B_num_cols, size_t num_batches,

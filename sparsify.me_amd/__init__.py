@@ -92,6 +92,7 @@ _SIGS = {
                            _c_ptr, _c_ptr],
     "sm_spmm_coo_fast_workspace_size": [_c_size, _c_size, _c_size, _c_size, ctypes.POINTER(_c_size)],
     "sm_spmm_coo_fast_flag": [_c_ptr, ctypes.POINTER(_c_i), _c_ptr],
+    "sm_spmm_coo_fast_form": [_c_size, _c_size, _c_size, _c_size, _c_size, _c_f],
     "sm_spmm_coo_f32_fast": [_c_size, _c_size, _c_size, _c_size, _c_size, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_f, _c_f,
                              _c_ptr, _c_size, _c_ptr],
     "sm_fill_uniform_f16": [_c_ptr, _c_size, ctypes.c_uint64, _c_f, _c_f, _c_ptr],
@@ -120,6 +121,8 @@ _SIGS["sm_spmma_i8_q"] = [_c_ptr, _c_ptr, _c_ptr, _c_size, _c_size, _c_size, _c_
 for _name in ("sm_prune24", "sm_prune24_check", "sm_compress24", "sm_decompress24", "sm_spmma", "sm_spmma_fused",
               "sm_gemm_rowmajor", "sm_fill_uniform", "sm_im2col", "sm_im2col_compress24"):
     _SIGS[_name + "_bf16"] = _SIGS[_name + "_f16"]
+_SIGS["sm_spmma_fused_f32_split_prepare"] = [_c_ptr, _c_size, _c_size, _c_size, _c_size, _c_i, _c_ptr, _c_size, _c_ptr]
+_SIGS["sm_spmma_fused_f32_split_prepared"] = [_c_ptr, _c_ptr, _c_ptr] + [_c_size] * 8 + [_c_i, _c_size, _c_f, _c_f, _c_ptr]
 _SIGS["sm_spmma_fused_workspace_size"] = [ctypes.POINTER(_c_size)]
 _SIGS["sm_spmma_fused_streamk_plan"] = [_c_size, _c_size, _c_size, _c_size, ctypes.POINTER(_c_i), ctypes.POINTER(ctypes.c_uint)]
 _SIGS["sm_gemm_rowmajor_f16_ws"] = [_c_ptr, _c_ptr, _c_ptr] + [_c_size] * 8 + [_c_f, _c_f, _c_ptr, _c_size, _c_ptr]
@@ -429,6 +432,24 @@ def spmma_fused_f32_split(A, B, C, m, n, k, workspace, lda=None, batch=1, stride
             workspace.numel() * workspace.element_size(), float(alpha), float(beta), _stream())
     if check or rc not in (0, STATUS_NOT_SUPPORTED):
         _check(rc, "sm_spmma_fused_f32_split")
+    return rc
+
+
+def spmma_fused_f32_split_prepare(B, n, k, workspace, batch=1, strideB=0, planes=3):
+    """Split B (fp32, k x n) into its bfloat16 planes once (weights that stay the same across calls): sm_spmma_fused_f32_split_prepare."""
+    _check(lib().sm_spmma_fused_f32_split_prepare(_dev(B), n, k, batch, strideB, planes, _dev(workspace), workspace.numel() * workspace.element_size(), _stream()),
+           "sm_spmma_fused_f32_split_prepare")
+
+
+def spmma_fused_f32_split_prepared(A, workspace, C, m, n, k, lda=None, batch=1, strideA=None, strideB=0, strideC=None, planes=3, alpha=1.0, beta=0.0, check=True):
+    """The split-form product from prepared planes of B (spmma_fused_f32_split_prepare): same C as spmma_fused_f32_split, no per-call pass over B."""
+    lda = k if lda is None else lda
+    strideA = m * lda if strideA is None else strideA
+    strideC = m * n if strideC is None else strideC
+    rc = lib().sm_spmma_fused_f32_split_prepared(_dev(A), _dev(workspace), _dev(C), m, n, k, lda, batch, strideA, strideB, strideC, planes,
+                                                 workspace.numel() * workspace.element_size(), float(alpha), float(beta), _stream())
+    if check or rc not in (0, STATUS_NOT_SUPPORTED):
+        _check(rc, "sm_spmma_fused_f32_split_prepared")
     return rc
 
 

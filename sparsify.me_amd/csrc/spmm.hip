@@ -10,6 +10,7 @@
 #include <cstdlib>
 
 #include "sm_common.h"
+#include "coo_fast.h"
 
 namespace sm {
 
@@ -810,32 +811,42 @@ namespace sm {
 int gemm_f16_f32out(const void* A, const void* B2, float* C, size_t M, size_t N, size_t K, size_t lda, size_t ldb, size_t ldc, float alpha,
                     float beta, hipStream_t st, const float* alpha_dev, const int* skip_flag);  // gemm_f16.hip
 
-// Header of the fast form's workspace (round 4: power-of-two operand scales, so that the 2^-11 bound does not depend on the
-// operands' magnitude, and a range flag, so that a caller can tell when it did not hold).  All written on the device.
-struct CooFastHdr {
-  int flag;            // != 0: an element left the fp16 range under the call's scales -> C was NOT written (the GEMM returns at once)
-  unsigned max_b;      // bit pattern of max |b| over a strided sample of the dense operand (the scale's ESTIMATE)
-  unsigned max_a;      // bit pattern of max |a| over all values of A (exact)
-  float inv_scale[2];                  // 2^-y, 2^-x (the inverse scales of A and of the dense operand), written by the split kernel,
-                                       // applied to the fp32 sums one after the other (each a normal float)
-};
-constexpr size_t COO_FAST_HDR_BYTES = 256;
-
 // max |a| over all values of A (exact) and max |b| over a SAMPLE of the dense operand: `nchunks` runs of 1024 contiguous floats
 // spread evenly over it (whole cache lines: a strided element sample costs a line per element -- 35 us for a 10^6-element sample,
 // measured in round 4's first form -- where these 4 MB cost 2-3)
-__global__ __launch_bounds__(256) void coo_fast_scan_kernel(const float* __restrict__ vals, size_t nnz, const float* __restrict__ B, size_t nb, size_t nchunks,
-                                                            size_t chunk_step, CooFastHdr* hdr) {
+// (round 5: 128 workgroups of 1024 threads, every thread's loads independent of one another -- four in flight -- and ONE pair of atomics per
+// workgroup: the first form's 1024 wave-level atomics on two addresses and its dependent loads cost 26-28 us per call, profiles/coo_kernels_r05ab.txt)
+__global__ __launch_bounds__(1024) void coo_fast_scan_kernel(const float* __restrict__ vals, size_t nnz, const float* __restrict__ B, size_t nb, size_t nchunks,
+                                                             size_t chunk_step, CooFastHdr* hdr) {
+  __shared__ unsigned red[2][16];
   unsigned ma = 0u, mb = 0u;
-  const size_t t0 = blockIdx.x * (size_t)256 + threadIdx.x, nt = (size_t)gridDim.x * 256;
-  for (size_t i = t0; i < nnz; i += nt) { const unsigned u = __builtin_bit_cast(unsigned, vals[i]) & 0x7fffffffu; ma = u > ma ? u : ma; }
-  for (size_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
-    const size_t i = c * chunk_step + 4u * threadIdx.x;  // chunk_step % 4 == 0, B 16-byte aligned
-    if (i + 4 <= nb) {
-      const f4 v = *reinterpret_cast<const f4*>(B + i);
+  const size_t t0 = blockIdx.x * (size_t)1024 + threadIdx.x, nt = (size_t)gridDim.x * 1024;
+  for (size_t i = t0; i < nnz; i += 4 * nt) {
+    float v[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { const unsigned u = __builtin_bit_cast(unsigned, v[e]) & 0x7fffffffu; mb = u > mb ? u : mb; }
+    for (int j = 0; j < 4; ++j) v[j] = i + j * nt < nnz ? vals[i + j * nt] : 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const unsigned u = __builtin_bit_cast(unsigned, v[j]) & 0x7fffffffu;
+      ma = u > ma ? u : ma;
     }
+  }
+  const size_t units = nchunks * 256;  // (chunk, 16-byte piece of it)
+  for (size_t u0 = t0; u0 < units; u0 += 4 * nt) {
+    f4 v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const size_t u = u0 + j * nt, i = (u >> 8) * chunk_step + 4u * (u & 255u);  // chunk_step % 4 == 0, B 16-byte aligned
+      v[j] = u < units && i + 4 <= nb ? *reinterpret_cast<const f4*>(B + i) : f4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float ve = v[j][e];  // (a named copy: __builtin_bit_cast applied to a vector ELEMENT expression reads element 0 with this compiler)
+        const unsigned u = __builtin_bit_cast(unsigned, ve) & 0x7fffffffu;
+        mb = u > mb ? u : mb;
+      }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -844,26 +855,20 @@ __global__ __launch_bounds__(256) void coo_fast_scan_kernel(const float* __restr
     mb = xb > mb ? xb : mb;
   }
   if ((threadIdx.x & 63u) == 0) {
-    if (ma) atomicMax(&hdr->max_a, ma);
-    if (mb) atomicMax(&hdr->max_b, mb);
+    red[0][threadIdx.x >> 6] = ma;
+    red[1][threadIdx.x >> 6] = mb;
+  }
+  __syncthreads();
+  if (threadIdx.x < 32u) {
+    unsigned x = red[threadIdx.x >> 4][threadIdx.x & 15u];
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) {
+      const unsigned y = (unsigned)__shfl_xor((int)x, o);
+      x = y > x ? y : x;
+    }
+    if ((threadIdx.x & 15u) == 0 && x) atomicMax(threadIdx.x == 0 ? &hdr->max_a : &hdr->max_b, x);
   }
 }
-// scale = 2^(target - floor(log2(max))), kept a finite normal float; max = 0 / inf / NaN -> 1 (the conversion pass then flags inf / NaN)
-__device__ __forceinline__ int coo_fast_scale_exp(unsigned maxbits, int target) {
-  const int e = (int)(maxbits >> 23) - 127;
-  if (maxbits == 0u || maxbits >= 0x7f800000u) return 0;
-  int x = target - (e < -126 ? -126 : e);
-  x = x > 126 ? 126 : (x < -126 ? -126 : x);
-  return x;
-}
-// sampled max |b| -> [2^12, 2^13): elements up to 8 x the sample's maximum still convert; max |a| -> [2^13, 2^14): room for
-// duplicates that add up.  Every kernel derives the scales from the two maxima itself (no separate launch).
-__device__ __forceinline__ float coo_fast_pow2(int x) { return __builtin_bit_cast(float, (unsigned)(x + 127) << 23); }
-// |x * scale| must not exceed fp16's largest finite value (and x must be finite): then fp16(x * scale) has relative error
-// <= 2^-11 in the normal range and ABSOLUTE error <= 2^-25 below it (|x * scale| < 2^-14: more than 2^26 below the operand's
-// largest element) -- the bound stated in include/sparsifyme.h.  Underflow is therefore not flagged: with ~10^8 elements of
-// ordinary data a few always fall that far below the maximum, and what they lose is 2^-37 of the maximum each.
-__device__ __forceinline__ bool coo_fast_out_of_range(float xs) { return !(__builtin_fabsf(xs) <= 65504.0f); }
 __global__ __launch_bounds__(256) void f32_to_f16_scaled_kernel(const float* __restrict__ in, _Float16* __restrict__ out, size_t n8, CooFastHdr* hdr) {
   const float sc = coo_fast_pow2(coo_fast_scale_exp(hdr->max_b, 12));
   bool bad = false;
@@ -906,6 +911,15 @@ __global__ __launch_bounds__(256) void split_f16x2_scaled_kernel(const float* __
 }
 }  // namespace sm
 
+namespace sm {
+void coo_fast_scan(const float* vals, size_t nnz, const float* B, size_t nB, CooFastHdr* hdr, hipStream_t st) {
+  // <= 1024 chunks of 1024 floats, evenly spread (a dense operand of <= 1 M elements is scanned whole)
+  const size_t nchunks = nB / 1024 < 1024 ? (nB + 1023) / 1024 : 1024;
+  const size_t chunk_step = nchunks >= 1024 ? (nB / nchunks) & ~(size_t)3 : 1024;
+  coo_fast_scan_kernel<<<128, 1024, 0, st>>>(vals, nnz, B, nB, nchunks, chunk_step, hdr);
+}
+}  // namespace sm
+
 static bool coo_fast_sizes(size_t m, size_t k, size_t n, size_t b, size_t* b16, size_t* at32, size_t* aop) {
   size_t nv, e;
   if (__builtin_mul_overflow(n, b, &nv) || __builtin_mul_overflow(nv, k, &e) || __builtin_mul_overflow(e, (size_t)2, b16) ||
@@ -924,7 +938,23 @@ extern "C" int sm_spmm_coo_fast_workspace_size(size_t A_num_rows, size_t A_num_c
     return SM_STATUS_NOT_SUPPORTED;
   }
   *bytes = sm::COO_FAST_HDR_BYTES + b16 + at32 + aop;
+  // the sparse-matrix-instruction form (spmm_coo_smfmac.hip) lays the same workspace out its own way
+  size_t nv = 0;
+  if (!__builtin_mul_overflow(B_num_cols, num_batches, &nv)) {
+    const size_t sp = sm::coo_smfmac_workspace(A_num_rows, A_num_cols, nv);
+    if (sp > *bytes) *bytes = sp;
+  }
   return SM_STATUS_SUCCESS;
+}
+
+extern "C" int sm_spmm_coo_fast_form(size_t A_num_rows, size_t A_num_cols, size_t A_nnz, size_t B_num_cols, size_t num_batches, float beta) {
+  size_t nv = 0, need = 0;
+  if (__builtin_mul_overflow(B_num_cols, num_batches, &nv) || nv == 0 || nv > 0x7fffffffull || A_num_rows == 0 ||
+      sm_spmm_coo_fast_workspace_size(A_num_rows, A_num_cols, B_num_cols, num_batches, &need) != SM_STATUS_SUCCESS)
+    return 0;
+  static const int smfmac_env = sm::tuning_int("SM_COO_SMFMAC", 1);  // (tuning builds only; the product never reads the environment)
+  if (smfmac_env && sm::coo_smfmac_takes(A_num_rows, A_num_cols, A_nnz, nv, nullptr, nullptr, beta)) return 2;
+  return A_num_cols != 0 && A_num_cols % 64 == 0 && A_num_rows % 4 == 0 && A_num_rows >= 8 ? 1 : 0;
 }
 
 extern "C" int sm_spmm_coo_f32_fast(size_t A_num_rows, size_t A_num_cols, size_t A_nnz, size_t B_num_cols, size_t num_batches,
@@ -939,6 +969,11 @@ extern "C" int sm_spmm_coo_f32_fast(size_t A_num_rows, size_t A_num_cols, size_t
   }
   size_t need = 0;
   const int rs = sm_spmm_coo_fast_workspace_size(m, k, B_num_cols, num_batches, &need);
+  // round 5: beta == 0 and a sparse enough A -> the product on the SPARSE matrix instruction (one prepared 2:4 image of A + the few entries
+  // that do not fit it, the dense operand converted in the loader), any k
+  static const int smfmac_env = tuning_int("SM_COO_SMFMAC", 1);  // tuning aid: 0 = always the dense-MFMA pipeline
+  if (rs == SM_STATUS_SUCCESS && workspace_bytes >= need && nv <= 0x7fffffffull && smfmac_env && coo_smfmac_takes(m, k, A_nnz, nv, B, C, beta))
+    return coo_smfmac_product(m, k, A_nnz, nv, rows, cols, vals, B, C, alpha, workspace, (hipStream_t)stream);
   if (rs != SM_STATUS_SUCCESS || k == 0 || k % 64 != 0 || m % 4 != 0 || m < 8 || !aligned16(B) || !aligned16(C) || workspace_bytes < need || nv > 0x7fffffffull) {
     set_error("sm_spmm_coo_f32_fast: needs cols %% 64 == 0 (cols > 0), rows %% 4 == 0, 16-byte aligned B and C and the workspace of sm_spmm_coo_fast_workspace_size "
               "(use sm_spmm_coo_f32_packed)");
@@ -952,10 +987,7 @@ extern "C" int sm_spmm_coo_f32_fast(size_t A_num_rows, size_t A_num_cols, size_t
   _Float16* Aop = (_Float16*)((char*)B16 + round_up(nv * k * 2, 256));
   if (hipMemsetAsync(ws, 0, COO_FAST_HDR_BYTES + k * m * 4, st) != hipSuccess) return check_launch("hipMemsetAsync");  // header and A^T in one node
   const size_t nB = nv * k;
-  // <= 1024 chunks of 1024 floats, evenly spread (a dense operand of <= 1 M elements is scanned whole)
-  const size_t nchunks = nB / 1024 < 1024 ? (nB + 1023) / 1024 : 1024;
-  const size_t chunk_step = nchunks >= 1024 ? (nB / nchunks) & ~(size_t)3 : 1024;
-  coo_fast_scan_kernel<<<256, 256, 0, st>>>(vals, A_nnz, B, nB, nchunks, chunk_step, hdr);
+  coo_fast_scan(vals, A_nnz, B, nB, hdr, st);
   const size_t n8 = nB / 8;  // k % 64 == 0
   f32_to_f16_scaled_kernel<<<stream_grid(n8, 256), 256, 0, st>>>(B, B16, n8, hdr);
   if (A_nnz) coo_scatter_dense_kernel<<<stream_grid(A_nnz, 256), 256, 0, st>>>(rows, cols, vals, A_nnz, m, k, AT);

@@ -752,11 +752,13 @@ extern "C" int sm_spmma_fused_f32_split_workspace(size_t n, size_t k, size_t bat
   return SM_STATUS_SUCCESS;
 }
 
+// prepared: false = split B into `workspace` first (one streaming pass per call), then multiply; true = `workspace` already holds B's planes
+// (sm_spmma_fused_f32_split_prepare: weights that stay the same across calls are split once) and B is not read at all (it may be null)
 static int f32_split_product(bool dense, const float* A, const float* B, float* C, size_t m, size_t n, size_t k, size_t lda, size_t batch, size_t strideA,
                              size_t strideB, size_t strideC, int planes, void* workspace, size_t workspace_bytes, float alpha, float beta,
-                             sm_stream_t stream) {
+                             sm_stream_t stream, bool prepared = false) {
   using namespace sm;
-  if (!A || !B || !C || lda < k || (planes != 2 && planes != 3)) {
+  if (!A || (!B && !prepared) || !C || lda < k || (planes != 2 && planes != 3)) {
     set_error("sm_spmma_fused_f32_split: invalid argument");
     return SM_STATUS_INVALID_VALUE;
   }
@@ -765,7 +767,7 @@ static int f32_split_product(bool dense, const float* A, const float* B, float* 
   const bool span = (k % 64 != 0 || lda % 4 != 0) && k != 0 && lda == k && n <= 128 && (batch == 1 || (strideB == 0 && strideA == m * lda && strideC == m * n)) &&
                     (m * batch * k * 4) % 16 == 0 &&
                     ((size_t)128 * k * 4 + 256 + 1023) / 1024 * 1024 + (size_t)planes * ((k + 63) / 64 * 64) * (n <= 64 ? 64 : 128) * 2 <= 160 * 1024;
-  if (k == 0 || (!span && (k % 64 != 0 || lda % 4 != 0)) || n % 8 != 0 || strideA % 4 != 0 || strideB % 8 != 0 || strideC % 4 != 0 || !aligned16(A) || !aligned16(B) ||
+  if (k == 0 || (!span && (k % 64 != 0 || lda % 4 != 0)) || n % 8 != 0 || strideA % 4 != 0 || strideB % 8 != 0 || strideC % 4 != 0 || !aligned16(A) || (!prepared && !aligned16(B)) ||
       !aligned16(C) || m * batch > 0x7fffffffull || n > 0x7fffffffull || k > 0x7fffffffull || lda > 0x7fffffffull) {
     set_error("sm_spmma_fused_f32_split: needs k %% 64 == 0 (or a ragged k with n <= 128, lda == k and one tall A that fits the span form), n %% 8 == 0 and "
               "16-byte aligned A, B and C (use sm_spmma_fused_f32)");
@@ -786,9 +788,11 @@ static int f32_split_product(bool dense, const float* A, const float* B, float* 
   const size_t plane = nb * k * n, items = plane / 8;
   unsigned short* P = (unsigned short*)workspace;
   const unsigned grid = (unsigned)std::min<size_t>((items + 255) / 256, 4096);
-  if (planes == 3) split_planes_kernel<3><<<dim3(grid), dim3(256), 0, st>>>(B, P, items, plane);
-  else split_planes_kernel<2><<<dim3(grid), dim3(256), 0, st>>>(B, P, items, plane);
-  if (const int rc = check_launch("split_planes_kernel")) return rc;
+  if (!prepared) {
+    if (planes == 3) split_planes_kernel<3><<<dim3(grid), dim3(256), 0, st>>>(B, P, items, plane);
+    else split_planes_kernel<2><<<dim3(grid), dim3(256), 0, st>>>(B, P, items, plane);
+    if (const int rc = check_launch("split_planes_kernel")) return rc;
+  }
   SplitArgs a = {};
   a.A = A; a.Bp = P; a.C = C;
   a.sA = strideA; a.sBp = strideB ? k * n : 0; a.plane = plane; a.sC = strideC;
@@ -841,4 +845,34 @@ extern "C" int sm_gemm_rowmajor_f32_split(const float* A, const float* B, float*
                                           size_t strideB, size_t strideC, int planes, void* workspace, size_t workspace_bytes, float alpha, float beta,
                                           sm_stream_t stream) {
   return f32_split_product(true, A, B, C, m, n, k, lda, batch, strideA, strideB, strideC, planes, workspace, workspace_bytes, alpha, beta, stream);
+}
+
+// B's bfloat16 planes once, for operands that stay the same across calls (weights): sm_spmma_fused_f32_split_prepare writes them into
+// `workspace` (sm_spmma_fused_f32_split_workspace bytes), sm_spmma_fused_f32_split_prepared multiplies from them -- the same kernels, the
+// same C bit for bit as sm_spmma_fused_f32_split, without the per-call streaming pass over B.
+extern "C" int sm_spmma_fused_f32_split_prepare(const float* B, size_t n, size_t k, size_t batch, size_t strideB, int planes, void* workspace,
+                                                size_t workspace_bytes, sm_stream_t stream) {
+  using namespace sm;
+  size_t need = 0;
+  if (!B || (planes != 2 && planes != 3) || n % 8 != 0 || !aligned16(B)) {
+    set_error("sm_spmma_fused_f32_split_prepare: invalid argument (n %% 8 == 0, a 16-byte aligned B, planes 2 or 3)");
+    return SM_STATUS_INVALID_VALUE;
+  }
+  if (const int rc = sm_spmma_fused_f32_split_workspace(n, k, batch, strideB, planes, &need)) return rc;
+  if (!workspace || workspace_bytes < need || !aligned16(workspace) || (strideB && strideB != k * n)) {
+    set_error("sm_spmma_fused_f32_split_prepare: workspace of %zu bytes (16-byte aligned) required; a strided B must be packed", need);
+    return SM_STATUS_INVALID_VALUE;
+  }
+  const size_t nb = strideB ? batch : 1, plane = nb * k * n, items = plane / 8;
+  if (items == 0) return SM_STATUS_SUCCESS;
+  const unsigned grid = (unsigned)std::min<size_t>((items + 255) / 256, 4096);
+  if (planes == 3) split_planes_kernel<3><<<dim3(grid), dim3(256), 0, (hipStream_t)stream>>>(B, (unsigned short*)workspace, items, plane);
+  else split_planes_kernel<2><<<dim3(grid), dim3(256), 0, (hipStream_t)stream>>>(B, (unsigned short*)workspace, items, plane);
+  return check_launch("split_planes_kernel");
+}
+extern "C" int sm_spmma_fused_f32_split_prepared(const float* A, const void* planes_workspace, float* C, size_t m, size_t n, size_t k, size_t lda, size_t batch,
+                                                 size_t strideA, size_t strideB, size_t strideC, int planes, size_t workspace_bytes, float alpha, float beta,
+                                                 sm_stream_t stream) {
+  return f32_split_product(false, A, nullptr, C, m, n, k, lda, batch, strideA, strideB, strideC, planes, const_cast<void*>(planes_workspace), workspace_bytes, alpha, beta,
+                           stream, true);
 }

@@ -1046,6 +1046,34 @@ def test_f32_split_cols_last_stage_waits_for_its_own_b(gpu, dense, planes, k):
         assert torch.equal(C.view(torch.int32), Ce.view(torch.int32)), f"repetition {rep}: the split form differs from the exact kernel"
 
 
+@pytest.mark.parametrize("planes", [3, 2])
+@pytest.mark.parametrize("shape", [(256, 64, 128, 3, False), (200, 256, 192, 2, True), (130, 512, 64, 2, False), (64, 40, 72, 2, False)])
+def test_f32_split_prepared_planes_equal_per_call(gpu, shape, planes):
+    """sm_spmma_fused_f32_split_prepare + _prepared (B's planes once, for weights): bit-equal to sm_spmma_fused_f32_split, with B shared and per batch,
+    and the prepared call never reads B (it is freed before the call)."""
+    import torch
+    m, n, k, batch, per_batch = shape
+    g = torch.Generator().manual_seed(m * 7 + n + k)
+    dA = (torch.rand(batch * m * k, generator=g) * 2 - 1).cuda()
+    nb = batch if per_batch else 1
+    dB = (torch.rand(nb * k * n, generator=g) * 2 - 1).cuda()
+    sB = k * n if per_batch else 0
+    ws = torch.empty(gpu.spmma_fused_f32_split_workspace(n, k, batch=batch, strideB=sB, planes=planes), dtype=torch.uint8, device="cuda")
+    C0 = torch.full((batch * m * n,), 0.5, device="cuda")
+    C1 = C0.clone()
+    gpu.spmma_fused_f32_split(dA, dB, C0, m, n, k, ws, batch=batch, strideB=sB, planes=planes, alpha=1.5, beta=-0.25)
+    ws.zero_()
+    gpu.spmma_fused_f32_split_prepare(dB, n, k, ws, batch=batch, strideB=sB, planes=planes)
+    torch.cuda.synchronize()
+    del dB
+    for _ in range(2):                      # the planes survive a call
+        C1.fill_(0.5)
+        gpu.spmma_fused_f32_split_prepared(dA, ws, C1, m, n, k, batch=batch, strideB=sB, planes=planes, alpha=1.5, beta=-0.25)
+        assert torch.equal(C0, C1)
+    with pytest.raises(gpu.SparsifymeError):
+        gpu.spmma_fused_f32_split_prepare(dA, n, k, ws[:64], batch=batch, strideB=sB, planes=planes)
+
+
 def test_spmma_f32_split_edges(gpu):
     """What the split form declines, and what a non-finite operand value does: it stays in the first piece, so the outputs it
     reaches are non-finite (NaN where the exact form may say inf: inf meets a zero low piece) and every other output is untouched."""
@@ -1602,6 +1630,186 @@ def test_spmm_coo_fast_flags_what_does_not_convert_and_leaves_c_alone(gpu):
     dC = to_dev(np.ones(8 * 8, dtype=np.float32))
     z = torch.zeros(64, dtype=torch.uint8, device="cuda")
     assert gpu.lib().sm_spmm_coo_f32_fast(8, 0, 0, 8, 1, None, None, None, z.data_ptr(), dC.data_ptr(), 1.0, 0.0, z.data_ptr(), 64, None) == gpu.STATUS_NOT_SUPPORTED
+
+
+def _coo_fast_check(gpu, orc, m, n, k, batches, r, c, v, B, alpha, tol=None):
+    """one beta == 0 call of sm_spmm_coo_f32_fast against the oracle on every output; returns (flag, C)"""
+    import ctypes
+    import torch
+    C0 = np.full(batches * m * n, 7.0, dtype=np.float32)
+    dC = to_dev(C0.copy())
+    nb = ctypes.c_size_t(0)
+    assert gpu.lib().sm_spmm_coo_fast_workspace_size(m, k, n, batches, ctypes.byref(nb)) == 0
+    ws = torch.full((nb.value,), 0x5A, dtype=torch.uint8, device="cuda")
+    one = lambda dt: torch.zeros(1, dtype=dt, device="cuda")
+    dr, dc_, dv = (to_dev(r), to_dev(c), to_dev(v)) if r.size else (one(torch.int32), one(torch.int32), one(torch.float32))
+    dB = to_dev(B)
+    rc = gpu.lib().sm_spmm_coo_f32_fast(m, k, r.size, n, batches, dr.data_ptr(), dc_.data_ptr(), dv.data_ptr(), dB.data_ptr(), dC.data_ptr(), alpha, 0.0,
+                                        ws.data_ptr(), nb.value, None)
+    assert rc == 0, gpu.lib().sm_last_error()
+    flag = ctypes.c_int(-1)
+    assert gpu.lib().sm_spmm_coo_fast_flag(ws.data_ptr(), ctypes.byref(flag), None) == 0
+    got = host(dC)
+    if flag.value == 0:
+        want = C0.copy()
+        orc.spmm_coo(m, k, r.size, n, batches, r, c, v, B, want, alpha, 0.0)
+        absA = np.zeros((m, k))
+        np.add.at(absA, (r, c), np.abs(v.astype(np.float64)))
+        scale = np.concatenate([(abs(alpha) * (np.abs(B[bb * k * n:(bb + 1) * k * n].astype(np.float64)).reshape(n, k) @ absA.T)).reshape(-1) for bb in range(batches)])
+        err = np.abs(got.astype(np.float64) - want.astype(np.float64))
+        worst = float(np.max(err / np.maximum(scale, 1e-30)))
+        assert worst <= (tol or COO_FAST_TOL), f"sparse-instruction coo {m}x{n}x{k}x{batches}: worst error {worst:.3e} of the scale"
+        assert np.array_equal(got[scale == 0], np.zeros(int((scale == 0).sum()), dtype=np.float32))   # nothing to add: exactly alpha * 0
+    return flag.value, got
+
+
+@pytest.mark.parametrize("shape", [(8, 8, 64, 1), (132, 33, 128, 3), (300, 130, 250, 2), (20, 5, 192, 4), (128, 64, 64, 2), (260, 72, 147, 3), (64, 40, 90, 2),
+                                   (516, 24, 200, 5), (4, 3, 7, 1), (1000, 16, 1148, 2), (256, 200, 512, 1)], ids=lambda s_: "x".join(map(str, s_)))
+@pytest.mark.parametrize("order", ["sorted", "shuffled", "duplicates", "dense_strips"])
+def test_spmm_coo_smfmac_small_vs_oracle(gpu, orc, shape, order):
+    """The sparse-matrix-instruction form of sm_spmm_coo_f32_fast (beta == 0, density <= 20 %: sm_spmm_coo_fast_form == 2) on every output
+    against the oracle, inside the dense-MFMA form's bound: ragged row / column tiles, k % 64 != 0 and k % 4 != 0 (the stem layer's 147),
+    unsorted input, duplicates (added), strips with three and four non-zeros (the bucket entries), an empty matrix."""
+    m, n, k, batches = shape
+    rng = np.random.default_rng(m * 7 + n + k)
+    dens = rng.uniform(0, 1, (m, k)) < (0.07 if order == "dense_strips" else 0.15)
+    if order == "dense_strips":   # whole strips and runs of three on top of a sparse background; still under 20 %
+        for _ in range(max(1, m * k // 80)):
+            i, j = int(rng.integers(0, m)), int(rng.integers(0, max(1, k - 4)))
+            dens[i, j:j + int(rng.integers(3, 6))] = True
+    r, c = np.nonzero(dens)
+    r, c = r.astype(np.int32), c.astype(np.int32)
+    if order == "duplicates" and r.size:
+        r, c = np.concatenate([r, r[:50]]), np.concatenate([c, c[:50]])
+    r, c = r[:m * k // 5], c[:m * k // 5]     # (tiny shapes: stay under the 20 % the form takes)
+    v = rng.uniform(-1, 1, r.size).astype(np.float32)
+    if order == "shuffled":
+        p_ = rng.permutation(r.size)
+        r, c, v = r[p_].copy(), c[p_].copy(), v[p_].copy()
+    B = rng.uniform(-1, 1, batches * k * n).astype(np.float32)
+    assert r.size * 5 <= m * k and gpu.lib().sm_spmm_coo_fast_form(m, k, r.size, n, batches, 0.0) == 2
+    assert gpu.lib().sm_spmm_coo_fast_form(m, k, r.size, n, batches, 0.5) == (1 if k % 64 == 0 and m >= 8 else 0)
+    flag, _ = _coo_fast_check(gpu, orc, m, n, k, batches, r, c, v, B, 0.75)
+    assert flag == 0
+    if order == "sorted":   # an empty matrix: C = 0 exactly
+        e = np.zeros(0, dtype=np.int32)
+        flag, got = _coo_fast_check(gpu, orc, m, n, k, batches, e, e, np.zeros(0, dtype=np.float32), B, 1.0)
+        assert flag == 0 and not got.any()
+
+
+def test_spmm_coo_smfmac_is_reproducible_and_exact_on_integers(gpu):
+    """Small-integer data (every product and sum exact in fp16 x fp32): the sparse-instruction form equals the integer product bit for bit --
+    image, index nibbles, bucket entries and the result map all in place -- and two calls give the same bits."""
+    import ctypes
+    import torch
+    m, n, k, batches = 388, 150, 328, 2
+    rng = np.random.default_rng(99)
+    dens = rng.uniform(0, 1, (m, k)) < 0.17
+    r, c = np.nonzero(dens)
+    r, c = r.astype(np.int32), c.astype(np.int32)
+    v = rng.integers(-8, 9, r.size).astype(np.float32)
+    B = rng.integers(-8, 9, batches * k * n).astype(np.float32)
+    A = np.zeros((m, k))
+    np.add.at(A, (r, c), v.astype(np.float64))
+    want = np.concatenate([(B[bb * k * n:(bb + 1) * k * n].astype(np.float64).reshape(n, k) @ A.T).reshape(-1) for bb in range(batches)]) * 2.0
+    nb = ctypes.c_size_t(0)
+    gpu.lib().sm_spmm_coo_fast_workspace_size(m, k, n, batches, ctypes.byref(nb))
+    outs = []
+    for _ in range(2):
+        ws = torch.zeros(nb.value, dtype=torch.uint8, device="cuda")
+        dC = torch.full((batches * m * n,), 3.0, device="cuda")
+        dr, dc_, dv, dB = to_dev(r), to_dev(c), to_dev(v), to_dev(B)
+        assert gpu.lib().sm_spmm_coo_f32_fast(m, k, r.size, n, batches, dr.data_ptr(), dc_.data_ptr(), dv.data_ptr(), dB.data_ptr(), dC.data_ptr(), 2.0, 0.0,
+                                              ws.data_ptr(), nb.value, None) == 0
+        outs.append(host(dC))
+    assert np.array_equal(outs[0].astype(np.float64), want) and np.array_equal(outs[0], outs[1])
+
+
+def test_spmm_coo_smfmac_flags(gpu, orc):
+    """The sparse-instruction form's flag: a non-finite or far-out-of-range element of B -> flag, the tiles that read it left alone (here: one
+    tile = all of C); a non-finite A value or a 128 x 64 block with more third / fourth non-zeros than its bucket holds -> flag, C untouched;
+    and the same operands under 2^30 and 2^-30 convert (the scales), flag 0."""
+    m, n, k, batches = 128, 32, 64, 2
+    rng = np.random.default_rng(5)
+    r = np.repeat(np.arange(m, dtype=np.int32), 4)
+    c = rng.integers(0, k, r.size).astype(np.int32)
+    v = rng.uniform(-1, 1, r.size).astype(np.float32)
+    B = rng.uniform(-1, 1, batches * k * n).astype(np.float32)
+    for poison in (np.float32("inf"), np.float32("nan")):
+        Bp = B.copy()
+        Bp[777] = poison
+        flag, got = _coo_fast_check(gpu, orc, m, n, k, batches, r, c, v, Bp, 1.0)
+        assert flag != 0 and np.array_equal(got, np.full(got.size, 7.0, dtype=np.float32))
+    vp = v.copy()
+    vp[100] = np.float32("inf")
+    flag, got = _coo_fast_check(gpu, orc, m, n, k, batches, r, c, vp, B, 1.0)
+    assert flag != 0 and np.array_equal(got, np.full(got.size, 7.0, dtype=np.float32))
+    for mag in (2.0 ** 30, 2.0 ** -30):
+        flag, _ = _coo_fast_check(gpu, orc, m, n, k, batches, r, c, (v * mag).astype(np.float32), (B * mag).astype(np.float32), 1.0)
+        assert flag == 0
+    # one fully dense 128 x 64 block inside a 1024 x 64 matrix (12.5 % dense overall): 4096 third / fourth non-zeros in one bucket of 256
+    m2 = 1024
+    rr, cc = np.meshgrid(np.arange(128, dtype=np.int32), np.arange(64, dtype=np.int32), indexing="ij")
+    r2, c2 = rr.reshape(-1).copy(), cc.reshape(-1).copy()
+    v2 = rng.uniform(-1, 1, r2.size).astype(np.float32)
+    assert gpu.lib().sm_spmm_coo_fast_form(m2, k, r2.size, n, batches, 0.0) == 2
+    flag, got = _coo_fast_check(gpu, orc, m2, n, k, batches, r2, c2, v2, B, 1.0)
+    assert flag != 0 and np.array_equal(got, np.full(got.size, 7.0, dtype=np.float32))
+    # the same block at a quarter of the rows' strips full (two per strip: nothing for the buckets) is fine
+    keep = (c2 % 4) < 2
+    flag, _ = _coo_fast_check(gpu, orc, m2, n, k, batches, r2[keep], c2[keep], v2[keep], B, 1.0)
+    assert flag == 0
+
+
+@pytest.mark.parametrize("shape", [s_ for s_, o_ in COO_CASES if o_ == "sorted"], ids=lambda v: "x".join(map(str, v)))
+def test_spmm_coo_smfmac_config5_resnet50_shapes(gpu, orc, shape):
+    """sm_spmm_coo_f32_fast with beta == 0 at config 5's sizes (b = 32, 10 % dense, every ResNet-50 shape incl. k = 147): the sparse-instruction
+    form (k <= 128, few-row matrices with k <= 512, ragged k) or the dense-MFMA pipeline (sm_spmm_coo_fast_form says which): sampled rows x vectors
+    against the fp64 oracle within the bound."""
+    import ctypes
+    import torch
+    m, n, k = shape
+    batches = 32
+    alpha = 1.25
+    r, c, v, rng = _coo_problem(m, k, m + k)
+    nnz = r.size
+    form = gpu.lib().sm_spmm_coo_fast_form(m, k, nnz, n, batches, 0.0)
+    # the rule of coo_smfmac_takes: where the dense-MFMA pipeline applies (k % 64 == 0) it keeps the longer-K shapes
+    nst = -(-k // 64)
+    assert form == (2 if k % 64 != 0 or nst <= 2 or (m <= 256 and nst <= 8) else 1)
+    dB = torch.empty(batches * k * n, dtype=torch.float32, device="cuda")
+    gpu.fill_uniform(dB, 0xC00 + n, -1.0, 1.0)
+    dC = torch.full((batches * m * n,), 5.0, dtype=torch.float32, device="cuda")
+    dr, dc, dv = to_dev(r), to_dev(c), to_dev(v)
+    nb = ctypes.c_size_t(0)
+    assert gpu.lib().sm_spmm_coo_fast_workspace_size(m, k, n, batches, ctypes.byref(nb)) == 0
+    ws = torch.full((nb.value,), 0x5A, dtype=torch.uint8, device="cuda")
+    assert gpu.lib().sm_spmm_coo_f32_fast(m, k, nnz, n, batches, dr.data_ptr(), dc.data_ptr(), dv.data_ptr(), dB.data_ptr(), dC.data_ptr(), alpha, 0.0,
+                                          ws.data_ptr(), nb.value, None) == 0, gpu.lib().sm_last_error()
+    flag = ctypes.c_int(-1)
+    assert gpu.lib().sm_spmm_coo_fast_flag(ws.data_ptr(), ctypes.byref(flag), None) == 0 and flag.value == 0
+    rs = np.unique(np.concatenate([[0, m - 1, 127, 128], rng.integers(0, m, 40)]))
+    rs = rs[rs < m]
+    vecs = [(0, 0), (batches - 1, n - 1)] + [(int(rng.integers(0, batches)), int(rng.integers(0, n))) for _ in range(14)]
+    remap = -np.ones(m, dtype=np.int64)
+    remap[rs] = np.arange(rs.size)
+    keep = remap[r] >= 0
+    sr, sc, sv = remap[r[keep]].astype(np.int32), c[keep].copy(), v[keep].copy()
+    Bh = np.concatenate([host(dB[(bb * n + j) * k:(bb * n + j + 1) * k]) for bb, j in vecs])
+    want = np.zeros(len(vecs) * rs.size, dtype=np.float32)
+    orc.spmm_coo(rs.size, k, sr.size, len(vecs), 1, sr, sc, sv, Bh, want, alpha, 0.0)
+    Ch = host(dC).reshape(batches, n, m)
+    got = np.stack([Ch[bb, j, rs] for bb, j in vecs]).reshape(-1)
+    absA = np.zeros((rs.size, k))
+    np.add.at(absA, (sr, sc), np.abs(sv.astype(np.float64)))
+    scale = abs(alpha) * (np.abs(Bh.astype(np.float64)).reshape(len(vecs), k) @ absA.T).reshape(-1)
+    err = np.abs(got.astype(np.float64) - want.astype(np.float64))
+    worst = float(np.max(err / np.maximum(scale, 1e-30)))
+    assert worst <= COO_FAST_TOL, f"sparse-instruction coo {shape}: worst error {worst:.3e} of the scale, bound {COO_FAST_TOL:.3e}"
+    empty = np.setdiff1d(np.arange(m), np.unique(r))
+    if empty.size:   # rows without non-zeros: exactly zero
+        assert not Ch[:, :, int(empty[0])].any()
+    assert np.isfinite(Ch).all()
 
 
 @pytest.mark.parametrize("shape", [(150, 33, 90, 3), (64, 9, 48, 2), (300, 130, 260, 1), (17, 5, 129, 4), (129, 64, 128, 2), (50, 70, 1000, 3), (33, 300, 52, 1)],
