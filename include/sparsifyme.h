@@ -346,7 +346,7 @@ int sm_spmm_coo_f32_packed(size_t A_num_rows, size_t A_num_cols, size_t A_nnz, s
  * C and sm_spmm_coo_fast_workspace_size bytes of workspace (SM_STATUS_NOT_SUPPORTED when the sizes overflow size_t);
  * SM_STATUS_NOT_SUPPORTED otherwise (use the exact entry points).
  * Round 5 -- the SPARSE matrix instruction for the same call: with beta == 0, A_num_rows % 4 == 0 and at most 20 % of A's entries present
- * (sm_spmm_coo_fast_form says which form a call gets: where both apply, this one for A_num_cols <= 128 and for few-row matrices with A_num_cols <= 512), A becomes a 2:4 image (per 1 x 4 strip its first two non-zeros, scaled and split hi + lo
+ * (sm_spmm_coo_fast_form says which form a call gets: where both apply, this one for A_num_cols <= 128 and for matrices of at most 256 rows), A becomes a 2:4 image (per 1 x 4 strip its first two non-zeros, scaled and split hi + lo
  * as above; a random 10 %-dense A has a third non-zero in 0.4 % of its strips -- those entries are kept as fp32 values beside the image) and
  * the product runs on v_smfmac_f32_16x16x64_f16 with the dense operand converted inside the kernel's loader: no fp16 copy of B, any
  * A_num_cols (k % 64 != 0, k % 4 != 0 included).  Same error bound.  Flag, this form: A out of range, or a 32 x 64 block of A with more than

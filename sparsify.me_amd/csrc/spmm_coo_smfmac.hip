@@ -22,9 +22,11 @@
 // that met it is not stored (beta == 0: the caller recomputes C by the exact form anyway); an A value out of range or a bucket beyond
 // its capacity (a 32 x 64 block with more than 64 third / fourth non-zeros: far denser than this form is meant for) raises it before the
 // matrix kernel starts, which then returns at once.
-// Measured (profiles/coo_config5_r05a*.txt, coo_ablate_r05a*.txt): 45-165 us per call over config 5's shapes = 0.06-0.51 of the HBM roofline;
+// Measured (profiles/coo_config5_r05am.txt, coo_ablate_r05ac.txt, coo_ablate_r05al.txt): 45-165 us per call over config 5's shapes = 0.06-0.51 of the HBM roofline;
 // the call's scan / scatter / image kernels are 25-45 us of that, and a stage of the matrix kernel costs one load latency: B must pass through
 // registers to become fp16, so its loads are one stage ahead at most (four or eight waves per tile: the same times).
+#include <type_traits>
+
 #include "coo_fast.h"
 #include "mma_tile.h"
 
@@ -334,6 +336,208 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void spmm_coo_smfmac_kernel(const 
   }
 }
 
+// ---- producer / consumer form (k % 4 == 0): what the kernel above cannot do is keep B's loads more than one stage ahead -- B has to pass
+// through registers to become fp16, and with 64 accumulators a wave has none to spare -- so each of its stages waits out one load latency.
+// Here a workgroup is EIGHT waves.  Waves 4-7 only bring B in: LDS-DMA (no registers) of the raw fp32 columns into a staging ring three stages
+// deep, each lane then reads back the 16 bytes it fetched itself (so the ring needs no synchronisation beyond the wave's own vmcnt), scales,
+// checks the range, rounds to fp16 and writes the [column][64 k] image of the NEXT stage.  Waves 0-3 only multiply: A fragments and bucket
+// entries from registers loaded two stages ahead, the SMFMACs and the bucket multiply-adds of the CURRENT stage.  One barrier per stage; the
+// conversion's vector ALU work runs under the other waves' matrix instructions.  One workgroup per CU (128 KiB of LDS).
+__device__ __attribute__((aligned(256))) const unsigned char sm_coo_zero_page[256] = {0};
+
+__global__ __launch_bounds__(512, 2) void spmm_coo_smfmac_pc_kernel(const CooSmArgs p) {
+  constexpr int BM = 128, BN = 128, FM = 2, FN = 8, SB = BN * 128, CP = BM * 4 + 16, RS = 3, SSTG = BN * 256;
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 images of SB][RS staging slots of SSTG]; epilogue: [BN][CP] over the front
+  __shared__ int wg_bad;
+  const unsigned tid = threadIdx.x, lane = tid & 63u;
+  const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (__builtin_amdgcn_readfirstlane(p.hdr->flag) != 0) return;  // A left the range / a bucket overflowed: C untouched, the caller falls back
+  if (tid == 0) wg_bad = 0;
+  const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
+  const unsigned per_slice = (unsigned)p.tiles_m * (unsigned)p.slice_w;
+  const unsigned sl = lid / per_slice, rem = lid - sl * per_slice;
+  const unsigned width = (sl + 1u) * (unsigned)p.slice_w <= (unsigned)p.tiles_nv ? (unsigned)p.slice_w : (unsigned)p.tiles_nv - sl * (unsigned)p.slice_w;
+  const unsigned tile_m = rem / width, tile_nv = sl * (unsigned)p.slice_w + (rem - tile_m * width);
+  const int m0 = (int)tile_m * BM;
+  const long long n0 = (long long)tile_nv * BN;
+  const int xb = coo_fast_scale_exp(p.hdr->max_b, 12), xa = coo_fast_scale_exp(p.hdr->max_a, 13);
+  const int nst = p.nst;
+  char* const stg = smem + 2 * SB;
+  const unsigned g = lane >> 4, r16 = lane & 15u;
+  f4 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+
+  if (wave >= 4u) {
+    // ================= producers: wave w brings columns 32 (w - 4) .. + 31, lane -> (column + (lane >> 4), 16-byte piece lane & 15)
+    const unsigned pw = wave - 4u, piece = lane & 15u, csub = lane >> 4;
+    const float scb = coo_fast_pow2(xb);
+    const char* bsrc[8];
+    unsigned bdst[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const unsigned col = pw * 32u + 4u * i + csub;
+      bsrc[i] = n0 + col < p.nv ? reinterpret_cast<const char*>(p.B + (size_t)(n0 + col) * p.k + 4u * piece) : nullptr;
+      bdst[i] = a_off(col, piece >> 1) + 8u * (piece & 1u);
+    }
+    const char* const zero = reinterpret_cast<const char*>(sm_coo_zero_page) + 16u * piece;
+    auto dma = [&](int s) {  // always eight instructions (stages past the end and masked lanes read the zero page): vmcnt counts whole stages
+      char* dst = stg + (s % RS) * SSTG + pw * 8192u;
+      const bool kin = s < nst && s * 64 + 4 * (int)piece < p.k && !SM_COO_ABL(2);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const char* src = kin && bsrc[i] ? bsrc[i] + (size_t)s * 256 : zero;
+        __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)(dst + i * 1024), 16, 0, 0);
+      }
+    };
+    bool bad = false;
+    auto convert = [&](int s) {  // the lane's own eight pieces of stage s: staging -> scaled fp16 image
+      const char* src = stg + (s % RS) * SSTG + pw * 8192u + 16u * lane;
+      char* Bs = smem + (s & 1) * SB;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const f4 x = *reinterpret_cast<const f4*>(src + i * 1024) * scb;
+        bad |= coo_fast_out_of_range(x[0]) || coo_fast_out_of_range(x[1]) || coo_fast_out_of_range(x[2]) || coo_fast_out_of_range(x[3]);
+        typedef _Float16 hv4 __attribute__((ext_vector_type(4)));
+        const hv4 h = {(_Float16)x[0], (_Float16)x[1], (_Float16)x[2], (_Float16)x[3]};
+        *reinterpret_cast<hv4*>(Bs + bdst[i]) = h;
+      }
+    };
+    dma(0);
+    dma(1);
+    dma(2);
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");  // stage 0 has landed
+    convert(0);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    for (int s = 0; s < nst; ++s) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the reads of staging slot s % RS (stage s, converted last time round) are done
+      dma(s + 3);
+      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");  // stage s + 1 has landed (s + 2 and s + 3 may still be in flight)
+      if (s + 1 < nst) convert(s + 1);
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // nothing of the ring in flight when the epilogue image takes the LDS over
+    if (bad) wg_bad = 1;
+  } else {
+    // ================= consumers: wave w multiplies rows 32 w .. + 31 x all 128 columns
+    size_t aoff[FM];
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      int row = m0 + (int)wave * 32 + 16 * i + (int)r16;
+      row = row < p.m ? row : p.m - 1;
+      aoff[i] = (size_t)row * 4 + g;
+    }
+    u4 ah[3][FM], al[3][FM];
+    unsigned am[3][FM];
+    u2 rent[3];
+    // The loads are issued by hand and counted by hand: always seven per stage (a stage past the end re-reads the last one), so that
+    // "s_waitcnt vmcnt(14)" after issuing stage s + 2 means exactly "stage s has arrived".  Left to the compiler, the loop-carried
+    // counters made it drain vmcnt to 0 in front of the first use -- the loads it had just issued included.
+    auto load_ar = [&](int s, auto slot_c) {
+      constexpr int slot = decltype(slot_c)::value;
+      s = s < nst ? s : nst - 1;
+      const size_t so = (size_t)s * p.m * 4;
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        const u4* ph = reinterpret_cast<const u4*>(p.hi) + so + aoff[i];
+        const u4* pl = reinterpret_cast<const u4*>(p.lo) + so + aoff[i];
+        const unsigned short* pm = p.meta + so + aoff[i];
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ah[slot][i]) : "v"(ph) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(al[slot][i]) : "v"(pl) : "memory");
+        asm volatile("global_load_ushort %0, %1, off" : "=v"(am[slot][i]) : "v"(pm) : "memory");
+      }
+      const u2* pr = p.rlist + (((size_t)tile_m * nst + s) * 4 + wave) * CS_SEG + lane;
+      u2& re = rent[slot];
+      asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(re) : "v"(pr) : "memory");
+    };
+    auto stage = [&](int s, auto slot_c, auto next_c) {
+      constexpr int slot = decltype(slot_c)::value;
+      load_ar(s + 2, next_c);  // two stages ahead, into the slot stage s - 1 used
+      static_assert(FM == 2, "seven loads per stage");
+      u2& re = rent[slot];
+      asm volatile("s_waitcnt vmcnt(14)"
+                   : "+v"(ah[slot][0]), "+v"(ah[slot][1]), "+v"(al[slot][0]), "+v"(al[slot][1]), "+v"(am[slot][0]), "+v"(am[slot][1]), "+v"(re)
+                   :: "memory");
+      const char* Bs = smem + (s & 1) * SB;
+      if (!SM_COO_ABL(4))
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const unsigned col = 16u * j + r16;
+        const u4 b0 = *reinterpret_cast<const u4*>(Bs + a_off(col, g));
+        const u4 b1 = *reinterpret_cast<const u4*>(Bs + a_off(col, 4u + g));
+        typedef uint32_t u8v __attribute__((ext_vector_type(8)));
+        const h16 bf = __builtin_bit_cast(h16, u8v{b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]});
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+          acc[i][j] = smfmac16<false>(__builtin_bit_cast(h8, ah[slot][i]), bf, acc[i][j], (int)am[slot][i]);
+          acc[i][j] = smfmac16<false>(__builtin_bit_cast(h8, al[slot][i]), bf, acc[i][j], (int)am[slot][i]);
+        }
+      }
+      {
+        const u2 my = rent[slot];
+        const int ne = SM_COO_ABL(1) ? 0 : (int)__builtin_popcountll(__ballot(my[0] != CS_EMPTY));  // the valid slots are a prefix of the segment
+        for (int e = 0; e < ne; ++e) {
+          const unsigned pos = (unsigned)__builtin_amdgcn_readlane((int)my[0], e);
+          const int vbits = __builtin_amdgcn_readlane((int)my[1], e);
+          const float v = __builtin_bit_cast(float, vbits);
+          const unsigned rr = pos & 127u, kk = pos >> 8;
+          const float vs = ((rr >> 2) & 3u) == g ? v : 0.f;
+          float bj[FN];
+#pragma unroll
+          for (int j = 0; j < FN; ++j)
+            bj[j] = (float)*reinterpret_cast<const _Float16*>(Bs + a_off(16u * j + r16, kk >> 3) + 2u * (kk & 7u));
+          const unsigned sel = ((rr >> 4) & 1u) * 4u + (rr & 3u);
+#define SM_COO_CASE(S)                                                                                                         \
+  if (sel == S) {                                                                                                              \
+    _Pragma("unroll") for (int j = 0; j < FN; ++j) acc[S >> 2][j][S & 3] = __builtin_fmaf(vs, bj[j], acc[S >> 2][j][S & 3]); \
+  }
+          SM_COO_CASE(0) SM_COO_CASE(1) SM_COO_CASE(2) SM_COO_CASE(3) SM_COO_CASE(4) SM_COO_CASE(5) SM_COO_CASE(6) SM_COO_CASE(7)
+#undef SM_COO_CASE
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // (the A / entry loads of later stages stay in flight)
+    };
+    using c0 = std::integral_constant<int, 0>;
+    using c1 = std::integral_constant<int, 1>;
+    using c2 = std::integral_constant<int, 2>;
+    load_ar(0, c0{});
+    load_ar(1, c1{});
+    asm volatile("s_barrier" ::: "memory");  // image 0 is in place
+    for (int s = 0; s < nst; s += 3) {
+      stage(s, c0{}, c2{});
+      if (s + 1 < nst) stage(s + 1, c1{}, c0{});
+      if (s + 2 < nst) stage(s + 2, c2{}, c1{});
+    }
+  }
+  __syncthreads();
+  if (wg_bad) {  // an element of B this tile read does not convert under the call's scale: the tile is not stored
+    if (tid == 0) atomicOr(&p.hdr->flag, 1);
+    return;
+  }
+  const float ia = coo_fast_pow2(-xa), ib = coo_fast_pow2(-xb);
+  if (wave < 4u) {
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const f4 o = acc[i][j] * ia * ib * p.alpha;
+        *reinterpret_cast<f4*>(smem + (16u * j + r16) * CP + (wave * 32u + 16u * i + 4u * g) * 4u) = o;
+      }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const unsigned q = tid + 512u * i, col = q >> 5, ch = q & 31u;
+    const int row = m0 + 4 * (int)ch;
+    if (n0 + col < p.nv && row < p.m) {  // m % 4 == 0: whole pieces
+      const f4 o = *reinterpret_cast<const f4*>(smem + col * CP + ch * 16u);
+      __builtin_nontemporal_store(o, reinterpret_cast<f4*>(p.C + (size_t)(n0 + col) * p.m + row));
+    }
+  }
+}
+
 static size_t coo_smfmac_layout(size_t m, size_t k, size_t* o_hi, size_t* o_lo, size_t* o_meta, size_t* o_list) {
   const size_t kc = round_up(k, 64), nst = kc / 64, tiles_m = ceil_div(m, (size_t)128);
   size_t o = COO_FAST_HDR_BYTES;
@@ -359,13 +563,15 @@ bool coo_smfmac_takes(size_t m, size_t k, size_t nnz, size_t nv, const float* B,
   if (nnz * 5 > m * k) return false;  // denser than 20 %: the buckets grow with the square of the density, the dense-MFMA pipeline takes it
   const size_t tiles = ceil_div(m, (size_t)128) * ceil_div(nv, (size_t)128), nst = ceil_div(k, (size_t)64);
   if (tiles > 0x7fffffffull || nv > 0x7fffffffull) return false;
-  // Where both matrix-core forms apply, this one is taken where it measured faster on the same box (profiles/coo_forms_r05ai.txt, us per call, dense-MFMA
-  // pipeline -> this form): k <= 128 (12544 x 64 x 64 59 -> 46, 12544 x 256 x 64 127 -> 104, 3136 x 512 x 128 98 -> 85) and few-row matrices with k <= 512
-  // (196 x 2048 x 512 123 -> 86).  Longer K: a stage of this kernel waits out one load latency (B passes through registers on its way to fp16, so its
-  // loads are one stage ahead at most) and the pipeline's LDS-DMA rings win (3136 x 128 x 1152 106 vs 167, 784 x 256 x 2304 111 vs 157, 196 x 512 x 4608 189 vs 281).
+  // Where both matrix-core forms apply, this one is taken where it measured faster on the same box (profiles/coo_forms_r05ai.txt, coo_forms_r05al.txt; us per
+  // call, dense-MFMA pipeline -> this form): k <= 128 (12544 x 64 x 64 59 -> 46, 12544 x 256 x 64 127 -> 104, 3136 x 512 x 128 98 -> 85) and matrices of at
+  // most 256 rows, where B is the traffic and the producer / consumer kernel streams it once, converting on the way (196 x 512 x 4608 189 -> 135,
+  // 196 x 512 x 2048 98 -> 73, 196 x 2048 x 512 123 -> 86).  Elsewhere a 128 x 128 tile pulls 49 KB per stage through the CU's L1 for 128 SMFMACs -- the
+  // L2-to-CU rate, not the matrix pipe, sets the pace (everything but the loads switched off: still 100 of 130 us, coo_ablate_r05al.txt) -- and the pipeline's
+  // 256 x 256 tiles on fp16 operands win (3136 x 128 x 1152 106 vs 154, 784 x 256 x 2304 111 vs 148, 12544 x 64 x 576 141 vs 173).
   const bool dense_form_applies = k % 64 == 0 && m >= 8;
   static const int rule_env = tuning_int("SM_COO_SMFMAC", 1);  // tuning aid: 2 = wherever this form can run (the caller handles 0 = never)
-  if (rule_env != 2 && dense_form_applies && !(nst <= 2 || (m <= 256 && nst <= 8))) return false;
+  if (rule_env != 2 && dense_form_applies && !(nst <= 2 || m <= 256)) return false;
   return true;
 }
 
@@ -402,6 +608,15 @@ int coo_smfmac_product(size_t m, size_t k, size_t nnz, size_t nv, const int* row
   if (const int rc = check_launch("sm_spmm_coo_f32_fast: 2:4 image of A")) return rc;
   constexpr size_t lds = 128 * (128 * 4 + 16);  // the epilogue image; the two B stages (32 KiB) live inside it
   const unsigned grid = (unsigned)((size_t)a.tiles_m * a.tiles_nv);
+  // the producer / consumer kernel (one workgroup per CU) where B is the traffic: few row tiles, several stages; the one-role kernel (two per CU) elsewhere
+  static const int pc_env = tuning_int("SM_COO_PC", 1);  // tuning aid: 0 = the one-role kernel everywhere, 2 = this one wherever k % 4 == 0
+  if (k % 4 == 0 && pc_env && (pc_env == 2 || (a.tiles_m <= 2 && a.nst >= 3))) {
+    constexpr size_t lds_pc = 2 * 128 * 128 + 3 * 128 * 256;  // two images + the staging ring (the epilogue image fits inside)
+    static LdsOptIn lds_optin_pc;
+    if (const int rc = ensure_dyn_lds(lds_optin_pc, reinterpret_cast<const void*>(&spmm_coo_smfmac_pc_kernel), lds_pc, "spmm_coo_smfmac_pc_kernel")) return rc;
+    spmm_coo_smfmac_pc_kernel<<<grid, 512, lds_pc, st>>>(a);
+    return check_launch("spmm_coo_smfmac_pc_kernel");
+  }
   static const int nw_env = tuning_int("SM_COO_WAVES", 4);  // tuning aid: 8 = eight waves of 16 rows (measured the same to 5 % slower on long K, profiles/coo_waves_r05af.txt)
   static LdsOptIn lds_optin[4];
 #define SM_COO_LAUNCH(I, KV, W)                                                                                                                          \

@@ -1664,7 +1664,7 @@ def _coo_fast_check(gpu, orc, m, n, k, batches, r, c, v, B, alpha, tol=None):
 
 
 @pytest.mark.parametrize("shape", [(8, 8, 64, 1), (132, 33, 128, 3), (300, 130, 250, 2), (20, 5, 192, 4), (128, 64, 64, 2), (260, 72, 147, 3), (64, 40, 90, 2),
-                                   (516, 24, 200, 5), (4, 3, 7, 1), (1000, 16, 1148, 2), (256, 200, 512, 1)], ids=lambda s_: "x".join(map(str, s_)))
+                                   (516, 24, 200, 5), (4, 3, 7, 1), (1000, 16, 1148, 2), (256, 200, 512, 1), (196, 130, 1152, 2), (68, 40, 200, 3), (200, 16, 448, 1)], ids=lambda s_: "x".join(map(str, s_)))
 @pytest.mark.parametrize("order", ["sorted", "shuffled", "duplicates", "dense_strips"])
 def test_spmm_coo_smfmac_small_vs_oracle(gpu, orc, shape, order):
     """The sparse-matrix-instruction form of sm_spmm_coo_f32_fast (beta == 0, density <= 20 %: sm_spmm_coo_fast_form == 2) on every output
@@ -1764,7 +1764,7 @@ def test_spmm_coo_smfmac_flags(gpu, orc):
 @pytest.mark.parametrize("shape", [s_ for s_, o_ in COO_CASES if o_ == "sorted"], ids=lambda v: "x".join(map(str, v)))
 def test_spmm_coo_smfmac_config5_resnet50_shapes(gpu, orc, shape):
     """sm_spmm_coo_f32_fast with beta == 0 at config 5's sizes (b = 32, 10 % dense, every ResNet-50 shape incl. k = 147): the sparse-instruction
-    form (k <= 128, few-row matrices with k <= 512, ragged k) or the dense-MFMA pipeline (sm_spmm_coo_fast_form says which): sampled rows x vectors
+    form (k <= 128, matrices of at most 256 rows, ragged k) or the dense-MFMA pipeline (sm_spmm_coo_fast_form says which): sampled rows x vectors
     against the fp64 oracle within the bound."""
     import ctypes
     import torch
@@ -1776,7 +1776,7 @@ def test_spmm_coo_smfmac_config5_resnet50_shapes(gpu, orc, shape):
     form = gpu.lib().sm_spmm_coo_fast_form(m, k, nnz, n, batches, 0.0)
     # the rule of coo_smfmac_takes: where the dense-MFMA pipeline applies (k % 64 == 0) it keeps the longer-K shapes
     nst = -(-k // 64)
-    assert form == (2 if k % 64 != 0 or nst <= 2 or (m <= 256 and nst <= 8) else 1)
+    assert form == (2 if k % 64 != 0 or nst <= 2 or m <= 256 else 1)
     dB = torch.empty(batches * k * n, dtype=torch.float32, device="cuda")
     gpu.fill_uniform(dB, 0xC00 + n, -1.0, 1.0)
     dC = torch.full((batches * m * n,), 5.0, dtype=torch.float32, device="cuda")
