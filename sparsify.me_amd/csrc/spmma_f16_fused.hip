@@ -1891,6 +1891,9 @@ static int spmma_fused16(size_t ngroup, const void* const* Ag, const void* const
     if (big_env < 8 && (big_env & 2) && n > 64 && n <= 128) return nsb == 3 ? launch_fused_big<128, BF, 3, 3, true>(a, st) : launch_fused_big<128, BF, 3, 2, true>(a, st);
   }
 #endif
+  // (round 5: 128-column direct tiles at ANY n -- every column tile re-reading its A rows through L2, as 12544 x 256 x 64 does at 0.89 of its roofline -- measured on
+  //  the shapes the A-stationary and wide kernels serve: slower on all of them, 3136 x 512 x 128 x 4 147 vs 129 us, 784 x 1024 x 256 x 6 164 vs 114, 784 x 256 x 2304 x 6
+  //  303 vs 195, 196 x 512 x 2048 x 2 55 vs 32 (profiles/ab_direct_any_r05an.txt; the rows whose two columns agree went to the big form before the hook).  Removed.)
   if (!wide_env && (n <= 128 || (n <= 256 && k <= 64))) {
 #ifdef SM_TUNING
     if (tuning_int("SM_FUSED_NW", 4) == 8) {  // eight waves of 16 rows per workgroup: the same LDS, twice the waves per SIMD
