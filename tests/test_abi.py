@@ -84,3 +84,30 @@ def test_missing_library_fails_loudly(pkg, tmp_path, monkeypatch):
         assert "no CPU fallback" in str(e)
     else:
         raise AssertionError("a missing HIP library must raise")
+
+
+def test_coo_fast_form_rule_and_workspace_are_host_logic(pkg):
+    """sm_spmm_coo_fast_form / sm_spmm_coo_fast_workspace_size run on the host: which matrix-core form a strided_coo call with the fast option
+    gets (include/sparsifyme.h: the sparse matrix instruction for k <= 128, for matrices of at most 256 rows and for every k the dense-MFMA
+    pipeline cannot take; beta != 0 and dense A: the pipeline or nothing), and a workspace that covers both layouts."""
+    L = pkg.lib()
+    form = lambda m, k, nnz, n, b, beta: L.sm_spmm_coo_fast_form(m, k, nnz, n, b, ctypes.c_float(beta))
+    d = lambda m, k: m * k // 10
+    assert form(12544, 64, d(12544, 64), 64, 32, 0.0) == 2          # k <= 128
+    assert form(3136, 128, d(3136, 128), 512, 32, 0.0) == 2
+    assert form(12544, 147, d(12544, 147), 64, 32, 0.0) == 2        # ragged k: only the sparse-instruction form takes it
+    assert form(12544, 147, d(12544, 147), 64, 32, 0.5) == 0        # ... and only with beta == 0
+    assert form(196, 4608, d(196, 4608), 512, 32, 0.0) == 2         # at most 256 rows
+    assert form(3136, 1152, d(3136, 1152), 128, 32, 0.0) == 1       # many rows, long K: the dense-MFMA pipeline
+    assert form(3136, 1152, d(3136, 1152), 128, 32, 1.0) == 1
+    assert form(12544, 64, 12544 * 64 // 3, 64, 32, 0.0) == 1       # denser than 20 %
+    assert form(130, 64, 100, 64, 2, 0.0) == 0                      # rows % 4 != 0: neither
+    assert form(0, 64, 0, 64, 2, 0.0) == 0 and form(128, 64, 10, 0, 2, 0.0) == 0
+    for (m, k, n, b) in ((12544, 576, 64, 32), (196, 4608, 512, 32), (8, 64, 8, 1), (1000, 1148, 16, 2)):
+        nb = ctypes.c_size_t(0)
+        assert L.sm_spmm_coo_fast_workspace_size(m, k, n, b, ctypes.byref(nb)) == 0
+        kc, nst, tm = -(-k // 64) * 64, -(-k // 64), -(-m // 128)
+        ru = lambda x: -(-x // 256) * 256
+        sparse_layout = 256 + ru(m * kc * 4) + 2 * ru(nst * m * 64) + ru(nst * m * 8) + tm * nst * 256 * 8
+        dense_layout = 256 + ru(n * b * k * 2) + 2 * ru(k * m * 4)
+        assert nb.value >= max(sparse_layout, dense_layout)
