@@ -83,19 +83,16 @@ static int launch_fill(void* out, size_t count, uint64_t seed, float lo, float h
   return check_launch("fill_uniform_kernel");
 }
 
-// Plain streaming copy (16-byte non-temporal loads and stores, grid-stride): the yardstick bench.py times in the same
-// process as the step -- what HBM delivers to the simplest possible kernel on this part, on this day.
+// Plain streaming copy: the yardstick bench.py times in the same process as the step -- what HBM delivers to the simplest possible kernel on this
+// part, on this day, on this data.  ONE 16-byte non-temporal load and store per thread, no loop (round 5; tools/probes/copy_probe.hip,
+// profiles/copy_probe_r05a{p,q,r}.txt, pseudo-random data, 3.7 GB each way): 6.5-6.6 TB/s where the grid-stride form it replaces (4 096 workgroups, four
+// pieces per thread and trip) gave 5.3-5.9 -- the dispatcher handing out workgroups in address order keeps the chip's reads and writes inside a few
+// megabytes at any moment, a grid-stride loop smears them over gridDim x 16 KiB; one contiguous chunk per workgroup is worst (4.4-4.8).  The rate also
+// depends on the DATA: the same copy of a buffer of equal bytes runs 15 % faster (6.4 against 5.4 TB/s) -- which is why this yardstick copies the step's
+// own operands' worth of random halves, and why the guide's 6.29 TB/s float4 copy is reported beside it rather than instead of it.
 __global__ __launch_bounds__(256) void copy_bytes_kernel(const u4* __restrict__ src, u4* __restrict__ dst, size_t n16) {
-  const size_t stride = (size_t)gridDim.x * 256 * 4;
-  for (size_t i = (size_t)blockIdx.x * 256 * 4 + threadIdx.x; i < n16; i += stride) {
-    u4 v[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      if (i + (size_t)j * 256 < n16) v[j] = __builtin_nontemporal_load(src + i + (size_t)j * 256);
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      if (i + (size_t)j * 256 < n16) __builtin_nontemporal_store(v[j], dst + i + (size_t)j * 256);
-  }
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n16) __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
 }
 
 }  // namespace sm
@@ -109,7 +106,12 @@ int sm_copy_bytes(const void* src, void* dst, size_t bytes, sm_stream_t s) {
     return SM_STATUS_INVALID_VALUE;
   }
   const size_t n16 = bytes / 16;
-  sm::copy_bytes_kernel<<<sm::stream_grid((n16 + 3) / 4, 256), 256, 0, (hipStream_t)s>>>((const sm::u4*)src, (sm::u4*)dst, n16);
+  const size_t blocks = (n16 + 255) / 256;
+  if (blocks > 0x7fffffffull) {
+    sm::set_error("sm_copy_bytes: more than 2^31 workgroups (copy in pieces)");
+    return SM_STATUS_NOT_SUPPORTED;
+  }
+  sm::copy_bytes_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)s>>>((const sm::u4*)src, (sm::u4*)dst, n16);
   return sm::check_launch("copy_bytes_kernel");
 }
 

@@ -359,9 +359,10 @@ def extras(args, sm, torch, dev, layers, flops, t_full, Forked, make_runner, tim
                                          "copy_bytes": 2 * half, "copy_ms": t_copy * 1e3,
                                          "step_algorithmic_bytes": step_bytes, "step_GBs": step_bytes / t_full / 1e9,
                                          "step_frac_of_device_copy": step_bytes / t_full / 1e9 / copy_GBs,
-                                         "source": "measured in this run: sm_copy_bytes (16-byte streaming copy kernel of libsparsifyme.so) over the "
-                                                   "timed step's own algorithmic byte count, half read + half written; guide_float4_copy_GBs = the float4 copy "
-                                                   "/opt/skills/guides/MI355X_MICROARCH.md:36 measures (6.29 TB/s), the stricter of the two yardsticks; context "
+                                         "source": "measured in this run: sm_copy_bytes (round 5: one 16-byte non-temporal load + store per thread, no loop -- the "
+                                                   "fastest of the copy forms of tools/probes/copy_probe.hip, 6.5-6.6 TB/s on random data where the grid-stride form used "
+                                                   "until round 4 gave 5.3-5.9) over the timed step's own algorithmic byte count of random halves, half read + half written; "
+                                                   "guide_float4_copy_GBs = the float4 copy /opt/skills/guides/MI355X_MICROARCH.md:36 measures (6.29 TB/s); context "
                                                    "only -- `frac` is against the 8 TB/s specification"},
                            "families": fams_out}
 
