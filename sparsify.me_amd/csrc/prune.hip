@@ -568,7 +568,7 @@ static int launch_prune(const void* A_in, void* A_out, size_t m, size_t k, size_
   if (m == 0 || k == 0) return SM_STATUS_SUCCESS;
   if (alg == SM_PRUNE_STRIP) {
     const bool vec_ok = vec_ok_2d<T>(A_in, A_out, ld, 0);
-    prune_strip_kernel<T><<<stream_grid(m * ceil_div(k, 8), 256), 256, 0, st>>>((const T*)A_in, (T*)A_out, m, k, ld, vec_ok);
+    prune_strip_kernel<T><<<stream_grid(m * ceil_div(k, 8), 256, true), 256, 0, st>>>((const T*)A_in, (T*)A_out, m, k, ld, vec_ok);
     return check_launch("prune_strip_kernel");
   }
   // TILE moves 4 elements per row access: 8-byte (f16) / 16-byte (f32) alignment

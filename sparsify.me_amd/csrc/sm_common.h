@@ -82,9 +82,14 @@ inline BlobLayout blob_layout(size_t m, size_t k, size_t elt, size_t batch) {
 }
 
 // Grid size for grid-stride streaming kernels: enough blocks to fill 256 CUs x 8, capped.
-inline unsigned stream_grid(size_t work_items, unsigned block) {
+// `uncapped`: one item per thread and no second trip (round 5: the copy probe's finding -- workgroups handed out in address order keep the chip's traffic
+// inside a few megabytes at a time; a capped grid's stride loop smears it.  It pays where the kernel is a plain copy-like stream: STRIP prune of the 462 MB
+// operand 176 -> 155 us, 231 MB 85 -> 80; the check, compress, TILE and one-pass kernels do not move, profiles/prune_ab_r05as.txt).
+inline unsigned stream_grid(size_t work_items, unsigned block, bool uncapped = false) {
   size_t g = ceil_div(work_items, block);
-  if (g > 256u * 16u) g = 256u * 16u;
+  const size_t cap = (size_t)tuning_int("SM_STREAM_GRID_CAP", uncapped ? 0 : 256 * 16);  // tuning aid (A/B of the cap): 0 = none
+  if (cap && g > cap) g = cap;
+  if (g > 0x7fffffffull) g = 0x7fffffffull;
   if (g == 0) g = 1;
   return (unsigned)g;
 }
