@@ -312,6 +312,13 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned id, unsigned nwg) {
   return base + (id >> 3);
 }
 
+// One column tile per row tile: no operand panel is shared between workgroups (B is small and L2-resident everywhere), and the workgroups keep the
+// DISPATCH order -- the chip then reads one moving window of A instead of eight (one per XCD), which is what the fastest device copy does
+// (tools/probes/copy_probe.hip).  Measured on the direct fused kernel (profiles/ab_remap_r05a{t,u}.txt, same C bit for bit): 12544 x 64 x 576 x 3
+// 270.7 -> 252.4 us, 12544 x 64 x 256 x 2 93.5 -> 88.6, the others 0-1.5 % faster; on the kernels whose column tiles share A rows or whose B tiles
+// are large (big / wide / A-stationary) the XCD ranges stay: 0-5 % slower without them.
+__device__ __forceinline__ unsigned tile_order(unsigned id, unsigned nwg, bool dispatch_order) { return dispatch_order ? id : xcd_remap(id, nwg); }
+
 // ---- LDS-DMA (global_load_lds) plumbing shared by the pipelined kernels
 typedef __attribute__((address_space(1))) const void gptr_t;
 typedef __attribute__((address_space(3))) void lptr_t;

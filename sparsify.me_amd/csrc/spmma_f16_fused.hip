@@ -80,7 +80,11 @@ __global__ __launch_bounds__(64 * NWV, SM_DIRECT_MIN_WAVES(BN, NWV, BM)) void sp
   const unsigned tid = threadIdx.x, lane = tid & 63u;
   const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const unsigned tiles = (unsigned)p.tiles_m * (unsigned)p.tiles_n;
-  const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
+#ifdef SM_TUNING
+  const unsigned lid = tile_order(blockIdx.x, gridDim.x, !(p.ablate & 16));  // (tuning: SM_DIRECT_ABLATE bit 4 = the XCD ranges of rounds 1-4)
+#else
+  const unsigned lid = tile_order(blockIdx.x, gridDim.x, true);  // dispatch order: mma_tile.h
+#endif
   const unsigned gb = lid / tiles, trem = lid - gb * tiles;
   const unsigned grp = gb / (unsigned)p.batch, b = gb - grp * (unsigned)p.batch;
   const unsigned tile_m = trem / (unsigned)p.tiles_n, tile_n = trem - tile_m * (unsigned)p.tiles_n;
@@ -276,7 +280,11 @@ __global__ __launch_bounds__(512) void spmma_f16_fused_big_kernel(const FusedArg
   const unsigned tid = threadIdx.x, lane = tid & 63u;
   const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const unsigned tiles = (unsigned)p.tiles_m * (unsigned)p.tiles_n;
+#ifdef SM_TUNING
+  const unsigned lid = tile_order(blockIdx.x, gridDim.x, (p.ablate & 8) != 0);  // (tuning: SM_DIRECT_ABLATE bit 3 = dispatch order; measured 0-5 % slower here, mma_tile.h)
+#else
   const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
+#endif
   const unsigned gb = lid / tiles, trem = lid - gb * tiles;
   const unsigned grp = gb / (unsigned)p.batch, b = gb - grp * (unsigned)p.batch;
   const unsigned tile_m = trem / (unsigned)p.tiles_n, tile_n = trem - tile_m * (unsigned)p.tiles_n;
@@ -392,6 +400,9 @@ template <int BN, bool BF = false, int NSA = 3, int NSB = 2, bool ANT = true, bo
 static int launch_fused_big(const FusedArgs& a0, hipStream_t st) {
   constexpr int BM = 256;
   FusedArgs a = a0;
+#ifdef SM_TUNING
+  if (!a.ablate) a.ablate = tuning_int("SM_DIRECT_ABLATE", 0) & 24;
+#endif
   a.tiles_m = (a.Mrows + BM - 1) / BM;
   a.tiles_n = (a.N + BN - 1) / BN;
   const size_t nwg = (size_t)a.tiles_m * a.tiles_n * a.batch * a.ngroup;
@@ -527,7 +538,11 @@ __global__ __launch_bounds__(512) void spmma_f16_fused_sk_kernel(const FusedArgs
 
   const unsigned tid = threadIdx.x, lane = tid & 63u;
   const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef SM_TUNING
+  const unsigned lid = tile_order(blockIdx.x, gridDim.x, (p.ablate & 8) != 0);  // (tuning: SM_DIRECT_ABLATE bit 3 = dispatch order; measured 0-5 % slower here, mma_tile.h)
+#else
   const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
+#endif
   const unsigned tn = (unsigned)p.tiles_n;
   const unsigned slot = lid / tn, tile_n = lid - slot * tn;  // the tiles_n workgroups of a slot are neighbours: one XCD, one A stream
   const unsigned nkt = (unsigned)(p.K / 64);
@@ -786,6 +801,9 @@ template <int BN, bool BF = false, bool ANT = true, bool DENSE = false>
 static int launch_fused_sk(const FusedArgs& a0, void* workspace, size_t workspace_bytes, hipStream_t st) {
   constexpr int BM = 256;
   FusedArgs a = a0;
+#ifdef SM_TUNING
+  if (!a.ablate) a.ablate = tuning_int("SM_DIRECT_ABLATE", 0) & 24;
+#endif
   a.tiles_m = (a.Mrows + BM - 1) / BM;
   a.tiles_n = (a.N + BN - 1) / BN;
   const size_t panels = (size_t)a.tiles_m * a.batch * a.ngroup;
@@ -878,7 +896,11 @@ __global__ __launch_bounds__(256) void spmma_f16_fused_span_kernel(const FusedAr
   const unsigned tid = threadIdx.x, lane = tid & 63u;
   const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const unsigned tiles = (unsigned)p.tiles_m * (unsigned)p.tiles_n;
+#ifdef SM_TUNING
+  const unsigned lid = tile_order(blockIdx.x, gridDim.x, (p.ablate & 8) != 0);  // (tuning: SM_DIRECT_ABLATE bit 3 = dispatch order; measured 0-5 % slower here, mma_tile.h)
+#else
   const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
+#endif
   const unsigned grp = lid / tiles, trem = lid - grp * tiles;  // batch == 1: the batches are stacked rows
   const unsigned tile_m = trem / (unsigned)p.tiles_n, tile_n = trem - tile_m * (unsigned)p.tiles_n;
   const int m0 = (int)tile_m * BM, n0 = (int)tile_n * BN;
@@ -990,6 +1012,9 @@ __global__ __launch_bounds__(256) void spmma_f16_fused_span_kernel(const FusedAr
 template <int BN, bool BF = false, bool DENSE = false>
 static int launch_fused_span(const FusedArgs& a0, hipStream_t st) {
   FusedArgs a = a0;
+#ifdef SM_TUNING
+  if (!a.ablate) a.ablate = tuning_int("SM_DIRECT_ABLATE", 0) & 24;
+#endif
   a.tiles_m = (a.Mrows + 127) / 128;
   a.tiles_n = (a.N + BN - 1) / BN;
   const size_t nwg = (size_t)a.tiles_m * a.tiles_n * a.ngroup;
@@ -1055,7 +1080,11 @@ __global__ __launch_bounds__(64 * (WM * WN + 4 + NLB)) void spmma_f16_fused_wide
   const unsigned tid = threadIdx.x, lane = tid & 63u;
   const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const unsigned tiles = (unsigned)p.tiles_m * (unsigned)p.tiles_n;
+#ifdef SM_TUNING
+  const unsigned lid = tile_order(blockIdx.x, gridDim.x, (p.ablate & 8) != 0);  // (tuning: SM_DIRECT_ABLATE bit 3 = dispatch order; measured 0-5 % slower here, mma_tile.h)
+#else
   const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
+#endif
   const unsigned gb = lid / tiles, trem = lid - gb * tiles;
   const unsigned grp = gb / (unsigned)p.batch, b = gb - grp * (unsigned)p.batch;
   const unsigned tile_m = trem / (unsigned)p.tiles_n, tile_n = trem - tile_m * (unsigned)p.tiles_n;
@@ -1245,6 +1274,9 @@ __global__ __launch_bounds__(64 * (WM * WN + 4 + NLB)) void spmma_f16_fused_wide
 template <int BN, int WM, int WN, int NLB, int PF, int NSB, bool BF = false, bool ANT = true>
 static int launch_fused_wide(const FusedArgs& a0, hipStream_t st) {
   FusedArgs a = a0;
+#ifdef SM_TUNING
+  if (!a.ablate) a.ablate = tuning_int("SM_DIRECT_ABLATE", 0) & 24;
+#endif
   a.tiles_m = (a.Mrows + 127) / 128;
   a.tiles_n = (a.N + BN - 1) / BN;
   const size_t nwg = (size_t)a.tiles_m * a.tiles_n * a.batch * a.ngroup;
@@ -1527,6 +1559,9 @@ __global__ __launch_bounds__(64 * (WM * WN + 4 + NLB)) void spmma_f16_fused_wide
 template <int BN, int WM, int WN, int NLB, int PF, int NSB, bool BF = false>
 static int launch_fused_widep(const FusedArgs& a0, hipStream_t st) {
   FusedArgs a = a0;
+#ifdef SM_TUNING
+  if (!a.ablate) a.ablate = tuning_int("SM_DIRECT_ABLATE", 0) & 24;
+#endif
   a.tiles_m = (a.Mrows + 127) / 128;
   a.tiles_n = (a.N + BN - 1) / BN;
   const size_t nt = (size_t)a.tiles_m * a.tiles_n * a.batch * a.ngroup;
@@ -1574,7 +1609,11 @@ __global__ __launch_bounds__(64 * 16) void spmma_f16_fused_astat_kernel(const Fu
   const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nkt = p.K / 64;
   const unsigned per_batch = (unsigned)p.tiles_m * (unsigned)nsplit;
+#ifdef SM_TUNING
+  const unsigned lid = tile_order(blockIdx.x, gridDim.x, (p.ablate & 8) != 0);  // (tuning: SM_DIRECT_ABLATE bit 3 = dispatch order; measured 0-5 % slower here, mma_tile.h)
+#else
   const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
+#endif
   const unsigned gb = lid / per_batch, trem = lid - gb * per_batch;
   const unsigned grp = gb / (unsigned)p.batch, b = gb - grp * (unsigned)p.batch;
   const unsigned tile_m = trem / (unsigned)nsplit, split = trem - tile_m * (unsigned)nsplit;
@@ -1746,6 +1785,9 @@ static size_t astat_lds_bytes(int nkt, int nsb) { return (size_t)nkt * (128 * 72
 template <bool BF = false>
 static int launch_fused_astat(const FusedArgs& a0, hipStream_t st) {
   FusedArgs a = a0;
+#ifdef SM_TUNING
+  if (!a.ablate) a.ablate = tuning_int("SM_DIRECT_ABLATE", 0) & 24;
+#endif
   a.tiles_m = (a.Mrows + 127) / 128;
   a.tiles_n = (a.N + 127) / 128;
   // split the column range of a row panel over several workgroups until 3/4 of the CUs have one (a split re-selects

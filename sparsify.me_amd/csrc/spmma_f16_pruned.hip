@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void spmma_f16_pruned_kernel(const PrunedArgs 
 
   const unsigned tid = threadIdx.x, lane = tid & 63u;
   const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
+  const unsigned lid = tile_order(blockIdx.x, gridDim.x, true);  // one column tile per row panel: dispatch order (mma_tile.h)
   const unsigned b = lid / (unsigned)p.tiles_m, tile_m = lid - b * (unsigned)p.tiles_m;
   const int m0 = (int)tile_m * BM;
   const int nkt = p.K / 64;

@@ -36,6 +36,7 @@ struct SplitArgs {
   int Mrows, N, K, lda;
   int batch, tiles_m, tiles_n;
   float alpha, beta;
+  int xcd_ranges;  // tuning builds (SM_SPLIT_XCD=1): the XCD ranges of round 4 instead of the dispatch order for single-column-tile launches
 };
 
 __device__ __forceinline__ float as_f32(uint32_t x) { return __builtin_bit_cast(float, x); }
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(64 * NW) void spmma_f32_split_kernel(const SplitArg
   const unsigned tid = threadIdx.x, lane = tid & 63u;
   const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const unsigned tiles = (unsigned)p.tiles_m * (unsigned)p.tiles_n;
-  const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
+  const unsigned lid = tile_order(blockIdx.x, gridDim.x, p.tiles_n == 1 && !p.xcd_ranges);  // (mma_tile.h)
   const unsigned b = lid / tiles, trem = lid - b * tiles;
   const unsigned tile_m = trem / (unsigned)p.tiles_n, tile_n = trem - tile_m * (unsigned)p.tiles_n;
   const int m0 = (int)tile_m * BM, n0 = (int)tile_n * BN;
@@ -596,7 +597,7 @@ __global__ __launch_bounds__(512) void spmma_f32_split_span_kernel(const SplitAr
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const unsigned tid = threadIdx.x, lane = tid & 63u;
   const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
+  const unsigned lid = tile_order(blockIdx.x, gridDim.x, p.tiles_n == 1 && !p.xcd_ranges);  // (mma_tile.h)
   const unsigned tile_m = lid / (unsigned)p.tiles_n, tile_n = lid - tile_m * (unsigned)p.tiles_n;
   const int m0 = (int)tile_m * BM, n0 = (int)tile_n * BN;
   const int nkt = (p.K + 63) / 64;
@@ -794,6 +795,7 @@ static int f32_split_product(bool dense, const float* A, const float* B, float* 
     if (const int rc = check_launch("split_planes_kernel")) return rc;
   }
   SplitArgs a = {};
+  a.xcd_ranges = tuning_int("SM_SPLIT_XCD", 0);
   a.A = A; a.Bp = P; a.C = C;
   a.sA = strideA; a.sBp = strideB ? k * n : 0; a.plane = plane; a.sC = strideC;
   a.Mrows = (int)m; a.N = (int)n; a.K = (int)k; a.lda = (int)lda; a.batch = (int)batch;
