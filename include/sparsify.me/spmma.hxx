@@ -387,5 +387,38 @@ class spmma_plan_t {
   bool ready_ = false;
 };
 
+// Extension (round 5; float only): the bfloat16 planes of a B that stays the same across calls -- the weights of a layer -- for the product on the
+// sparse matrix instruction (spmma_options().f32_planes, sm_spmma_fused_f32_split): prepare() splits B once, multiply() then runs the same kernels
+// from those planes for any number of A / C -- the per-call streaming pass over B is gone, the results are those of spmma_fused<float> with the
+// same f32_planes bit for bit (the 2:4 selection is made inside, by the STRIP rule, on a dense A; a pruned A passes through unchanged).
+class spmma_f32_planes_t {
+ public:
+  // B: k x n row-major, one for all batches (per_batch_b = false) or batch_size of them back to back
+  spmma_f32_planes_t(std::size_t k, std::size_t n, int planes = 3, std::size_t batch_size = 1, bool per_batch_b = false)
+      : k_(k), n_(n), batch_(batch_size ? batch_size : 1), strideB_(per_batch_b ? k * n : 0), planes_(planes) {
+    std::size_t bytes = 0;
+    if (sm_spmma_fused_f32_split_workspace(n_, k_, batch_, strideB_, planes_, &bytes) == SM_STATUS_SUCCESS) ws_.resize(bytes ? bytes : 16);
+  }
+  std::size_t workspace_bytes() const { return ws_.size(); }
+  int prepare(const float* dB, hipStream_t stream = nullptr) {
+    if (ws_.size() == 0) return SM_STATUS_NOT_SUPPORTED;
+    const int rc = sm_spmma_fused_f32_split_prepare(dB, n_, k_, batch_, strideB_, planes_, ws_.data().get(), ws_.size(), stream);
+    ready_ = rc == SM_STATUS_SUCCESS;
+    return rc;
+  }
+  // C_b = alpha * A_b(2:4) * B + beta * C_b; A: batch_size contiguous m x k matrices, row-major.  SM_STATUS_NOT_SUPPORTED for the shapes the split form
+  // does not take (the caller then runs spmma_fused<float>).
+  int multiply(const float* dA, float* dC, std::size_t m, float alpha = 1.0f, float beta = 0.0f, hipStream_t stream = nullptr) {
+    if (!ready_) return SM_STATUS_INVALID_VALUE;
+    return sm_spmma_fused_f32_split_prepared(dA, ws_.data().get(), dC, m, n_, k_, k_, batch_, m * k_, strideB_, m * n_, planes_, ws_.size(), alpha, beta, stream);
+  }
+
+ private:
+  std::size_t k_, n_, batch_, strideB_;
+  int planes_;
+  device_vector<unsigned char> ws_;
+  bool ready_ = false;
+};
+
 namespace batched {}  // namespace batched
 }  // namespace sparsifyme

@@ -321,6 +321,34 @@ static void check_spmma(size_t m, size_t n, size_t k, size_t b, const char* tnam
   spmma_options().f32_planes = 0;
 }
 
+// spmma_f32_planes_t (round 5): B's planes prepared once == spmma_fused<float> with the same f32_planes, bit for bit, over two multiplies
+static void check_prepared_planes(size_t m, size_t n, size_t k, size_t b, int planes) {
+  if (k % 64 != 0 || n % 8 != 0) return;  // shapes the split form takes without the span rules
+  std::mt19937 gen(0x9a1 + (unsigned)(m + n * 3 + k * 5));
+  std::uniform_real_distribution<float> U(-1.f, 1.f);
+  std::vector<float> hA(b * m * k), hB(b * k * n);  // B per batch, as spmma_fused takes it (examples/spmma.cu:48-59)
+  for (auto& x : hA) x = U(gen);
+  for (auto& x : hB) x = U(gen);
+  device_vector<float> dA = hA, dB = hB, dC0(b * m * n), dC1(b * m * n);
+  spmma_options().f32_planes = planes;
+  spmma_fused<float>(dA.data().get(), dB.data().get(), dC0.data().get(), m, n, k, b);
+  spmma_options().f32_planes = 0;
+  spmma_f32_planes_t pl(k, n, planes, b, true);
+  bool ok = pl.prepare(dB.data().get()) == SM_STATUS_SUCCESS;
+  std::vector<float> h0(b * m * n), h1(b * m * n);
+  (void)hipMemcpy(h0.data(), dC0.data().get(), h0.size() * 4, hipMemcpyDeviceToHost);
+  for (int rep = 0; rep < 2 && ok; ++rep) {
+    (void)hipMemset(dC1.data().get(), 0xff, h1.size() * 4);
+    ok = pl.multiply(dA.data().get(), dC1.data().get(), m) == SM_STATUS_SUCCESS;
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpy(h1.data(), dC1.data().get(), h1.size() * 4, hipMemcpyDeviceToHost);
+    ok = ok && std::memcmp(h0.data(), h1.data(), h0.size() * 4) == 0;
+  }
+  char what[200];
+  std::snprintf(what, sizeof(what), "spmma_f32_planes_t planes = %d %zux%zux%zu b=%zu: C == spmma_fused<float> bit for bit", planes, m, n, k, b);
+  verdict(what, ok, false, "");
+}
+
 int main(int argc, char** argv) {
   if (argc < 2) {
     std::cout << "Usage: ./header_parity table.csv [--swap]" << std::endl;
@@ -349,6 +377,8 @@ int main(int argc, char** argv) {
     check_spmma<float>(m, n, k, b, "float");
     check_spmma<float>(m, n, k, b, "float, f32_planes = 3", 3);
     check_spmma<float>(m, n, k, b, "float, f32_planes = 2", 2);
+    check_prepared_planes(m, n, k, b, 3);
+    check_prepared_planes(m, n, k, b, 2);
   }
   std::printf("%d checks, %d failed%s\n", g_checks, g_fail, g_swap ? " (--swap: a check passes iff the rotated table was noticed)" : "");
   return g_fail == 0 && g_checks > 0 ? EXIT_SUCCESS : EXIT_FAILURE;

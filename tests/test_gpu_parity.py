@@ -1943,7 +1943,7 @@ def test_cpp_drivers_cli_contract(gpu):
 
 def test_values_through_the_cpp_headers_vs_oracle(gpu):
     """Row b of the scope table, by VALUE: tests/cpp/header_parity runs sparsify<2,2>, batched::gemm (N,N and T,N),
-    batched::spmm, batched::strided_coo and spmma<half / float> (N,N and T,N; float also with spmma_options().f32_planes = 3 / 2) through include/sparsify.me/*.hxx on a 3-row
+    batched::spmm, batched::strided_coo, spmma<half / float> (N,N and T,N; float also with spmma_options().f32_planes = 3 / 2) and spmma_f32_planes_t (prepared planes == spmma_fused<float>, bit for bit) through include/sparsify.me/*.hxx on a 3-row
     table and compares every result with the oracle (bit-exact masks / pruned A, the tight GEMM bound for the products).
     `--swap` then rotates the C pointer table handed to batched::gemm / batched::spmm: every such check must notice, i.e. a
     swapped pointer inside a header would turn this test red."""
@@ -1960,7 +1960,8 @@ def test_values_through_the_cpp_headers_vs_oracle(gpu):
         out = subprocess.run([exe, tab], capture_output=True, text=True, timeout=600)
         assert out.returncode == 0, out.stdout[-4000:] + out.stderr[-2000:]
         assert "MISMATCH" not in out.stdout and "Incorrect pruning" not in out.stderr
-        assert out.stdout.count(" ok") >= 3 * (3 + 1 + 1 + 1 + 4 + 12) + 2   # (T,N) gemm only where m >= k (the reference's lda = m); spmma<float> also with f32_planes = 3 / 2
+        assert out.stdout.count(" ok") >= 3 * (3 + 1 + 1 + 1 + 4 + 12) + 2 + 4   # (T,N) gemm only where m >= k (the reference's lda = m); spmma<float> also with f32_planes = 3 / 2; spmma_f32_planes_t on the two k % 64 == 0 rows
+        assert out.stdout.count("spmma_f32_planes_t") == 4
         sw = subprocess.run([exe, tab, "--swap"], capture_output=True, text=True, timeout=600)
         assert sw.returncode == 0, sw.stdout[-4000:] + sw.stderr[-2000:]
         assert sw.stdout.count("rotated pointer table detected") >= 3 * 2 + 2 and "did not notice" not in sw.stdout
