@@ -79,3 +79,73 @@ def fused_variant(n, k, m=None, b=None, count=1, cus=256):
 def ge_mod():
     import __graft_entry__ as ge
     return ge
+
+
+CONTRACT_LINE_MAX_BYTES = 4096   # BENCH_r05.json: a 20 KB line came back `parsed: null`; 14-18 KB lines (r02-r04) parsed.  Stay far below.
+
+
+def _r(x, nd=4):
+    return round(x, nd) if isinstance(x, float) else x
+
+
+def contract_line(out):
+    """The ONE stdout line of bench.py: the contract's fields + `roofline` + `cpu_baseline` + a handful of stage scalars, as a
+    compact JSON object of < CONTRACT_LINE_MAX_BYTES bytes.  Everything else the run measured (`stages` in full, `families`,
+    `yardstick`, `verified_layers`, the per-shape tables) stays in the detail object, which bench.py writes to a FILE
+    (--detail, default gpurun_out/bench_detail.json).  Pure function of the detail object: tests/test_bench_line.py feeds it a
+    synthetic round-5-sized `out` and checks the size and the fields."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "partition_mode",
+            "vs_baseline", "dtype", "data", "verified", "predicted")
+    line = {k: _r(out[k]) for k in keep if k in out}
+    cfg = out.get("config", {})
+    lib = cfg.get("library") or {}
+    line["config"] = {"workload": cfg.get("workload"), "path": (cfg.get("path") or "")[:200], "layers": cfg.get("layers"), "batch": cfg.get("batch"),
+                      "dense_equiv_gflop_per_step": _r(cfg.get("dense_equiv_gflop_per_step"), 1), "launch": (cfg.get("launch") or "")[:60],
+                      "streams": cfg.get("streams"), "partition": cfg.get("partition"), "layers_this_rank": cfg.get("layers_this_rank"), "parallelism": (cfg.get("parallelism") or "")[:120],
+                      "library": {"sm_version": lib.get("sm_version"), "sha256_16": lib.get("sha256_16")},
+                      "plan_costs": ((cfg.get("plan_costs") or {}).get("source") or "")[:80]}
+    rf = out.get("roofline")
+    if rf:
+        ts = rf.get("traffic_source") or {}
+        line["roofline"] = {k: _r(rf.get(k), 5) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "launches_per_step", "avg_launch_us",
+                                                          "algorithmic_bytes_per_launch", "algorithmic_flops_per_launch", "step_frac") if k in rf}
+        line["roofline"]["traffic_source"] = {"file": ts.get("file"), "stale": ts.get("stale")} if ts else None
+        fams = rf.get("families") or {}
+        if fams:   # one number per family: its fraction of the HBM peak (the full rows are in the detail file)
+            line["roofline"]["families_frac"] = {n_.replace("spmma_f16_fused_", "").replace("spmma_f32_", "f32_"): _r(f_.get("frac_of_hbm_peak"), 3) for n_, f_ in fams.items()}
+        ys = rf.get("yardstick") or {}
+        if ys:
+            line["roofline"]["device_copy_GBs"] = _r(ys.get("device_copy_GBs"), 1)
+            line["roofline"]["step_GBs"] = _r(ys.get("step_GBs"), 1)
+    cb = out.get("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = {"value": _r(cb.get("value"), 2), "unit": cb.get("unit"), "cores": cb.get("cores"), "kind": cb.get("kind"),
+                                "dense_value": _r(cb.get("dense_value"), 2), "sample": (cb.get("sample") or "")[:260]}
+    st = out.get("stages") or {}
+    scal = ("spmma_mul_ms", "spmma_mul_grouped_ms", "compress_ms", "dense_gemm_rowmajor_ms", "dense_gemm_rowmajor_grouped_ms", "dense_gemm_batched_colmajor_ms",
+            "speedup_full_vs_dense_rowmajor_grouped", "speedup_mul_grouped_vs_dense_rowmajor_grouped", "speedup_mul_vs_dense_batched",
+            "hbm_bound_speedup_ceiling", "api_spmma_ms", "api_spmma_one_kernel_ms", "api_spmma_one_kernel_layers", "api_spmma_two_pass_ms")
+    sline = {k: _r(st[k]) for k in scal if st.get(k) is not None}
+    if isinstance(st.get("conv_step"), dict):
+        sline["conv_step_ms"] = _r(st["conv_step"].get("conv_step_ms"))
+    if isinstance(st.get("f32_split"), dict):
+        sline["f32_split"] = {k: _r(v) for k, v in st["f32_split"].items() if k.endswith("_ms") and isinstance(v, float)}
+    if isinstance(st.get("config4_sweep"), dict):
+        c4 = st["config4_sweep"]
+        sline["config4_sweep"] = {k: _r(c4.get(k)) for k in ("ms_per_step", "value", "unit", "n_gpus", "partition_mode")}
+    if isinstance(st.get("matmul_mfma"), dict):
+        sline["matmul_mfma_frac"] = _r(st["matmul_mfma"].get("frac"))
+    line["stages"] = sline
+    if "emulated" in out:
+        line["emulated"] = out["emulated"]
+    if out.get("detail_file"):
+        line["detail_file"] = out["detail_file"]
+    import json
+    s = json.dumps(line, separators=(",", ":"))
+    if len(s) > CONTRACT_LINE_MAX_BYTES:   # never again an unparseable headline: drop the optional blocks, in this order
+        for k in ("stages", "emulated"):
+            line.pop(k, None)
+            s = json.dumps(line, separators=(",", ":"))
+            if len(s) <= CONTRACT_LINE_MAX_BYTES:
+                break
+    return s

@@ -68,6 +68,5 @@ def cpu_baseline(ge, shapes):
         fl += 2.0 * r * n * k * reps
     return {"value": fl / t_sparse / 1e9, "unit": "GF/s", "cores": orc.num_threads(), "kind": "port",
             "dense_value": fl / t_dense / 1e9,
-            "sample": f"UNTUNED port (naive row-parallel loops, no cache blocking): oracle sm_cpu_spmma_f32 (2:4 path) / sm_cpu_gemm_f32 (dense_value), fp32, one batch (b=1) of each of "
-                      f"the {len(uniq)} unique shapes of the table x {reps} repetitions ({fl / 1e9:.1f} dense-equivalent GFLOP, "
-                      f"{t_dense + t_sparse:.1f} s of CPU work); effective GF/s = dense-equivalent flops / time"}
+            "sample": f"untuned oracle port (sm_cpu_spmma_f32 = value, sm_cpu_gemm_f32 = dense_value; naive OpenMP row loops), fp32, b=1 of each of the "
+                      f"{len(uniq)} unique shapes x {reps} reps ({fl / 1e9:.1f} dense-equivalent GFLOP, {t_dense + t_sparse:.1f} s of CPU work)"}

@@ -337,6 +337,14 @@ def extras(args, sm, torch, dev, layers, flops, t_full, Forked, make_runner, tim
                            "note": "the fp32 2:4 kernel expands to dense fp32 MFMA (no fp32 sparse matrix instruction exists): executed = dense-equivalent flops",
                            "measured": "single stream, HIP events on the launch stream, hipGraph replay", "families": fams_out}
     else:
+        # round 6: the block names ONE kernel -- the family the step spends most of its time in (direct) -- with that kernel's own
+        # bytes, launches, event time and counter traffic; the five fused families together (one entry point) are `entry_point`
+        domk = max(rows, key=lambda n_: rows[n_]["seconds"])
+        rk = rows[domk]
+        entry = {"name": dom, "GBs": d["bytes"] / d["seconds"] / 1e9, "frac": d["bytes"] / d["seconds"] / 1e9 / HBM_PEAK_GBS, "launches_per_step": d["launches"],
+                 "avg_launch_us": d["seconds"] / d["launches"] * 1e6, "algorithmic_bytes_per_launch": d["bytes"] / d["launches"], "traffic": d["traffic"]}
+        d = dict(seconds=rk["seconds"], launches=rk["launches"], bytes=rk["bytes"], traffic=rk["traffic"])
+        dom = domk + "_kernel"
         GBs = d["bytes"] / d["seconds"] / 1e9
         # yardstick measured in THIS process: sm_copy_bytes (16-byte non-temporal loads + stores) moving the timed step's own
         # algorithmic byte count (half read, half written), same event timing as the families above
@@ -364,6 +372,7 @@ def extras(args, sm, torch, dev, layers, flops, t_full, Forked, make_runner, tim
                                                    "until round 4 gave 5.3-5.9) over the timed step's own algorithmic byte count of random halves, half read + half written; "
                                                    "guide_float4_copy_GBs = the float4 copy /opt/skills/guides/MI355X_MICROARCH.md:36 measures (6.29 TB/s); context "
                                                    "only -- `frac` is against the 8 TB/s specification"},
+                           "step_frac": step_bytes / t_full / 1e9 / HBM_PEAK_GBS, "entry_point": entry,
                            "families": fams_out}
 
 
