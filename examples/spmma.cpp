@@ -19,11 +19,19 @@
 int main(int argc, char** argv) {
   using namespace sparsifyme;
   using type_t = SM_TYPE;
-  if (argc != 5 && !(argc == 6 && sizeof(type_t) == 4)) {
-    std::cout << "Invalid # of arguments. Usage: ./spmma m n k b" << (sizeof(type_t) == 4 ? " [f32_planes: 0 | 2 | 3]" : "") << std::endl;
+  if (argc != 5 && argc != 6) {
+    std::cout << "Invalid # of arguments. Usage: ./spmma m n k b" << (sizeof(type_t) == 4 ? " [f32_planes: 0 | 2 | 3]" : " [fewest]") << std::endl;
     return EXIT_FAILURE;
   }
-  if (argc == 6) {
+  if (argc == 6 && sizeof(type_t) != 4) {
+    // optional fifth argument of the 16-bit drivers: "fewest" = spmma_options().fewest_passes (the whole sequence through
+    // sm_prune24_spmma_*: one measured time, printed first; the other two lines are 0).  Default: three measured stage times.
+    if (std::string(argv[5]) != "fewest") {
+      std::cout << "Invalid # of arguments. Usage: ./spmma m n k b [fewest]" << std::endl;
+      return EXIT_FAILURE;
+    }
+    spmma_options().fewest_passes = true;
+  } else if (argc == 6) {
     const int planes = std::stoi(argv[5]);
     if (planes != 0 && planes != 2 && planes != 3) {
       std::cout << "f32_planes must be 0, 2 or 3" << std::endl;

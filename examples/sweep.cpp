@@ -106,8 +106,10 @@ int main(int argc, char** argv) {
     spmma(A.data().get(), B.data().get(), C.data().get(), m, n, k, b);  // warm (prunes A in place)
     const auto st = spmma(A.data().get(), B.data().get(), C.data().get(), m, n, k, b);
     spmma_options().staged = false;
+    spmma_options().fewest_passes = true;  // spmma_call: the whole sequence through sm_prune24_spmma_* (no blob; one measured time)
     spmma(A.data().get(), B.data().get(), C.data().get(), m, n, k, b);  // warm
     const auto sc = spmma(A.data().get(), B.data().get(), C.data().get(), m, n, k, b);
+    spmma_options().fewest_passes = false;
     const double fl = 2.0 * m * n * k * b;
     out << m << "," << n << "," << k << "," << b << "," << gemm_ms << "," << prune_ms << "," << spmm_ms << "," << st[0] << ","
         << st[1] << "," << st[2] << "," << fl / gemm_ms / 1e6 << "," << fl / st[2] / 1e6 << "," << sc[0] + sc[1] + sc[2] << "\n";

@@ -301,7 +301,8 @@ def prune24_spmma(A_in, A_out, B, C, m, n, k, lda=None, batch=1, strideA=None, s
 
 
 def api_spmma_step_fused(A, Apruned, B, C, blob, d_valid, m, n, k, batch):
-    """api_spmma_step with the one-kernel form where it applies (n <= 128, k % 64 == 0, m % 4 == 0), the two-launch pair elsewhere."""
+    """api_spmma_step without a blob wherever sm_prune24_spmma_* takes the shape (one kernel for n <= 128, k % 64 == 0, m % 4 == 0; since round 6
+    the prune + flag pass followed by the exact fused kernel on the pruned operand elsewhere), the blob pair where it does not."""
     if prune24_spmma(A, Apruned, B, C, m, n, k, batch=batch, d_valid=d_valid, check=False) == STATUS_NOT_SUPPORTED:
         api_spmma_step(A, Apruned, B, C, blob, d_valid, m, n, k, batch)
 

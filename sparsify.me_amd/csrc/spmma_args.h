@@ -50,6 +50,11 @@ int gemm_dense_twin(const DenseTwinCall& c, hipStream_t st);
 int spmma_fused_thin(bool bf, int ngroup, const void* const* A, const void* const* B, void* const* C, size_t rows, size_t n, size_t k,
                      float alpha, float beta, hipStream_t st);
 
+// spmma_f16_fused.hip: does sm_spmma_fused_{f16,bf16} take this single problem with one of its EXACT forms (bit-identical to
+// sm_compress24 + sm_spmma; the thin form is excluded)?  Asked by the prune-in-place + multiply entry points before they touch A.
+bool spmma_fused16_takes_exact(const void* A, const void* B, const void* C, size_t m, size_t n, size_t k, size_t lda, size_t batch, size_t strideA, size_t strideB,
+                               size_t strideC);
+
 #ifdef SM_STAMP
 __device__ __forceinline__ unsigned long long sm_stamp() {
   unsigned long long t;

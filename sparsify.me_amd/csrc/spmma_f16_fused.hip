@@ -1819,6 +1819,31 @@ static int launch_fused_astat(const FusedArgs& a0, hipStream_t st) {
 
 using namespace sm;
 
+// Which shapes the two exact forms take -- ONE statement of each rule, used by spmma_fused16 below and by sm::spmma_fused16_takes_exact
+// (the prune-in-place + multiply entry points ask BEFORE they modify A, csrc/spmma_f16_pruned.hip).
+// span form: rows that are not whole 64-deep stages of 16-byte pieces, when A is one tall contiguous matrix, n <= 128 and a 128-row
+// span + the whole B fit the LDS (k = 147: the stem layer of every ResNet)
+static bool span_form_takes(size_t m, size_t n, size_t k, size_t lda, size_t batch, size_t strideA, size_t strideB, size_t strideC, bool all_aligned, bool c_aligned) {
+  return (k % 64 != 0 || lda % 8 != 0) && lda == k && n % 8 == 0 && n <= 128 && all_aligned && c_aligned && (batch == 1 || (strideB == 0 && strideA == m * lda && strideC == m * n)) &&
+         (m * batch * k * 2) % 16 == 0 && m * batch <= 0x7fffffffull && k <= 0x7fffffffull &&
+         ((size_t)128 * k * 2 + 1152) + ((k + 63) / 64 * 64) * (n <= 64 ? 64 : 128) * 2 <= 160 * 1024;
+}
+// whole 64-deep stages of 16-byte aligned rows (every other kernel of this file)
+static bool stage_forms_take(size_t n, size_t k, size_t lda, size_t strideA, size_t strideB, bool all_aligned) {
+  return !(k % 64 != 0 || lda % 8 != 0 || strideA % 8 != 0 || n % 8 != 0 || strideB % 8 != 0 || !all_aligned);
+}
+static bool dims_fit_int(size_t m, size_t n, size_t k, size_t lda, size_t batch) {
+  return !(m * batch > 0x7fffffffull || n > 0x7fffffffull || k > 0x7fffffffull || lda > 0x7fffffffull);
+}
+bool sm::spmma_fused16_takes_exact(const void* A, const void* B, const void* C, size_t m, size_t n, size_t k, size_t lda, size_t batch, size_t strideA, size_t strideB,
+                                   size_t strideC) {
+  if (!A || !B || !C || lda < k || m == 0 || n == 0 || batch == 0) return false;
+  if (n < 8 && k <= 64) return false;  // the thin form: inside the tight bound of the product, not the staged pair's bits
+  const bool all_aligned = aligned16(A) && aligned16(B), c_aligned = aligned16(C);
+  if (span_form_takes(m, n, k, lda, batch, strideA, strideB, strideC, all_aligned, c_aligned)) return true;
+  return stage_forms_take(n, k, lda, strideA, strideB, all_aligned) && dims_fit_int(m, n, k, lda, batch);
+}
+
 template <bool BF>
 static int spmma_fused16(size_t ngroup, const void* const* Ag, const void* const* Bg, void* const* Cg, size_t m, size_t n, size_t k, size_t lda,
                          size_t batch, size_t strideA, size_t strideB, size_t strideC, float alpha, float beta,
@@ -1846,9 +1871,7 @@ static int spmma_fused16(size_t ngroup, const void* const* Ag, const void* const
   }
   // rows that are not whole 64-deep stages of 16-byte pieces: the span form, when A is one tall contiguous matrix, n <= 128
   // and a 128-row span + the whole B fit the LDS (k = 147: the stem layer of every ResNet)
-  if ((k % 64 != 0 || lda % 8 != 0) && lda == k && n % 8 == 0 && n <= 128 && all_aligned && c_aligned && (batch == 1 || (strideB == 0 && strideA == m * lda && strideC == m * n)) &&
-      (m * batch * k * 2) % 16 == 0 && m * batch <= 0x7fffffffull && k <= 0x7fffffffull &&
-      ((size_t)128 * k * 2 + 1152) + ((k + 63) / 64 * 64) * (n <= 64 ? 64 : 128) * 2 <= 160 * 1024) {
+  if (span_form_takes(m, n, k, lda, batch, strideA, strideB, strideC, all_aligned, c_aligned)) {
     FusedArgs a = {};
     for (size_t g = 0; g < (size_t)MAXG; ++g) {
       const size_t s_ = g < ngroup ? g : 0;
@@ -1861,7 +1884,7 @@ static int spmma_fused16(size_t ngroup, const void* const* Ag, const void* const
     return n <= 64 ? launch_fused_span<64, BF>(a, st) : launch_fused_span<128, BF>(a, st);
   }
   // whole 64-deep stages of 16-byte aligned rows only; anything else: sm_compress24_f16 + sm_spmma_f16
-  if (k % 64 != 0 || lda % 8 != 0 || strideA % 8 != 0 || n % 8 != 0 || strideB % 8 != 0 || !all_aligned) {
+  if (!stage_forms_take(n, k, lda, strideA, strideB, all_aligned)) {
     set_error("sm_spmma_fused_{f16,bf16}: needs k %% 64 == 0, n %% 8 == 0 and 16-byte aligned rows (use the staged path)");
     return SM_STATUS_NOT_SUPPORTED;
   }
@@ -1869,7 +1892,7 @@ static int spmma_fused16(size_t ngroup, const void* const* Ag, const void* const
     set_error("sm_spmma_fused_{f16,bf16}_grouped: needs 16-byte aligned C operands");
     return SM_STATUS_NOT_SUPPORTED;
   }
-  if (m * batch > 0x7fffffffull || n > 0x7fffffffull || k > 0x7fffffffull || lda > 0x7fffffffull) {
+  if (!dims_fit_int(m, n, k, lda, batch)) {
     set_error("sm_spmma_fused_{f16,bf16}: dimension exceeds 2^31-1");
     return SM_STATUS_NOT_SUPPORTED;
   }

@@ -206,9 +206,24 @@ static int prune24_spmma16(const void* A_in, void* A, const void* B, void* C, si
   if (m == 0 || n == 0 || batch == 0) return SM_STATUS_SUCCESS;
   if (n > 128 || n % 8 != 0 || k == 0 || k % 64 != 0 || m % 4 != 0 || lda % 8 != 0 || strideA % 8 != 0 || strideB % 8 != 0 || !aligned16(A) || !aligned16(A_in) || !aligned16(B) ||
       m * batch > 0x7fffffffull || k > 0x7fffffffull || lda > 0x7fffffffull) {
-    set_error("sm_prune24_spmma_{f16,bf16}: needs n <= 128, n %% 8 == 0, k %% 64 == 0, m %% 4 == 0 and 16-byte aligned rows "
-              "(use sm_prune24_compress24 + sm_spmma)");
-    return SM_STATUS_NOT_SUPPORTED;
+    // (round 6) Every other shape the exact fused kernels take (n > 128: 35 of ResNet-50's 49 layers; ragged k: the stem layer): TWO launches and
+    // still no blob -- (1) prune in place + flag as one pass over A (sm_prune24_compress24_* with a null blob: read A, write A), (2) the fused
+    // kernel on the PRUNED operand: its STRIP selection of a 2:4 strip is what sm_compress24 stores for that strip, so C is the staged
+    // sequence's bit for bit.  HBM bytes: 2 A + C + B when the pruned A (<= 116 MB on those layers) is still in the 256 MiB Infinity Cache
+    // for launch 2, against 3.125 A + C + B of the blob pair.  Why not ONE kernel there: with several column tiles per row panel every
+    // element of A has several readers and an in-place writer (a torn 4 x 4 tile prunes differently), and the few-tile shapes (98-196
+    // workgroups) would run the TILE rule -- ~520 VALU instructions per tile, the API path's real bound -- on a fraction of
+    // the chip's SIMDs; the one-pass prune spreads it over all of them.
+    if (k == 0 || !spmma_fused16_takes_exact(A, B, C, m, n, k, lda, batch, strideA, strideB, strideC)) {
+      set_error("sm_prune24_spmma_{f16,bf16}: shape / alignment not taken by the one-kernel form nor by the exact fused kernels "
+                "(use sm_prune24_compress24 + sm_spmma)");
+      return SM_STATUS_NOT_SUPPORTED;
+    }
+    int rc = BF ? sm_prune24_compress24_bf16(A_in, A, m, k, lda, batch, strideA, nullptr, d_valid, alg, stream)
+                : sm_prune24_compress24_f16(A_in, A, m, k, lda, batch, strideA, nullptr, d_valid, alg, stream);
+    if (rc != SM_STATUS_SUCCESS) return rc;
+    return BF ? sm_spmma_fused_bf16(A, B, C, m, n, k, lda, batch, strideA, strideB, strideC, alpha, beta, stream)
+              : sm_spmma_fused_f16(A, B, C, m, n, k, lda, batch, strideA, strideB, strideC, alpha, beta, stream);
   }
   PrunedArgs a = {};
   a.Ain = (const half_t*)A_in; a.A = (half_t*)A; a.B = (const half_t*)B; a.C = (half_t*)C; a.d_valid = d_valid;

@@ -252,9 +252,10 @@ static void check_coo(size_t m, size_t n, size_t k, size_t b) {
 // planes = 3 / 2 (float only): spmma_options().f32_planes -- the multiply on the sparse matrix instruction through bfloat16 splits;
 // same pruned A bit for bit, C within 2^-21 / 2^-13 of sum|a||b| on top of the fp32 terms (include/sparsifyme.h)
 template <typename T>
-static void check_spmma(size_t m, size_t n, size_t k, size_t b, const char* tname, int planes = 0) {
+static void check_spmma(size_t m, size_t n, size_t k, size_t b, const char* tname, int planes = 0, bool fewest = false) {
   constexpr bool F32 = sizeof(T) == 4;
   spmma_options().f32_planes = planes;
+  spmma_options().fewest_passes = fewest;  // (round 6) the whole sequence through sm_prune24_spmma_*: same dA, same dC
   std::mt19937 gen(0xa24 + (unsigned)(m + n * 3 + k * 5));
   std::uniform_real_distribution<float> U(-1.f, 1.f);
   using bits_t = typename std::conditional<F32, float, uint16_t>::type;
@@ -319,6 +320,7 @@ static void check_spmma(size_t m, size_t n, size_t k, size_t b, const char* tnam
     verdict(what, ok, false, detail);
   }
   spmma_options().f32_planes = 0;
+  spmma_options().fewest_passes = false;
 }
 
 // spmma_f32_planes_t (round 5): B's planes prepared once == spmma_fused<float> with the same f32_planes, bit for bit, over two multiplies
@@ -374,6 +376,7 @@ int main(int argc, char** argv) {
     check_spmm(m, n, k, b);
     check_coo(m, n, k, b);
     check_spmma<_Float16>(m, n, k, b, "half");
+    check_spmma<_Float16>(m, n, k, b, "half, fewest_passes", 0, true);
     check_spmma<float>(m, n, k, b, "float");
     check_spmma<float>(m, n, k, b, "float, f32_planes = 3", 3);
     check_spmma<float>(m, n, k, b, "float, f32_planes = 2", 2);

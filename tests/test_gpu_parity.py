@@ -737,7 +737,11 @@ def test_model_zoo_tables_full_size(gpu, orc, table):
         pass
 
 
-PRUNE_SPMMA_SHAPES = [(128, 64, 64, 1), (196, 128, 256, 2), (132, 72, 192, 3), (4, 8, 64, 1), (260, 128, 128, 2), (3136, 128, 512, 2), (12544, 64, 576, 1)]
+PRUNE_SPMMA_SHAPES = [(128, 64, 64, 1), (196, 128, 256, 2), (132, 72, 192, 3), (4, 8, 64, 1), (260, 128, 128, 2), (3136, 128, 512, 2), (12544, 64, 576, 1),
+                      # round 6: everything the exact fused kernels take runs as prune-in-place pass + fused kernel on the pruned operand (no blob):
+                      # n > 128 (direct two-tile / big / wide / astat forms), ragged k (span form), m % 4 != 0 (per-batch tiles)
+                      (196, 256, 256, 2), (196, 512, 128, 2), (132, 264, 192, 3), (784, 256, 1024, 2), (196, 2048, 512, 1), (196, 512, 2048, 2), (12544, 256, 64, 1),
+                      (196, 64, 147, 2), (130, 256, 64, 2), (130, 64, 64, 3)]
 
 
 @pytest.mark.parametrize("alg", [0, 1], ids=["tile", "strip"])
@@ -765,7 +769,11 @@ def test_prune_spmma_one_kernel(gpu, orc, alg, shape, bf, kind):
     gpu.fill_uniform(C0, 0xC1 + m, -1.0, 1.0)
     # the staged reference on the GPU: prune -> compress -> spmma
     P = dA.clone()
-    gpu.prune24(P, P, batch * m, k, k, alg)
+    if m % 4 == 0 or alg == 1:
+        gpu.prune24(P, P, batch * m, k, k, alg)
+    else:  # a 4 x 4 tile never spans two batch matrices: per matrix
+        for b_ in range(batch):
+            gpu.prune24(P[b_ * m * k:(b_ + 1) * m * k], P[b_ * m * k:(b_ + 1) * m * k], m, k, k, alg)
     blob = torch.empty(gpu.compress24_size(m, k, 2, batch), dtype=torch.uint8, device="cuda")
     gpu.compress24(P, m, k, k, batch, m * k, blob)
     for (alpha, beta, inplace) in [(1.0, 0.0, False), (0.5, -2.0, True)]:
@@ -784,9 +792,62 @@ def test_prune_spmma_one_kernel(gpu, orc, alg, shape, bf, kind):
         chk = torch.ones(1, dtype=torch.int32, device="cuda")
         gpu.prune24_check(Aout, batch * m, k, k, chk)
         assert int(chk.item()) == 0
-    if batch * m * k <= 200000 and not bf:  # small: the pruned operand against the oracle directly
-        want = orc.prune24(bits(host(dA)), batch * m, k, k, orc.TILE if alg == 0 else orc.STRIP)
+    if batch * m * k <= 200000 and not bf:  # small: the pruned operand AND the product against the oracle directly
+        oalg = orc.TILE if alg == 0 else orc.STRIP
+        if m % 4 == 0 or alg == 1:
+            want = orc.prune24(bits(host(dA)), batch * m, k, k, oalg)
+        else:
+            hA = bits(host(dA))
+            want = np.concatenate([orc.prune24(hA[b_ * m * k:(b_ + 1) * m * k], m, k, k, oalg) for b_ in range(batch)])
         assert np.array_equal(bits(host(P)), want)
+        Cx = torch.empty(batch * m * n, dtype=tdt, device="cuda")
+        gpu.prune24_spmma(dA.clone(), torch.empty_like(dA), dB, Cx, m, n, k, batch=batch, alg=alg)
+        ob = orc.compress24(want, m, k, k, batch)
+        Cor = np.zeros(batch * m * n, dtype=np.uint16)
+        orc.spmma(ob, bits(host(dB)), Cor, m, n, k, batch, 0)
+        Pm = np.abs(want.view(np.float16).astype(np.float64)).reshape(batch, m, k)
+        Bm = np.abs(host(dB).astype(np.float64)).reshape(k, n)
+        scale = np.stack([Pm[b_] @ Bm for b_ in range(batch)]).reshape(-1)
+        check_close(host(Cx), Cor.view(np.float16), scale, FP16_TOL, f"prune24_spmma {shape} alg {alg} vs oracle", k)
+
+
+def _resnet50_unique():
+    import csv
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "datasets", "resnet50.csv"), newline="") as fh:
+        rows = [tuple(int(x) for x in r[:4]) for r in list(csv.reader(fh))[1:] if r]
+    return sorted(set(rows))
+
+
+@pytest.mark.parametrize("shape", _resnet50_unique(), ids=lambda s_: "x".join(map(str, s_)))
+def test_prune_spmma_takes_every_resnet50_layer_full_size(gpu, shape):
+    """sm_prune24_spmma_f16 -- TILE prune IN PLACE + flag + multiply, no blob -- on each of the 17 unique ResNet-50
+    shapes at b = 32: dA and dC bit-identical to the staged sequence (sm_prune24 TILE, sm_compress24, sm_spmma), flag clear; and the flag
+    of the independent check rises on the unpruned operand (flag semantics)."""
+    import torch
+    m, n, k, batch = shape
+    dA = torch.empty(batch * m * k, dtype=torch.float16, device="cuda")
+    gpu.fill_uniform(dA, 0xA6 + m + k, -1.0, 1.0)
+    dB = torch.empty(k * n, dtype=torch.float16, device="cuda")
+    gpu.fill_uniform(dB, 0xB6 + n, -1.0, 1.0)
+    chk = torch.zeros(1, dtype=torch.int32, device="cuda")
+    gpu.prune24_check(dA, batch * m, k, k, chk)
+    assert int(chk.item()) != 0, "a dense random operand must fail the 2:4 check"
+    P = dA.clone()
+    gpu.prune24(P, P, batch * m, k, k, 0)      # m % 4 == 0 on every ResNet-50 layer: the batch is one tall matrix
+    blob = torch.empty(gpu.compress24_size(m, k, 2, batch), dtype=torch.uint8, device="cuda")
+    gpu.compress24(P, m, k, k, batch, m * k, blob)
+    Cref = torch.empty(batch * m * n, dtype=torch.float16, device="cuda")
+    gpu.spmma(blob, dB, Cref, m, n, k, batch)
+    del blob
+    C = torch.full_like(Cref, 3.0)
+    valid = torch.full((1,), 5, dtype=torch.int32, device="cuda")
+    rc = gpu.prune24_spmma(dA, dA, dB, C, m, n, k, batch=batch, alg=0, d_valid=valid, check=False)
+    assert rc == 0, "sm_prune24_spmma_f16 must take every ResNet-50 layer"
+    assert int(valid.item()) == 0
+    assert torch.equal(dA.view(torch.int16), P.view(torch.int16)), "dA (pruned in place) differs from sm_prune24 TILE"
+    assert torch.equal(C.view(torch.int16), Cref.view(torch.int16)), "dC differs from spmma(compress(prune(A)))"
 
 
 def test_prune_spmma_rejects_what_it_cannot_take(gpu):
@@ -795,9 +856,12 @@ def test_prune_spmma_rejects_what_it_cannot_take(gpu):
     B = torch.zeros(256 * 256, dtype=torch.float16, device="cuda")
     C = torch.zeros(200 * 256, dtype=torch.float16, device="cuda")
     NS = gpu.STATUS_NOT_SUPPORTED
-    assert gpu.prune24_spmma(A, A, B, C, 196, 256, 256, check=False) == NS       # n > 128: two column tiles would both rewrite A
-    assert gpu.prune24_spmma(A, A, B, C, 196, 64, 72, check=False) == NS         # k % 64 != 0
-    assert gpu.prune24_spmma(A, A, B, C, 130, 64, 64, check=False) == NS         # m % 4 != 0: a 4 x 4 tile would straddle two batches
+    # (round 6: n > 128, ragged k and m % 4 != 0 are TAKEN now -- prune pass + exact fused kernel, test_prune_spmma_one_kernel)
+    snap = A.clone()
+    assert gpu.prune24_spmma(A, A, B, C, 196, 60, 64, check=False) == NS          # n % 8 != 0: no exact fused form
+    assert gpu.prune24_spmma(A, A, B, C, 196, 4, 64, check=False) == NS           # thin shapes: the fused form there is not the staged pair's bits
+    assert gpu.prune24_spmma(A[4:], A[4:], B, C, 196, 256, 64, check=False) == NS  # 8-byte aligned A
+    assert torch.equal(A, snap), "a refused call must leave A untouched"
     with pytest.raises(gpu.SparsifymeError):
         gpu.prune24_spmma(A, A, B, C, 196, 64, 64, alg=7)
 
@@ -1885,12 +1949,20 @@ def test_cpp_drivers_cli_contract(gpu):
     lines = out.stdout.strip().splitlines()
     assert out.returncode == 0 and [l.split(":")[0] for l in lines] == ["Pruning Time (ms)", "Compression Time (ms)", "SpMMA Time (ms)"]
     assert "Incorrect pruning" not in out.stderr
-    # this shape runs as ONE kernel (sm_prune24_spmma_f16): one measured time, reported first; nothing compressed, no separate multiply
+    # default (round 6): THREE measured, non-zero stage times on every shape, as the reference returns and prints them (spmma.hxx:117,
+    # examples/spmma.cu:64-66): one-pass prune + check + compress | blob allocation | multiply
     vals = [float(l.split(":")[1]) for l in lines]
-    assert vals[0] > 0.0 and vals[1] == 0.0 and vals[2] == 0.0
-    out = run("spmma", 196, 256, 128, 4)   # n > 128: one-pass prune + check + compress, then the multiply -- three measured values
+    assert all(v > 0.0 for v in vals)
+    out = run("spmma", 196, 256, 128, 4)
     vals = [float(l.split(":")[1]) for l in out.stdout.strip().splitlines()]
     assert out.returncode == 0 and all(v > 0.0 for v in vals) and "Incorrect pruning" not in out.stderr
+    # opt-in (spmma_options().fewest_passes; the driver's optional fifth argument): the whole sequence through sm_prune24_spmma_f16, no
+    # blob -- one measured time, reported first; nothing compressed, no separately timed multiply
+    for shape_ in [(196, 64, 128, 4), (196, 256, 128, 4)]:
+        out = run("spmma", *shape_, "fewest")
+        vals = [float(l.split(":")[1]) for l in out.stdout.strip().splitlines()]
+        assert out.returncode == 0 and vals[0] > 0.0 and vals[1] == 0.0 and vals[2] == 0.0 and "Incorrect pruning" not in out.stderr
+    assert run("spmma", 196, 64, 128, 4, "nonsense").returncode != 0
     # the reference's own instantiation (type_t = float, examples/spmma.cu:24): one-pass prune + check + compress since round 3
     if not os.path.exists(os.path.join(bins, "spmma_f32")):
         subprocess.run(["make", "-C", os.path.join(root, "examples"), "-j4"], check=True, capture_output=True)

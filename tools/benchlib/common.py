@@ -124,7 +124,7 @@ def contract_line(out):
     st = out.get("stages") or {}
     scal = ("spmma_mul_ms", "spmma_mul_grouped_ms", "compress_ms", "dense_gemm_rowmajor_ms", "dense_gemm_rowmajor_grouped_ms", "dense_gemm_batched_colmajor_ms",
             "speedup_full_vs_dense_rowmajor_grouped", "speedup_mul_grouped_vs_dense_rowmajor_grouped", "speedup_mul_vs_dense_batched",
-            "hbm_bound_speedup_ceiling", "api_spmma_ms", "api_spmma_one_kernel_ms", "api_spmma_one_kernel_layers", "api_spmma_two_pass_ms")
+            "hbm_bound_speedup_ceiling", "api_spmma_ms", "api_spmma_one_kernel_ms", "api_spmma_one_kernel_layers", "api_spmma_no_blob_layers", "api_spmma_frac_of_byte_floor")
     sline = {k: _r(st[k]) for k in scal if st.get(k) is not None}
     if isinstance(st.get("conv_step"), dict):
         sline["conv_step_ms"] = _r(st["conv_step"].get("conv_step_ms"))

@@ -127,13 +127,29 @@ def extras(args, sm, torch, dev, layers, flops, t_full, Forked, make_runner, tim
         out["stages"]["api_spmma_gfs"] = gfs(t_api)
         out["stages"]["api_spmma_sequence"] = sm.API_SPMMA_SEQUENCE
         if not f32 and hasattr(sm, "api_spmma_step_fused"):
-            # round 4: the same sequence as ONE kernel (sm_prune24_spmma_*: TILE prune written to the second buffer, flag, multiply,
-            # no blob) on the layers it takes (n <= 128, k % 64 == 0, m % 4 == 0); the two-launch pair on the others
-            t_api1 = sec_per_call(Forked(lambda L: sm.api_spmma_step_fused(L["A"], L["Aapi"], L["B"], L["C"], L["blob"], valid, L["m"], L["n"], L["k"], L["b"])))
+            # rounds 4 + 6: the same sequence WITHOUT a blob through sm_prune24_spmma_*: ONE kernel (TILE prune written to the second buffer, flag,
+            # multiply) on the layers it takes (n <= 128, k % 64 == 0, m % 4 == 0); on every other layer the exact fused kernels take (round 6: all
+            # of ResNet-50) the prune + flag pass over A followed by the fused kernel on the pruned operand; the blob pair only where neither applies
+            taken = {}
+
+            def api_no_blob(L):
+                rc = sm.prune24_spmma(L["A"], L["Aapi"], L["B"], L["C"], L["m"], L["n"], L["k"], batch=L["b"], d_valid=valid, check=False)
+                taken[L["li"]] = rc == 0
+                if rc != 0:
+                    sm.api_spmma_step(L["A"], L["Aapi"], L["B"], L["C"], L["blob"], valid, L["m"], L["n"], L["k"], L["b"])
+            t_api1 = sec_per_call(Forked(api_no_blob))
             n_one = sum(1 for L in layers if L["n"] <= 128 and L["n"] % 8 == 0 and L["k"] % 64 == 0 and L["m"] % 4 == 0)
             out["stages"]["api_spmma_one_kernel_ms"] = t_api1 * 1e3
             out["stages"]["api_spmma_one_kernel_gfs"] = gfs(t_api1)
             out["stages"]["api_spmma_one_kernel_layers"] = n_one
+            out["stages"]["api_spmma_no_blob_layers"] = sum(1 for v in taken.values() if v)
+            out["stages"]["api_spmma_no_blob_sequence"] = ("sm_prune24_spmma_*: one kernel on %d layers; prune + flag pass (sm_prune24_compress24_* with a null blob) + "
+                                                           "sm_spmma_fused_* on the pruned operand on %d; blob pair on %d" % (n_one, sum(1 for v in taken.values() if v) - n_one,
+                                                                                                                            sum(1 for v in taken.values() if not v)))
+            # the byte floor of the sequence with A pruned in place: 2 A + C + B at the HBM peak
+            floor_b = sum(L["b"] * s * (2 * L["m"] * L["k"] + L["m"] * L["n"]) + s * L["k"] * L["n"] for L in layers)
+            out["stages"]["api_spmma_byte_floor_ms"] = floor_b / (HBM_PEAK_GBS * 1e9) * 1e3
+            out["stages"]["api_spmma_frac_of_byte_floor"] = floor_b / (HBM_PEAK_GBS * 1e9) / t_api1
         for L in layers:
             del L["Aapi"]
 
