@@ -92,6 +92,11 @@ def main():
                     help="element type (BASELINE's metric is quoted on f16; bf16 runs the same kernels with the bfloat16 matrix "
                          "instructions; f32 is BASELINE config 2: sm_compress24_f32 + sm_spmma_f32 against the fp32 dense GEMMs, "
                          "default table resnet18)")
+    ap.add_argument("--f32-planes", type=int, choices=[0, 2, 3], default=3,
+                    help="--dtype f32: 3 (default since round 6) / 2 = the multiply on the sparse matrix instruction through exact bfloat16 "
+                         "splits of both operands (sm_spmma_fused_f32_split: |error| <= 2^-21 / 2^-13 of sum|a||b|; north_star allows 1e-3, the "
+                         "reference's library computes float operands in TF32) -- the default of sparsifyme::spmma<float> too "
+                         "(spmma_options().f32_planes); 0 = the exact fp32 form (dense fp32 MFMA work on the selected operand)")
     ap.add_argument("--streams", type=int, default=8,
                     help="HIP streams the independent layers of a step are spread over (fork/join inside the step)")
     ap.add_argument("--graphs", choices=["single", "per-stream"], default="single",
@@ -179,16 +184,28 @@ def main():
             costs = {tuple(int(x) for x in k_.split("x")): tuple(v) for k_, v in json.load(open(args.costs_file)).items()}
             plan_costs = {"source": "measured by the N = 1 child of this emulation (--costs-file)"}
         elif world > 1:
-            box = [mg.measure_costs(sm, torch, shapes, tdt) if rank == 0 else None]
+            box = [mg.measure_costs(sm, torch, shapes, tdt, world=world) if rank == 0 else None]
             dist.broadcast_object_list(box, src=0)
             costs = box[0]
             plan_costs = {"source": "measured in setup by rank 0 on this node (one grouped launch per unique shape), broadcast to all ranks"}
         if costs:
             mg.set_measured_costs(costs)
-            plan_costs["us_per_instance"] = {"x".join(map(str, k_)): round(v[0], 2) for k_, v in costs.items()}
+            plan_costs["us_per_instance"] = {"x".join(map(str, k_)): [round(x, 2) for x in v] for k_, v in costs.items()}
     elif args.costs_file and plan_world == 1 and not f32:   # the N = 1 child of an emulation: measure for the rank children
-        costs = mg.measure_costs(sm, torch, shapes, tdt)
+        costs = mg.measure_costs(sm, torch, shapes, tdt, world=(2, 4, 8))
         json.dump({"x".join(map(str, k_)): list(v) for k_, v in costs.items()}, open(args.costs_file, "w"))
+    elif plan_world == 1 and world == 1 and not f32 and args.plan_costs == "measure" and not args.no_extras and args.emu_rank is None:
+        # (round 6) a plain N = 1 run measures the plan costs on THIS box too -- at the full batch and at a rank's share for
+        # 2 / 4 / 8 ranks -- and records them with the hybrid plan's predicted imbalance (max / mean modelled rank time), so that the line
+        # of the first box of a node says what the N > 1 runs on that node will plan with.  Setup, outside the timed region.
+        costs = mg.measure_costs(sm, torch, shapes, tdt, world=(2, 4, 8))
+        mg.set_measured_costs(costs)
+        plan_costs = {"source": "measured in setup on this box (one grouped launch per unique shape, at b and at b / 2, b / 4, b / 8 for the shapes "
+                                "the hybrid plan splits by batch index)",
+                      "us_per_instance": {"x".join(map(str, k_)): [round(x, 2) for x in v] for k_, v in costs.items()},
+                      "hybrid_plan_predicted": {str(w_): {"max_over_mean": round(max(l_) / (sum(l_) / w_), 4), "max_rank_us": round(max(l_), 1),
+                                                          "speedup_vs_n1_modelled": round(sum(mg.plan_loads(shapes, 1, "hybrid")) / max(l_), 3)}
+                                                for w_ in (2, 4, 8) for l_ in [mg.plan_loads(shapes, w_, "hybrid")]}}
     units = mg.plan_units(shapes, plan_world, plan_rank, args.scaling)
     es = 4 if f32 else 2
 
@@ -219,6 +236,13 @@ def main():
         return layers
     layers = build_layers(shapes, units)
     flops = mg.unit_flops(shapes, units)
+    if f32 and args.f32_planes:
+        # the split form's workspace (B's bfloat16 planes, written by every call) per layer, and -- asked once, in setup -- whether the form
+        # takes the layer (k % 64 == 0 or the span form, n % 8 == 0); the others run the exact kernels
+        for L in layers:
+            L["ws"] = torch.empty(max(16, sm.spmma_fused_f32_split_workspace(L["n"], L["k"], planes=args.f32_planes)), dtype=torch.uint8, device=dev)
+            L["split"] = sm.spmma_fused_f32_split(L["A"], L["B"], L["C"], L["m"], L["n"], L["k"], L["ws"], batch=L["b"], planes=args.f32_planes, check=False) == 0
+        torch.cuda.synchronize()
 
     # The layers of a step are independent problems (the reference's sweep runs them as separate
     # processes, examples/profiling.py:6-17), so a step forks them over a few HIP streams and joins:
@@ -289,7 +313,9 @@ def main():
     # (f-1) the fused kernel computes the same C bit for bit straight from the dense A (the 2:4 selection
     # and compaction happen in registers / LDS; no blob goes to HBM)
     def layer_path(L):
-        if use_fused(L):
+        if L.get("split"):
+            sm.spmma_fused_f32_split(L["A"], L["B"], L["C"], L["m"], L["n"], L["k"], L["ws"], batch=L["b"], planes=args.f32_planes)
+        elif use_fused(L):
             sm.spmma_fused(L["A"], L["B"], L["C"], L["m"], L["n"], L["k"], batch=L["b"])
         else:
             layer_staged(L)
@@ -474,8 +500,12 @@ def main():
     nfused = sum(use_fused(L) for L in layers)
     sfx = args.dtype
     if f32:
+        nsplit = sum(1 for L in layers if L.get("split"))
         path_desc = ("auto: sm_spmma_fused_f32 on %d layers (k %% 32 == 0), sm_compress24_f32 + sm_spmma_f32 on %d" % (nfused, len(layers) - nfused)
                      if args.path == "auto" else "staged: sm_compress24_f32 + sm_spmma_f32 on every layer")
+        if nsplit:
+            path_desc = ("sm_spmma_fused_f32_split (planes = %d: v_smfmac_f32_16x16x64_bf16 on exact bfloat16 pieces, B split per call) on %d layers; on the other %d: "
+                         % (args.f32_planes, nsplit, len(layers) - nsplit)) + path_desc
     elif args.path == "auto":
         path_desc = ("auto: sm_spmma_fused_%s on %d layers (n <= %d or k <= %d), sm_compress24_%s + sm_spmma_%s on %d"
                      % (sfx, nfused, args.fused_max_n, args.fused_max_k_wide, sfx, sfx, len(layers) - nfused))
@@ -512,6 +542,12 @@ def main():
     # What was timed, checked (not timed): C of one layer per kernel family, as the last timed step left it, against
     # sm_compress24 + sm_spmma on the same operands, bit for bit (the fused kernels' contract; tests/test_gpu_parity.py holds
     # the full matrix of cases).  A mismatch fails the run: a fast step with different results is not a measurement.
+    #  a stream-K fix-up that timed out leaves a dirty flag page and an invalid C: every workspace the timed step used is
+    # inspected here, after the loop (a 4 KiB read-back each; never inside the timed region)
+    for key_, ws_ in sk_ws.items():
+        if ws_ is not None and sm.spmma_fused_workspace_state(ws_) != 0:
+            sys.stderr.write("bench: stream-K workspace of shape %s is not clean after the timed loop (a fix-up timed out)\n" % (key_,))
+            raise SystemExit(4)
     if not f32 and args.path == "auto":
         checked, ok = [], True
         seen = set()

@@ -155,6 +155,11 @@ struct spmma_fns<__half> : spmma_fns_f16 {};
 // staged = true (-DSPARSIFYME_SPMMA_STAGED): the reference's three stages as three separately launched, separately timed steps
 // (prune + check + readback | blob allocation + compress | multiply), for stage-level comparisons.
 // dA and dC end bit-identical in all three modes.
+// f32_planes (float operands only): 3 (default since round 6; -DSPARSIFYME_F32_PLANES=0 / 2 changes it) / 2 = the multiply on the sparse
+// matrix instruction through exact bfloat16 splits of both operands (sm_spmma_fused_f32_split: |error| <= 2^-21 / 2^-13 of sum |a||b| --
+// north_star allows 1e-3 relative for fp32 and the reference's cuSPARSELt computes float operands in TF32, 2^-11 -- 1.5-1.9 x the dense
+// fp32 GEMM where the exact form is 0.86 x; same 2:4 mask bit for bit); 0 = the exact fp32 forms (dense fp32 MFMA work on the selected
+// operand).  Shapes the split form does not take (k % 64 != 0 with n > 128, n % 8 != 0) run the exact form whatever the setting.
 struct spmma_options_t {
 #ifdef SPARSIFYME_SPMMA_STAGED
   bool staged = true;
@@ -169,7 +174,7 @@ struct spmma_options_t {
 #ifdef SPARSIFYME_F32_PLANES
   int f32_planes = SPARSIFYME_F32_PLANES;
 #else
-  int f32_planes = 0;
+  int f32_planes = 3;
 #endif
 };
 inline spmma_options_t& spmma_options() {

@@ -60,3 +60,4 @@ inline std::vector<mat_sz> read_shapes(std::string filename) {
 
 #include <sparsify.me/util/timer.hxx>
 #include <sparsify.me/util/launch.hxx>
+#include <sparsify.me/util/alias.hxx>  // namespace sparsify = sparsifyme, only with -DSPARSIFYME_NAMESPACE_ALIAS

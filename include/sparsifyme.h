@@ -187,11 +187,18 @@ int sm_spmma_fused_bf16_grouped(size_t count, const void* const* A, const void* 
  * means a fix-up wait gave up after ~0.3 s and the result is invalid -- it cannot happen with a zeroed flag page and one call at a time per workspace).  Calls that may run concurrently
  * (different streams) need a workspace each; the grouped form's launches share one.  Nothing is allocated or synchronised inside. */
 int sm_spmma_fused_workspace_size(size_t* bytes);
+/* State of a workspace's flag page after the stream has drained (blocks on `stream`; a 4 KiB read-back -- outside timed regions):
+ * *state = 0 clean; 1 a fix-up timed out (word 1023 set: that launch's C is invalid and a late flag may still be raised); 2 flags raised
+ * without a recorded timeout (a launch still running, or a page that was never zeroed).  After 1 or 2: zero the first 4096 bytes
+ * (hipMemsetAsync) before the next call on this workspace -- a dirty page makes the next launch add a stale partial, silently. */
+int sm_spmma_fused_workspace_state(const void* workspace, int* state, sm_stream_t stream);
 /* What the workspace entry points do with `problems` same-shape problems of `rows` x n x k (rows = m * batch when the batches share B
  * and are stacked): *takes = 1 when they run the stream-K form, and the decomposition in plan[0 .. 24]: tg, wg, groups_full, tgl,
  * wgl, slots, longest slot range (stage units), cut[0 .. 8], cutl[0 .. 8] -- row panels (256 rows of a problem, in problem order) x
  * k / 64 stage units, groups of tg panels cut into wg slot ranges at cut[] (the last group: tgl panels, wgl slots, cutl[]); a tile
- * that lies inside one slot range is bit-identical to the no-workspace result.  For tests, bench.py and schedulers; no device work. */
+ * that lies inside one slot range is bit-identical to the no-workspace result.  For tests, bench.py and schedulers; no device work.
+ * Answered for beta == 0 and a 16-byte aligned C with strideC % 8 == 0 (what the dispatch's A-stationary exception for n > 256,
+ * k <= 512 requires): with another beta / C alignment those shapes may run stream-K although *takes = 0 here.  plan: >= 25 unsigned. */
 int sm_spmma_fused_streamk_plan(size_t rows, size_t n, size_t k, size_t problems, int* takes, unsigned* plan);
 /* The dense entry points with the same workspace: the dense twin of the stream-K form (the dense GEMM the 2:4 path is measured
  * against gets the tile economy the 2:4 path gets); same workspace contract, same bit-identity statement for uncut tiles. */

@@ -124,6 +124,7 @@ for _name in ("sm_prune24", "sm_prune24_check", "sm_compress24", "sm_decompress2
 _SIGS["sm_spmma_fused_f32_split_prepare"] = [_c_ptr, _c_size, _c_size, _c_size, _c_size, _c_i, _c_ptr, _c_size, _c_ptr]
 _SIGS["sm_spmma_fused_f32_split_prepared"] = [_c_ptr, _c_ptr, _c_ptr] + [_c_size] * 8 + [_c_i, _c_size, _c_f, _c_f, _c_ptr]
 _SIGS["sm_spmma_fused_workspace_size"] = [ctypes.POINTER(_c_size)]
+_SIGS["sm_spmma_fused_workspace_state"] = [_c_ptr, ctypes.POINTER(_c_i), _c_ptr]
 _SIGS["sm_spmma_fused_streamk_plan"] = [_c_size, _c_size, _c_size, _c_size, ctypes.POINTER(_c_i), ctypes.POINTER(ctypes.c_uint)]
 _SIGS["sm_gemm_rowmajor_f16_ws"] = [_c_ptr, _c_ptr, _c_ptr] + [_c_size] * 8 + [_c_f, _c_f, _c_ptr, _c_size, _c_ptr]
 _SIGS["sm_gemm_rowmajor_bf16_ws"] = _SIGS["sm_gemm_rowmajor_f16_ws"]
@@ -364,7 +365,7 @@ def spmma_fused_streamk_plan(rows, n, k, problems=1):
     """(takes, plan): whether the workspace entry points run the stream-K form on `problems` problems of rows x n x k, and its
     decomposition as a dict (tg, wg, groups_full, tgl, wgl, slots, units, cut, cutl) -- sm_spmma_fused_streamk_plan."""
     takes = _c_i(0)
-    buf = (ctypes.c_uint * 32)()
+    buf = (ctypes.c_uint * 32)()   # the entry point writes plan[0 .. 24] (include/sparsifyme.h: >= 25 unsigned)
     _check(lib().sm_spmma_fused_streamk_plan(rows, n, k, problems, ctypes.byref(takes), buf), "sm_spmma_fused_streamk_plan")
     v = list(buf)
     return bool(takes.value), dict(tg=v[0], wg=v[1], groups_full=v[2], tgl=v[3], wgl=v[4], slots=v[5], units=v[6], cut=v[7:16], cutl=v[16:25])
@@ -378,6 +379,14 @@ def streamk_whole_panels(plan, panels, nkt):
     base = plan["groups_full"] * plan["tg"] * nkt
     cuts.update(base + c for c in plan["cutl"][:plan["wgl"] + 1])
     return [t for t in range(panels) if not any(t * nkt < u < (t + 1) * nkt for u in cuts)]
+
+
+def spmma_fused_workspace_state(ws):
+    """0 = the workspace's flag page is clean; 1 = a stream-K fix-up timed out (that launch's C is invalid); 2 = flags raised without a recorded
+    timeout.  Blocks on the current stream (sm_spmma_fused_workspace_state); after 1 / 2 zero the first 4096 bytes before the next call."""
+    st = _c_i(-1)
+    _check(lib().sm_spmma_fused_workspace_state(_dev(ws), ctypes.byref(st), _stream()), "sm_spmma_fused_workspace_state")
+    return st.value
 
 
 def spmma_fused_workspace():

@@ -377,9 +377,11 @@ extern "C" int sm_conv_spmma_fused_bf16(const void* X, const void* B, void* C, s
 static bool conv_prefers_blob(size_t out_h, size_t out_w, size_t K) { return out_h * out_w <= 256 && K >= 2048; }
 static bool conv_implicit_takes_geometry(size_t N, size_t Cin, size_t H, size_t W, size_t kh, size_t kw, size_t stride, size_t pad, size_t dil) {
   ConvArgs a = {};
-  // (the 128-column tile's LDS: n_out is not known to the query)
-  return (W % 8 == 0 && conv_geometry_plan(N, Cin, H, W, kh, kw, stride, pad, dil, true, 128, a) == nullptr) ||
-         conv_geometry_plan(N, Cin, H, W, kh, kw, stride, pad, dil, false, 128, a) == nullptr;
+  // (the 128-column tile's LDS: n_out is not known to the query.)  The 4-byte plan only: the 16-byte plan also needs a
+  // 16-byte aligned X, which the query cannot see -- a geometry ONLY that plan takes (W % 8 == 0 with W + border > 128 halves, e.g. W = 224)
+  // would otherwise get "no workspace needed" and then NOT_SUPPORTED for a 4-byte aligned X with nothing to fall back on.  Such a
+  // geometry is sized for the blob; sm_conv_spmma_* still runs the implicit kernel on it when X turns out 16-byte aligned.
+  return conv_geometry_plan(N, Cin, H, W, kh, kw, stride, pad, dil, false, 128, a) == nullptr;
 }
 
 extern "C" int sm_conv_spmma_workspace(size_t N, size_t Cin, size_t H, size_t W, size_t kh, size_t kw, size_t stride, size_t pad, size_t dilation,

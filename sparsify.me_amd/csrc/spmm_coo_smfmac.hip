@@ -510,6 +510,15 @@ __global__ __launch_bounds__(512, 2) void spmm_coo_smfmac_pc_kernel(const CooSmA
       if (s + 1 < nst) stage(s + 1, c1{}, c0{});
       if (s + 2 < nst) stage(s + 2, c2{}, c1{});
     }
+    //  the last two stages issued their clamped look-ahead loads (up to 14, into ah / al / am / rent) and nothing above waits
+    // for them: the compiler does not see hand-issued loads, considers those registers dead and may hand them to the epilogue's temporaries,
+    // and the workgroup barrier below carries no vmcnt wait.  Drain them here -- the registers are named as read-write operands so that none
+    // is reused before the wait -- exactly as the producers do before their epilogue.
+    asm volatile("s_waitcnt vmcnt(0)"
+                 : "+v"(ah[0][0]), "+v"(ah[0][1]), "+v"(ah[1][0]), "+v"(ah[1][1]), "+v"(ah[2][0]), "+v"(ah[2][1]), "+v"(al[0][0]), "+v"(al[0][1]), "+v"(al[1][0]),
+                   "+v"(al[1][1]), "+v"(al[2][0]), "+v"(al[2][1])
+                 :: "memory");
+    asm volatile("" : "+v"(am[0][0]), "+v"(am[0][1]), "+v"(am[1][0]), "+v"(am[1][1]), "+v"(am[2][0]), "+v"(am[2][1]), "+v"(rent[0]), "+v"(rent[1]), "+v"(rent[2]));
   }
   __syncthreads();
   if (wg_bad) {  // an element of B this tile read does not convert under the call's scale: the tile is not stored

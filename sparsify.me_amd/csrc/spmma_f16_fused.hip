@@ -1931,8 +1931,12 @@ static int spmma_fused16(size_t ngroup, const void* const* Ag, const void* const
     const bool astat_shape = n > 256 && k <= 512 && beta == 0.0f && aligned16(C) && (strideC % 8 == 0);
     SkPlan pl;
     if (sk_takes((size_t)a.Mrows, (size_t)a.batch * a.ngroup, n, k, astat_shape, pl) &&
-        workspace_bytes >= sk_workspace_bytes((size_t)pl.slots * ((n + 255) / 256), 256) && aligned16(workspace))
-      return n <= 256 ? launch_fused_sk<256, BF, true>(a, workspace, workspace_bytes, st) : launch_fused_sk<256, BF, false>(a, workspace, workspace_bytes, st);
+        workspace_bytes >= sk_workspace_bytes((size_t)pl.slots * ((n + 255) / 256), 256) && aligned16(workspace)) {
+      //  the stream-K launcher's own limits (32-bit tile offsets, panel and workgroup counts) are "not taken", not a failure
+      // of the call: a _ws call must succeed wherever the same call without a workspace does -- fall through to the forms below
+      const int rc = n <= 256 ? launch_fused_sk<256, BF, true>(a, workspace, workspace_bytes, st) : launch_fused_sk<256, BF, false>(a, workspace, workspace_bytes, st);
+      if (rc != SM_STATUS_NOT_SUPPORTED) return rc;
+    }
   }
   if (big_rule == 8 && !wide_env && n > 128 && k > 64) {
     const size_t cus = (size_t)device_cu_count(), nb = (size_t)a.batch * a.ngroup;
@@ -2029,6 +2033,28 @@ extern "C" int sm_spmma_fused_workspace_size(size_t* bytes) {
   *bytes = sk_workspace_bytes((size_t)device_cu_count(), 256);
   return SM_STATUS_SUCCESS;
 }
+// State of a stream-K workspace's flag page: 0 = clean (all flags zero: ready for the next launch), 1 = a fix-up timed
+// out (word 1023 = 0xdead: a tile of that launch was stored WITHOUT a partial, and the late contributor's flag may still be raised),
+// 2 = flags raised but no timeout recorded (a launch is still running, or the page was never zeroed).  Anything but 0 after the
+// stream has drained means: discard that launch's C and zero the page (hipMemsetAsync of its first 4096 bytes) before the next call.
+// Blocks on `stream` (a 4 KiB read-back): call it outside timed regions.
+extern "C" int sm_spmma_fused_workspace_state(const void* workspace, int* state, sm_stream_t stream) {
+  if (!workspace || !state) {
+    set_error("sm_spmma_fused_workspace_state: invalid argument");
+    return SM_STATUS_INVALID_VALUE;
+  }
+  unsigned h[1024];
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemcpyAsync(h, workspace, sizeof(h), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+    return check_launch("sm_spmma_fused_workspace_state");
+  bool dirty = false;
+  for (int i = 0; i < 1023; ++i) dirty = dirty || h[i] != 0u;
+  *state = h[1023] != 0u ? 1 : (dirty ? 2 : 0);
+  return SM_STATUS_SUCCESS;
+}
+// The rule's answer for a launch with beta == 0 and a 16-byte aligned, 8-element-strided C -- what the A-stationary exception of the
+// dispatch (spmma_fused16: astat_shape) also asks for; with another beta / C alignment the n > 256, k <= 512 shapes are NOT A-stationary
+// shapes and the _ws call may run stream-K where this query says no (state the assumption).
 extern "C" int sm_spmma_fused_streamk_plan(size_t rows, size_t n, size_t k, size_t problems, int* takes, unsigned* plan) {
   if (!takes || !plan) {
     set_error("sm_spmma_fused_streamk_plan: invalid argument");

@@ -984,7 +984,7 @@ SPLIT_TOL = {3: 2.0 ** -21, 2: 2.0 ** -13}  # sm_spmma_fused_f32_split: |error| 
 @pytest.mark.parametrize("planes", [3, 2])
 @pytest.mark.parametrize("ab", [(1.0, 0.0), (0.5, -2.0)])
 @pytest.mark.parametrize("kind", ["uniform", "ties"])
-def test_spmma_f32_split(gpu, shape, planes, ab, kind):
+def test_spmma_f32_split(gpu, orc, shape, planes, ab, kind):
     """sm_spmma_fused_f32_split -- the fp32 2:4 product on v_smfmac_f32_16x16x64_bf16 through exact bfloat16 splits.  On small-integer
     data every piece product is exact, so C must EQUAL the exact fp32 kernel's bit for bit (same mask, ties included); on U(-1, 1)
     data the error against the fp64 product of the STRIP-pruned operand stays inside SPLIT_TOL * sum|a||b| + the fp32 accumulation
@@ -1007,12 +1007,24 @@ def test_spmma_f32_split(gpu, shape, planes, ab, kind):
         gpu.spmma_fused(dA, dB, Ce, m, n, k, batch=batch, alpha=alpha, beta=beta)
     else:   # ragged k (the span form): the exact fused kernel does not take it; the dense fp32 kernel on the pruned operand is the same product
         gpu.gemm_rowmajor(P, dB, Ce, m, n, k, batch=batch, alpha=alpha, beta=beta)
+    #  mask and reference from the ORACLE, not from the HIP prune: the oracle's STRIP-pruned operand must be what the
+    # HIP prune wrote (bit for bit) and is what the fp64 reference below multiplies; the oracle's own product (compress -> sm_spmma_f32_ref, fp64
+    # accumulation, rounded to fp32) is held against the split form at north_star's tolerance as well
+    Po = orc.prune24(A.view(np.uint32), batch * m, k, k, orc.STRIP)
+    assert np.array_equal(host(P).view(np.uint32), Po), "HIP STRIP prune differs from the oracle's"
     if kind == "ties" and beta == 0.0:
         assert torch.equal(Cs.view(torch.int32), Ce.view(torch.int32)), "exact data: the split form must equal the fp32 kernel bit for bit"
+        Co = np.zeros(batch * m * n, dtype=np.float32)
+        orc.spmma(orc.compress24(Po, m, k, k, batch), B, Co, m, n, k, batch, 0, alpha=alpha, beta=0.0)
+        assert np.array_equal(host(Cs), Co), "exact data: the split form must equal the oracle's product"
         return
-    P64 = host(P).astype(np.float64).reshape(batch * m, k)
+    P64 = Po.view(np.float32).astype(np.float64).reshape(batch * m, k)
     B64 = B.astype(np.float64).reshape(k, n)
     ref = alpha * (P64 @ B64).reshape(-1) + beta * C0.astype(np.float64)
+    Co = C0.copy()
+    orc.spmma(orc.compress24(Po, m, k, k, batch), B, Co, m, n, k, batch, 0, alpha=alpha, beta=beta)
+    sc_ = abs(alpha) * (np.abs(P64) @ np.abs(B64)).reshape(-1) + abs(beta) * np.abs(C0.astype(np.float64))
+    assert not (np.abs(host(Cs).astype(np.float64) - Co.astype(np.float64)) > FP32_TOL * np.maximum(sc_, 1e-30)).any(), "split form vs orc.spmma outside 1e-3"
     scale = abs(alpha) * (np.abs(P64) @ np.abs(B64)).reshape(-1) + abs(beta) * np.abs(C0.astype(np.float64))
     err = np.abs(host(Cs).astype(np.float64) - ref)
     bound = (SPLIT_TOL[planes] + 2.0 * k * 2.0 ** -24) * scale + 2.0 ** -22 * np.abs(ref) + 1e-30
@@ -1025,7 +1037,7 @@ def test_spmma_f32_split(gpu, shape, planes, ab, kind):
                                    (300, 64, 147, 2), (130, 72, 100, 1)], ids=lambda s_: "x".join(map(str, s_)))
 @pytest.mark.parametrize("planes", [3, 2])
 @pytest.mark.parametrize("kind", ["uniform", "ties"])
-def test_gemm_f32_split_dense(gpu, shape, planes, kind):
+def test_gemm_f32_split_dense(gpu, orc, shape, planes, kind):
     """sm_gemm_rowmajor_f32_split: the dense product by the same bfloat16 pieces (v_mfma_f32_16x16x32_bf16).  Exact data: equal to
     sm_gemm_rowmajor_f32 bit for bit; U(-1, 1): inside SPLIT_TOL * sum|a||b| + the fp32 accumulation bound of the fp64 product."""
     import torch
@@ -1038,9 +1050,15 @@ def test_gemm_f32_split_dense(gpu, shape, planes, kind):
     Ce = torch.zeros(batch * m * n, dtype=torch.float32, device="cuda")
     gpu.spmma_fused_f32_split(dA, dB, Cs, m, n, k, ws, batch=batch, planes=planes, dense=True)
     gpu.gemm_rowmajor(dA, dB, Ce, m, n, k, batch=batch)
+    #  ... and against the ORACLE's dense product (sm_cpu_gemm-free: orc.gemm_rowmajor, fp64 accumulation)
+    Co = np.zeros(batch * m * n, dtype=np.float32)
+    orc.gemm_rowmajor(A, B, Co, m, n, k, batch=batch)
     if kind == "ties":
         assert torch.equal(Cs.view(torch.int32), Ce.view(torch.int32))
+        assert np.array_equal(host(Cs), Co), "exact data: the dense split form must equal the oracle's product"
         return
+    sc_ = (np.abs(A.astype(np.float64)).reshape(batch * m, k) @ np.abs(B.astype(np.float64)).reshape(k, n)).reshape(-1)
+    assert not (np.abs(host(Cs).astype(np.float64) - Co.astype(np.float64)) > FP32_TOL * np.maximum(sc_, 1e-30)).any(), "dense split form vs oracle outside 1e-3"
     A64, B64 = A.astype(np.float64).reshape(batch * m, k), B.astype(np.float64).reshape(k, n)
     ref, scale = (A64 @ B64).reshape(-1), (np.abs(A64) @ np.abs(B64)).reshape(-1)
     err = np.abs(host(Cs).astype(np.float64) - ref)
@@ -1401,7 +1419,21 @@ def test_full_size_properties_resnet18_f32(gpu, orc, shape):
     Cdref = np.zeros(rows * n, dtype=np.float32)
     orc.gemm_rowmajor(host(P[b * m * k: b * m * k + rows * k]), Bh, Cdref, rows, n, k)
     check_close(host(Cd[b * m * n: b * m * n + rows * n]), Cdref, scale, FP32_TOL, f"resnet18 f32 gemm_rm sampled {shape}", k, "f32")
-    del C, Cd, P, blob
+    # (round 6) the DEFAULT fp32 path since this round -- the split form, planes = 3 (spmma_options().f32_planes, bench.py --dtype f32) -- at
+    # full size: everywhere within 2^-21 sum|ab| + the accumulation bound of the exact kernel's C, and the sampled rows against the ORACLE
+    # (its compress -> sm_spmma_f32_ref product: fp64 accumulation) inside SPLIT_TOL[3] * sum|ab| + the fp32 accumulation bound
+    ws = torch.empty(max(16, gpu.spmma_fused_f32_split_workspace(n, k, planes=3)), dtype=torch.uint8, device="cuda")
+    Cs = torch.full_like(C, -5.0)
+    assert gpu.spmma_fused_f32_split(dA, dB, Cs, m, n, k, ws, batch=batch, planes=3, check=False) == 0, "the split form must take every ResNet-18 layer"
+    worst = ((Cs - C).abs() / Cd.clamp_min(1e-30)).max().item()
+    assert worst <= SPLIT_TOL[3] + 4 * k * 2.0 ** -24, f"split (planes 3) vs exact: {worst:.3e} relative to sum|ab|"
+    got = host(Cs[b * m * n: b * m * n + rows * n]).astype(np.float64)
+    P64 = orc.decompress24(ob, rows, k, k, np.uint32).view(np.float32).astype(np.float64).reshape(rows, k)
+    ref64 = (P64 @ Bh.astype(np.float64).reshape(k, n)).reshape(-1)
+    bound = (SPLIT_TOL[3] + 2.0 * k * 2.0 ** -24) * scale + 2.0 ** -22 * np.abs(ref64) + 1e-30
+    assert float((np.abs(got - ref64) / bound).max()) <= 1.0, "split (planes 3) sampled rows vs the oracle's operand in fp64"
+    assert not (np.abs(got - Cref.astype(np.float64)) > FP32_TOL * np.maximum(scale, 1e-30)).any(), "split (planes 3) vs orc.spmma outside north_star's 1e-3"
+    del C, Cd, P, blob, Cs, ws
     # the reference's own layout (gemm.hxx:80-81, examples/gemm.cu:60-90): column-major, pointer arrays, shared B
     Ccm = torch.full((batch * m * n,), -3.0, dtype=torch.float32, device="cuda")
     ptrs = lambda base, stride, cnt: torch.tensor([base.data_ptr() + 4 * stride * i for i in range(cnt)], dtype=torch.int64, device="cuda")
@@ -2032,11 +2064,25 @@ def test_values_through_the_cpp_headers_vs_oracle(gpu):
         out = subprocess.run([exe, tab], capture_output=True, text=True, timeout=600)
         assert out.returncode == 0, out.stdout[-4000:] + out.stderr[-2000:]
         assert "MISMATCH" not in out.stdout and "Incorrect pruning" not in out.stderr
-        assert out.stdout.count(" ok") >= 3 * (3 + 1 + 1 + 1 + 4 + 12) + 2 + 4   # (T,N) gemm only where m >= k (the reference's lda = m); spmma<float> also with f32_planes = 3 / 2; spmma_f32_planes_t on the two k % 64 == 0 rows
+        assert out.stdout.count(" ok") >= 3 * (3 + 1 + 1 + 1 + 4 + 4 + 12) + 2 + 4   # (T,N) gemm only where m >= k (the reference's lda = m); spmma<float> also with f32_planes = 3 / 2; spmma_f32_planes_t on the two k % 64 == 0 rows
         assert out.stdout.count("spmma_f32_planes_t") == 4
         sw = subprocess.run([exe, tab, "--swap"], capture_output=True, text=True, timeout=600)
         assert sw.returncode == 0, sw.stdout[-4000:] + sw.stderr[-2000:]
         assert sw.stdout.count("rotated pointer table detected") >= 3 * 2 + 2 and "did not notice" not in sw.stdout
+
+
+def test_sparsify_namespace_alias_through_the_headers(gpu):
+    """The `sparsify::` spelling BASELINE's north_star uses (sparsify::sparsify / spmma / spmm / gemm): opt-in through
+    -DSPARSIFYME_NAMESPACE_ALIAS (include/sparsify.me/util/alias.hxx; SURVEY.md 8(b): a global alias next to the drivers' `using namespace
+    sparsifyme;` would make `sparsify<2,2>(...)` ambiguous).  tests/cpp/alias_parity reaches every operator through the alias and holds
+    its values against the oracle; spmma() must return three non-zero stage times (the default since round 6)."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run(["make", "-C", os.path.join(root, "tests", "cpp")], check=True, capture_output=True)
+    out = subprocess.run([os.path.join(root, "tests", "cpp", "bin", "alias_parity")], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert "MISMATCH" not in out.stdout and out.stdout.count(": ok") == 6 and "6 checks, 0 failed" in out.stdout
 
 
 # ---------------------------------------------------------------------------------------------
@@ -2232,9 +2278,11 @@ def test_fused_streamk_vs_oracle(gpu, orc, shape, bf, ab):
     torch.cuda.synchronize()
     assert _sk_ran(ws), "the shape was meant to take the stream-K kernel"
     assert bool((ws[:4096] == 0).all().item()), "flags not handed back as zero"
+    assert gpu.spmma_fused_workspace_state(ws) == 0
     C2 = mk(C0.copy())
     gpu.spmma_fused(dA, dB, C2, m, n, k, batch=batch, alpha=alpha, beta=beta, workspace=ws)
     assert torch.equal(C1.view(torch.int16), C2.view(torch.int16)), "stream-K result differs between two runs"
+    assert gpu.spmma_fused_workspace_state(ws) == 0
     ob = orc.compress24(A, m, k, k, batch)
     Cref = C0.copy()
     kw = dict(alpha=alpha, beta=beta)
@@ -2248,6 +2296,43 @@ def test_fused_streamk_vs_oracle(gpu, orc, shape, bf, ab):
         P = np.abs(orc.decompress24(ob, m, k, k, np.uint16, batch=batch).view(np.float16).astype(np.float64)).reshape(batch * m, k)
         scale = abs(alpha) * (P @ np.abs(Bm.view(np.float16).astype(np.float64)).reshape(k, n)).reshape(-1) + abs(beta) * np.abs(C0.view(np.float16).astype(np.float64))
         check_close(host(C1), Cref.view(np.float16), scale, FP16_TOL, f"stream-K {shape}", k)
+
+
+def test_fused_workspace_state_reports_a_dirty_flag_page(gpu):
+    """sm_spmma_fused_workspace_state: 0 for a clean page, 1 when the timeout word (1023) is set, 2 for raised flags without
+    it -- what a caller (and bench.py, after its timed loop) asks before trusting a stream-K launch's C or reusing the workspace."""
+    import torch
+    ws = gpu.spmma_fused_workspace()
+    assert gpu.spmma_fused_workspace_state(ws) == 0
+    flags = ws[:4096].view(torch.int32)
+    flags[17] = 1
+    assert gpu.spmma_fused_workspace_state(ws) == 2
+    flags[1023] = 0xdead
+    assert gpu.spmma_fused_workspace_state(ws) == 1
+    flags.zero_()
+    assert gpu.spmma_fused_workspace_state(ws) == 0
+
+
+def test_conv_spmma_workspace_covers_w224_with_a_4_byte_aligned_x(gpu):
+    """a geometry only the 16-byte patch plan takes (W % 8 == 0, W + border > 128 halves: W = 224) with an X that is only
+    4-byte aligned -- the workspace query must size the blob for it, and sm_conv_spmma_* must then run (the pair) instead of returning
+    NOT_SUPPORTED; the result equals the aligned call's bit for bit."""
+    import torch
+    N, Cin, H, W, n_out = 1, 8, 16, 224, 64
+    need = gpu.conv_spmma_workspace(N, Cin, H, W, 3, 3, 1, 1, 1)
+    assert need > 0
+    Xbuf = torch.empty(N * Cin * H * W + 8, dtype=torch.float16, device="cuda")
+    gpu.fill_uniform(Xbuf, 0x224, -1.0, 1.0)
+    X4 = Xbuf[2:2 + N * Cin * H * W]          # 4-byte aligned, not 16
+    X16 = X4.clone()
+    B = torch.empty(Cin * 9 * n_out, dtype=torch.float16, device="cuda")
+    gpu.fill_uniform(B, 0x225, -1.0, 1.0)
+    ws = torch.empty(need, dtype=torch.uint8, device="cuda")
+    C4 = torch.empty(N * H * W * n_out, dtype=torch.float16, device="cuda")
+    C16 = torch.empty_like(C4)
+    gpu.conv_spmma(X4, B, C4, N, Cin, H, W, 3, 3, 1, 1, 1, n_out, workspace=ws)
+    gpu.conv_spmma(X16, B, C16, N, Cin, H, W, 3, 3, 1, 1, 1, n_out, workspace=ws)
+    assert torch.equal(C4.view(torch.int16), C16.view(torch.int16))
 
 
 @pytest.mark.parametrize("case", [(196, 512, 4608, 32, 3), (196, 512, 4608, 32, 1), (784, 256, 4608, 32, 3)], ids=lambda c: "x".join(map(str, c)))

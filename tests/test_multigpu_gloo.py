@@ -124,3 +124,50 @@ def test_plans_cover_every_layer_batch_unit_exactly_once():
     assert [u[0][1:] for u in w] == [(0, 32), (32, 64), (64, 96), (96, 128)]
     # seeds depend on (layer, global batch index) only
     assert mg.unit_seed(5, 3, 7) == mg.unit_seed(5, 3, 7) != mg.unit_seed(5, 3, 8) != mg.unit_seed(5, 4, 7)
+
+
+def test_hybrid_plan_balance_survives_perturbed_costs():
+    """the hybrid plan built from ANOTHER cost table -- every shape's time off by up to +-20 %, as another box's
+    measurements would be -- stays balanced: max / mean of the ranks' modelled times <= 1.08 at 2, 4 and 8 ranks, over 100 seeded
+    perturbations of the fallback table; every plan still covers every (layer, batch index) exactly once.  (The same perturbed costs
+    evaluated on the UNperturbed plan -- i.e. planning with another box's numbers -- reach 1.16 at 8 ranks: why bench.py measures the
+    costs on the box it runs on and records them in its N = 1 line.)"""
+    import random
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as ge
+    mg = ge.load_package_module("multigpu")
+    shapes = _tables(["resnet50"])
+    rng = random.Random(20260605)
+    worst = {2: 0.0, 4: 0.0, 8: 0.0}
+    try:
+        for trial in range(100):
+            mg.set_measured_costs({k: (v * rng.uniform(0.8, 1.2), 32) for k, v in mg.MEASURED_US_B32.items()})
+            for w in worst:
+                loads = mg.plan_loads(shapes, w, "hybrid")
+                worst[w] = max(worst[w], max(loads) / (sum(loads) / w))
+                if trial % 25 == 0:
+                    seen = {}
+                    for r in range(w):
+                        for l, lo, hi in mg.plan_units(shapes, w, r, "hybrid"):
+                            for bi in range(lo, hi):
+                                assert (l, bi) not in seen
+                                seen[(l, bi)] = r
+                    assert len(seen) == sum(b for _, _, _, b in shapes)
+    finally:
+        mg.set_measured_costs(None)
+    assert worst[2] <= 1.08 and worst[4] <= 1.08 and worst[8] <= 1.08, worst
+
+
+def test_measured_costs_at_a_rank_share_are_used_as_measured():
+    """set_measured_costs with a shape's time at two batch sizes (the full b and a rank's share): layer_cost returns the measured value
+    at each, and scales from the nearest one elsewhere -- a batch slice of a layer does not cost b_share / b of the whole layer."""
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as ge
+    mg = ge.load_package_module("multigpu")
+    try:
+        mg.set_measured_costs({(12544, 64, 576): (90.0, 32, 14.0, 4)})
+        assert mg.layer_cost(12544, 64, 576, 32) == 90.0 and mg.layer_cost(12544, 64, 576, 4) == 14.0
+        assert mg.layer_cost(12544, 64, 576, 8) == 28.0        # nearest measured batch (4), scaled
+        assert mg.layer_cost(12544, 64, 576, 24) == 67.5       # nearest measured batch (32), scaled
+    finally:
+        mg.set_measured_costs(None)

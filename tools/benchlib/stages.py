@@ -161,6 +161,15 @@ def extras(args, sm, torch, dev, layers, flops, t_full, Forked, make_runner, tim
                            "accumulation; mask = the exact path's) + split_planes_kernel (B's pieces, once per call, into a workspace)"}
         for L in layers:
             L["ws"] = torch.empty(max(16, sm.spmma_fused_f32_split_workspace(L["n"], L["k"], planes=3)), dtype=torch.uint8, device=dev)
+        # the exact fp32 form (the headline until round 5; --f32-planes 0), timed here when the step itself runs the split form
+        def layer_exact(L):
+            (sm.spmma_fused(L["A"], L["B"], L["C"], L["m"], L["n"], L["k"], batch=L["b"]) if use_fused(L) else
+             (sm.compress24(L["A"], L["m"], L["k"], L["k"], L["b"], L["m"] * L["k"], L["blob"]),
+              sm.spmma(L["blob"], L["B"], L["C"], L["m"], L["n"], L["k"], L["b"], 0)))
+        t_exact = sec_per_call(Forked(layer_exact)) if any(L.get("split") for L in layers) else t_full
+        split["exact_fused_ms"] = t_exact * 1e3
+        split["exact_fused_speedup_vs_dense_rowmajor"] = t_drm / t_exact
+        split["timed_path_speedup_vs_dense_rowmajor"] = t_drm / t_full
         for planes in (3, 2):
             def layer_split(L, planes=planes):
                 if sm.spmma_fused_f32_split(L["A"], L["B"], L["C"], L["m"], L["n"], L["k"], L["ws"], batch=L["b"], planes=planes, check=False) != 0:
@@ -172,7 +181,7 @@ def extras(args, sm, torch, dev, layers, flops, t_full, Forked, make_runner, tim
             split[key + "_ms"] = t_sp * 1e3
             split[key + "_gfs"] = gfs(t_sp)
             split[key + "_speedup_vs_dense_rowmajor"] = t_drm / t_sp
-            split[key + "_speedup_vs_exact_fused"] = t_full / t_sp
+            split[key + "_speedup_vs_exact_fused"] = t_exact / t_sp
             split[key + "_hbm_frac"] = sum(L["b"] * 4 * (L["m"] * L["k"] + L["m"] * L["n"]) + 4 * L["k"] * L["n"] for L in layers) / t_sp / (HBM_PEAK_GBS * 1e9)
         # B's planes kept across calls (round 5: sm_spmma_fused_f32_split_prepare once, untimed -- B is the layer's weights in the reference's
         # use -- then sm_spmma_fused_f32_split_prepared per step): the same C bit for bit, without the per-call pass over B
@@ -229,8 +238,6 @@ def extras(args, sm, torch, dev, layers, flops, t_full, Forked, make_runner, tim
                 split["planes%d_max_rel_diff_vs_exact" % planes] = d / max(Ce.double().abs().max().item(), 1e-30)
             split["diff_layer"] = [L["m"], L["n"], L["k"], L["b"]]
             del Ce
-        for L in layers:
-            del L["ws"]
         out["stages"]["f32_split"] = split
 
     if not f32 and os.path.basename(args.tables.split(",")[0] if args.tables else (args.table or "resnet50")).startswith("resnet50"):
@@ -273,8 +280,24 @@ def extras(args, sm, torch, dev, layers, flops, t_full, Forked, make_runner, tim
         fam["compress"] = dict(names=["compress_kernel"], layers=staged,
                                call=lambda L: sm.compress24(L["A"], L["m"], L["k"], L["k"], L["b"], L["m"] * L["k"], L["blob"]),
                                bytes=lambda L: L["b"] * L["m"] * L["k"] * (s + s / 2 + 1 / 8))
-        fam["spmma_f32_fused"] = dict(names=["gemm_f32_dma_kernel"], layers=[L for L in layers if use_fused(L)],
+        fam["spmma_f32_fused"] = dict(names=["gemm_f32_dma_kernel"], layers=[L for L in layers if use_fused(L) and not L.get("split")],
                                       call=lambda L: sm.spmma_fused(L["A"], L["B"], L["C"], L["m"], L["n"], L["k"], batch=L["b"]), bytes=A_fu)
+        # round 6: the split form is the timed path by default (--f32-planes 3): one family per kernel it dispatches to.  Bytes = the dense fp32
+        # A once + C + B (fp32, read by the per-call split pass) + B's planes written and read (planes x 2 bytes per element, each way)
+        pl_ = getattr(args, "f32_planes", 0)
+        A_split = lambda L: A_fu(L) + 2.0 * pl_ * 2 * L["k"] * L["n"]
+
+        def split_kernel_of(L):
+            if L["k"] % 64 != 0:
+                return "span"
+            return "cols" if 128 < L["n"] <= 256 else "tile"
+        for var, kname in (("tile", "spmma_f32_split_kernel"), ("cols", "spmma_f32_split_cols_kernel"), ("span", "spmma_f32_split_span_kernel")):
+            fam["spmma_f32_split_" + var] = dict(names=[kname], layers=[L for L in layers if L.get("split") and split_kernel_of(L) == var],
+                                                 call=lambda L: sm.spmma_fused_f32_split(L["A"], L["B"], L["C"], L["m"], L["n"], L["k"], L["ws"], batch=L["b"], planes=pl_),
+                                                 bytes=A_split)
+        staged = [L for L in staged if not L.get("split")]
+        fam["spmma_f32"]["layers"] = staged
+        fam["compress"]["layers"] = staged
     else:
         staged = [L for L in layers if not use_fused(L)]
         fam["spmma_f16"] = dict(names=["spmma_f16_dma_kernel", "spmma_f16_pc_kernel", "spmma_f16_kernel", "spmma_f16_splitk_kernel"],
@@ -299,7 +322,7 @@ def extras(args, sm, torch, dev, layers, flops, t_full, Forked, make_runner, tim
                                                  call=lambda L: sm.spmma_fused(L["A"], L["B"], L["C"], L["m"], L["n"], L["k"], batch=L["b"]),
                                                  bytes=A_fu)
     traffic_tab, tsrc = {}, None
-    tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")  # tools/pmc_traffic.py, from rocprofv3 --pmc passes
+    tpath = os.path.join(ROOT, "profiles", "traffic_f32_latest.json" if f32 else "traffic_latest.json")  # tools/pmc_traffic.py, from rocprofv3 --pmc passes
     if os.path.exists(tpath):
         try:
             traffic_tab = json.load(open(tpath))
@@ -342,7 +365,20 @@ def extras(args, sm, torch, dev, layers, flops, t_full, Forked, make_runner, tim
     d = gsum[dom]
     fams_out = {n_: {"ms_per_step": r_["seconds"] * 1e3, "launches": r_["launches"], "layers": r_["layers"], "GBs": r_["GBs"], "frac_of_hbm_peak": r_["GBs"] / HBM_PEAK_GBS,
                      "hbm_traffic_per_launch": r_["traffic"]} for n_, r_ in rows.items()}
-    if f32:
+    if f32 and any(n_.startswith("spmma_f32_split") for n_ in rows):
+        # the split form: bound by the HBM stream of the fp32 A (the 6 / 3 sparse bf16 instructions per block are 0.52 / 0.26 ms of matrix
+        # time on ResNet-18 against 0.96 ms of bytes at the peak)
+        domf = max((n_ for n_ in rows if n_.startswith("spmma_f32_split")), key=lambda n_: rows[n_]["seconds"])
+        r_ = rows[domf]
+        step_bytes = sum(rows[n_]["bytes"] for n_ in rows if n_ != "compress")
+        out["roofline"] = {"bound": "hbm", "achieved": r_["GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": r_["GBs"] / HBM_PEAK_GBS, "traffic": r_["traffic"],
+                           "traffic_source": tsrc if (r_["traffic"] is not None or (tsrc and tsrc["stale"])) else None,
+                           "kernel": fam[domf]["names"][0], "launches_per_step": r_["launches"], "avg_launch_us": r_["seconds"] / r_["launches"] * 1e6,
+                           "algorithmic_bytes_per_launch": r_["bytes"] / r_["launches"], "step_frac": step_bytes / t_full / 1e9 / HBM_PEAK_GBS,
+                           "matrix_pipe": {"executed_TFs_dense_equivalent": r_["TFs"] * 2 * getattr(args, "f32_planes", 3), "peak_TFs": 5000.0,
+                                           "note": "planes = 3: six v_smfmac_f32_16x16x64_bf16 per 16 x 16 x 64 block (three at planes = 2)"},
+                           "measured": "single stream, one kernel family at a time, HIP events on the launch stream, hipGraph replay", "families": fams_out}
+    elif f32:
         domf = max((n_ for n_ in rows if n_.startswith("spmma_f32")), key=lambda n_: rows[n_]["seconds"])
         r_ = rows[domf]
         out["roofline"] = {"bound": "mfma", "achieved": r_["TFs"], "peak": F32_MATRIX_PEAK_TFS, "unit": "TFLOP/s",
