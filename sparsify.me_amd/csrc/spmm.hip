@@ -293,6 +293,10 @@ __global__ __launch_bounds__(64 * LDS_WAVES) void spmm_csr_lds_kernel(size_t A_r
       for (int gi = 0; gi < G; ++gi)
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
+          // (round 6: these 32 predicated loads compile to one exec-mask branch each -- 62 s_and_saveexec + s_cbranch per round in the ISA.
+          // Unconditional loads from a clamped index with the value zeroed by a select made the inner loop branch-free (32 loads, 32
+          // ds_read_b128, 32 v_pk_fma_f32) and the kernel 3-5 % SLOWER on all 17 config-5 shapes (gpurun_out r06c vs r06a: 0.321 -> 0.339 ms
+          // on 12544 x 64 x 576): the branches skip the loads of the ragged row tails, which is worth more than the scalar work costs.  Kept.)
           const int i = e0[gi] + base + EL * u + (int)e;
           const bool ok = i < e1[gi];
           ci[gi][u] = ok ? colsidx[i] : 0;
