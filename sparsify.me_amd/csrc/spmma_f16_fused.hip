@@ -1938,6 +1938,12 @@ static int spmma_fused16(size_t ngroup, const void* const* Ag, const void* const
       if (rc != SM_STATUS_NOT_SUPPORTED) return rc;
     }
   }
+#ifdef SM_TUNING
+  // (round 6, the residency experiment VERDICT round 5 asked for -- tuning builds only: SM_FUSED_D256=1) the few-tile shapes on 128 x 256 DIRECT
+  // tiles: four waves, a ring of two 48 KiB stages = 96 KiB, so that a 48-64 KiB direct workgroup of ANOTHER launch fits on the same CU beside
+  // it (the big / wide / A-stationary workgroups hold the whole LDS or 16 waves).  Measured with tools/overlap_probe.py: DESIGN.md 4.2.
+  if (tuning_int("SM_FUSED_D256", 0) && n > 128 && k > 64) return launch_fused_direct<256, 2, BF, 128, 4, false>(a, st);
+#endif
   if (big_rule == 8 && !wide_env && n > 128 && k > 64) {
     const size_t cus = (size_t)device_cu_count(), nb = (size_t)a.batch * a.ngroup;
     const size_t t_big = ((size_t)a.Mrows + 255) / 256 * ((n + 255) / 256) * nb, t_wide = ((size_t)a.Mrows + 127) / 128 * ((n + 255) / 256) * nb;

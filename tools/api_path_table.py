@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Where the time of the API-faithful sequence (sparsifyme::spmma(): TILE prune in place + check + multiply, spmma.hxx:82-113)
+"""(round 6: the `one-kern` column is sm_prune24_spmma_* on EVERY shape -- one kernel for n <= 128, the prune + flag pass followed by the fused kernel
+on the pruned operand elsewhere; no blob in either.)  Where the time of the API-faithful sequence (sparsifyme::spmma(): TILE prune in place + check + multiply, spmma.hxx:82-113)
 goes, per unique shape of a table: the two-launch form (sm_prune24_compress24 + sm_spmma) and the one-kernel form
 (sm_prune24_spmma, where it applies), each launch alone on one stream, hipGraph-timed on resident operands.
 bytes = what the sequence has to move: A read + pruned A written (+ blob written and read back in the two-launch form) + B + C.
