@@ -285,6 +285,86 @@ __global__ __launch_bounds__(256) void prune_tile2_kernel(const T* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------
+// TILE on rows that are NOT whole 16-byte pieces (round 6: k % 8 != 0 or an odd row pitch -- the 7 x 7 x 3 stem layer of every ResNet,
+// k = 147: rows of 294 bytes), 16-bit types, ONE contiguous matrix (ld == k): SPAN form.  prune_tile_kernel above then moves single
+// halves (16 two-byte loads and stores per tile: 2.8 TB/s of traffic where the aligned kernel reaches 4.6).  Here a workgroup owns
+// SPAN_ROWS (a multiple of 8, chosen by the launcher) consecutive rows = ONE contiguous span of 16-byte pieces whatever k is: it comes into LDS by
+// plain 16-byte loads (whole lines), the tiles are evaluated out of LDS with two-byte reads (SPAN_ROWS / 4 tile rows x ceil(k / 4) tiles per span,
+// row tails and the matrix's last rows completed with virtual zeros as the oracle does), the pruned halves are written back INTO the LDS
+// image and the span leaves by 16-byte stores.  In place or out of place (a workgroup owns its rows).  d_valid (may be null): raised when a
+// stored strip holds more than two values != 0 -- derived from what is stored, as the one-pass kernels derive it -- so the API sequence
+// needs no separate check pass on this shape.  The last span may be short and may end off a 16-byte boundary: its tail bytes move as halves.
+// ---------------------------------------------------------------------------------------------
+template <bool BF>
+__global__ __launch_bounds__(256) void prune_tile_span_kernel(const uint16_t* A_in, uint16_t* A_out, size_t m, unsigned k,
+                                                              int* d_valid, const unsigned SPAN_ROWS /* a multiple of 8: the span is whole 16-byte pieces */) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t tspan[];
+  const unsigned tid = threadIdx.x;
+  const size_t r0 = (size_t)blockIdx.x * SPAN_ROWS;
+  const unsigned rows = m - r0 < SPAN_ROWS ? (unsigned)(m - r0) : SPAN_ROWS;
+  const size_t e0 = r0 * k;                       // first element of the span: r0 * k * 2 bytes = a multiple of 64
+  const unsigned elems = rows * k, pieces = elems / 8u, tail0 = pieces * 8u;
+  const u4* src = reinterpret_cast<const u4*>(A_in + e0);
+  for (unsigned i = tid; i < pieces; i += 256u) reinterpret_cast<u4*>(tspan)[i] = __builtin_nontemporal_load(src + i);
+  for (unsigned i = tail0 + tid; i < elems; i += 256u) tspan[i] = A_in[e0 + i];
+  __syncthreads();
+  const unsigned tpr = (k + 3u) / 4u, trows = (rows + 3u) / 4u, tiles = tpr * trows;
+  bool bad = false;
+  for (unsigned t = tid; t < tiles; t += 256u) {
+    const unsigned tr = t / tpr, tc = t - tr * tpr, c0 = 4u * tc;
+    const unsigned ncol = k - c0 < 4u ? k - c0 : 4u, nrow = rows - 4u * tr < 4u ? rows - 4u * tr : 4u;
+    uint16_t v[4][4];
+    float mag[4][4];
+#pragma unroll
+    for (unsigned r = 0; r < 4; ++r)
+#pragma unroll
+      for (unsigned c = 0; c < 4; ++c) {
+        v[r][c] = (r < nrow && c < ncol) ? tspan[(4u * tr + r) * k + c0 + c] : (uint16_t)0;
+        mag[r][c] = mag_sel<BF>(v[r][c]);
+      }
+    const unsigned keep = tile_keepmask(mag);
+#pragma unroll
+    for (unsigned r = 0; r < 4; ++r) {
+      unsigned nz = 0;
+#pragma unroll
+      for (unsigned c = 0; c < 4; ++c) {
+        const bool kept = (keep >> (4u * r + c)) & 1u;
+        if (r < nrow && c < ncol && !kept) tspan[(4u * tr + r) * k + c0 + c] = 0;
+        nz += (kept && (v[r][c] & 0x7fffu) != 0) ? 1u : 0u;
+      }
+      bad |= nz > 2u;
+    }
+  }
+  __syncthreads();
+  u4* dst = reinterpret_cast<u4*>(A_out + e0);
+  for (unsigned i = tid; i < pieces; i += 256u) dst[i] = reinterpret_cast<const u4*>(tspan)[i];
+  for (unsigned i = tail0 + tid; i < elems; i += 256u) A_out[e0 + i] = tspan[i];
+  if (d_valid && __any(bad)) {
+    if ((tid & 63u) == 0) raise_flag(d_valid);
+  }
+}
+
+// the span form's launcher: SM_STATUS_NOT_SUPPORTED when the shape is not its (then the element-wise kernel runs)
+int prune24_tile_span_u16(const void* A_in, void* A_out, size_t m, size_t k, size_t ld, bool bf, int* d_valid, hipStream_t st) {
+  if (ld != k || k == 0 || m == 0 || (size_t)8 * k * 2 > 64 * 1024 || !aligned16(A_in) || !aligned16(A_out) || m * k > ((size_t)1 << 40)) return SM_STATUS_NOT_SUPPORTED;
+  // rows per span: the multiple of 8 (<= 64, span within 64 KiB) whose tile count fills whole rounds of the workgroup's 256 threads best
+  // (k = 147: 37 tiles per tile row -- 32 rows = 296 tiles = two rounds at 58 %; 24 rows = 222 tiles = one round at 87 %)
+  const size_t tpr = (k + 3) / 4;
+  unsigned span_rows = 8;
+  double best = 0.0;
+  for (unsigned r = 8; r <= 64 && (size_t)r * k * 2 <= 64 * 1024; r += 8) {
+    const size_t tiles = (size_t)(r / 4) * tpr;
+    const double util = (double)tiles / (double)(ceil_div(tiles, (size_t)256) * 256);
+    if (util > best + 1e-9) { best = util; span_rows = r; }
+  }
+  const size_t spans = ceil_div(m, (size_t)span_rows), lds = (size_t)span_rows * k * 2;
+  if (spans > 0x7fffffffull) return SM_STATUS_NOT_SUPPORTED;
+  if (bf) prune_tile_span_kernel<true><<<(unsigned)spans, 256, lds, st>>>((const uint16_t*)A_in, (uint16_t*)A_out, m, (unsigned)k, d_valid, span_rows);
+  else prune_tile_span_kernel<false><<<(unsigned)spans, 256, lds, st>>>((const uint16_t*)A_in, (uint16_t*)A_out, m, (unsigned)k, d_valid, span_rows);
+  return check_launch("prune_tile_span_kernel");
+}
+
+// ---------------------------------------------------------------------------------------------
 // (a2) prune check (K4): any strip with more than two non-zeros -> *d_valid |= 1
 // ---------------------------------------------------------------------------------------------
 template <typename T>
@@ -580,6 +660,10 @@ static int launch_prune(const void* A_in, void* A_out, size_t m, size_t k, size_
   if (sizeof(T) == 2 && k % 8 == 0 && vec_ok_2d<T>(A_in, A_out, ld, 0)) {
     prune_tile2_kernel<T, BF><<<stream_grid(ceil_div(m, 4) * (k / 8), 256), 256, 0, st>>>((const T*)A_in, (T*)A_out, m, k, ld);
     return check_launch("prune_tile2_kernel");
+  }
+  if (sizeof(T) == 2) {  // (round 6) ragged rows of one contiguous 16-bit matrix: the span form (no flag wanted here)
+    const int rc = prune24_tile_span_u16(A_in, A_out, m, k, ld, BF, nullptr, st);
+    if (rc != SM_STATUS_NOT_SUPPORTED) return rc;
   }
   prune_tile_kernel<T, BF><<<stream_grid(ceil_div(m, 4) * ceil_div(k, 4), 256), 256, 0, st>>>((const T*)A_in, (T*)A_out, m, k, ld, vec_ok);
   return check_launch("prune_tile_kernel");

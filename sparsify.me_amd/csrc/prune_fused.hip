@@ -356,6 +356,8 @@ extern "C" int sm_prune24_f16(const void*, void*, size_t, size_t, size_t, int, s
 extern "C" int sm_prune24_bf16(const void*, void*, size_t, size_t, size_t, int, sm_stream_t);
 namespace sm {
 int prune_check_accumulate_u16(const void* A, size_t m, size_t k, size_t ld, int* d_valid, hipStream_t st);  // ORs into *d_valid
+// prune.hip (round 6): TILE prune of one contiguous 16-bit matrix with ragged rows through LDS spans, the flag raised in the same pass
+int prune24_tile_span_u16(const void* A_in, void* A_out, size_t m, size_t k, size_t ld, bool bf, int* d_valid, hipStream_t st);
 }
 extern "C" int sm_compress24_f16(const void*, size_t, size_t, size_t, size_t, size_t, void*, sm_stream_t);
 
@@ -380,18 +382,25 @@ static int prune_compress16(const void* A_in, void* A_out, size_t m, size_t k, s
     // the batch as one tall matrix when its matrices are back to back and no TILE can straddle two of them
     const bool tall = batch == 1 || (strideA == m * ld && (alg == SM_PRUNE_STRIP || m % 4 == 0));
     const size_t nbm = tall ? 1 : batch, rows = tall ? m * batch : m;
+    bool flag_done = false;
     if (A_out) {
-      for (size_t b = 0; b < nbm && rc == SM_STATUS_SUCCESS; ++b) {
-        const uint16_t* ai = (const uint16_t*)A_in + b * strideA;
-        uint16_t* ao = (uint16_t*)A_out + b * strideA;
-        rc = BF ? sm_prune24_bf16(ai, ao, rows, k, ld, alg, stream) : sm_prune24_f16(ai, ao, rows, k, ld, alg, stream);
+      // (round 6) TILE on one contiguous matrix with ragged rows (the stem layer, k = 147): the span form prunes AND raises the flag in
+      // one pass -- no separate check pass (the flag is derived from the stored values, as the one-pass kernel derives it)
+      if (alg == SM_PRUNE_TILE && nbm == 1 && prune24_tile_span_u16(A_in, A_out, rows, k, ld, BF, d_valid, st) == SM_STATUS_SUCCESS) {
+        flag_done = true;
+      } else {
+        for (size_t b = 0; b < nbm && rc == SM_STATUS_SUCCESS; ++b) {
+          const uint16_t* ai = (const uint16_t*)A_in + b * strideA;
+          uint16_t* ao = (uint16_t*)A_out + b * strideA;
+          rc = BF ? sm_prune24_bf16(ai, ao, rows, k, ld, alg, stream) : sm_prune24_f16(ai, ao, rows, k, ld, alg, stream);
+        }
       }
       src = A_out;
     } else if (alg == SM_PRUNE_TILE && blob) {
       set_error("%s: TILE + blob without A_out needs k %% 64 == 0 and 16-byte aligned rows", name);
       return SM_STATUS_NOT_SUPPORTED;
     }
-    if (rc == SM_STATUS_SUCCESS && d_valid && A_out) {
+    if (rc == SM_STATUS_SUCCESS && d_valid && A_out && !flag_done) {
       // the flag of every batch matrix is OR-ed into *d_valid (zeroed above)
       for (size_t b = 0; b < nbm && rc == SM_STATUS_SUCCESS; ++b)
         rc = prune_check_accumulate_u16((const uint16_t*)A_out + b * strideA, rows, k, ld, d_valid, st);

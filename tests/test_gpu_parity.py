@@ -84,7 +84,10 @@ def test_sparsify_positional_generic_block_and_unaligned(gpu, orc):
 # (a2) prune STRIP / TILE + check
 # ---------------------------------------------------------------------------------------------
 PRUNE_SHAPES = [(1, 4, 4), (4, 4, 4), (3, 5, 5), (7, 147, 147), (10, 147, 152), (16, 64, 64), (33, 72, 80),
-                (196, 512, 512), (784, 1024, 1024), (130, 260, 264), (5, 3, 3), (257, 8, 8)]
+                (196, 512, 512), (784, 1024, 1024), (130, 260, 264), (5, 3, 3), (257, 8, 8),
+                # round 6: the span form of TILE (16-bit types, ld == k, ragged rows): several 32-row spans, a short last span that ends off a
+                # 16-byte boundary, m % 4 != 0, k % 4 != 0, the widest k whose span still fits (1022) and one beyond it (element-wise kernel)
+                (129, 147, 147), (100, 30, 30), (64, 1022, 1022), (40, 1026, 1026), (3136, 147, 147)]
 
 
 @pytest.mark.parametrize("dtype", [np.float16, np.float32])
@@ -173,7 +176,9 @@ def test_compress24_bit_exact(gpu, orc, dtype, shape, pruned_first):
 PC_SHAPES = [(4, 64, 64, 1, 0), (196, 512, 512, 2, 0), (130, 128, 128, 3, 0), (130, 128, 136, 3, 24), (7, 64, 64, 5, 0),
              (784, 1152, 1152, 1, 0), (33, 576, 576, 2, 0), (257, 64, 72, 1, 0),
              # shapes the one-pass kernel does not take (k % 64 != 0, odd leading dimension): the three-launch sequence
-             (12, 147, 147, 2, 0), (20, 72, 72, 2, 0), (9, 8, 8, 3, 0)]
+             (12, 147, 147, 2, 0), (20, 72, 72, 2, 0), (9, 8, 8, 3, 0),
+             # round 6: ragged rows through the span form of TILE -- one tall matrix (flag raised in the same pass) and m % 4 != 0 (per batch matrix)
+             (196, 147, 147, 3, 0), (130, 147, 147, 2, 0)]
 
 
 @pytest.mark.parametrize("alg", [0, 1], ids=["tile", "strip"])
