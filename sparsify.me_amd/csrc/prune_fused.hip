@@ -32,7 +32,10 @@ struct PruneFusedArgs {
 // k / (8 LPR) passes before it moves to its next group of tile rows (grid-stride over waves).  The next pass's four
 // 16-byte loads are issued before the current pass's selection starts.
 // FLAT: the batch is one tall matrix (contiguous batches and m % 4 == 0, or batch == 1).
-template <bool BF, bool TILE, bool FLAT>
+// BLOB = false (round 6): the prune + flag pass of the no-blob API sequence (sm_prune24_spmma_* for n > 128: vals == null) -- the blob's
+// STRIP re-selection of every pruned strip (8 x 16 vector instructions per item with the TILE rule, ~11 % of the kernel's) and the metadata
+// gathering are compiled out instead of computed and dropped.
+template <bool BF, bool TILE, bool FLAT, bool BLOB = true>
 __global__ __launch_bounds__(256) void prune_compress_kernel(const PruneFusedArgs p) {
   bool bad = false;
   const unsigned lane = threadIdx.x & 63u;
@@ -125,7 +128,8 @@ __global__ __launch_bounds__(256) void prune_compress_kernel(const PruneFusedArg
           // tests/test_gpu_parity.py runs on this kernel's output).
           ok2 &= __builtin_popcount(rm) <= 2 && pr[r] < 6u;
           strip_mask(v[r][2 * t], v[r][2 * t + 1], rm, o[r][2 * t], o[r][2 * t + 1]);
-          strip_select_f16(o[r][2 * t], o[r][2 * t + 1], kp[r][t], nb[r][t]);
+          if constexpr (BLOB) strip_select_f16(o[r][2 * t], o[r][2 * t + 1], kp[r][t], nb[r][t]);
+          else { kp[r][t] = 0; nb[r][t] = 0; }
         }
       }
     } else {
@@ -143,21 +147,26 @@ __global__ __launch_bounds__(256) void prune_compress_kernel(const PruneFusedArg
     const size_t stage = cur.pc >> 3;
     const unsigned q2 = cur.pc & 7u;  // byte of the row's 8 metadata bytes / 8-byte piece of its 64 value bytes
     uint16_t* dst = p.A_out ? p.A_out + cur.aoff : nullptr;
-    uint16_t* vdst = p.vals ? p.vals + (stage * p.M + cur.R0) * 32 + q2 * 4 : nullptr;
-    unsigned char* mdst = p.vals ? p.meta + (stage * p.M + cur.R0) * 8 + q2 : nullptr;
+    uint16_t* vdst = (BLOB && p.vals) ? p.vals + (stage * p.M + cur.R0) * 32 + q2 * 4 : nullptr;
+    unsigned char* mdst = (BLOB && p.vals) ? p.meta + (stage * p.M + cur.R0) * 8 + q2 : nullptr;
 #pragma unroll
     for (unsigned r = 0; r < 4; ++r) {
-      const int mb = (int)(nb[r][0] | (nb[r][1] << 4));
-      // the four metadata bytes of a lane quad (same rows, same stage, consecutive q2) -> one dword
-      const unsigned b0 = (unsigned)__builtin_amdgcn_update_dpp(0, mb, 0x00, 0xf, 0xf, true);
-      const unsigned b1 = (unsigned)__builtin_amdgcn_update_dpp(0, mb, 0x55, 0xf, 0xf, true);
-      const unsigned b2 = (unsigned)__builtin_amdgcn_update_dpp(0, mb, 0xaa, 0xf, 0xf, true);
-      const unsigned b3 = (unsigned)__builtin_amdgcn_update_dpp(0, mb, 0xff, 0xf, 0xf, true);
+      unsigned b0 = 0, b1 = 0, b2 = 0, b3 = 0;
+      if constexpr (BLOB) {
+        const int mb = (int)(nb[r][0] | (nb[r][1] << 4));
+        // the four metadata bytes of a lane quad (same rows, same stage, consecutive q2) -> one dword
+        b0 = (unsigned)__builtin_amdgcn_update_dpp(0, mb, 0x00, 0xf, 0xf, true);
+        b1 = (unsigned)__builtin_amdgcn_update_dpp(0, mb, 0x55, 0xf, 0xf, true);
+        b2 = (unsigned)__builtin_amdgcn_update_dpp(0, mb, 0xaa, 0xf, 0xf, true);
+        b3 = (unsigned)__builtin_amdgcn_update_dpp(0, mb, 0xff, 0xf, 0xf, true);
+      }
       if (r < cur.nrows) {
         if (dst) *reinterpret_cast<u4*>(dst) = u4{o[r][0], o[r][1], o[r][2], o[r][3]};
-        if (vdst) {
-          __builtin_nontemporal_store(u2{kp[r][0], kp[r][1]}, reinterpret_cast<u2*>(vdst + r * 32));
-          if ((lane & 3u) == 0) *reinterpret_cast<unsigned*>(mdst + r * 8) = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+        if constexpr (BLOB) {
+          if (vdst) {
+            __builtin_nontemporal_store(u2{kp[r][0], kp[r][1]}, reinterpret_cast<u2*>(vdst + r * 32));
+            if ((lane & 3u) == 0) *reinterpret_cast<unsigned*>(mdst + r * 8) = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+          }
         }
       }
       if (dst) dst += p.ld;
@@ -436,7 +445,10 @@ static int prune_compress16(const void* A_in, void* A_out, size_t m, size_t k, s
   const size_t cap = (size_t)device_cu_count() * 8;  // 2 blocks per SIMD: the kernel holds ~3 waves per SIMD
   if (blocks > cap) blocks = cap;
   const unsigned grid = (unsigned)(blocks ? blocks : 1);
-  if (alg == SM_PRUNE_TILE) {
+  if (alg == SM_PRUNE_TILE && !blob) {  // the prune + flag pass alone (no blob wanted): the blob's re-selection compiled out
+    if (flat) prune_compress_kernel<BF, true, true, false><<<grid, 256, 0, st>>>(a);
+    else prune_compress_kernel<BF, true, false, false><<<grid, 256, 0, st>>>(a);
+  } else if (alg == SM_PRUNE_TILE) {
     if (flat) prune_compress_kernel<BF, true, true><<<grid, 256, 0, st>>>(a);
     else prune_compress_kernel<BF, true, false><<<grid, 256, 0, st>>>(a);
   } else {
