@@ -520,7 +520,8 @@ def main():
         path_desc += ("; the fused layers run as %d grouped launches (sm_spmma_fused_%s_grouped: one grid per <= 8 same-shape instances, "
                       "same kernels, same C)" % (n_launch_groups, sfx))
     out = {
-        "metric": "effective GF/s (2:4 spmma vs dense gemm) on ResNet-50 layer shapes",
+        "metric": "effective GF/s (2:4 spmma vs dense gemm) on ResNet-50 layer shapes" if "resnet50" in names and not f32 else
+                  "effective GF/s (2:4 spmma vs dense gemm) on the layer shapes of " + names.replace(".csv", ""),
         "value": value, "unit": "GF/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak" if args.scaling == "weak" else "strong",
         "partition_mode": args.scaling,  # the real mode name (`scaling` keeps the contract's two values: hybrid / lpt fix the total work = strong)
