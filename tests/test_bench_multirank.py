@@ -27,6 +27,28 @@ def test_bench_two_ranks_complete_and_roll_up():
 
 
 @pytest.mark.gpu
+def test_bench_prints_one_small_contract_line_and_writes_the_detail_file(tmp_path):
+    """VERDICT round 5, item 1, on the GPU: `python bench.py` prints exactly ONE stdout line, < 4 KB, that parses and carries the
+    contract's fields with `roofline` and `cpu_baseline`; the stages / families / per-shape tables are in the detail file it names."""
+    detail = tmp_path / "detail.json"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--settle-ms", "50", "--detail", str(detail)],
+                         cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = out.stdout.splitlines()
+    assert len(lines) == 1 and len(lines[0].encode()) < 4096
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["dtype"] == "f16" and d["verified"] is True and d["value"] > 0
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["kernel"] == "spmma_f16_fused_direct_kernel" and 0.0 < rf["frac"] < 1.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1 and d["cpu_baseline"]["value"] > 0
+    full = json.load(open(detail))
+    assert "stages" in full and "families" in full["roofline"] and "verified_layers" in full and full["stages"]["api_spmma_no_blob_layers"] == 49
+
+
+@pytest.mark.gpu
 def test_bench_gpus2_starts_its_own_ranks():
     """`python bench.py --gpus 2` with NO launcher around it: the process starts two ranks itself (child processes),
     relays rank 0's line and reports n_gpus == 2 (it used to run one rank silently)."""
