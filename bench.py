@@ -118,6 +118,13 @@ def main():
                          "r's units of the --scaling plan; the parent reports max_r t_r, sum(flops) / max t and the spread, labelled "
                          "'predicted, single-GPU emulation' (no RCCL, no contention between ranks, one box's clock)")
     ap.add_argument("--emu-rank", type=int, default=None, help=argparse.SUPPRESS)  # child of --emulate-world: whose units to run
+    ap.add_argument("--rank-bias-file", default=None, help=argparse.SUPPRESS)     # child of --emulate-world: the per-rank bias (us) of a re-planning round
+    ap.add_argument("--rebalance", type=int, default=0,
+                    help="N > 1, hybrid plan: rounds of closed-loop balancing in SETUP (before the W warm-up steps): every rank times its own step, "
+                         "the times are all-gathered, the difference to the cost model becomes a per-rank bias and every rank re-plans with it; the "
+                         "best plan measured is kept.  Default 0 = plan once from the per-shape costs measured on the box: in the 8-rank emulation the "
+                         "loop did not pay (max rank time 0.2574 -> 0.2700 -> 0.2562 ms over two rounds, profiles/rebalance_r06h.txt: a rank's excess "
+                         "over its modelled sum moves with the layers it holds, it is not a per-rank constant)")
     ap.add_argument("--detail", default=None,
                     help="where the full detail object (stages, families, yardstick, verified_layers, per-shape tables) is written; "
                          "default gpurun_out/bench_detail[_<dtype>].json.  stdout carries the compact contract line only")
@@ -206,7 +213,8 @@ def main():
                       "hybrid_plan_predicted": {str(w_): {"max_over_mean": round(max(l_) / (sum(l_) / w_), 4), "max_rank_us": round(max(l_), 1),
                                                           "speedup_vs_n1_modelled": round(sum(mg.plan_loads(shapes, 1, "hybrid")) / max(l_), 3)}
                                                 for w_ in (2, 4, 8) for l_ in [mg.plan_loads(shapes, w_, "hybrid")]}}
-    units = mg.plan_units(shapes, plan_world, plan_rank, args.scaling)
+    rank_bias = json.load(open(args.rank_bias_file)) if (args.rank_bias_file and args.scaling == "hybrid") else None
+    units = mg.plan_units(shapes, plan_world, plan_rank, args.scaling, rank_bias)
     es = 4 if f32 else 2
 
     def build_layers(shapes_, units_):
@@ -250,25 +258,29 @@ def main():
     # layer stay ordered on one stream.
     side = [torch.cuda.Stream() for _ in range(max(0, args.streams - 1))]
     nstreams = len(side) + 1
-    chains = [[] for _ in range(nstreams)]  # stream w runs chains[w] in order
-    cnt = [0, 0]
-    for i, L in enumerate(layers):
-        w = i % nstreams
-        if args.sched == "split" and nstreams >= 2:
-            big = 0 if L["m"] * L["b"] >= 784 * 128 else 1
-            half = [nstreams // 2, nstreams - nstreams // 2]
-            w = (0 if big == 0 else half[0]) + cnt[big] % half[big]
-            cnt[big] += 1
-        chains[w].append(L)
-    if args.sched == "lpt":  # longest chain first by the layers' bytes (A + B + C: what the kernels stream), largest layers first
-        def cost(L):
-            return L["b"] * (L["m"] * L["k"] + L["m"] * L["n"]) + L["k"] * L["n"]
-        chains = [[] for _ in range(nstreams)]
-        load = [0] * nstreams
-        for L in sorted(layers, key=cost, reverse=True):
-            w = load.index(min(load))
-            chains[w].append(L)
-            load[w] += cost(L)
+    def make_chains(layers_):
+        """stream w runs chains[w] in order (the ungrouped step; the grouped step spreads work ITEMS instead: spread())"""
+        chains_ = [[] for _ in range(nstreams)]
+        cnt = [0, 0]
+        for i, L in enumerate(layers_):
+            w = i % nstreams
+            if args.sched == "split" and nstreams >= 2:
+                big = 0 if L["m"] * L["b"] >= 784 * 128 else 1
+                half = [nstreams // 2, nstreams - nstreams // 2]
+                w = (0 if big == 0 else half[0]) + cnt[big] % half[big]
+                cnt[big] += 1
+            chains_[w].append(L)
+        if args.sched == "lpt":  # longest chain first by the layers' bytes (A + B + C: what the kernels stream), largest layers first
+            def cost(L):
+                return L["b"] * (L["m"] * L["k"] + L["m"] * L["n"]) + L["k"] * L["n"]
+            chains_ = [[] for _ in range(nstreams)]
+            load = [0] * nstreams
+            for L in sorted(layers_, key=cost, reverse=True):
+                w = load.index(min(load))
+                chains_[w].append(L)
+                load[w] += cost(L)
+        return chains_
+    chains = make_chains(layers)
 
     class Forked:
         """A step whose layers are spread over the streams: fork, one chain of layers per stream, join."""
@@ -397,13 +409,14 @@ def main():
                 else:
                     self.per_layer(Ls[0])
 
-    if grouped:
-        items = [("group", Ls) for _, Ls in fused_groups([L for L in layers if use_fused(L)])]
-        items += [("single", [L]) for L in layers if not use_fused(L)]
-        step_full = ForkedItems(spread(items), run_group, layer_path)
-        n_launch_groups = sum((len(Ls) + 7) // 8 for kind, Ls in items if kind == "group")
-    else:
-        step_full = Forked(layer_path)
+    def assemble(layers_):
+        """the timed step of these layers: (callable, number of grouped launches)"""
+        if grouped:
+            items = [("group", Ls) for _, Ls in fused_groups([L for L in layers_ if use_fused(L)])]
+            items += [("single", [L]) for L in layers_ if not use_fused(L)]
+            return ForkedItems(spread(items), run_group, layer_path), sum((len(Ls) + 7) // 8 for kind, Ls in items if kind == "group")
+        return Forked(layer_path), 0
+    step_full, n_launch_groups = assemble(layers)
 
     def barrier():
         if world > 1:
@@ -465,6 +478,46 @@ def main():
         return e0.elapsed_time(e1) * 1e-3 / reps
 
     run_full = make_runner(step_full)
+    # Closed-loop balancing of the hybrid plan (round 6; N > 1 only, SETUP -- before the settle and warm-up steps): a rank's step of ~10
+    # launches over 8 streams is not the sum of its launches alone, so the plan built from per-shape costs leaves 12-17 % between the
+    # slowest rank and the mean at 8 ranks.  Every rank times its own step, the times are all-gathered (the same list on every rank), the
+    # difference to the cost model becomes a per-rank bias (multigpu.rebalance_bias) and every rank re-plans with it and rebuilds its
+    # operands; the best plan measured is kept.  No matrix data crosses ranks: the operand of (layer, global batch index) is seeded.
+    rebalance_log = []
+    if world > 1 and args.scaling == "hybrid" and args.rebalance > 0 and args.emu_rank is None and not f32:
+        def gather_us():
+            box = [None] * world
+            dist.all_gather_object(box, event_seconds(run_full, 5) * 1e6)
+            return [float(x) for x in box]
+
+        times = gather_us()
+        rebalance_log.append({"round": 0, "rank_us": [round(t, 1) for t in times], "max_over_mean": round(max(times) / (sum(times) / world), 4)})
+        best_t, best_bias, cur_bias = max(times), None, None
+        for it in range(args.rebalance + 1):
+            last = it == args.rebalance
+            if last and cur_bias is best_bias:
+                break          # the plan in place is the best one measured
+            if last:
+                nxt = best_bias  # one more re-plan: back to the best plan measured
+            else:
+                nxt = mg.rebalance_bias(times, mg.plan_loads(shapes, world, "hybrid", rank_bias=cur_bias))
+            run_full = step_full = layers = chains = None   # release the operands and the graph of the plan being replaced
+            torch.cuda.empty_cache()
+            units = mg.plan_units(shapes, world, rank, "hybrid", nxt)
+            layers = build_layers(shapes, units)
+            flops = mg.unit_flops(shapes, units)
+            chains = make_chains(layers)
+            step_full, n_launch_groups = assemble(layers)
+            run_full = make_runner(step_full)
+            cur_bias = nxt
+            if last:
+                rebalance_log.append({"round": "kept", "bias_us": None if nxt is None else [round(x, 1) for x in nxt]})
+                break
+            times = gather_us()
+            rebalance_log.append({"round": it + 1, "bias_us": [round(x, 1) for x in nxt], "rank_us": [round(t, 1) for t in times],
+                                  "max_over_mean": round(max(times) / (sum(times) / world), 4)})
+            if max(times) < best_t:
+                best_t, best_bias = max(times), nxt
     if args.settle_ms > 0:  # part of the setup, like the buffer fills and the graph capture: not one of the K timed steps
         t_end = time.perf_counter() + args.settle_ms * 1e-3
         while time.perf_counter() < t_end:
@@ -598,6 +651,8 @@ def main():
         if not ok:
             sys.stderr.write("bench: the timed step's C differs from compress + spmma: " + json.dumps(checked) + "\n")
             raise SystemExit(4)
+    if rebalance_log:
+        plan_costs["rebalance_rounds"] = rebalance_log
     out["config"]["plan_costs"] = plan_costs
     if config4 is not None:
         out.setdefault("stages", {})["config4_sweep"] = config4

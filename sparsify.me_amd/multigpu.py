@@ -129,7 +129,7 @@ def shard_units(num_layers, batch, world, rank, mode="weak"):
     return plan_units([(0, 0, 0, batch)] * num_layers, world, rank, mode)
 
 
-def plan_units(shapes, world, rank, mode="weak"):
+def plan_units(shapes, world, rank, mode="weak", rank_bias=None):
     """shapes: [(m, n, k, b)] of the concatenated tables.  Returns this rank's [(layer, batch_begin, batch_end)].
     weak  : all layers, global batch indices [rank*b, (rank+1)*b)
     strong: all layers, [g*b/G, (g+1)*b/G) of each layer's batch (SURVEY.md 8(e) primary partitioning; B replicated)
@@ -138,7 +138,11 @@ def plan_units(shapes, world, rank, mode="weak"):
     hybrid: strong scaling (total work fixed) with the granularity chosen per SHAPE GROUP: the layers of a shape whose grouped
             launch still fills the chip on a rank's batch share (count x m x b / world >= HYBRID_FILL_ROWS rows) are split by
             batch index as in `strong`; the others stay whole and are placed in same-shape chunks, longest measured time first
-            (layer_cost()), on top of the split layers' equal shares.  What `bench.py --gpus N` uses by default on one table"""
+            (layer_cost()), on top of the split layers' equal shares.  What `bench.py --gpus N` uses by default on one table.
+            rank_bias (round 6; hybrid only): per-rank microseconds added to a rank's load before anything is placed -- the difference
+            between what a rank's step MEASURED and what the cost model said (a step of ~10 launches over 8 streams is not the sum of
+            its launches alone); bench.py measures it in setup, all-gathers it and re-plans (closed-loop balancing; the same list on
+            every rank, so every rank computes the same plan)"""
     if mode not in MODES:
         raise ValueError(mode)
     if world < 1 or not (0 <= rank < world):
@@ -156,7 +160,9 @@ def plan_units(shapes, world, rank, mode="weak"):
         groups = {}
         for l, sh in enumerate(shapes):
             groups.setdefault(sh, []).append(l)
-        out, load, whole_groups = [], [0.0] * world, []
+        out, load, whole_groups = [], ([float(x) for x in rank_bias] if rank_bias else [0.0] * world), []
+        if len(load) != world:
+            raise ValueError("rank_bias needs one entry per rank")
         for (m, n, k, b), ls in groups.items():
             if world == 1 or (b >= world and len(ls) * m * (b // world) >= HYBRID_FILL_ROWS):
                 for l in ls:  # split by batch index as in `strong`
@@ -261,11 +267,19 @@ def rollup(flops_done, seconds, device=None, force_collective=False):
     return float(f.item()), float(t.item())
 
 
-def plan_loads(shapes, world, mode="hybrid"):
+def rebalance_bias(measured_us, modelled_us, old_bias=None):
+    """The per-rank bias of the next planning round: what each rank's step measured minus what the cost model says its units cost
+    (without any bias), shifted so that the smallest entry is 0 (only differences between ranks matter to the planner)."""
+    raw = [float(t) - float(m) for t, m in zip(measured_us, modelled_us)]
+    lo = min(raw)
+    return [x - lo for x in raw]
+
+
+def plan_loads(shapes, world, mode="hybrid", rank_bias=None):
     """Modelled time (us, layer_cost()) of every rank's units under `mode`: what the plan balances.  max / mean of it is the plan's
     predicted imbalance -- bench.py records it for N = 2 / 4 / 8 from the costs it measured on the box at N = 1, and
     tests/test_multigpu_gloo.py holds it under 8 % for cost tables perturbed by +-20 % (another box's numbers)."""
     loads = []
     for r in range(world):
-        loads.append(sum(layer_cost(shapes[l][0], shapes[l][1], shapes[l][2], hi - lo) for l, lo, hi in plan_units(shapes, world, r, mode)))
+        loads.append(sum(layer_cost(shapes[l][0], shapes[l][1], shapes[l][2], hi - lo) for l, lo, hi in plan_units(shapes, world, r, mode, rank_bias)))
     return loads

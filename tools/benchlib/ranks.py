@@ -22,10 +22,10 @@ def emulate_world(args):
         if skip:
             skip -= 1
             continue
-        if a in ("--emulate-world", "--scaling", "--gpus"):
+        if a in ("--emulate-world", "--scaling", "--gpus", "--rebalance"):
             skip = 1
             continue
-        if a.startswith(("--emulate-world=", "--scaling=", "--gpus=")):
+        if a.startswith(("--emulate-world=", "--scaling=", "--gpus=", "--rebalance=")):
             continue
         argv.append(a)
 
@@ -44,9 +44,34 @@ def emulate_world(args):
     shapes = [s_ for t in (args.tables or args.table or ("resnet18" if args.dtype == "f32" else "resnet50")).split(",") for s_ in read_shapes(table_path(t))]
     identical = mode == "weak" or (mode == "strong" and all(b % N == 0 for _, _, _, b in shapes))
     ranks = [0] if identical else list(range(N))
-    per = {r: child(["--scaling", mode, "--emulate-world", str(N), "--emu-rank", str(r)]) for r in ranks}
-    ms = [per[r if not identical else 0]["ms_per_step"] for r in range(N)]
-    gf = [per[r if not identical else 0]["emulated"]["dense_equiv_gflop_per_step"] for r in range(N)]
+    def run_ranks(bias_file=None):
+        extra = ["--rank-bias-file", bias_file] if bias_file else []
+        per_ = {r: child(["--scaling", mode, "--emulate-world", str(N), "--emu-rank", str(r)] + extra) for r in ranks}
+        return ([per_[r if not identical else 0]["ms_per_step"] for r in range(N)],
+                [per_[r if not identical else 0]["emulated"]["dense_equiv_gflop_per_step"] for r in range(N)])
+    ms, gf = run_ranks()
+    # Closed-loop balancing (round 6; hybrid only, --rebalance R rounds): what a real N-GPU run does in its setup -- every rank measures its
+    # own step, the times are all-gathered, the difference to the cost model becomes a per-rank bias and every rank re-plans with it
+    # (multigpu.rebalance_bias / plan_units(rank_bias=...)) -- emulated here by running the rank children again with the bias in a file.
+    rounds = []
+    if mode == "hybrid" and not identical and getattr(args, "rebalance", 0) > 0 and N > 1:
+        import __graft_entry__ as ge
+        mg = ge.load_package_module("multigpu")
+        costs = {tuple(int(x) for x in k_.split("x")): tuple(v) for k_, v in json.load(open(costs_file)).items()}
+        mg.set_measured_costs(costs)
+        best = (max(ms), ms, gf, None)
+        bias = None
+        rounds.append({"round": 0, "max_ms": max(ms), "spread": (max(ms) - min(ms)) / (sum(ms) / len(ms))})
+        for it in range(args.rebalance):
+            modelled = mg.plan_loads(shapes, N, "hybrid", rank_bias=bias)
+            bias = mg.rebalance_bias([t * 1e3 for t in ms], modelled)
+            bf = os.path.join(os.path.dirname(costs_file), "bias_%d.json" % it)
+            json.dump(bias, open(bf, "w"))
+            ms, gf = run_ranks(bf)
+            rounds.append({"round": it + 1, "max_ms": max(ms), "spread": (max(ms) - min(ms)) / (sum(ms) / len(ms)), "bias_us": [round(x, 1) for x in bias]})
+            if max(ms) < best[0]:
+                best = (max(ms), ms, gf, bias)
+        _, ms, gf, _ = best   # a real run keeps the best plan it measured (one more re-plan when the last round was not the best)
     tmax = max(ms)
     total = sum(gf)
     out = {"metric": base["metric"], "value": total / (tmax * 1e-3), "unit": "GF/s", "n_gpus": N,
@@ -55,7 +80,7 @@ def emulate_world(args):
            "predicted": True, "partition_mode": mode, "scaling": "weak" if mode == "weak" else "strong",
            "per_rank_ms": ms, "per_rank_gflop": gf, "max_ms": tmax, "min_ms": min(ms),
            "spread": (max(ms) - min(ms)) / (sum(ms) / len(ms)),
-           "ranks_measured": ranks, "ranks_identical_by_construction": identical,
+           "ranks_measured": ranks, "ranks_identical_by_construction": identical, "rebalance_rounds": rounds,
            "n1_ms": base["ms_per_step"], "n1_value": base["value"],
            "predicted_speedup_vs_n1": (total / (tmax * 1e-3)) / base["value"],
            "steps": args.steps, "warmup": args.warmup, "dtype": args.dtype, "data": "synthetic",
