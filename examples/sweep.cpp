@@ -96,7 +96,9 @@ int main(int argc, char** argv) {
         Cf[i].resize(m * n);
         Cs[i] = Cf[i].data().get();
       }
-      if (h.blocked_cols > 0 && h.blocked_rows > 0) {
+      // (2 x 2 blocks need even m and k and whole block columns: the 7 x 7 x 3 stem layer, k = 147, has no such operand -- the reference's
+      //  examples/spmm.cu:45-56 would build a truncated one; its column stays 0 here instead of an error line from the operator)
+      if (h.blocked_cols > 0 && h.blocked_rows > 0 && m % bs == 0 && k % bs == 0 && h.ell_cols % bs == 0) {
         batched::spmm(As.data(), Bf.data().get(), Cs.data(), m, n, k, b);  // warm
         spmm_ms = batched::spmm(As.data(), Bf.data().get(), Cs.data(), m, n, k, b);
       }
