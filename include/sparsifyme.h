@@ -115,13 +115,19 @@ int sm_prune24_compress24_bf16(const void* A_in, void* A_out, size_t m, size_t k
 int sm_prune24_compress24_f32(const float* A_in, float* A_out, size_t m, size_t k, size_t ld, size_t batch, size_t strideA,
                               void* blob, int* d_valid, int alg, sm_stream_t stream);
 
-/* ---- (a2 + a4 in ONE kernel, round 4) the whole call sequence of sparsifyme::spmma() (spmma.hxx:82-113: prune TILE in place,
- *      check, compress, multiply) without a compressed blob: reads A_in once, writes the pruned operand to A_out (A_in itself:
- *      in place, what the reference does; or a second buffer), raises *d_valid (NULL: not wanted; 0 iff every strip written
- *      holds <= 2 non-zeros, derived from the stored values) and computes C_b = alpha * prune24(A_b) * B_b + beta * C_b.
- *      A_out is bit-identical to sm_prune24_*(A_in, alg), C to sm_spmma_*(sm_compress24_*(A_out)).  Takes n <= 128, n % 8 == 0,
- *      k % 64 == 0, m % 4 == 0 and 16-byte aligned rows; SM_STATUS_NOT_SUPPORTED otherwise (then: sm_prune24_compress24_* +
- *      sm_spmma_*, which is what include/sparsify.me/spmma.hxx falls back to). */
+/* ---- (a2 + a4 without a blob, rounds 4 + 6) the whole call sequence of sparsifyme::spmma() (spmma.hxx:82-113: prune TILE in place,
+ *      check, compress, multiply) with NO compressed blob: reads A_in, writes the pruned operand to A_out (A_in itself: in place, what
+ *      the reference does; or a second buffer), raises *d_valid (NULL: not wanted; 0 iff every strip written holds <= 2 non-zeros,
+ *      derived from the stored values) and computes C_b = alpha * prune24(A_b) * B_b + beta * C_b.  A_out is bit-identical to
+ *      sm_prune24_*(A_in, alg) (per batch matrix when m % 4 != 0), C to sm_spmma_*(sm_compress24_*(A_out)).
+ *      ONE kernel (A read once, written once) for n <= 128, n % 8 == 0, k % 64 == 0, m % 4 == 0 and 16-byte aligned rows.  Since round 6
+ *      every other shape the EXACT fused kernels take -- n > 128 (k % 64 == 0, n % 8 == 0, 16-byte aligned rows), ragged k with
+ *      n <= 128 on one contiguous A with a shared B (the span form), m % 4 != 0 -- runs as TWO launches inside the call: the prune + flag
+ *      pass over A (sm_prune24_compress24_* with a null blob) and sm_spmma_fused_* on the pruned operand (its STRIP selection of a 2:4
+ *      strip is what sm_compress24 stores for it); HBM bytes 2 A + C + B while the pruned A stays in the 256 MiB Infinity Cache between
+ *      the two.  SM_STATUS_NOT_SUPPORTED -- decided BEFORE A is touched -- otherwise (n % 8 != 0, n < 8, unaligned operands): then
+ *      sm_prune24_compress24_* + sm_spmma_*.  Any other failing status of the second launch (a refused LDS opt-in, a grid limit) is
+ *      returned after A_out has been written. */
 int sm_prune24_spmma_f16(const void* A_in, void* A_out, const void* B, void* C, size_t m, size_t n, size_t k, size_t lda,
                          size_t batch, size_t strideA, size_t strideB, size_t strideC, int alg, int* d_valid, float alpha,
                          float beta, sm_stream_t stream);
